@@ -1,0 +1,200 @@
+/*
+ * udt_kernels.h — C ABI of libudt_kernels.so: the MI355X (gfx950 / CDNA4) kernels behind the
+ * UDiffText denoising hot path.
+ *
+ * The reference (ZYM-PKU/UDiffText) is pure Python and owns no native boundary; its hot path reaches
+ * native arithmetic only through third-party wheels.  Each entry point below therefore replaces the
+ * third-party call the reference makes at the cited file:line (paths relative to the reference root):
+ *
+ *   udt_gemm            nn.Linear / nn.Conv2d(1x1) / nn.Conv2d(3x3) call sites:
+ *                         sgm/modules/attention.py:47-51,66-70 (GEGLU / FeedForward),
+ *                         sgm/modules/attention.py:193-199,215-218 (to_q/to_k/to_v/to_out),
+ *                         sgm/modules/attention.py:375,395,407,411 (proj_in / proj_out),
+ *                         sgm/modules/diffusionmodules/openaimodel.py:186,223-230,240 (ResBlock convs + skip),
+ *                         sgm/modules/diffusionmodules/openaimodel.py:85-101,132-146 (Up/Downsample),
+ *                         sgm/modules/diffusionmodules/openaimodel.py:210-216,340-344 (emb_layers, time_embed),
+ *                         sgm/modules/diffusionmodules/model.py:59-68,74-85,108-124,128-148 (VAE convs),
+ *                         sgm/modules/diffusionmodules/model.py:214-226,232-256 (VAE attention 1x1 convs),
+ *                         sgm/models/autoencoder.py:297-298 (quant_conv / post_quant_conv),
+ *                         sgm/modules/encoders/modules.py:1103-1104 (nn.TransformerEncoderLayer linears)
+ *   udt_attn_fwd        xformers.ops.memory_efficient_attention  sgm/modules/attention.py:246
+ *   udt_xattn_fwd       einsum / softmax / einsum               sgm/modules/attention.py:152-172
+ *                       (also nn.MultiheadAttention inside nn.TransformerEncoderLayer,
+ *                        sgm/modules/encoders/modules.py:1103-1104,1164)
+ *   udt_softmax_rows    softmax of the VAE single-head attention  sgm/modules/diffusionmodules/model.py:246
+ *   udt_gn_stats / udt_gn_apply
+ *                       GroupNorm32 + SiLU      sgm/modules/diffusionmodules/util.py:258-275,
+ *                                               sgm/modules/diffusionmodules/openaimodel.py:183-187,218-221,536-538
+ *                       GroupNorm(eps 1e-6)     sgm/modules/attention.py:82-85,402 ; model.py:48-52,128-143
+ *   udt_layernorm       nn.LayerNorm            sgm/modules/attention.py:297,310-311,315-339
+ *   udt_unet_input / udt_cfg_euler_step
+ *                       guider.prepare_inputs + denoiser scaling + CFG + Euler update
+ *                       sgm/modules/diffusionmodules/guiders.py:25-40, denoiser.py:22-28,
+ *                       denoiser_scaling.py:16-22, sampling_utils.py:8-9,39-40, sampling.py:85-86,348-351
+ *   udt_posterior_sample  DiagonalGaussianDistribution.sample  sgm/modules/distributions/distributions.py:24-41
+ *   udt_nchw_to_nhwc / udt_nhwc_to_nchw   layout change at the NCHW fp32 plugin boundary
+ *                       (rearrange "b c h w -> b (h w) c", sgm/modules/attention.py:405,412)
+ *   udt_embed_tokens    nn.Embedding + PositionalEncoding  sgm/modules/encoders/modules.py:1069-1085,1160-1163
+ *   udt_timestep_embedding  timestep_embedding  sgm/modules/diffusionmodules/util.py:206-230
+ *   udt_mask_downsample SpatialRescaler (bilinear x0.125)  sgm/modules/encoders/modules.py:843-857
+ *   udt_local_loss_maps head-mean + 3x3 blur + masked max of t_attn maps  sgm/modules/diffusionmodules/loss.py:192-235
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller; kernels borrow it for the stream-ordered
+ *     duration of the launch; the library allocates nothing on the data path and keeps no pointer.
+ *   - activations are bf16, channel-last ("NHWC": [batch, pixels, channels]); weights are bf16,
+ *     [out_features, K] with K contiguous; statistics / sampler state are fp32.
+ *   - return value: 0 on success, a negative udt_status otherwise.  Nothing throws or aborts.
+ *   - all launches are asynchronous on `stream` (a hipStream_t passed as void*).
+ */
+#ifndef UDT_KERNELS_H
+#define UDT_KERNELS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+  UDT_OK = 0,
+  UDT_ERR_BAD_SHAPE = -1,     /* dimension not supported by the kernel (alignment / range)      */
+  UDT_ERR_BAD_ARG = -2,       /* null pointer / inconsistent flags                                */
+  UDT_ERR_WORKSPACE = -3,     /* workspace too small (see udt_gemm_workspace_bytes)               */
+  UDT_ERR_HIP = -4,           /* a HIP runtime call failed; see udt_last_hip_error                */
+  UDT_ERR_NO_DEVICE = -5      /* no gfx950 device visible                                         */
+} udt_status;
+
+/* ---- epilogue / mode flags for udt_gemm ------------------------------------------------------- */
+#define UDT_GEMM_OUT_F32     (1 << 0)  /* out is fp32 instead of bf16                              */
+#define UDT_GEMM_GEGLU       (1 << 1)  /* out[:, j] = x_j * gelu_erf(gate_j); weight rows packed
+                                          in [32 x | 32 gate] blocks (see pack_geglu in Python)   */
+#define UDT_GEMM_RELU        (1 << 2)
+#define UDT_GEMM_TRANSPOSED  (1 << 3)  /* out is [batch_of_row][N][rows_per_batch] (V^T for attn)  */
+#define UDT_GEMM_CONV        (1 << 4)  /* implicit-GEMM convolution, A gathered from NHWC sources   */
+#define UDT_GEMM_SILU_OUT    (1 << 5)  /* out = silu(acc...) (time_embed MLP)                      */
+
+typedef struct {
+  /* operands */
+  const void* a;        /* bf16 [M, lda] (plain) or NHWC source 1 [B, Hin, Win, C1] (conv)        */
+  const void* a2;       /* conv only: optional NHWC source 2 [B, Hin, Win, C2] (channel concat)   */
+  const void* w;        /* bf16 [N, K] K-contiguous; conv: k = (ky*ksize + kx)*(C1+C2) + c        */
+  const float* bias;    /* [N] fp32 or NULL                                                       */
+  const void* residual; /* bf16 [M, ldr] or NULL, added in the epilogue                           */
+  const float* rowvec;  /* fp32 [M / rows_per_batch, N] or NULL (time-embedding broadcast add)    */
+  void* out;            /* bf16 / fp32 [M, ldo] (or transposed, see flag)                         */
+  int32_t M, N, K;
+  int32_t lda, ldo, ldr;
+  /* batched GEMM (grid.z): element strides between problems; batch = 1 for none                  */
+  int32_t batch;
+  int64_t stride_a, stride_w, stride_out, stride_res;
+  /* conv geometry (UDT_GEMM_CONV)                                                                */
+  int32_t Hin, Win, C1, C2, Hout, Wout;
+  int32_t ksize;        /* 1 or 3                                                                 */
+  int32_t stride;       /* 1 or 2                                                                 */
+  int32_t pad_t, pad_l; /* zero padding before the first row / column (bottom/right implicit)     */
+  int32_t upsample;     /* 1: sources are read through a nearest x2 upsample                      */
+  int32_t rows_per_batch; /* rows of M belonging to one sample (rowvec / transposed addressing)   */
+  int32_t flags;
+  float alpha;          /* acc * alpha before bias (softmax scale for QK^T GEMMs); 1.0 default    */
+} udt_gemm_desc;
+
+/* workspace (bytes) udt_gemm needs for this problem (split-K slabs); 0 if none */
+size_t udt_gemm_workspace_bytes(const udt_gemm_desc* d);
+int udt_gemm(const udt_gemm_desc* d, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- attention -------------------------------------------------------------------------------- */
+/* Flash attention forward, head_dim 64, no mask:  O = softmax(Q K^T * scale) V
+ *   q  : bf16, row (b, tok) at q  + b*q_bstride  + tok*ldq + h*64
+ *   k  : bf16, row (b, tok) at k  + b*k_bstride  + tok*ldk + h*64
+ *   vt : bf16 V transposed: element (b, h*64+d, tok) at vt + b*vt_bstride + (h*64+d)*ldvt + tok
+ *   o  : bf16, row (b, tok) at o  + b*o_bstride  + tok*ldo + h*64
+ * nk must be a multiple of 8. */
+int udt_attn_fwd(const void* q, const void* k, const void* vt, void* o,
+                 int32_t batch, int32_t heads, int32_t nq, int32_t nk,
+                 int32_t ldq, int32_t ldk, int32_t ldvt, int32_t ldo,
+                 int64_t q_bstride, int64_t k_bstride, int64_t vt_bstride, int64_t o_bstride,
+                 float scale, void* stream);
+
+/* Short-context attention (context length L <= 16; text cross-attention, LabelEncoder self-attn):
+ *   q  : bf16 [batch, nq, heads*head_dim] (ldq), k/v : bf16 rows (b, l) at k + (b*L + l)*ldkv + h*head_dim
+ *   o  : bf16 [batch, nq, heads*head_dim] (ldo)
+ *   probs (optional, may be NULL): fp32 [batch*heads, nq, L] — the softmax probabilities the
+ *   reference caches in attn_map_cache (attention.py:165-169), "(b h) n l" order.
+ * head_dim must be a multiple of 64. */
+int udt_xattn_fwd(const void* q, const void* k, const void* v, void* o, float* probs,
+                  int32_t batch, int32_t heads, int32_t head_dim, int32_t nq, int32_t L,
+                  int32_t ldq, int32_t ldkv, int32_t ldo, float scale, void* stream);
+
+/* Row softmax of a bf16 [rows, cols] matrix in place (ld elements between rows), fp32 math. */
+int udt_softmax_rows(void* x, int64_t rows, int32_t cols, int32_t ld, void* stream);
+
+/* ---- normalisation ---------------------------------------------------------------------------- */
+/* GroupNorm statistics over NHWC bf16 x [B, HW, C] with G groups (C % G == 0, C % 8 == 0).
+ * Writes per-chunk partial (sum, sumsq) to `partials` (fp32 [B, nchunks, G, 2]); nchunks is returned
+ * by udt_gn_nchunks(HW, C). */
+int32_t udt_gn_nchunks(int64_t HW, int32_t C);
+int udt_gn_stats(const void* x, float* partials, int32_t B, int64_t HW, int32_t C, int32_t G, void* stream);
+/* y = act((x - mean) * rstd * gamma + beta); act: 0 none, 1 SiLU.  y may alias x. */
+int udt_gn_apply(const void* x, void* y, const float* partials, const float* gamma, const float* beta,
+                 int32_t B, int64_t HW, int32_t C, int32_t G, float eps, int32_t act, void* stream);
+/* LayerNorm over the last dim of bf16 [rows, C] (C % 8 == 0, C <= 4096). */
+int udt_layernorm(const void* x, void* y, const float* gamma, const float* beta,
+                  int64_t rows, int32_t C, float eps, void* stream);
+
+/* ---- sampler / boundary elementwise ------------------------------------------------------------ */
+/* UNet input for one CFG step: x fp32 NCHW [B,4,h,w] -> xin bf16 NHWC [2B, h*w, cpad]; channels 0..3 of
+ * both halves = x * c_in; the other channels (mask / masked latent / zero pad) are left untouched. */
+int udt_unet_input(const float* x, void* xin, int32_t B, int32_t hw, int32_t cpad, float c_in, void* stream);
+/* eps fp32 [2B, hw, ld_eps] (uncond half first) -> x fp32 NCHW [B,4,h,w] updated in place:
+ *   den_u = x - sigma*eps_u ; den_c = x - sigma*eps_c ; den = den_u + scale*(den_c - den_u)
+ *   d = (x - den)/sigma ; x += d*(sigma_next - sigma)          (optionally writes den) */
+int udt_cfg_euler_step(float* x, const float* eps, float* denoised_out, int32_t B, int32_t hw, int32_t ld_eps,
+                       float sigma, float sigma_next, float cfg_scale, void* stream);
+/* z = scale * (mean + exp(0.5*clamp(logvar,-30,20)) * noise); moments fp32 [B, hw, ldm] NHWC (mean ch 0..3,
+ * logvar ch 4..7), noise fp32 NCHW [B,4,h,w], z fp32 NCHW [B,4,h,w]. */
+int udt_posterior_sample(const float* moments, const float* noise, float* z, int32_t B, int32_t hw, int32_t ldm,
+                         float scale, void* stream);
+/* fp32 NCHW [B,C,HW] -> bf16 NHWC [B,HW,cpad] (channels >= C zero-filled), value * scale */
+int udt_nchw_to_nhwc(const float* x, void* y, int32_t B, int32_t C, int64_t HW, int32_t cpad, float scale,
+                     void* stream);
+/* bf16 or fp32 NHWC [B,HW,ld] (first C channels) -> fp32 NCHW [B,C,HW] */
+int udt_nhwc_to_nchw(const void* x, float* y, int32_t B, int32_t C, int64_t HW, int32_t ld, int32_t src_is_f32,
+                     void* stream);
+/* write fp32 NCHW [B,C,HW] source into channels [c0, c0+C) of a bf16 NHWC buffer [B,HW,cpad] */
+int udt_nhwc_set_channels(const float* src, void* dst, int32_t B, int32_t C, int64_t HW, int32_t cpad, int32_t c0,
+                          void* stream);
+/* out bf16 [n_tok, D] = table[idx[i]] + pe[i % L]  (table fp32 [V, D], pe fp32 [L, D], idx int32) */
+int udt_embed_tokens(const int32_t* idx, const float* table, const float* pe, void* out, int32_t n_tok, int32_t L,
+                     int32_t D, void* stream);
+/* out bf16 [n, dim]: [cos(t f_k) | sin(t f_k)], f_k = exp(-ln(10000) k / (dim/2)); t int64-valued fp32 */
+int udt_timestep_embedding(const float* t, void* out, int32_t n, int32_t dim, void* stream);
+/* bilinear x1/8 (align_corners False) of fp32 [B,1,H,W] -> fp32 [B,1,H/8,W/8]: mean of the centre 2x2 */
+int udt_mask_downsample(const float* mask, float* out, int32_t B, int32_t H, int32_t W, void* stream);
+/* per-layer local-loss term: probs fp32 [B*heads, n, L] (n = size*size), mask fp32 [B,1,Hm,Wm],
+ * seg_mask fp32 [B, seg_l] -> loss fp32 [B] (+= accumulate): -min_l( max_n(mask_n * blur3x3(mean_h p)) + 1 - seg ) */
+int udt_local_loss(const float* probs, const float* mask, const float* seg_mask, const float* gkernel9,
+                   float* loss_accum, int32_t B, int32_t heads, int32_t size, int32_t L, int32_t seg_l,
+                   int32_t Hm, int32_t Wm, void* stream);
+/* x bf16 += y bf16 (n elements, n % 8 == 0) ; utility for residuals outside GEMM epilogues */
+int udt_add_bf16(void* x, const void* y, int64_t n, void* stream);
+
+/* ---- library services -------------------------------------------------------------------------- */
+const char* udt_version(void);
+const char* udt_status_string(int status);
+int udt_last_hip_error(void);            /* hipError_t of the last failing HIP call (0 if none)     */
+int udt_device_arch_ok(void);            /* 1 if device 0 reports gfx950                           */
+
+/* Per-op-class HIP-event timing on the launch stream (used by bench.py's roofline object).
+ * classes: 0 conv3x3, 1 gemm (linear/1x1), 2 attn, 3 xattn, 4 norm, 5 elementwise.               */
+#define UDT_PROF_NCLASS 6
+int udt_prof_enable(uint32_t class_mask);
+int udt_prof_reset(void);
+/* synchronises the recorded events and returns total ms / launch count for a class               */
+int udt_prof_get(int32_t op_class, double* total_ms, int64_t* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UDT_KERNELS_H */

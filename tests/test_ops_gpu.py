@@ -1,0 +1,359 @@
+"""Per-kernel numerics: every HIP op against a plain PyTorch fp32 reference of the same op, evaluated on
+the SAME bf16-rounded inputs (so the tolerance only has to cover fp32-accumulated bf16 products and the
+final bf16 rounding of the output).  Runs on the GPU box: ``pytest -m gpu``.
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+# tolerances (stated): outputs are bf16 (8 bit mantissa -> rel 2^-8 = 3.9e-3 per rounding)
+RTOL = 1.5e-2
+ATOL_BF16 = 2e-2
+
+
+def _close(got, ref, atol=ATOL_BF16, rtol=RTOL, what=""):
+    got = got.float()
+    ref = ref.float()
+    err = (got - ref).abs()
+    tol = atol + rtol * ref.abs()
+    bad = (err > tol).sum().item()
+    assert bad == 0, f"{what}: {bad}/{err.numel()} off, max err {err.max().item():.4g} (ref max {ref.abs().max().item():.4g})"
+
+
+def _rand(shape, dev, scale=1.0, seed=0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).to(dev)
+
+
+@pytest.fixture(scope="module")
+def ops(cuda):
+    import udifftext_amd  # noqa: F401
+    from udifftext_amd import lib, ops as O
+    lib.load()
+    assert lib.load().udt_device_arch_ok() == 1, "tests expect a gfx950 device"
+    return O
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 320, 320), (1000, 640, 1280), (96, 640, 2048),
+                                   (4096, 320, 2880), (512, 1280, 11520), (8, 1280, 320), (130, 4, 128)])
+def test_linear_plain(ops, cuda, M, N, K):
+    from udifftext_amd import packing
+    x = _rand((M, K), cuda, seed=1).bfloat16()
+    # asymmetric weights (transpose-detecting): scale grows with the row index
+    w = _rand((N, K), cuda, 1.0 / math.sqrt(K), seed=2) * (1.0 + torch.arange(N, device=cuda)[:, None] / N)
+    b = _rand((N,), cuda, seed=3)
+    wp = packing.pack_linear(w)
+    out = ops.linear(x, wp, packing.pad_bias(b), n_out=wp.shape[0])
+    ref = x.float() @ wp[:, :K].float().t() + packing.pad_bias(b)
+    _close(out, ref, what=f"linear {M}x{N}x{K}")
+
+
+def test_linear_epilogues(ops, cuda):
+    from udifftext_amd import lib as L, packing
+    M, N, K, rpb = 512, 640, 640, 128
+    x = _rand((M, K), cuda, seed=1).bfloat16()
+    w = packing.pack_linear(_rand((N, K), cuda, 1 / math.sqrt(K), seed=2))
+    b = _rand((N,), cuda, seed=3)
+    res = _rand((M, N), cuda, seed=4).bfloat16()
+    rv = _rand((M // rpb, N), cuda, seed=5)
+    ref = x.float() @ w.float().t() + b + res.float() + rv.repeat_interleave(rpb, 0)
+    out = ops.linear(x, w, b, residual=res, rowvec=rv, rows_per_batch=rpb)
+    _close(out, ref, what="bias+res+rowvec")
+    out32 = ops.linear(x, w, b, flags=L.GEMM_OUT_F32)
+    _close(out32, x.float() @ w.float().t() + b, atol=2e-3, rtol=1e-3, what="fp32 out")
+    outr = ops.linear(x, w, b, flags=L.GEMM_RELU)
+    _close(outr, torch.relu(x.float() @ w.float().t() + b), what="relu")
+    outs = ops.linear(x, w, b, flags=L.GEMM_SILU_OUT)
+    _close(outs, F.silu(x.float() @ w.float().t() + b), what="silu")
+    outa = ops.linear(x, w, None, alpha=0.125)
+    _close(outa, 0.125 * (x.float() @ w.float().t()), what="alpha")
+
+
+def test_linear_strided_input(ops, cuda):
+    from udifftext_amd import packing
+    M, K, N = 256, 320, 320
+    big = _rand((M, 3 * K), cuda, seed=7).bfloat16()
+    xv = big[:, K:2 * K]
+    w = packing.pack_linear(_rand((N, K), cuda, 1 / math.sqrt(K), seed=8))
+    out = ops.linear(xv, w)
+    _close(out, xv.float() @ w.float().t(), what="strided A")
+
+
+def test_geglu(ops, cuda):
+    from udifftext_amd import lib as L, packing
+    M, Cc = 300, 320
+    inner = 4 * Cc
+    x = _rand((M, Cc), cuda, seed=1).bfloat16()
+    w = _rand((2 * inner, Cc), cuda, 1 / math.sqrt(Cc), seed=2)
+    b = _rand((2 * inner,), cuda, 0.5, seed=3)
+    wp, bp = packing.pack_geglu(w, b)
+    out = ops.linear(x, wp, bp, flags=L.GEMM_GEGLU)
+    assert out.shape == (M, inner)
+    proj = x.float() @ w.bfloat16().float().t() + b
+    val, gate = proj.chunk(2, dim=-1)
+    _close(out, val * F.gelu(gate), what="geglu")
+
+
+def test_transposed_out(ops, cuda):
+    from udifftext_amd import lib as L, packing
+    B, T, Cc = 3, 64, 320
+    x = _rand((B * T, Cc), cuda, seed=1).bfloat16()
+    w = packing.pack_linear(_rand((Cc, Cc), cuda, 1 / math.sqrt(Cc), seed=2))
+    out = ops.linear(x, w, flags=L.GEMM_TRANSPOSED, rows_per_batch=T)
+    ref = (x.float() @ w.float().t()).reshape(B, T, Cc).permute(0, 2, 1)
+    _close(out, ref, what="V^T")
+
+
+def test_bmm(ops, cuda):
+    B, M, N, K = 2, 256, 192, 512
+    a = _rand((B, M, K), cuda, seed=1).bfloat16()
+    w = _rand((B, N, K), cuda, 1 / math.sqrt(K), seed=2).bfloat16()
+    out = ops.bmm_nt(a, w, alpha=0.5)
+    _close(out, 0.5 * torch.einsum("bmk,bnk->bmn", a.float(), w.float()), what="bmm")
+
+
+CONV_CASES = [
+    # B, H, W, C1, C2, N, k, stride, pad, ups
+    (2, 16, 16, 64, 0, 320, 3, 1, (1, 1), False),
+    (2, 32, 32, 320, 0, 320, 3, 1, (1, 1), False),
+    (1, 16, 16, 640, 640, 640, 3, 1, (1, 1), False),     # skip concat
+    (2, 16, 16, 320, 0, 320, 3, 2, (1, 1), False),       # UNet downsample
+    (2, 16, 16, 128, 0, 128, 3, 2, (0, 0), False),       # VAE downsample (pad right/bottom only)
+    (2, 8, 8, 1280, 0, 1280, 3, 1, (1, 1), True),        # nearest x2 + conv
+    (2, 8, 8, 1280, 1280, 1280, 3, 1, (1, 1), False),    # deep, split-K
+    (2, 16, 16, 640, 320, 320, 1, 1, (0, 0), False),     # 1x1 skip on a concat
+    (1, 24, 40, 128, 0, 4, 3, 1, (1, 1), False),         # narrow output, non-square
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv(ops, cuda, case):
+    from udifftext_amd import packing
+    B, H, W, C1, C2, N, k, stride, pad, ups = case
+    x1 = _rand((B, H, W, C1), cuda, seed=1).bfloat16()
+    x2 = _rand((B, H, W, C2), cuda, seed=2).bfloat16() if C2 else None
+    Cin = C1 + C2
+    w = _rand((N, Cin, k, k), cuda, 1 / math.sqrt(Cin * k * k), seed=3)
+    w = w * (1.0 + torch.arange(k * k, device=cuda).reshape(1, 1, k, k) / 4.0)   # tap-asymmetric
+    b = _rand((N,), cuda, seed=4)
+    wp = packing.pack_conv(w, [C1, C2] if C2 else None)
+    if stride == 2 and pad == (0, 0):
+        Hv, Wv = H, W
+        out_hw = ((Hv + 1 - k) // 2 + 1, (Wv + 1 - k) // 2 + 1)
+    else:
+        out_hw = None
+    out = ops.conv2d(x1, wp, packing.pad_bias(b), ksize=k, stride=stride, pad=pad, upsample=ups, x2=x2, out_hw=out_hw,
+                     n_out=wp.shape[0])
+    xin = x1 if x2 is None else torch.cat([x1, x2], dim=3)
+    xin = xin.float().permute(0, 3, 1, 2)
+    if ups:
+        xin = F.interpolate(xin, scale_factor=2, mode="nearest")
+    wq = w.bfloat16().float()
+    if stride == 2 and pad == (0, 0):
+        xin = F.pad(xin, (0, 1, 0, 1))
+        ref = F.conv2d(xin, wq, b, stride=2, padding=0)
+    else:
+        ref = F.conv2d(xin, wq, b, stride=stride, padding=pad)
+    ref = ref.permute(0, 2, 3, 1)
+    _close(out[..., :N], ref, what=f"conv {case}")
+
+
+def test_conv_epilogue(ops, cuda):
+    from udifftext_amd import packing
+    B, H, W, Cc, N = 2, 16, 16, 320, 320
+    x = _rand((B, H, W, Cc), cuda, seed=1).bfloat16()
+    w = _rand((N, Cc, 3, 3), cuda, 1 / math.sqrt(Cc * 9), seed=3)
+    b = _rand((N,), cuda, seed=4)
+    res = _rand((B, H, W, N), cuda, seed=5).bfloat16()
+    temb = _rand((B, N), cuda, seed=6)
+    out = ops.conv2d(x, packing.pack_conv(w), b, residual=res, rowvec=temb)
+    ref = F.conv2d(x.float().permute(0, 3, 1, 2), w.bfloat16().float(), b, padding=1).permute(0, 2, 3, 1)
+    ref = ref + res.float() + temb[:, None, None, :]
+    _close(out, ref, what="conv epilogue")
+
+
+@pytest.mark.parametrize("B,H,N,Nk", [(2, 5, 256, 256), (1, 10, 1024, 1024), (2, 20, 64, 64), (1, 20, 16, 16),
+                                      (1, 5, 4096, 4096), (1, 5, 200, 136)])
+def test_flash_attention(ops, cuda, B, H, N, Nk):
+    Cc = H * 64
+    qkv = _rand((B, max(N, Nk), 3 * Cc), cuda, seed=1).bfloat16()
+    q = qkv[:, :N, :Cc]
+    k = qkv[:, :Nk, Cc:2 * Cc]
+    v = qkv[:, :Nk, 2 * Cc:]
+    vt = v.permute(0, 2, 1).contiguous()
+    out = ops.attention(q, k, vt, H, 0.125)
+    qh = q.float().reshape(B, N, H, 64).permute(0, 2, 1, 3)
+    kh = k.float().reshape(B, Nk, H, 64).permute(0, 2, 1, 3)
+    vh = v.float().reshape(B, Nk, H, 64).permute(0, 2, 1, 3)
+    ref = F.scaled_dot_product_attention(qh, kh, vh).permute(0, 2, 1, 3).reshape(B, N, Cc)
+    _close(out, ref, what=f"attn {B,H,N,Nk}")
+
+
+def test_flash_attention_spike(ops, cuda):
+    """a key row that dominates one query late in the sequence (forces a large online-softmax rescale)"""
+    B, H, N = 1, 5, 512
+    Cc = H * 64
+    q = _rand((B, N, Cc), cuda, seed=1).bfloat16()
+    k = _rand((B, N, Cc), cuda, seed=2).bfloat16()
+    v = _rand((B, N, Cc), cuda, seed=3).bfloat16()
+    k[0, 400] = (q[0, 17].float() * 4).bfloat16()
+    out = ops.attention(q, k, v.permute(0, 2, 1).contiguous(), H, 0.125)
+    qh, kh, vh = (t.float().reshape(B, N, H, 64).permute(0, 2, 1, 3) for t in (q, k, v))
+    ref = F.scaled_dot_product_attention(qh, kh, vh).permute(0, 2, 1, 3).reshape(B, N, Cc)
+    _close(out, ref, what="attn spike")
+
+
+@pytest.mark.parametrize("B,H,D,N,Lc", [(2, 5, 64, 1024, 12), (4, 20, 64, 64, 12), (3, 8, 256, 12, 12), (1, 10, 64, 300, 1)])
+def test_xattention(ops, cuda, B, H, D, N, Lc):
+    Cc = H * D
+    q = _rand((B, N, Cc), cuda, seed=1).bfloat16()
+    kv = _rand((B, Lc, 2 * Cc), cuda, seed=2).bfloat16()
+    k, v = kv[..., :Cc], kv[..., Cc:]
+    probs = torch.empty((B * H, N, Lc), dtype=torch.float32, device=cuda)
+    out = ops.xattention(q, k, v, H, D, D ** -0.5, probs=probs)
+    qh = q.float().reshape(B, N, H, D).permute(0, 2, 1, 3)
+    kh = k.float().reshape(B, Lc, H, D).permute(0, 2, 1, 3)
+    vh = v.float().reshape(B, Lc, H, D).permute(0, 2, 1, 3)
+    sim = qh @ kh.transpose(-1, -2) * D ** -0.5
+    sim = torch.softmax(sim, dim=-1) if Lc > 1 else torch.sigmoid(sim)   # attention.py:159-162
+    ref = (sim @ vh).permute(0, 2, 1, 3).reshape(B, N, Cc)
+    _close(out, ref, what="xattn out")
+    _close(probs, sim.reshape(B * H, N, Lc), atol=1e-4, rtol=1e-3, what="xattn probs")
+
+
+def test_softmax_rows(ops, cuda):
+    x = _rand((300, 1024), cuda, 3.0, seed=1).bfloat16()
+    ref = torch.softmax(x.float(), dim=-1)
+    ops.softmax_rows_(x)
+    _close(x, ref, atol=1e-3, what="softmax rows")
+
+
+@pytest.mark.parametrize("B,HW,Cc,silu,eps", [(2, 4096, 320, True, 1e-5), (2, 1024, 960, True, 1e-5),
+                                              (3, 64, 2560, True, 1e-5), (1, 16384, 128, True, 1e-6),
+                                              (2, 256, 1280, False, 1e-6), (1, 100, 512, True, 1e-6)])
+def test_group_norm(ops, cuda, B, HW, Cc, silu, eps):
+    x = (_rand((B, HW, Cc), cuda, 2.0, seed=1) + 0.7).bfloat16()
+    g = _rand((Cc,), cuda, seed=2) * 0.2 + 1.0
+    b = _rand((Cc,), cuda, seed=3) * 0.2
+    out = ops.group_norm(x, g, b, 32, eps, silu)
+    ref = F.group_norm(x.float().permute(0, 2, 1), 32, g, b, eps)
+    if silu:
+        ref = F.silu(ref)
+    _close(out, ref.permute(0, 2, 1), what=f"gn {B,HW,Cc}")
+
+
+@pytest.mark.parametrize("rows,Cc", [(1000, 320), (513, 640), (64, 1280), (36, 2048)])
+def test_layer_norm(ops, cuda, rows, Cc):
+    x = (_rand((rows, Cc), cuda, 2.0, seed=1) + 0.3).bfloat16()
+    g = _rand((Cc,), cuda, seed=2) * 0.2 + 1.0
+    b = _rand((Cc,), cuda, seed=3) * 0.2
+    out = ops.layer_norm(x, g, b, 1e-5)
+    _close(out, F.layer_norm(x.float(), (Cc,), g, b, 1e-5), what=f"ln {rows,Cc}")
+
+
+def test_sampler_elementwise(ops, cuda):
+    B, h, w = 3, 16, 24
+    x = _rand((B, 4, h, w), cuda, 10.0, seed=1)
+    xin = torch.zeros((2 * B, h, w, 64), dtype=torch.bfloat16, device=cuda)
+    xin[..., 4:9] = 1.5
+    ops.unet_input(x, xin, 0.37)
+    ref = (x * 0.37).permute(0, 2, 3, 1)
+    _close(xin[:B, ..., :4], ref, what="unet_input uc half")
+    _close(xin[B:, ..., :4], ref, what="unet_input c half")
+    assert (xin[..., 4:9].float() == 1.5).all() and (xin[..., 9:].float() == 0).all()
+
+    eps = _rand((2 * B, h, w, 4), cuda, seed=2)
+    sigma, sigma_next, scale = 3.2, 2.9, 5.0
+    x0 = x.clone()
+    den = torch.empty_like(x)
+    ops.cfg_euler_step(x, eps, sigma, sigma_next, scale, denoised=den)
+    eu, ec = eps[:B].permute(0, 3, 1, 2), eps[B:].permute(0, 3, 1, 2)
+    du, dc = x0 - sigma * eu, x0 - sigma * ec
+    dref = du + scale * (dc - du)
+    xref = x0 + (x0 - dref) / sigma * (sigma_next - sigma)
+    assert torch.allclose(den, dref, atol=1e-4, rtol=1e-5)
+    assert torch.allclose(x, xref, atol=1e-4, rtol=1e-5)
+
+
+def test_layout_and_misc(ops, cuda):
+    x = _rand((2, 9, 8, 12), cuda, seed=1)
+    y = ops.nchw_to_nhwc(x, 64, 0.5)
+    _close(y[..., :9], (x * 0.5).permute(0, 2, 3, 1), what="nchw->nhwc")
+    assert (y[..., 9:].float() == 0).all()
+    back = ops.nhwc_to_nchw(y, 9)
+    _close(back, x * 0.5, what="nhwc->nchw")
+    f32 = _rand((2, 8, 12, 8), cuda, seed=2)
+    assert torch.equal(ops.nhwc_to_nchw(f32, 4), f32[..., :4].permute(0, 3, 1, 2).contiguous())
+
+    dst = torch.zeros((2, 8, 12, 64), dtype=torch.bfloat16, device=cuda)
+    src = _rand((2, 5, 8, 12), cuda, seed=3)
+    ops.nhwc_set_channels(src, dst, 4)
+    _close(dst[..., 4:9], src.permute(0, 2, 3, 1), what="set channels")
+
+    mom = _rand((2, 8, 12, 8), cuda, seed=4)
+    mom[..., 4:] *= 20
+    noise = _rand((2, 4, 8, 12), cuda, seed=5)
+    z = ops.posterior_sample(mom, noise, 0.18215)
+    mean = mom[..., :4].permute(0, 3, 1, 2)
+    logvar = mom[..., 4:].permute(0, 3, 1, 2).clamp(-30, 20)
+    assert torch.allclose(z, 0.18215 * (mean + torch.exp(0.5 * logvar) * noise), rtol=1e-5, atol=1e-5)
+
+    t = torch.tensor([999.0, 979.0, 19.0, 0.0], device=cuda)
+    te = ops.timestep_embedding(t, 320)
+    freqs = torch.exp(-math.log(10000) * torch.arange(160, device=cuda, dtype=torch.float32) / 160)
+    args = t[:, None] * freqs[None]
+    _close(te, torch.cat([torch.cos(args), torch.sin(args)], -1), atol=1e-2, what="timestep embedding")
+
+    mask = (_rand((2, 1, 64, 96), cuda, seed=6) > 0).float()
+    md = ops.mask_downsample(mask)
+    assert torch.allclose(md, F.interpolate(mask, scale_factor=0.125, mode="bilinear"), atol=1e-6)
+
+    idx = torch.randint(0, 95, (24,), device=cuda, dtype=torch.int32)
+    table = _rand((95, 256), cuda, seed=7)
+    pe = _rand((12, 256), cuda, seed=8)
+    emb = ops.embed_tokens(idx, table, pe)
+    _close(emb, table[idx.long()] + pe.repeat(2, 1), what="embed")
+
+    a = _rand((1024,), cuda, seed=9).bfloat16()
+    b = _rand((1024,), cuda, seed=10).bfloat16()
+    ref = a.float() + b.float()
+    _close(ops.add_(a, b), ref, what="add")
+
+
+def test_local_loss(ops, cuda):
+    B, heads, size, Lc, seg_l = 2, 5, 16, 12, 12
+    n = size * size
+    probs = torch.softmax(_rand((B * heads, n, Lc), cuda, 2.0, seed=1), dim=-1).contiguous()
+    mask = torch.zeros((B, 1, 64, 64), device=cuda)
+    mask[:, :, 20:40, 8:56] = 1
+    seg = torch.zeros((B, seg_l), device=cuda)
+    seg[0, :4] = 1
+    seg[1, :9] = 1
+    xs = torch.arange(3, device=cuda).float()
+    g1 = torch.exp(-(xs - 1) ** 2 / 2)
+    gk = (g1[:, None] * g1[None, :])
+    gk = (gk / gk.sum()).reshape(9).contiguous()
+    loss = torch.zeros((B,), device=cuda)
+    ops.local_loss_accumulate(probs, mask, seg, gk, loss, heads, size)
+    am = probs.reshape(B, heads, n, Lc)[..., :seg_l].permute(0, 1, 3, 2).mean(1).reshape(B, seg_l, size, size)
+    am = F.conv2d(am, gk.reshape(1, 1, 3, 3).repeat(seg_l, 1, 1, 1), padding=1, groups=seg_l).reshape(B, seg_l, n)
+    mm = F.interpolate(mask, (size, size)).tile((1, seg_l, 1, 1)).reshape(B, seg_l, n)
+    pl = (mm * am).max(-1)[0] + (1 - seg)
+    ref = -pl.min(-1)[0]
+    assert torch.allclose(loss, ref, atol=1e-5, rtol=1e-4), (loss, ref)
+
+
+def test_error_codes(ops, cuda):
+    from udifftext_amd import packing
+    x = torch.zeros((128, 100), dtype=torch.bfloat16, device=cuda)      # K not a multiple of 64
+    w = torch.zeros((64, 100), dtype=torch.bfloat16, device=cuda)
+    with pytest.raises(ValueError):
+        ops.linear(x, w)
+    with pytest.raises(ValueError):
+        ops.attention(torch.zeros((1, 12, 64), dtype=torch.bfloat16, device=cuda),
+                      torch.zeros((1, 12, 64), dtype=torch.bfloat16, device=cuda),
+                      torch.zeros((1, 64, 12), dtype=torch.bfloat16, device=cuda), 1, 0.125)   # nk % 8

@@ -1,0 +1,136 @@
+// api.hip — library services of libudt_kernels.so: version, status strings, the shared zero page used
+// by the LDS-DMA gathers, and per-op-class HIP-event timing for bench.py's roofline object.
+#include "common.h"
+
+#include <mutex>
+#include <string.h>
+#include <vector>
+
+namespace {
+
+std::mutex g_mu;
+int g_last_hip_error = 0;
+uint16_t* g_zero_page = nullptr;
+
+struct ProfRec {
+  hipEvent_t start, stop;
+  int cls;
+};
+uint32_t g_prof_mask = 0;
+std::vector<ProfRec> g_recs;        // recorded, not yet folded
+std::vector<ProfRec> g_pool;        // reusable event pairs
+double g_total_ms[UDT_PROF_NCLASS] = {0};
+int64_t g_launches[UDT_PROF_NCLASS] = {0};
+
+}  // namespace
+
+int udt_set_hip_error(hipError_t e) {
+  if (e == hipSuccess) return UDT_OK;
+  std::lock_guard<std::mutex> lk(g_mu);
+  g_last_hip_error = (int)e;
+  return UDT_ERR_HIP;
+}
+
+const uint16_t* udt_zero_page() {
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (!g_zero_page) {
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, 4096);
+    if (e != hipSuccess) { g_last_hip_error = (int)e; return nullptr; }
+    e = hipMemset(p, 0, 4096);
+    if (e != hipSuccess) { g_last_hip_error = (int)e; return nullptr; }
+    g_zero_page = reinterpret_cast<uint16_t*>(p);
+  }
+  return g_zero_page;
+}
+
+UdtProfScope::UdtProfScope(int cls_, hipStream_t s_) : cls(cls_), s(s_), rec(nullptr) {
+  if (!(g_prof_mask & (1u << cls))) return;
+  std::lock_guard<std::mutex> lk(g_mu);
+  ProfRec r;
+  if (!g_pool.empty()) {
+    r = g_pool.back();
+    g_pool.pop_back();
+  } else {
+    if (hipEventCreate(&r.start) != hipSuccess) return;
+    if (hipEventCreate(&r.stop) != hipSuccess) return;
+  }
+  r.cls = cls;
+  hipEventRecord(r.start, s);
+  g_recs.push_back(r);
+  rec = reinterpret_cast<void*>(g_recs.size());   // 1-based index
+}
+
+UdtProfScope::~UdtProfScope() {
+  if (!rec) return;
+  std::lock_guard<std::mutex> lk(g_mu);
+  const size_t idx = reinterpret_cast<size_t>(rec) - 1;
+  if (idx < g_recs.size()) hipEventRecord(g_recs[idx].stop, s);
+}
+
+static void fold_records_locked() {
+  for (auto& r : g_recs) {
+    hipEventSynchronize(r.stop);
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, r.start, r.stop) == hipSuccess) {
+      g_total_ms[r.cls] += (double)ms;
+      g_launches[r.cls] += 1;
+    }
+    g_pool.push_back(r);
+  }
+  g_recs.clear();
+}
+
+extern "C" const char* udt_version(void) { return "udt_kernels 0.1.0 (gfx950)"; }
+
+extern "C" const char* udt_status_string(int status) {
+  switch (status) {
+    case UDT_OK: return "ok";
+    case UDT_ERR_BAD_SHAPE: return "unsupported shape / alignment";
+    case UDT_ERR_BAD_ARG: return "bad argument (null pointer or inconsistent flags)";
+    case UDT_ERR_WORKSPACE: return "workspace too small";
+    case UDT_ERR_HIP: return "HIP runtime error (see udt_last_hip_error)";
+    case UDT_ERR_NO_DEVICE: return "no gfx950 device";
+    default: return "unknown status";
+  }
+}
+
+extern "C" int udt_last_hip_error(void) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  return g_last_hip_error;
+}
+
+extern "C" int udt_device_arch_ok(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return 0;
+  hipDeviceProp_t prop;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 0;
+  if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+  return strncmp(prop.gcnArchName, "gfx950", 6) == 0 ? 1 : 0;
+}
+
+extern "C" int udt_prof_enable(uint32_t class_mask) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  g_prof_mask = class_mask;
+  return UDT_OK;
+}
+
+extern "C" int udt_prof_reset(void) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  fold_records_locked();
+  for (int i = 0; i < UDT_PROF_NCLASS; ++i) {
+    g_total_ms[i] = 0.0;
+    g_launches[i] = 0;
+  }
+  return UDT_OK;
+}
+
+extern "C" int udt_prof_get(int32_t op_class, double* total_ms, int64_t* launches) {
+  if (op_class < 0 || op_class >= UDT_PROF_NCLASS || !total_ms || !launches) return UDT_ERR_BAD_ARG;
+  std::lock_guard<std::mutex> lk(g_mu);
+  fold_records_locked();
+  *total_ms = g_total_ms[op_class];
+  *launches = g_launches[op_class];
+  return UDT_OK;
+}

@@ -1,0 +1,402 @@
+// attention.hip — attention kernels for gfx950.
+//
+// udt_attn_fwd: flash attention forward, head_dim 64 (UNet self-attention; replaces
+//   xformers.ops.memory_efficient_attention at sgm/modules/attention.py:246).
+//   One workgroup = 128 queries of one (batch, head); 4 waves x 32 queries.  K and V^T tiles of 64 keys
+//   arrive by 16-byte LDS-DMA into a double-buffered, XOR-swizzled LDS image (same scheme as gemm.hip).
+//   Scores are computed "swapped": S^T = K·Q^T with the K fragment as MFMA A operand, so every lane owns
+//   ONE query column and 32 of the tile's 64 keys -> the online-softmax row max / row sum are lane-local
+//   plus one cross-half shuffle, and the rescale factor is a per-lane scalar for the O^T accumulator
+//   (O^T = V^T·P^T, V^T fragment as A operand).  The P fragment is fed to the second MFMA in the key
+//   order the first MFMA produced it (keys 4*hi+{0..3} and 8+4*hi+{0..3} of each 16-key step); the V^T
+//   fragment is read from LDS in the matching order (two 8-byte reads), so no cross-lane permute is needed.
+//
+// udt_xattn_fwd: short-context attention (L <= 16 keys; the text cross-attention t_attn over the 12
+//   character embeddings, sgm/modules/attention.py:152-172, and the LabelEncoder's 12-token
+//   self-attention).  VALU kernel: one lane per (query, head), K/V of the (batch, head) broadcast from LDS,
+//   optional write-out of the softmax probabilities ("attn_map_cache", attention.py:165-169).
+//
+// udt_softmax_rows: in-place row softmax (VAE single-head attention, model.py:246, computed as
+//   GEMM -> softmax -> GEMM because head_dim = 512 does not fit a register-resident flash tile).
+#include "common.h"
+
+namespace {
+
+struct AttnParams {
+  const uint16_t* q;
+  const uint16_t* k;
+  const uint16_t* vt;
+  uint16_t* o;
+  const uint16_t* zero;
+  int heads, nq, nk;
+  int ldq, ldk, ldvt, ldo;
+  long long sq, sk, svt, so;
+  float scale_log2e;
+};
+
+constexpr int KV_TILE = 64;
+constexpr int TILE_BYTES = 64 * 128;   // 64 rows x 128 B (K tile, and V^T tile)
+
+__global__ void __launch_bounds__(256) attn_d64_kernel(const AttnParams p) {
+  __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];   // [buf][K | VT]
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = tid & 63;
+  const int l31 = lane & 31;
+  const int hi = lane >> 5;
+  const int bh = blockIdx.y;
+  const int b = bh / p.heads;
+  const int h = bh - b * p.heads;
+
+  const uint16_t* __restrict__ Q = p.q + (long long)b * p.sq + h * 64;
+  const uint16_t* __restrict__ K = p.k + (long long)b * p.sk + h * 64;
+  const uint16_t* __restrict__ VT = p.vt + (long long)b * p.svt + (long long)h * 64 * p.ldvt;
+  uint16_t* __restrict__ O = p.o + (long long)b * p.so + h * 64;
+
+  // this lane's query
+  const int qi = blockIdx.x * 128 + wave * 32 + l31;
+  const bool qok = qi < p.nq;
+
+  // Q fragments (B operand of S^T = K Q^T): 8 consecutive d at 16*ks + 8*hi
+  bf16x8_t qf[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    const uint16_t* g = qok ? (Q + (long long)qi * p.ldq + ks * 16 + hi * 8) : p.zero;
+    qf[ks] = *reinterpret_cast<const bf16x8_t*>(g);
+  }
+
+  // staging: each wave moves 2 K pieces and 2 V^T pieces (1 KiB each) per tile
+  const int l3 = lane >> 3;
+  const int pslot = lane & 7;
+  int st_row[2], st_koff[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    st_row[i] = (wave * 2 + i) * 8 + l3;
+    st_koff[i] = (pslot ^ ((st_row[i] >> 1) & 7)) * 8;
+  }
+  auto stage = [&](int buf, int kt) {
+    char* kbuf = smem + buf * 2 * TILE_BYTES;
+    char* vbuf = kbuf + TILE_BYTES;
+    const int key0 = kt * KV_TILE;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int key = key0 + st_row[i];
+      const uint16_t* g = (key < p.nk) ? (K + (long long)key * p.ldk + st_koff[i]) : p.zero;
+      glds16(g, kbuf + (wave * 2 + i) * 1024);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int kcol = key0 + st_koff[i];          // first of 8 keys of this 16-byte chunk
+      const uint16_t* g = (kcol < p.nk) ? (VT + (long long)st_row[i] * p.ldvt + kcol) : p.zero;
+      glds16(g, vbuf + (wave * 2 + i) * 1024);
+    }
+  };
+
+  f32x16 o_acc[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o_acc[i][r] = 0.f;
+  float m_run = -INFINITY;   // running max of (score * scale * log2e)
+  float l_run = 0.f;         // this lane's partial row sum
+
+  const int swz = (l31 >> 1) & 7;
+  const int frag_row = l31 * 128;
+  const int ntiles = (p.nk + KV_TILE - 1) / KV_TILE;
+  const float c = p.scale_log2e;
+
+  stage(0, 0);
+  for (int kt = 0; kt < ntiles; ++kt) {
+    const int cur = kt & 1;
+    wait_vmcnt0();
+    __syncthreads();
+    if (kt + 1 < ntiles) stage(cur ^ 1, kt + 1);
+    const char* kbuf = smem + cur * 2 * TILE_BYTES;
+    const char* vbuf = kbuf + TILE_BYTES;
+
+    // ---- S^T[64 keys x 32 queries] -----------------------------------------------------------------
+    f32x16 s[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[t][r] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int slot = ((ks * 2 + hi) ^ swz) << 4;
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const bf16x8_t kf = lds_read_frag(kbuf + frag_row + t * 32 * 128 + slot);
+        s[t] = mfma32(kf, qf[ks], s[t]);
+      }
+    }
+    // key of s[t][reg] = kt*64 + t*32 + 8*(reg>>2) + 4*hi + (reg&3)
+    if (kt * KV_TILE + KV_TILE > p.nk) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = kt * KV_TILE + t * 32 + 8 * (r >> 2) + 4 * hi + (r & 3);
+          if (key >= p.nk) s[t][r] = -INFINITY;
+        }
+    }
+
+    // ---- online softmax (per lane = per query) ------------------------------------------------------
+    float mx = s[0][0];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[t][r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float m_new = fmaxf(m_run, mx * c);
+    const float alpha = fast_exp2(m_run - m_new);
+    m_run = m_new;
+    float psum = 0.f;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float pv = fast_exp2(s[t][r] * c - m_new);
+        s[t][r] = pv;
+        psum += pv;
+      }
+    l_run = l_run * alpha + psum;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o_acc[i][r] *= alpha;
+
+    // ---- O^T += V^T · P^T ------------------------------------------------------------------------------
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {     // 16-key steps
+      const int t = s4 >> 1;
+      const int half = s4 & 1;
+      u32x4 pk;
+      pk[0] = pack_bf16x2(s[t][half * 8 + 0], s[t][half * 8 + 1]);
+      pk[1] = pack_bf16x2(s[t][half * 8 + 2], s[t][half * 8 + 3]);
+      pk[2] = pack_bf16x2(s[t][half * 8 + 4], s[t][half * 8 + 5]);
+      pk[3] = pack_bf16x2(s[t][half * 8 + 6], s[t][half * 8 + 7]);
+      const bf16x8_t pf = __builtin_bit_cast(bf16x8_t, pk);
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        const char* row = vbuf + (dt * 32 + l31) * 128;
+        const u32x2 lo = *reinterpret_cast<const u32x2*>(row + (((2 * s4) ^ swz) << 4) + 8 * hi);
+        const u32x2 hh = *reinterpret_cast<const u32x2*>(row + (((2 * s4 + 1) ^ swz) << 4) + 8 * hi);
+        u32x4 vv = {lo[0], lo[1], hh[0], hh[1]};
+        o_acc[dt] = mfma32(__builtin_bit_cast(bf16x8_t, vv), pf, o_acc[dt]);
+      }
+    }
+  }
+
+  // ---- epilogue: O[q][d] = O^T / l ------------------------------------------------------------------------
+  const float l_tot = l_run + __shfl_xor(l_run, 32);
+  const float inv = 1.0f / l_tot;
+  if (qok) {
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) {
+        const int d = dt * 32 + qd * 8 + hi * 4;
+        u32x2 pk = {pack_bf16x2(o_acc[dt][qd * 4 + 0] * inv, o_acc[dt][qd * 4 + 1] * inv),
+                    pack_bf16x2(o_acc[dt][qd * 4 + 2] * inv, o_acc[dt][qd * 4 + 3] * inv)};
+        *reinterpret_cast<u32x2*>(O + (long long)qi * p.ldo + d) = pk;
+      }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// short-context attention: L <= 16 keys, head_dim a multiple of 64
+struct XattnParams {
+  const uint16_t* q;
+  const uint16_t* k;
+  const uint16_t* v;
+  uint16_t* o;
+  float* probs;
+  int heads, head_dim, nq, L;
+  int ldq, ldkv, ldo;
+  float scale;
+};
+
+constexpr int XL_MAX = 16;
+
+// grid: (ceil(nq/256), heads, batch); each lane owns one query of head blockIdx.y
+__global__ void __launch_bounds__(256) xattn_kernel(const XattnParams p) {
+  extern __shared__ __attribute__((aligned(16))) char xsm[];
+  float* ks = reinterpret_cast<float*>(xsm);                 // [L][head_dim] fp32
+  float* vs = ks + p.L * p.head_dim;                         // [L][head_dim] fp32
+  const int h = blockIdx.y;
+  const int b = blockIdx.z;
+  const int D = p.head_dim;
+  // stage K and V of (b, h) as fp32
+  for (int i = threadIdx.x; i < p.L * D; i += 256) {
+    const int l = i / D;
+    const int d = i - l * D;
+    const long long off = ((long long)b * p.L + l) * p.ldkv + h * D + d;
+    ks[i] = bf16_bits_to_f32(p.k[off]);
+    vs[i] = bf16_bits_to_f32(p.v[off]);
+  }
+  __syncthreads();
+  const int qi = blockIdx.x * 256 + threadIdx.x;
+  if (qi >= p.nq) return;
+  const uint16_t* qrow = p.q + ((long long)b * p.nq + qi) * p.ldq + h * D;
+  float sc[XL_MAX];
+#pragma unroll
+  for (int l = 0; l < XL_MAX; ++l) sc[l] = 0.f;
+  for (int d0 = 0; d0 < D; d0 += 8) {
+    const u32x4 qv = *reinterpret_cast<const u32x4*>(qrow + d0);
+    float qf[8] = {bf16_lo(qv[0]), bf16_hi(qv[0]), bf16_lo(qv[1]), bf16_hi(qv[1]),
+                   bf16_lo(qv[2]), bf16_hi(qv[2]), bf16_lo(qv[3]), bf16_hi(qv[3])};
+#pragma unroll
+    for (int l = 0; l < XL_MAX; ++l) {
+      if (l < p.L) {
+        const float* kr = ks + l * D + d0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sc[l] += qf[j] * kr[j];
+      }
+    }
+  }
+  float mx = -INFINITY;
+#pragma unroll
+  for (int l = 0; l < XL_MAX; ++l)
+    if (l < p.L) {
+      sc[l] *= p.scale;
+      mx = fmaxf(mx, sc[l]);
+    }
+  if (p.L == 1) {
+    // a single context token: the reference applies a sigmoid instead of a softmax (attention.py:159-162)
+    sc[0] = 1.0f / (1.0f + __expf(-sc[0]));
+  } else {
+    float sum = 0.f;
+#pragma unroll
+    for (int l = 0; l < XL_MAX; ++l)
+      if (l < p.L) {
+        sc[l] = __expf(sc[l] - mx);
+        sum += sc[l];
+      }
+    const float inv = 1.0f / sum;
+#pragma unroll
+    for (int l = 0; l < XL_MAX; ++l) sc[l] = (l < p.L) ? sc[l] * inv : 0.f;
+  }
+  if (p.probs) {
+    float* pr = p.probs + (((long long)b * p.heads + h) * p.nq + qi) * p.L;
+#pragma unroll
+    for (int l = 0; l < XL_MAX; ++l)
+      if (l < p.L) pr[l] = sc[l];
+  }
+  uint16_t* orow = p.o + ((long long)b * p.nq + qi) * p.ldo + h * D;
+  for (int d0 = 0; d0 < D; d0 += 8) {
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int l = 0; l < XL_MAX; ++l) {
+      if (l < p.L) {
+        const float* vr = vs + l * D + d0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] += sc[l] * vr[j];
+      }
+    }
+    u32x4 pk = {pack_bf16x2(acc[0], acc[1]), pack_bf16x2(acc[2], acc[3]), pack_bf16x2(acc[4], acc[5]),
+                pack_bf16x2(acc[6], acc[7])};
+    *reinterpret_cast<u32x4*>(orow + d0) = pk;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// in-place row softmax over bf16 [rows, cols]; one workgroup per row, fp32 math
+__global__ void __launch_bounds__(256) softmax_rows_kernel(uint16_t* x, int cols, int ld) {
+  __shared__ float red[8];
+  uint16_t* row = x + (long long)blockIdx.x * ld;
+  const int tid = threadIdx.x;
+  const int nch = cols >> 3;
+  float mx = -INFINITY;
+  for (int ch = tid; ch < nch; ch += 256) {
+    const u32x4 v = *reinterpret_cast<const u32x4*>(row + ch * 8);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) mx = fmaxf(mx, fmaxf(bf16_lo(v[j]), bf16_hi(v[j])));
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+  if ((tid & 63) == 0) red[tid >> 6] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  float sum = 0.f;
+  for (int ch = tid; ch < nch; ch += 256) {
+    const u32x4 v = *reinterpret_cast<const u32x4*>(row + ch * 8);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) sum += __expf(bf16_lo(v[j]) - mx) + __expf(bf16_hi(v[j]) - mx);
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
+  if ((tid & 63) == 0) red[4 + (tid >> 6)] = sum;
+  __syncthreads();
+  sum = red[4] + red[5] + red[6] + red[7];
+  const float inv = 1.0f / sum;
+  for (int ch = tid; ch < nch; ch += 256) {
+    u32x4 v = *reinterpret_cast<const u32x4*>(row + ch * 8);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      v[j] = pack_bf16x2(__expf(bf16_lo(v[j]) - mx) * inv, __expf(bf16_hi(v[j]) - mx) * inv);
+    *reinterpret_cast<u32x4*>(row + ch * 8) = v;
+  }
+}
+
+}  // namespace
+
+extern "C" int udt_attn_fwd(const void* q, const void* k, const void* vt, void* o, int32_t batch, int32_t heads,
+                            int32_t nq, int32_t nk, int32_t ldq, int32_t ldk, int32_t ldvt, int32_t ldo,
+                            int64_t q_bstride, int64_t k_bstride, int64_t vt_bstride, int64_t o_bstride,
+                            float scale, void* stream) {
+  if (!q || !k || !vt || !o) return UDT_ERR_BAD_ARG;
+  if (batch <= 0 || heads <= 0 || nq <= 0 || nk <= 0) return UDT_ERR_BAD_SHAPE;
+  if (nk % 8 != 0 || ldq % 8 != 0 || ldk % 8 != 0 || ldvt % 8 != 0 || ldo % 4 != 0) return UDT_ERR_BAD_SHAPE;
+  AttnParams p;
+  p.q = reinterpret_cast<const uint16_t*>(q);
+  p.k = reinterpret_cast<const uint16_t*>(k);
+  p.vt = reinterpret_cast<const uint16_t*>(vt);
+  p.o = reinterpret_cast<uint16_t*>(o);
+  p.zero = udt_zero_page();
+  if (!p.zero) return UDT_ERR_HIP;
+  p.heads = heads; p.nq = nq; p.nk = nk;
+  p.ldq = ldq; p.ldk = ldk; p.ldvt = ldvt; p.ldo = ldo;
+  p.sq = q_bstride; p.sk = k_bstride; p.svt = vt_bstride; p.so = o_bstride;
+  p.scale_log2e = scale * 1.4426950408889634f;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  UdtProfScope prof(2, s);
+  dim3 grid((nq + 127) / 128, batch * heads);
+  hipLaunchKernelGGL(attn_d64_kernel, grid, dim3(256), 0, s, p);
+  UDT_CHECK_LAUNCH();
+  return UDT_OK;
+}
+
+extern "C" int udt_xattn_fwd(const void* q, const void* k, const void* v, void* o, float* probs, int32_t batch,
+                             int32_t heads, int32_t head_dim, int32_t nq, int32_t L, int32_t ldq, int32_t ldkv,
+                             int32_t ldo, float scale, void* stream) {
+  if (!q || !k || !v || !o) return UDT_ERR_BAD_ARG;
+  if (batch <= 0 || heads <= 0 || nq <= 0 || L <= 0 || L > XL_MAX) return UDT_ERR_BAD_SHAPE;
+  if (head_dim <= 0 || head_dim % 64 != 0 || ldq % 8 != 0 || ldo % 8 != 0) return UDT_ERR_BAD_SHAPE;
+  XattnParams p;
+  p.q = reinterpret_cast<const uint16_t*>(q);
+  p.k = reinterpret_cast<const uint16_t*>(k);
+  p.v = reinterpret_cast<const uint16_t*>(v);
+  p.o = reinterpret_cast<uint16_t*>(o);
+  p.probs = probs;
+  p.heads = heads; p.head_dim = head_dim; p.nq = nq; p.L = L;
+  p.ldq = ldq; p.ldkv = ldkv; p.ldo = ldo;
+  p.scale = scale;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  UdtProfScope prof(3, s);
+  const size_t smem = (size_t)2 * L * head_dim * sizeof(float);
+  dim3 grid((nq + 255) / 256, heads, batch);
+  hipLaunchKernelGGL(xattn_kernel, grid, dim3(256), smem, s, p);
+  UDT_CHECK_LAUNCH();
+  return UDT_OK;
+}
+
+extern "C" int udt_softmax_rows(void* x, int64_t rows, int32_t cols, int32_t ld, void* stream) {
+  if (!x) return UDT_ERR_BAD_ARG;
+  if (rows <= 0 || cols <= 0 || cols % 8 != 0 || ld % 8 != 0 || rows > 0x7fffffffLL) return UDT_ERR_BAD_SHAPE;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  UdtProfScope prof(2, s);
+  hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)rows), dim3(256), 0, s,
+                     reinterpret_cast<uint16_t*>(x), cols, ld);
+  UDT_CHECK_LAUNCH();
+  return UDT_OK;
+}

@@ -1,0 +1,60 @@
+// common.h — device helpers shared by the gfx950 kernels (wave64, MFMA, LDS-DMA staging).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/udt_kernels.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;   // one MFMA A/B operand (4 VGPRs)
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+
+#define UDT_DEVINL __device__ __forceinline__
+
+UDT_DEVINL float bf16_bits_to_f32(uint32_t v) { return __uint_as_float(v << 16); }
+UDT_DEVINL float bf16_lo(uint32_t packed) { return __uint_as_float(packed << 16); }
+UDT_DEVINL float bf16_hi(uint32_t packed) { return __uint_as_float(packed & 0xffff0000u); }
+
+// round-to-nearest-even fp32 -> bf16 pair packed in one dword (lo = first element)
+UDT_DEVINL uint32_t pack_bf16x2(float lo, float hi) {
+  f32x2 v = {lo, hi};
+  bf16x2_t b = __builtin_convertvector(v, bf16x2_t);
+  return __builtin_bit_cast(uint32_t, b);
+}
+
+UDT_DEVINL float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }   // v_exp_f32
+UDT_DEVINL float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+UDT_DEVINL float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+
+// 16-byte global -> LDS DMA.  `lds_wave_base` must be wave-uniform; lane l lands at base + 16*l.
+UDT_DEVINL void glds16(const void* gsrc, void* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+UDT_DEVINL void wait_vmcnt0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+UDT_DEVINL bf16x8_t lds_read_frag(const char* p) { return *reinterpret_cast<const bf16x8_t*>(p); }
+
+UDT_DEVINL f32x16 mfma32(bf16x8_t a, bf16x8_t b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+// ---- host-side helpers -------------------------------------------------------------------------
+int udt_set_hip_error(hipError_t e);   // records e, returns UDT_ERR_HIP (or UDT_OK when e == success)
+const uint16_t* udt_zero_page();       // >= 4 KiB of zeroed device memory (lazily allocated once)
+
+struct UdtProfScope {                  // brackets a launch with events when profiling is enabled
+  int cls; hipStream_t s; void* rec;
+  UdtProfScope(int cls_, hipStream_t s_);
+  ~UdtProfScope();
+};
+
+#define UDT_CHECK_LAUNCH()                                   \
+  do {                                                       \
+    hipError_t _e = hipGetLastError();                       \
+    if (_e != hipSuccess) return udt_set_hip_error(_e);      \
+  } while (0)

@@ -1,0 +1,274 @@
+// norm.hip — GroupNorm (statistics + apply with optional SiLU) and LayerNorm for NHWC bf16 activations.
+//
+// These are HBM-bound streaming kernels: 16-byte (8 x bf16) loads per lane, fp32 statistics.
+//   GroupNorm32 / SiLU : sgm/modules/diffusionmodules/util.py:258-275, openaimodel.py:183-187,218-221
+//   GroupNorm eps 1e-6 : sgm/modules/attention.py:82-85 ; sgm/modules/diffusionmodules/model.py:48-52
+//   LayerNorm          : sgm/modules/attention.py:297,310-311
+#include "common.h"
+
+namespace {
+
+constexpr int GN_MAX_C = 4096;
+
+// grid (nchunks, B).  Thread layout: R row-groups x c8 channel-chunks (8 channels = 16 B each).
+__global__ void __launch_bounds__(256) gn_stats_kernel(const uint16_t* __restrict__ x, float* __restrict__ partials,
+                                                       long long HW, int C, int G, int nchunks) {
+  extern __shared__ __attribute__((aligned(16))) float gsm[];   // [R][C] sums, then [R][C] sumsq
+  const int t = threadIdx.x;
+  const int c8 = C >> 3;
+  const int chunk = blockIdx.x;
+  const int b = blockIdx.y;
+  const long long rows_per_chunk = (HW + nchunks - 1) / nchunks;
+  const long long p0 = chunk * rows_per_chunk;
+  long long p1 = p0 + rows_per_chunk;
+  if (p1 > HW) p1 = HW;
+
+  int R, rg, cc0, cstep;
+  if (c8 <= 256) {
+    R = 256 / c8;
+    rg = t / c8;
+    cc0 = t - rg * c8;
+    cstep = c8;            // one channel chunk per thread
+    if (rg >= R) cc0 = c8; // inactive
+  } else {
+    R = 1; rg = 0; cc0 = t; cstep = 256;
+  }
+  float* ssum = gsm;
+  float* ssq = gsm + R * C;
+  const uint16_t* xb = x + (long long)b * HW * C;
+  for (int cc = cc0; cc < c8; cc += cstep) {
+    float s[8], q[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s[j] = q[j] = 0.f;
+    for (long long pix = p0 + rg; pix < p1; pix += R) {
+      const u32x4 v = *reinterpret_cast<const u32x4*>(xb + pix * C + cc * 8);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float a = bf16_lo(v[j]), bb = bf16_hi(v[j]);
+        s[2 * j] += a; q[2 * j] += a * a;
+        s[2 * j + 1] += bb; q[2 * j + 1] += bb * bb;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      ssum[rg * C + cc * 8 + j] = s[j];
+      ssq[rg * C + cc * 8 + j] = q[j];
+    }
+  }
+  __syncthreads();
+  if (t < G) {
+    const int cpg = C / G;
+    float a = 0.f, q = 0.f;
+    for (int r = 0; r < R; ++r)
+      for (int c = t * cpg; c < (t + 1) * cpg; ++c) {
+        a += ssum[r * C + c];
+        q += ssq[r * C + c];
+      }
+    float* dst = partials + (((long long)b * nchunks + chunk) * G + t) * 2;
+    dst[0] = a;
+    dst[1] = q;
+  }
+}
+
+// grid (blocks_per_sample, B); each workgroup normalises a contiguous span of one sample
+__global__ void __launch_bounds__(256) gn_apply_kernel(const uint16_t* __restrict__ x, uint16_t* __restrict__ y,
+                                                       const float* __restrict__ partials,
+                                                       const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, long long HW, int C, int G,
+                                                       int nchunks, float eps, int act, long long chunks_per_wg) {
+  extern __shared__ __attribute__((aligned(16))) float asm_[];   // [C] scale, [C] shift, [G] mean, [G] rstd
+  float* sc = asm_;
+  float* sh = asm_ + C;
+  float* gm = asm_ + 2 * C;
+  float* gr = gm + G;
+  const int t = threadIdx.x;
+  const int b = blockIdx.y;
+  const int cpg = C / G;
+  if (t < G) {
+    double a = 0.0, q = 0.0;
+    for (int k = 0; k < nchunks; ++k) {
+      const float* src = partials + (((long long)b * nchunks + k) * G + t) * 2;
+      a += (double)src[0];
+      q += (double)src[1];
+    }
+    const double n = (double)HW * (double)cpg;
+    const double mean = a / n;
+    double var = q / n - mean * mean;
+    if (var < 0.0) var = 0.0;
+    gm[t] = (float)mean;
+    gr[t] = (float)(1.0 / sqrt(var + (double)eps));
+  }
+  __syncthreads();
+  for (int c = t; c < C; c += 256) {
+    const int g = c / cpg;
+    const float a = gr[g] * gamma[c];
+    sc[c] = a;
+    sh[c] = beta[c] - gm[g] * a;
+  }
+  __syncthreads();
+  const int c8 = C >> 3;
+  const long long total = HW * c8;                 // 16-byte chunks in this sample
+  const long long begin = (long long)blockIdx.x * chunks_per_wg;
+  long long end = begin + chunks_per_wg;
+  if (end > total) end = total;
+  const uint16_t* xb = x + (long long)b * HW * C;
+  uint16_t* yb = y + (long long)b * HW * C;
+  for (long long i = begin + t; i < end; i += 256) {
+    const int cc = (int)(i % c8);
+    const u32x4 v = *reinterpret_cast<const u32x4*>(xb + i * 8);
+    u32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int c = cc * 8 + 2 * j;
+      float a = bf16_lo(v[j]) * sc[c] + sh[c];
+      float bb = bf16_hi(v[j]) * sc[c + 1] + sh[c + 1];
+      if (act == 1) {
+        a = silu_f(a);
+        bb = silu_f(bb);
+      }
+      o[j] = pack_bf16x2(a, bb);
+    }
+    *reinterpret_cast<u32x4*>(yb + i * 8) = o;
+  }
+}
+
+// one wave per row, 4 rows per workgroup; NCH = ceil(C / 512) 16-byte chunks per lane
+template <int NCH>
+__global__ void __launch_bounds__(256) layernorm_kernel(const uint16_t* __restrict__ x, uint16_t* __restrict__ y,
+                                                        const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, long long rows, int C,
+                                                        float eps) {
+  const int lane = threadIdx.x & 63;
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int c8 = C >> 3;
+  const uint16_t* xr = x + row * C;
+  float v[NCH][8];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int ch = lane + i * 64;
+    if (ch < c8) {
+      const u32x4 u = *reinterpret_cast<const u32x4*>(xr + ch * 8);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        v[i][2 * j] = bf16_lo(u[j]);
+        v[i][2 * j + 1] = bf16_hi(u[j]);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[i][j] = 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s += v[i][j];
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+  const float mean = s / (float)C;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int ch = lane + i * 64;
+    if (ch < c8) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float d = v[i][j] - mean;
+        q += d * d;
+      }
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) q += __shfl_xor(q, off);
+  const float rstd = rsqrtf(q / (float)C + eps);
+  uint16_t* yr = y + row * C;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int ch = lane + i * 64;
+    if (ch < c8) {
+      const f32x4 g0 = *reinterpret_cast<const f32x4*>(gamma + ch * 8);
+      const f32x4 g1 = *reinterpret_cast<const f32x4*>(gamma + ch * 8 + 4);
+      const f32x4 b0 = *reinterpret_cast<const f32x4*>(beta + ch * 8);
+      const f32x4 b1 = *reinterpret_cast<const f32x4*>(beta + ch * 8 + 4);
+      float o[8];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        o[j] = (v[i][j] - mean) * rstd * g0[j] + b0[j];
+        o[4 + j] = (v[i][4 + j] - mean) * rstd * g1[j] + b1[j];
+      }
+      u32x4 pk = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]),
+                  pack_bf16x2(o[6], o[7])};
+      *reinterpret_cast<u32x4*>(yr + ch * 8) = pk;
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int32_t udt_gn_nchunks(int64_t HW, int32_t C) {
+  (void)C;
+  int64_t n = HW / 128;
+  if (n < 1) n = 1;
+  if (n > 64) n = 64;
+  return (int32_t)n;
+}
+
+extern "C" int udt_gn_stats(const void* x, float* partials, int32_t B, int64_t HW, int32_t C, int32_t G,
+                            void* stream) {
+  if (!x || !partials) return UDT_ERR_BAD_ARG;
+  if (B <= 0 || HW <= 0 || C <= 0 || C % 8 != 0 || G <= 0 || G > 256 || C % G != 0 || C > GN_MAX_C)
+    return UDT_ERR_BAD_SHAPE;
+  const int nchunks = udt_gn_nchunks(HW, C);
+  const int c8 = C / 8;
+  const int R = c8 <= 256 ? 256 / c8 : 1;
+  const size_t smem = (size_t)2 * R * C * sizeof(float);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  UdtProfScope prof(4, s);
+  hipLaunchKernelGGL(gn_stats_kernel, dim3(nchunks, B), dim3(256), smem, s, reinterpret_cast<const uint16_t*>(x),
+                     partials, (long long)HW, C, G, nchunks);
+  UDT_CHECK_LAUNCH();
+  return UDT_OK;
+}
+
+extern "C" int udt_gn_apply(const void* x, void* y, const float* partials, const float* gamma, const float* beta,
+                            int32_t B, int64_t HW, int32_t C, int32_t G, float eps, int32_t act, void* stream) {
+  if (!x || !y || !partials || !gamma || !beta) return UDT_ERR_BAD_ARG;
+  if (B <= 0 || HW <= 0 || C <= 0 || C % 8 != 0 || G <= 0 || G > 256 || C % G != 0 || C > GN_MAX_C)
+    return UDT_ERR_BAD_SHAPE;
+  const int nchunks = udt_gn_nchunks(HW, C);
+  const long long total = (long long)HW * (C / 8);
+  const long long chunks_per_wg = 4096;   // 64 KiB of bf16 per workgroup
+  const int blocks = (int)((total + chunks_per_wg - 1) / chunks_per_wg);
+  const size_t smem = (size_t)(2 * C + 2 * G) * sizeof(float);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  UdtProfScope prof(4, s);
+  hipLaunchKernelGGL(gn_apply_kernel, dim3(blocks, B), dim3(256), smem, s, reinterpret_cast<const uint16_t*>(x),
+                     reinterpret_cast<uint16_t*>(y), partials, gamma, beta, (long long)HW, C, G, nchunks, eps, act,
+                     chunks_per_wg);
+  UDT_CHECK_LAUNCH();
+  return UDT_OK;
+}
+
+extern "C" int udt_layernorm(const void* x, void* y, const float* gamma, const float* beta, int64_t rows, int32_t C,
+                             float eps, void* stream) {
+  if (!x || !y || !gamma || !beta) return UDT_ERR_BAD_ARG;
+  if (rows <= 0 || C <= 0 || C % 8 != 0 || C > 4096) return UDT_ERR_BAD_SHAPE;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const int nch = (C + 511) / 512;
+  const unsigned blocks = (unsigned)((rows + 3) / 4);
+  const uint16_t* xp = reinterpret_cast<const uint16_t*>(x);
+  uint16_t* yp = reinterpret_cast<uint16_t*>(y);
+  UdtProfScope prof(4, s);
+#define UDT_LN_CASE(N)                                                                                        \
+  case N:                                                                                                     \
+    hipLaunchKernelGGL(layernorm_kernel<N>, dim3(blocks), dim3(256), 0, s, xp, yp, gamma, beta, (long long)rows, \
+                       C, eps);                                                                               \
+    break;
+  switch (nch) {
+    UDT_LN_CASE(1) UDT_LN_CASE(2) UDT_LN_CASE(3) UDT_LN_CASE(4) UDT_LN_CASE(5) UDT_LN_CASE(6) UDT_LN_CASE(7)
+    UDT_LN_CASE(8)
+    default: return UDT_ERR_BAD_SHAPE;
+  }
+#undef UDT_LN_CASE
+  UDT_CHECK_LAUNCH();
+  return UDT_OK;
+}

@@ -1,0 +1,107 @@
+"""ctypes binding of libudt_kernels.so (C ABI declared in include/udt_kernels.h).
+
+The library is built in-tree by ``udifftext_amd.build``.  There is NO fallback: if the shared object is
+missing, or a compute entry point is called without a gfx950 device, the call raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libudt_kernels.so")
+
+# flags (mirror include/udt_kernels.h)
+GEMM_OUT_F32 = 1 << 0
+GEMM_GEGLU = 1 << 1
+GEMM_RELU = 1 << 2
+GEMM_TRANSPOSED = 1 << 3
+GEMM_CONV = 1 << 4
+GEMM_SILU_OUT = 1 << 5
+
+PROF_CONV3X3, PROF_GEMM, PROF_ATTN, PROF_XATTN, PROF_NORM, PROF_ELEMENTWISE = range(6)
+
+
+class GemmDesc(C.Structure):
+    _fields_ = [
+        ("a", C.c_void_p), ("a2", C.c_void_p), ("w", C.c_void_p), ("bias", C.c_void_p),
+        ("residual", C.c_void_p), ("rowvec", C.c_void_p), ("out", C.c_void_p),
+        ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
+        ("lda", C.c_int32), ("ldo", C.c_int32), ("ldr", C.c_int32),
+        ("batch", C.c_int32),
+        ("stride_a", C.c_int64), ("stride_w", C.c_int64), ("stride_out", C.c_int64), ("stride_res", C.c_int64),
+        ("Hin", C.c_int32), ("Win", C.c_int32), ("C1", C.c_int32), ("C2", C.c_int32),
+        ("Hout", C.c_int32), ("Wout", C.c_int32),
+        ("ksize", C.c_int32), ("stride", C.c_int32), ("pad_t", C.c_int32), ("pad_l", C.c_int32),
+        ("upsample", C.c_int32), ("rows_per_batch", C.c_int32), ("flags", C.c_int32), ("alpha", C.c_float),
+    ]
+
+
+# every symbol include/udt_kernels.h declares: name -> (restype, argtypes)
+_vp, _i32, _i64, _f32, _fp = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_void_p
+SYMBOLS = {
+    "udt_gemm_workspace_bytes": (C.c_size_t, [C.POINTER(GemmDesc)]),
+    "udt_gemm": (C.c_int, [C.POINTER(GemmDesc), _vp, C.c_size_t, _vp]),
+    "udt_attn_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32,
+                               _i64, _i64, _i64, _i64, _f32, _vp]),
+    "udt_xattn_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _fp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp]),
+    "udt_softmax_rows": (C.c_int, [_vp, _i64, _i32, _i32, _vp]),
+    "udt_gn_nchunks": (_i32, [_i64, _i32]),
+    "udt_gn_stats": (C.c_int, [_vp, _fp, _i32, _i64, _i32, _i32, _vp]),
+    "udt_gn_apply": (C.c_int, [_vp, _vp, _fp, _fp, _fp, _i32, _i64, _i32, _i32, _f32, _i32, _vp]),
+    "udt_layernorm": (C.c_int, [_vp, _vp, _fp, _fp, _i64, _i32, _f32, _vp]),
+    "udt_unet_input": (C.c_int, [_fp, _vp, _i32, _i32, _i32, _f32, _vp]),
+    "udt_cfg_euler_step": (C.c_int, [_fp, _fp, _fp, _i32, _i32, _i32, _f32, _f32, _f32, _vp]),
+    "udt_posterior_sample": (C.c_int, [_fp, _fp, _fp, _i32, _i32, _i32, _f32, _vp]),
+    "udt_nchw_to_nhwc": (C.c_int, [_fp, _vp, _i32, _i32, _i64, _i32, _f32, _vp]),
+    "udt_nhwc_to_nchw": (C.c_int, [_vp, _fp, _i32, _i32, _i64, _i32, _i32, _vp]),
+    "udt_nhwc_set_channels": (C.c_int, [_fp, _vp, _i32, _i32, _i64, _i32, _i32, _vp]),
+    "udt_embed_tokens": (C.c_int, [_vp, _fp, _fp, _vp, _i32, _i32, _i32, _vp]),
+    "udt_timestep_embedding": (C.c_int, [_fp, _vp, _i32, _i32, _vp]),
+    "udt_mask_downsample": (C.c_int, [_fp, _fp, _i32, _i32, _i32, _vp]),
+    "udt_local_loss": (C.c_int, [_fp, _fp, _fp, _fp, _fp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "udt_add_bf16": (C.c_int, [_vp, _vp, _i64, _vp]),
+    "udt_version": (C.c_char_p, []),
+    "udt_status_string": (C.c_char_p, [C.c_int]),
+    "udt_last_hip_error": (C.c_int, []),
+    "udt_device_arch_ok": (C.c_int, []),
+    "udt_prof_enable": (C.c_int, [C.c_uint32]),
+    "udt_prof_reset": (C.c_int, []),
+    "udt_prof_get": (C.c_int, [_i32, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+}
+
+_lib = None
+
+
+class UdtError(RuntimeError):
+    pass
+
+
+def load() -> C.CDLL:
+    """Load the shared object (once) and type every entry point.  Raises if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise UdtError(
+            f"{LIB_PATH} not found: the HIP extension is not built. Run `python -m udifftext_amd.build` "
+            "(or __graft_entry__.build()). There is no CPU fallback for the product path.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)   # AttributeError if the .so does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(status: int, what: str = "") -> None:
+    if status == 0:
+        return
+    lib = load()
+    msg = lib.udt_status_string(status).decode()
+    if status == -4:
+        msg += f" [hipError {lib.udt_last_hip_error()}]"
+    if status in (-1, -2):
+        raise ValueError(f"{what}: {msg}")
+    raise UdtError(f"{what}: {msg}")

@@ -1,0 +1,318 @@
+"""Thin torch-tensor front end over the C ABI (device pointers + the current HIP stream).
+
+torch is used for device memory and stream plumbing only; every computation below is a launch into
+libudt_kernels.so.  All functions raise if a tensor is not on a GPU — there is no CPU path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import lib as L
+
+_workspace: dict = {}
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise L.UdtError("udifftext_amd ops need device tensors (no CPU fallback)")
+    return t.data_ptr()
+
+
+def _ws(nbytes: int, device) -> torch.Tensor:
+    key = (device.type, device.index)
+    buf = _workspace.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(nbytes, 64 << 20), dtype=torch.uint8, device=device)
+        _workspace[key] = buf
+    return buf
+
+
+def _bf16(t: torch.Tensor) -> None:
+    if t.dtype != torch.bfloat16:
+        raise ValueError(f"expected bf16 tensor, got {t.dtype}")
+
+
+# ------------------------------------------------------------------------------------------------ GEMM
+def gemm_desc(**kw) -> L.GemmDesc:
+    d = L.GemmDesc()
+    d.batch = 1
+    d.alpha = 1.0
+    for k, v in kw.items():
+        setattr(d, k, v)
+    return d
+
+
+def run_gemm(d: L.GemmDesc, device) -> None:
+    lib = L.load()
+    need = lib.udt_gemm_workspace_bytes(C.byref(d))
+    ws_ptr, ws_bytes = None, 0
+    if need:
+        ws = _ws(need, device)
+        ws_ptr, ws_bytes = ws.data_ptr(), ws.numel()
+    L.check(lib.udt_gemm(C.byref(d), ws_ptr, ws_bytes, _stream()), "udt_gemm")
+
+
+def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, *, out: Optional[torch.Tensor] = None,
+           residual: Optional[torch.Tensor] = None, rowvec: Optional[torch.Tensor] = None, rows_per_batch: int = 0,
+           flags: int = 0, alpha: float = 1.0, n_out: Optional[int] = None) -> torch.Tensor:
+    """out[M, N] = epilogue(x[M, K] @ w[N, K]^T).  x may be a strided row view (last dim contiguous)."""
+    _bf16(x); _bf16(w)
+    K = x.shape[-1]
+    x2 = x.reshape(-1, K) if x.is_contiguous() else x
+    assert x2.dim() == 2 and x2.stride(1) == 1
+    M = x2.shape[0]
+    N = w.shape[0] if n_out is None else n_out
+    assert w.shape[1] == K and w.is_contiguous()
+    n_cols = N // 2 if (flags & L.GEMM_GEGLU) else N
+    if out is None:
+        dt = torch.float32 if (flags & L.GEMM_OUT_F32) else torch.bfloat16
+        if flags & L.GEMM_TRANSPOSED:
+            assert rows_per_batch > 0
+            out = torch.empty((M // rows_per_batch, N, rows_per_batch), dtype=dt, device=x.device)
+        else:
+            out = torch.empty((M, n_cols), dtype=dt, device=x.device)
+    ldo = out.stride(0) if not (flags & L.GEMM_TRANSPOSED) else 0
+    d = gemm_desc(a=_ptr(x2), w=_ptr(w), bias=_ptr(bias), residual=_ptr(residual), rowvec=_ptr(rowvec), out=_ptr(out),
+                  M=M, N=N, K=K, lda=x2.stride(0), ldo=ldo, ldr=(residual.stride(0) if residual is not None else 0),
+                  rows_per_batch=rows_per_batch, flags=flags, alpha=alpha)
+    run_gemm(d, x.device)
+    return out
+
+
+def bmm_nt(a: torch.Tensor, w: torch.Tensor, *, out: Optional[torch.Tensor] = None, alpha: float = 1.0) -> torch.Tensor:
+    """Batched out[b] = a[b] @ w[b]^T with a [B, M, K], w [B, N, K] (bf16, contiguous)."""
+    _bf16(a); _bf16(w)
+    B, M, K = a.shape
+    N = w.shape[1]
+    assert a.is_contiguous() and w.is_contiguous() and w.shape[0] == B and w.shape[2] == K
+    if out is None:
+        out = torch.empty((B, M, N), dtype=torch.bfloat16, device=a.device)
+    d = gemm_desc(a=_ptr(a), w=_ptr(w), out=_ptr(out), M=M, N=N, K=K, lda=K, ldo=N, batch=B,
+                  stride_a=M * K, stride_w=N * K, stride_out=M * N, alpha=alpha)
+    run_gemm(d, a.device)
+    return out
+
+
+def conv2d(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, *, ksize: int = 3, stride: int = 1,
+           pad: Optional[tuple] = None, upsample: bool = False, x2: Optional[torch.Tensor] = None,
+           out_hw: Optional[tuple] = None, residual: Optional[torch.Tensor] = None,
+           rowvec: Optional[torch.Tensor] = None, flags: int = 0, n_out: Optional[int] = None,
+           out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """NHWC convolution as implicit GEMM.  x [B,H,W,C1] (+ optional x2 [B,H,W,C2], channel concat) bf16;
+    w [N, ksize*ksize*(C1+C2)] packed tap-major.  Returns [B,Hout,Wout,N]."""
+    _bf16(x); _bf16(w)
+    assert x.is_contiguous() and w.is_contiguous()
+    B, H, W_, C1 = x.shape
+    C2 = 0
+    if x2 is not None:
+        _bf16(x2)
+        assert x2.is_contiguous() and x2.shape[:3] == x.shape[:3]
+        C2 = x2.shape[3]
+    Hv, Wv = (H * 2, W_ * 2) if upsample else (H, W_)
+    if pad is None:
+        pad = (ksize // 2, ksize // 2)
+    if out_hw is None:
+        out_hw = ((Hv + 2 * pad[0] - ksize) // stride + 1, (Wv + 2 * pad[1] - ksize) // stride + 1)
+    Ho, Wo = out_hw
+    N = w.shape[0] if n_out is None else n_out
+    K = ksize * ksize * (C1 + C2)
+    assert w.shape[1] == K, (w.shape, K)
+    M = B * Ho * Wo
+    if out is None:
+        dt = torch.float32 if (flags & L.GEMM_OUT_F32) else torch.bfloat16
+        out = torch.empty((B, Ho, Wo, N), dtype=dt, device=x.device)
+    d = gemm_desc(a=_ptr(x), a2=_ptr(x2), w=_ptr(w), bias=_ptr(bias), residual=_ptr(residual), rowvec=_ptr(rowvec),
+                  out=_ptr(out), M=M, N=N, K=K, lda=0, ldo=out.stride(2),
+                  ldr=(residual.stride(2) if residual is not None else 0),
+                  Hin=H, Win=W_, C1=C1, C2=C2, Hout=Ho, Wout=Wo, ksize=ksize, stride=stride, pad_t=pad[0], pad_l=pad[1],
+                  upsample=1 if upsample else 0, rows_per_batch=Ho * Wo, flags=flags | L.GEMM_CONV)
+    run_gemm(d, x.device)
+    return out
+
+
+# ------------------------------------------------------------------------------------------- attention
+def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, heads: int, scale: float,
+              out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """q,k: [B, N, *] row views whose first heads*64 columns are the head-major projections (last dim
+    contiguous); vt: [B, heads*64, Nk].  Returns o [B, Nq, heads*64]."""
+    _bf16(q); _bf16(k); _bf16(vt)
+    B, Nq = q.shape[0], q.shape[1]
+    Nk = k.shape[1]
+    assert q.stride(2) == 1 and k.stride(2) == 1 and vt.stride(2) == 1
+    if out is None:
+        out = torch.empty((B, Nq, heads * 64), dtype=torch.bfloat16, device=q.device)
+    L.check(L.load().udt_attn_fwd(_ptr(q), _ptr(k), _ptr(vt), _ptr(out), B, heads, Nq, Nk,
+                                  q.stride(1), k.stride(1), vt.stride(1), out.stride(1),
+                                  q.stride(0), k.stride(0), vt.stride(0), out.stride(0), scale, _stream()),
+            "udt_attn_fwd")
+    return out
+
+
+def xattention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, head_dim: int, scale: float,
+               probs: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """q [B, Nq, heads*head_dim]; k, v row views [B, L, *] sharing one row stride; probs fp32 [B*heads, Nq, L]."""
+    _bf16(q); _bf16(k); _bf16(v)
+    B, Nq = q.shape[0], q.shape[1]
+    Lc = k.shape[1]
+    assert q.is_contiguous() or (q.stride(2) == 1 and q.stride(0) == Nq * q.stride(1))
+    assert k.stride(2) == 1 and v.stride(2) == 1 and k.stride(1) == v.stride(1)
+    assert k.stride(0) == Lc * k.stride(1) and v.stride(0) == Lc * v.stride(1)
+    if out is None:
+        out = torch.empty((B, Nq, heads * head_dim), dtype=torch.bfloat16, device=q.device)
+    if probs is not None:
+        assert probs.dtype == torch.float32 and probs.is_contiguous() and probs.numel() == B * heads * Nq * Lc
+    L.check(L.load().udt_xattn_fwd(_ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(probs), B, heads, head_dim, Nq, Lc,
+                                   q.stride(1), k.stride(1), out.stride(1), scale, _stream()), "udt_xattn_fwd")
+    return out
+
+
+def softmax_rows_(x: torch.Tensor) -> torch.Tensor:
+    _bf16(x)
+    assert x.is_contiguous()
+    cols = x.shape[-1]
+    L.check(L.load().udt_softmax_rows(_ptr(x), x.numel() // cols, cols, cols, _stream()), "udt_softmax_rows")
+    return x
+
+
+# --------------------------------------------------------------------------------------- normalisation
+def group_norm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, groups: int, eps: float, silu: bool,
+               out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """x bf16 NHWC [B, ..., C] -> same shape; statistics in fp32 over (pixels, C/groups)."""
+    _bf16(x)
+    assert x.is_contiguous()
+    B, Cc = x.shape[0], x.shape[-1]
+    HW = x.numel() // (B * Cc)
+    lib = L.load()
+    nch = lib.udt_gn_nchunks(HW, Cc)
+    part = torch.empty((B, nch, groups, 2), dtype=torch.float32, device=x.device)
+    L.check(lib.udt_gn_stats(_ptr(x), _ptr(part), B, HW, Cc, groups, _stream()), "udt_gn_stats")
+    if out is None:
+        out = torch.empty_like(x)
+    L.check(lib.udt_gn_apply(_ptr(x), _ptr(out), _ptr(part), _ptr(gamma), _ptr(beta), B, HW, Cc, groups, eps,
+                             1 if silu else 0, _stream()), "udt_gn_apply")
+    return out
+
+
+def layer_norm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-5,
+               out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _bf16(x)
+    assert x.is_contiguous()
+    Cc = x.shape[-1]
+    if out is None:
+        out = torch.empty_like(x)
+    L.check(L.load().udt_layernorm(_ptr(x), _ptr(out), _ptr(gamma), _ptr(beta), x.numel() // Cc, Cc, eps, _stream()),
+            "udt_layernorm")
+    return out
+
+
+# ---------------------------------------------------------------------------------------- elementwise
+def unet_input(x: torch.Tensor, xin: torch.Tensor, c_in: float) -> None:
+    B, _, h, w = x.shape
+    L.check(L.load().udt_unet_input(_ptr(x), _ptr(xin), B, h * w, xin.shape[-1], c_in, _stream()), "udt_unet_input")
+
+
+def cfg_euler_step(x: torch.Tensor, eps: torch.Tensor, sigma: float, sigma_next: float, scale: float,
+                   denoised: Optional[torch.Tensor] = None) -> None:
+    B, _, h, w = x.shape
+    assert x.dtype == torch.float32 and eps.dtype == torch.float32 and x.is_contiguous() and eps.is_contiguous()
+    L.check(L.load().udt_cfg_euler_step(_ptr(x), _ptr(eps), _ptr(denoised), B, h * w, eps.shape[-1], sigma, sigma_next,
+                                        scale, _stream()), "udt_cfg_euler_step")
+
+
+def posterior_sample(moments: torch.Tensor, noise: torch.Tensor, scale: float) -> torch.Tensor:
+    """moments fp32 NHWC [B, h, w, ld>=8]; noise fp32 NCHW [B,4,h,w] -> z fp32 NCHW."""
+    B, h, w, ld = moments.shape
+    assert moments.dtype == torch.float32 and noise.dtype == torch.float32 and moments.is_contiguous()
+    z = torch.empty((B, 4, h, w), dtype=torch.float32, device=moments.device)
+    L.check(L.load().udt_posterior_sample(_ptr(moments), _ptr(noise.contiguous()), _ptr(z), B, h * w, ld, scale,
+                                          _stream()), "udt_posterior_sample")
+    return z
+
+
+def nchw_to_nhwc(x: torch.Tensor, cpad: int, scale: float = 1.0) -> torch.Tensor:
+    assert x.dtype == torch.float32 and x.is_contiguous()
+    B, Cc, H, W_ = x.shape
+    y = torch.empty((B, H, W_, cpad), dtype=torch.bfloat16, device=x.device)
+    L.check(L.load().udt_nchw_to_nhwc(_ptr(x), _ptr(y), B, Cc, H * W_, cpad, scale, _stream()), "udt_nchw_to_nhwc")
+    return y
+
+
+def nhwc_to_nchw(x: torch.Tensor, channels: int) -> torch.Tensor:
+    assert x.is_contiguous() and x.dtype in (torch.float32, torch.bfloat16)
+    B, H, W_, ld = x.shape
+    y = torch.empty((B, channels, H, W_), dtype=torch.float32, device=x.device)
+    L.check(L.load().udt_nhwc_to_nchw(_ptr(x), _ptr(y), B, channels, H * W_, ld, 1 if x.dtype == torch.float32 else 0,
+                                      _stream()), "udt_nhwc_to_nchw")
+    return y
+
+
+def nhwc_set_channels(src: torch.Tensor, dst: torch.Tensor, c0: int) -> None:
+    assert src.dtype == torch.float32 and src.is_contiguous() and dst.dtype == torch.bfloat16 and dst.is_contiguous()
+    B, Cc, H, W_ = src.shape
+    L.check(L.load().udt_nhwc_set_channels(_ptr(src), _ptr(dst), B, Cc, H * W_, dst.shape[-1], c0, _stream()),
+            "udt_nhwc_set_channels")
+
+
+def embed_tokens(idx: torch.Tensor, table: torch.Tensor, pe: torch.Tensor) -> torch.Tensor:
+    assert idx.dtype == torch.int32 and idx.is_contiguous()
+    n_tok = idx.numel()
+    Lc, D = pe.shape
+    out = torch.empty((n_tok, D), dtype=torch.bfloat16, device=idx.device)
+    L.check(L.load().udt_embed_tokens(_ptr(idx), _ptr(table), _ptr(pe), _ptr(out), n_tok, Lc, D, _stream()),
+            "udt_embed_tokens")
+    return out
+
+
+def timestep_embedding(t: torch.Tensor, dim: int) -> torch.Tensor:
+    assert t.dtype == torch.float32 and t.is_contiguous()
+    out = torch.empty((t.numel(), dim), dtype=torch.bfloat16, device=t.device)
+    L.check(L.load().udt_timestep_embedding(_ptr(t), _ptr(out), t.numel(), dim, _stream()), "udt_timestep_embedding")
+    return out
+
+
+def mask_downsample(mask: torch.Tensor) -> torch.Tensor:
+    assert mask.dtype == torch.float32 and mask.is_contiguous()
+    B, _, H, W_ = mask.shape
+    out = torch.empty((B, 1, H // 8, W_ // 8), dtype=torch.float32, device=mask.device)
+    L.check(L.load().udt_mask_downsample(_ptr(mask), _ptr(out), B, H, W_, _stream()), "udt_mask_downsample")
+    return out
+
+
+def local_loss_accumulate(probs: torch.Tensor, mask: torch.Tensor, seg_mask: torch.Tensor, gk9: torch.Tensor,
+                          loss: torch.Tensor, heads: int, size: int) -> None:
+    B = mask.shape[0]
+    Lc = probs.shape[-1]
+    L.check(L.load().udt_local_loss(_ptr(probs), _ptr(mask), _ptr(seg_mask), _ptr(gk9), _ptr(loss), B, heads, size, Lc,
+                                    seg_mask.shape[1], mask.shape[2], mask.shape[3], _stream()), "udt_local_loss")
+
+
+def add_(x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
+    _bf16(x); _bf16(y)
+    assert x.is_contiguous() and y.is_contiguous() and x.numel() == y.numel()
+    L.check(L.load().udt_add_bf16(_ptr(x), _ptr(y), x.numel(), _stream()), "udt_add_bf16")
+    return x
+
+
+# ------------------------------------------------------------------------------------------ profiling
+def prof_enable(mask: int) -> None:
+    L.check(L.load().udt_prof_enable(mask), "udt_prof_enable")
+
+
+def prof_reset() -> None:
+    L.check(L.load().udt_prof_reset(), "udt_prof_reset")
+
+
+def prof_get(op_class: int):
+    ms = C.c_double(0.0)
+    n = C.c_int64(0)
+    L.check(L.load().udt_prof_get(op_class, C.byref(ms), C.byref(n)), "udt_prof_get")
+    return ms.value, n.value

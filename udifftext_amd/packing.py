@@ -1,0 +1,81 @@
+"""Weight repacking from the reference's checkpoint layouts (fp32, NCHW conv kernels, [out,in] linears)
+into the device layouts the gfx950 kernels consume (bf16, K-contiguous rows, K padded to 64).
+
+Checkpoint key names/shapes are the reference's (SURVEY.md §8b "Checkpoint contract"); packing happens
+after ``load_state_dict`` in each module's ``prepare()``.
+"""
+from __future__ import annotations
+
+import torch
+
+KPAD = 64
+
+
+def _round_up(v: int, m: int) -> int:
+    return (v + m - 1) // m * m
+
+
+def pad_channels(c: int) -> int:
+    return _round_up(c, KPAD)
+
+
+def pack_linear(w: torch.Tensor, n_pad_to: int = 4) -> torch.Tensor:
+    """[N, K] fp32 -> bf16 [Npad, Kpad] (zero padded)."""
+    N, K = w.shape
+    Np, Kp = _round_up(N, n_pad_to), _round_up(K, KPAD)
+    out = torch.zeros((Np, Kp), dtype=torch.bfloat16, device=w.device)
+    out[:N, :K] = w.to(torch.bfloat16)
+    return out.contiguous()
+
+
+def pack_conv(w: torch.Tensor, segments=None, n_pad_to: int = 4) -> torch.Tensor:
+    """[N, Cin, kh, kw] fp32 -> bf16 [Npad, kh*kw*Cpad], k = (ky*kw + kx)*Cpad + c.
+
+    ``segments`` lists the channel counts of concatenated sources; each is padded to 64 separately
+    (the UNet's skip concats are all multiples of 64 already, so this is the identity there)."""
+    N, Cin, kh, kw = w.shape
+    if segments is None:
+        segments = [Cin]
+    assert sum(segments) == Cin
+    Np = _round_up(N, n_pad_to)
+    parts = []
+    c0 = 0
+    for seg in segments:
+        sp = pad_channels(seg)
+        blk = torch.zeros((Np, kh, kw, sp), dtype=torch.bfloat16, device=w.device)
+        blk[:N, :, :, :seg] = w[:, c0:c0 + seg].permute(0, 2, 3, 1).to(torch.bfloat16)
+        parts.append(blk)
+        c0 += seg
+    out = torch.cat(parts, dim=3) if len(parts) > 1 else parts[0]
+    return out.reshape(Np, -1).contiguous()
+
+
+def pad_bias(b: torch.Tensor | None, n_pad_to: int = 4) -> torch.Tensor | None:
+    if b is None:
+        return None
+    N = b.shape[0]
+    Np = _round_up(N, n_pad_to)
+    out = torch.zeros((Np,), dtype=torch.float32, device=b.device)
+    out[:N] = b.float()
+    return out
+
+
+def geglu_permutation(inner: int) -> torch.Tensor:
+    """Row permutation for a GEGLU projection [2*inner, C]: packed rows come in blocks of 64 =
+    [32 value rows | the 32 matching gate rows] so that one wave's accumulator holds both
+    (gemm.hip, UDT_GEMM_GEGLU).  ``inner`` must be a multiple of 32."""
+    assert inner % 32 == 0
+    blocks = inner // 32
+    idx = torch.empty((blocks, 2, 32), dtype=torch.long)
+    base = torch.arange(32)
+    for k in range(blocks):
+        idx[k, 0] = 32 * k + base
+        idx[k, 1] = inner + 32 * k + base
+    return idx.reshape(-1)
+
+
+def pack_geglu(w: torch.Tensor, b: torch.Tensor):
+    """GEGLU.proj weight [2*inner, C] / bias [2*inner] -> permuted bf16 weight, fp32 bias."""
+    inner = w.shape[0] // 2
+    perm = geglu_permutation(inner).to(w.device)
+    return pack_linear(w[perm]), b[perm].float().contiguous()
