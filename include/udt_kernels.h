@@ -86,6 +86,7 @@ typedef struct {
   void* out;            /* bf16 / fp32 [M, ldo] (or transposed, see flag)                         */
   int32_t M, N, K;
   int32_t lda, ldo, ldr;
+  int32_t ldw;          /* elements between rows of w (0 = K)                                       */
   /* batched GEMM (grid.z): element strides between problems; batch = 1 for none                  */
   int32_t batch;
   int64_t stride_a, stride_w, stride_out, stride_res;
@@ -96,6 +97,7 @@ typedef struct {
   int32_t pad_t, pad_l; /* zero padding before the first row / column (bottom/right implicit)     */
   int32_t upsample;     /* 1: sources are read through a nearest x2 upsample                      */
   int32_t rows_per_batch; /* rows of M belonging to one sample (rowvec / transposed addressing)   */
+  int32_t ld_rowvec;    /* elements between rows of rowvec (0 = N)                                 */
   int32_t flags;
   float alpha;          /* acc * alpha before bias (softmax scale for QK^T GEMMs); 1.0 default    */
 } udt_gemm_desc;
@@ -135,10 +137,14 @@ int udt_softmax_rows(void* x, int64_t rows, int32_t cols, int32_t ld, void* stre
  * Writes per-chunk partial (sum, sumsq) to `partials` (fp32 [B, nchunks, G, 2]); nchunks is returned
  * by udt_gn_nchunks(HW, C). */
 int32_t udt_gn_nchunks(int64_t HW, int32_t C);
-int udt_gn_stats(const void* x, float* partials, int32_t B, int64_t HW, int32_t C, int32_t G, void* stream);
-/* y = act((x - mean) * rstd * gamma + beta); act: 0 none, 1 SiLU.  y may alias x. */
-int udt_gn_apply(const void* x, void* y, const float* partials, const float* gamma, const float* beta,
-                 int32_t B, int64_t HW, int32_t C, int32_t G, float eps, int32_t act, void* stream);
+int udt_gn_stats(const void* x, const void* x2, float* partials, int32_t B, int64_t HW, int32_t C, int32_t C2,
+                 int32_t G, void* stream);
+/* y = act((x - mean) * rstd * gamma + beta); act: 0 none, 1 SiLU.  y may alias x when x2 == NULL.
+ * x2 (optional, C2 channels) is a second NHWC source concatenated after x's C channels (UNet skip concat,
+ * openaimodel.py:620); statistics and output cover the C + C2 concatenated channels, y is [B, HW, C + C2]. */
+int udt_gn_apply(const void* x, const void* x2, void* y, const float* partials, const float* gamma,
+                 const float* beta, int32_t B, int64_t HW, int32_t C, int32_t C2, int32_t G, float eps, int32_t act,
+                 void* stream);
 /* LayerNorm over the last dim of bf16 [rows, C] (C % 8 == 0, C <= 4096). */
 int udt_layernorm(const void* x, void* y, const float* gamma, const float* beta,
                   int64_t rows, int32_t C, float eps, void* stream);
@@ -148,10 +154,10 @@ int udt_layernorm(const void* x, void* y, const float* gamma, const float* beta,
  * both halves = x * c_in; the other channels (mask / masked latent / zero pad) are left untouched. */
 int udt_unet_input(const float* x, void* xin, int32_t B, int32_t hw, int32_t cpad, float c_in, void* stream);
 /* eps fp32 [2B, hw, ld_eps] (uncond half first) -> x fp32 NCHW [B,4,h,w] updated in place:
- *   den_u = x - sigma*eps_u ; den_c = x - sigma*eps_c ; den = den_u + scale*(den_c - den_u)
+ *   den_u = x + c_out*eps_u ; den_c = x + c_out*eps_c (c_out = -quantised sigma) ; den = den_u + scale*(den_c - den_u)
  *   d = (x - den)/sigma ; x += d*(sigma_next - sigma)          (optionally writes den) */
 int udt_cfg_euler_step(float* x, const float* eps, float* denoised_out, int32_t B, int32_t hw, int32_t ld_eps,
-                       float sigma, float sigma_next, float cfg_scale, void* stream);
+                       float c_out, float sigma, float sigma_next, float cfg_scale, void* stream);
 /* z = scale * (mean + exp(0.5*clamp(logvar,-30,20)) * noise); moments fp32 [B, hw, ldm] NHWC (mean ch 0..3,
  * logvar ch 4..7), noise fp32 NCHW [B,4,h,w], z fp32 NCHW [B,4,h,w]. */
 int udt_posterior_sample(const float* moments, const float* noise, float* z, int32_t B, int32_t hw, int32_t ldm,

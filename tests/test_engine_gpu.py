@@ -1,0 +1,197 @@
+"""End-to-end parity of the MI355X engine (HIP kernels behind the sgm surface) against
+  (a) the golden vectors captured from the real reference (tests/golden/*.npz), and
+  (b) the fp32 CPU oracle on the same seeded inputs / synthetic weights.
+
+Arithmetic: bf16 storage + MFMA products, fp32 accumulation / statistics / sampler state.  Stated tolerances
+(relative to the tensor's RMS, "rel_rms"; and worst element relative to the max magnitude, "rel_max"):
+    single network call (UNet eps, VAE, LabelEncoder) : rel_rms <= 2e-2, rel_max <= 8e-2
+    10 chaotic Euler steps with random weights (latent): rel_rms <= 6e-2
+Measured values are written to gpurun_out/parity_report.txt.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+REPORT = os.path.join(ROOT, "gpurun_out", "parity_report.txt")
+
+
+def _metrics(got, ref):
+    got = torch.as_tensor(got).double().cpu()
+    ref = torch.as_tensor(ref).double().cpu()
+    err = (got - ref)
+    rms = ref.pow(2).mean().sqrt().item()
+    return err.pow(2).mean().sqrt().item() / max(rms, 1e-30), err.abs().max().item() / max(ref.abs().max().item(), 1e-30)
+
+
+def _check(name, got, ref, rel_rms, rel_max=None):
+    r, m = _metrics(got, ref)
+    os.makedirs(os.path.dirname(REPORT), exist_ok=True)
+    with open(REPORT, "a") as f:
+        f.write(f"{name:55s} rel_rms {r:.3e} (tol {rel_rms:.0e})  rel_max {m:.3e}\n")
+    assert r <= rel_rms, f"{name}: rel_rms {r:.3e} > {rel_rms}"
+    if rel_max is not None:
+        assert m <= rel_max, f"{name}: rel_max {m:.3e} > {rel_max}"
+
+
+@pytest.fixture(scope="module")
+def eg():
+    return np.load(os.path.join(GOLD, "engine_golden.npz"))
+
+
+@pytest.fixture(scope="module")
+def engine(cuda):
+    from udifftext_amd import lib, pipeline
+    assert lib.load().udt_device_arch_ok() == 1
+    torch.set_grad_enabled(False)
+    return pipeline.build_engine(cuda)
+
+
+@pytest.fixture(scope="module")
+def cond256(engine, cuda):
+    from udifftext_amd import pipeline, synth
+    batch = synth.synthetic_batch(1, 256, 256, 4, seed=0)
+    torch.manual_seed(1234)
+    batch, buc = pipeline.prepare_batch(batch, cuda)
+    c, uc = engine.conditioner.get_unconditional_conditioning(batch, batch_uc=buc, force_uc_zero_embeddings=["label"])
+    return batch, c, uc
+
+
+def test_label_encoder_vs_reference_golden(engine, eg):
+    le = engine.conditioner.embedders[0]
+    emb = le(["TEXT", "Diffusion", "MI355XNative", "Te9~ é"])
+    assert emb.shape == (4, 12, 2048) and emb.dtype == torch.float32
+    _check("LabelEncoder (12 layers) vs reference", emb[:, :, ::16].cpu(), eg["g3_label_sub"], 2e-2, 8e-2)
+
+
+def test_vae_vs_reference_golden(engine, eg, cuda):
+    g = torch.Generator().manual_seed(5)
+    img = torch.rand((1, 3, 64, 64), generator=g) * 2 - 1
+    fs = engine.first_stage_model
+    mom = fs.encode_moments(img.to(cuda))
+    from udifftext_amd import ops
+    _check("VAE encoder moments 64x64 vs reference", ops.nhwc_to_nchw(mom, 8).cpu(), eg["g5_moments"], 2e-2, 8e-2)
+    z8 = torch.randn((1, 4, 8, 8), generator=g) * 3.0
+    dec = fs.decode(z8.to(cuda))
+    _check("VAE decoder 8x8 -> 64x64 vs reference", dec.cpu(), eg["g5_decoded"], 2e-2, 8e-2)
+
+
+def test_conditioner_vs_reference_golden(cond256, eg):
+    _, c, uc = cond256
+    assert c["concat"].shape == (1, 5, 32, 32) and uc["t_crossattn"].abs().max().item() == 0.0
+    _check("conditioner c.concat vs reference", c["concat"].cpu(), eg["g6_c_concat"], 2e-2, 8e-2)
+    _check("conditioner uc.concat vs reference", uc["concat"].cpu(), eg["g6_uc_concat"], 2e-2, 8e-2)
+    _check("conditioner c.t_crossattn vs reference", c["t_crossattn"][:, :, ::16].cpu(), eg["g6_c_txt_sub"], 2e-2, 8e-2)
+    np.testing.assert_allclose(c["concat"][:, :1].cpu().numpy(), eg["g6_c_concat"][:, :1], atol=1e-6)   # mask: exact
+    assert not torch.allclose(c["concat"][:, 1:], uc["concat"][:, 1:])      # different posterior noise (RNG contract)
+
+
+def test_unet_call_vs_reference_golden(engine, cond256, eg, cuda):
+    batch, _, _ = cond256
+    # feed the REFERENCE's conditioning so that only the UNet is under test
+    x7 = torch.from_numpy(eg["g7_x"]).to(cuda)
+    ucc, cc = torch.from_numpy(eg["g6_uc_concat"]).to(cuda), torch.from_numpy(eg["g6_c_concat"]).to(cuda)
+    le = engine.conditioner.embedders[0]
+    tctx = torch.cat([torch.zeros((1, 12, 2048), device=cuda), le(batch["label"])])
+    xin = torch.cat([torch.cat([x7, x7]), torch.cat([ucc, cc])], dim=1)
+    unet = engine.model.diffusion_model
+    eps = unet(xin, timesteps=torch.tensor([999, 999], device=cuda), t_context=tctx)
+    assert eps.shape == (2, 4, 32, 32) and eps.dtype == torch.float32
+    _check("UNet eps (CFG pair, 32x32 latent) vs reference", eps.cpu(), eg["g7_eps"], 2e-2, 8e-2)
+    names = json.load(open(os.path.join(GOLD, "attn_map_names.json")))
+    for item, (name, heads, size, shape) in zip(unet.attn_map_cache, names):
+        assert item["name"] == name and item["size"] == size and list(item["attn_map"].shape) == shape
+        f = item["attn_map"].float().reshape(-1)
+        step = max(1, f.numel() // 2048)
+        _check(f"t_attn map {name}", f[::step][:2048].cpu(), eg[f"g7_attn_{name}_sub"], 3e-2)
+    ll = engine.loss_fn.get_min_local_loss(unet.attn_map_cache, batch["mask"], batch["seg_mask"])
+    _check("get_min_local_loss vs reference", ll.cpu(), eg["g8_local_loss"], 3e-2)
+
+
+def test_per_block_activations_vs_oracle(engine, cond256, eg, cuda):
+    """per-block parity inside the UNet (taps of the oracle == reference goldens, see test_oracle_golden)"""
+    from udifftext_amd import ops
+    unet = engine.model.diffusion_model
+    taps = {}
+    hooks = []
+    for i, blk in enumerate(unet.input_blocks):
+        hooks.append(blk.register_forward_hook(lambda m, a, o, i=i: taps.__setitem__(f"input_blocks.{i}", o)))
+    hooks.append(unet.middle_block.register_forward_hook(lambda m, a, o: taps.__setitem__("middle_block", o)))
+    for i, blk in enumerate(unet.output_blocks):
+        hooks.append(blk.register_forward_hook(lambda m, a, o, i=i: taps.__setitem__(f"output_blocks.{i}", o)))
+    batch, c, uc = cond256
+    x7 = torch.from_numpy(eg["g7_x"]).to(cuda)
+    xin = torch.cat([torch.cat([x7, x7]), torch.cat([uc["concat"], c["concat"]])], dim=1)
+    tctx = torch.cat([uc["t_crossattn"], c["t_crossattn"]])
+    # hooks need module __call__: run the blocks through forward_nhwc's module calls
+    unet(xin, timesteps=torch.tensor([999, 999], device=cuda), t_context=tctx)
+    for h in hooks:
+        h.remove()
+    if not taps:
+        pytest.skip("block hooks not triggered by forward_nhwc")
+    for k, v in taps.items():
+        nchw = ops.nhwc_to_nchw(v.contiguous(), v.shape[-1])
+        f = nchw.float().reshape(-1)
+        step = max(1, f.numel() // 2048)
+        _check(f"UNet block {k}", f[::step][:2048].cpu(), eg[f"g7_tap_{k}_sub"], 3e-2)
+
+
+def test_ten_step_sampling_vs_reference_golden(engine, cond256, eg, cuda):
+    """BASELINE config #1: 256x256, 10 steps, 'TEXT', batch 1, CFG 5 — latent after the full loop + decode"""
+    from udifftext_amd import config as C, pipeline
+    batch, c, uc = cond256
+    sampler = pipeline.init_sampling(10, 5.0, cuda)
+    cfgs = C.default_runtime_config(steps=10, batch_size=1, noise_iters=0)
+    torch.manual_seed(99)
+    x0 = sampler.get_init_noise(cfgs, engine, cond=c, batch=batch, uc=uc)
+    np.testing.assert_array_equal(x0.cpu().numpy(), eg["g9_x0"])          # CPU RNG draw order
+    z = sampler(engine, x0.clone(), cond=c, batch=batch, uc=uc)
+    _check("10-step latent (config #1) vs reference", z.cpu(), eg["g9_latent"], 6e-2)
+    dec = engine.decode_first_stage(z)
+    _check("decoded image of the 10-step latent vs reference", dec[:, :, ::8, ::8].cpu(), eg["g9_decoded_sub"], 1e-1)
+
+
+def test_noise_search_vs_reference_golden(engine, cond256, eg, cuda):
+    from udifftext_amd import config as C, pipeline
+    batch, c, uc = cond256
+    sampler = pipeline.init_sampling(10, 5.0, cuda)
+    cfgs = C.default_runtime_config(steps=10, batch_size=1, noise_iters=2)
+    torch.manual_seed(77)
+    xs = sampler.get_init_noise(cfgs, engine, cond=c, batch=batch, uc=uc)
+    np.testing.assert_array_equal(xs.cpu().numpy(), eg["g9_search_x0"])    # same candidate wins
+
+
+def test_full_size_properties(engine, cuda):
+    """512x512 (BASELINE config #2 shapes, batch 2): size-independent properties of the path"""
+    from udifftext_amd import config as C, pipeline, synth
+    B = 2
+    sampler = pipeline.init_sampling(3, 5.0, cuda)
+    cfgs = C.default_runtime_config(steps=3, batch_size=B, noise_iters=0)
+    torch.manual_seed(3)
+    s1, z1 = pipeline.predict(cfgs, engine, sampler, synth.synthetic_batch(B, 512, 512, 9, seed=1))
+    torch.manual_seed(3)
+    s2, z2 = pipeline.predict(cfgs, engine, sampler, synth.synthetic_batch(B, 512, 512, 9, seed=1))
+    assert s1.shape == (B, 3, 512, 512) and z1.shape == (B, 4, 64, 64)
+    assert torch.isfinite(s1).all() and float(s1.min()) >= 0.0 and float(s1.max()) <= 1.0
+    assert torch.equal(z1, z2) and torch.equal(s1, s2)                      # deterministic given the seed
+    # batch independence: image 0 alone gives the same latent as image 0 inside the batch of 2
+    torch.manual_seed(3)
+    b1 = synth.synthetic_batch(B, 512, 512, 9, seed=1)
+    one = {k: (v[:1] if isinstance(v, torch.Tensor) else v[:1]) for k, v in b1.items()}
+    cfg1 = C.default_runtime_config(steps=3, batch_size=1, noise_iters=0)
+    # same CPU draws for sample 0: c-noise, uc-noise, x0 are drawn per batch, so draw with B and slice
+    torch.manual_seed(3)
+    nc, nuc, nx = torch.randn(B, 4, 64, 64), torch.randn(B, 4, 64, 64), torch.randn(B, 4, 64, 64)
+    import unittest.mock as mock
+    draws = iter([nc[:1], nuc[:1], nx[:1]])
+    with mock.patch("torch.randn", side_effect=lambda *a, **k: next(draws)):
+        _, z_one = pipeline.predict(cfg1, engine, sampler, one)
+    r, _ = _metrics(z_one.cpu(), z1[:1].cpu())
+    # different batch => different tile / split-K plans => bf16-rounding-level differences, amplified over 3 steps
+    assert r < 5e-2, f"batch dependence: {r}"

@@ -59,7 +59,8 @@ def test_linear_epilogues(ops, cuda):
     w = packing.pack_linear(_rand((N, K), cuda, 1 / math.sqrt(K), seed=2))
     b = _rand((N,), cuda, seed=3)
     res = _rand((M, N), cuda, seed=4).bfloat16()
-    rv = _rand((M // rpb, N), cuda, seed=5)
+    rvbig = _rand((M // rpb, 3 * N), cuda, seed=5)
+    rv = rvbig[:, N:2 * N]                                        # strided row vector (ld_rowvec)
     ref = x.float() @ w.float().t() + b + res.float() + rv.repeat_interleave(rpb, 0)
     out = ops.linear(x, w, b, residual=res, rowvec=rv, rows_per_batch=rpb)
     _close(out, ref, what="bias+res+rowvec")
@@ -114,6 +115,9 @@ def test_bmm(ops, cuda):
     w = _rand((B, N, K), cuda, 1 / math.sqrt(K), seed=2).bfloat16()
     out = ops.bmm_nt(a, w, alpha=0.5)
     _close(out, 0.5 * torch.einsum("bmk,bnk->bmn", a.float(), w.float()), what="bmm")
+    qk = _rand((B, M, 2 * K), cuda, seed=3).bfloat16()          # strided q / k views of one projection
+    out = ops.bmm_nt(qk[..., :K], qk[..., K:], alpha=K ** -0.5)
+    _close(out, K ** -0.5 * torch.einsum("bmk,bnk->bmn", qk[..., :K].float(), qk[..., K:].float()), what="bmm strided")
 
 
 CONV_CASES = [
@@ -246,6 +250,19 @@ def test_group_norm(ops, cuda, B, HW, Cc, silu, eps):
     _close(out, ref.permute(0, 2, 1), what=f"gn {B,HW,Cc}")
 
 
+@pytest.mark.parametrize("C1,C2", [(1280, 640), (640, 320), (1280, 1280)])
+def test_group_norm_concat(ops, cuda, C1, C2):
+    B, HW = 2, 256
+    x1 = (_rand((B, HW, C1), cuda, 2.0, seed=1) + 0.7).bfloat16()
+    x2 = (_rand((B, HW, C2), cuda, 0.5, seed=4) - 0.3).bfloat16()
+    g = _rand((C1 + C2,), cuda, seed=2) * 0.2 + 1.0
+    b = _rand((C1 + C2,), cuda, seed=3) * 0.2
+    out = ops.group_norm(x1, g, b, 32, 1e-5, True, x2=x2)
+    cat = torch.cat([x1, x2], dim=-1).float()
+    ref = F.silu(F.group_norm(cat.permute(0, 2, 1), 32, g, b, 1e-5)).permute(0, 2, 1)
+    _close(out, ref, what=f"gn concat {C1}+{C2}")
+
+
 @pytest.mark.parametrize("rows,Cc", [(1000, 320), (513, 640), (64, 1280), (36, 2048)])
 def test_layer_norm(ops, cuda, rows, Cc):
     x = (_rand((rows, Cc), cuda, 2.0, seed=1) + 0.3).bfloat16()
@@ -270,7 +287,7 @@ def test_sampler_elementwise(ops, cuda):
     sigma, sigma_next, scale = 3.2, 2.9, 5.0
     x0 = x.clone()
     den = torch.empty_like(x)
-    ops.cfg_euler_step(x, eps, sigma, sigma_next, scale, denoised=den)
+    ops.cfg_euler_step(x, eps, sigma, sigma_next, scale, denoised=den, c_out=-sigma)
     eu, ec = eps[:B].permute(0, 3, 1, 2), eps[B:].permute(0, 3, 1, 2)
     du, dc = x0 - sigma * eu, x0 - sigma * ec
     dref = du + scale * (dc - du)

@@ -25,7 +25,7 @@ __global__ void unet_input_kernel(const float* __restrict__ x, uint16_t* __restr
 }
 
 __global__ void cfg_euler_kernel(float* __restrict__ x, const float* __restrict__ eps, float* __restrict__ den_out,
-                                 int B, int hw, int ld, float sigma, float sigma_next, float scale) {
+                                 int B, int hw, int ld, float c_out, float sigma, float sigma_next, float scale) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= B * hw) return;
   const int b = i / hw;
@@ -36,8 +36,8 @@ __global__ void cfg_euler_kernel(float* __restrict__ x, const float* __restrict_
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
     const float xv = xb[c * hw];
-    const float du = eu[c] * (-sigma) + xv;           // network(...)*c_out + input*c_skip  (denoiser.py:28)
-    const float dc = ec[c] * (-sigma) + xv;
+    const float du = eu[c] * c_out + xv;           // network(...)*c_out + input*c_skip  (denoiser.py:28)
+    const float dc = ec[c] * c_out + xv;
     const float den = du + scale * (dc - du);         // sampling_utils.py:8-9
     const float d = (xv - den) / sigma;               // to_d, sampling_utils.py:39-40
     xb[c * hw] = xv + d * (sigma_next - sigma);       // euler_step, sampling.py:85-86
@@ -228,12 +228,12 @@ extern "C" int udt_unet_input(const float* x, void* xin, int32_t B, int32_t hw, 
 }
 
 extern "C" int udt_cfg_euler_step(float* x, const float* eps, float* denoised_out, int32_t B, int32_t hw,
-                                  int32_t ld_eps, float sigma, float sigma_next, float cfg_scale, void* stream) {
+                                  int32_t ld_eps, float c_out, float sigma, float sigma_next, float cfg_scale, void* stream) {
   if (!x || !eps) return UDT_ERR_BAD_ARG;
   if (B <= 0 || hw <= 0 || ld_eps < 4 || ld_eps % 4 != 0 || sigma == 0.f) return UDT_ERR_BAD_SHAPE;
   UDT_STREAM;
   hipLaunchKernelGGL(cfg_euler_kernel, dim3(nblk((long long)B * hw)), dim3(256), 0, s, x, eps, denoised_out, B, hw,
-                     ld_eps, sigma, sigma_next, cfg_scale);
+                     ld_eps, c_out, sigma, sigma_next, cfg_scale);
   UDT_CHECK_LAUNCH();
   return UDT_OK;
 }

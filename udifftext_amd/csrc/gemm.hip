@@ -32,10 +32,11 @@ struct GemmParams {
   const float* rowvec;
   void* out;
   int M, N, K;
-  int lda, ldo, ldr;
+  int lda, ldo, ldr, ldw;
   long long sA, sW, sO, sR;
   int Hin, Win, C1, C2, Hout, Wout, ksz, stride, pad_t, pad_l, ups;
   int rows_per_batch;
+  int ldrv;
   int flags;
   float alpha;
   int tiles_m, tiles_n;
@@ -116,7 +117,7 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmParams p) {
     const int row = ci * 8 + l3;
     w_koff[i] = (pslot ^ ((row >> 1) & 7)) * 8;
     const int n = n0 + row;
-    w_rowoff[i] = (n < p.N) ? (long long)n * p.K : -1;
+    w_rowoff[i] = (n < p.N) ? (long long)n * p.ldw : -1;
   }
 
   const int Ctot = p.C1 + p.C2;
@@ -306,7 +307,7 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmParams p) {
               for (int r = 0; r < 4; ++r) v[r] += bv[r];
             }
             if (p.rowvec) {
-              const f32x4 rv = *reinterpret_cast<const f32x4*>(p.rowvec + (long long)b * p.N + n);
+              const f32x4 rv = *reinterpret_cast<const f32x4*>(p.rowvec + (long long)b * p.ldrv + n);
 #pragma unroll
               for (int r = 0; r < 4; ++r) v[r] += rv[r];
             }
@@ -363,7 +364,7 @@ __global__ void __launch_bounds__(256) splitk_finalize_kernel(const float* __res
   }
   if (p.rowvec) {
     const int b = m / p.rows_per_batch;
-    const f32x4 rv = *reinterpret_cast<const f32x4*>(p.rowvec + (long long)b * p.N + n);
+    const f32x4 rv = *reinterpret_cast<const f32x4*>(p.rowvec + (long long)b * p.ldrv + n);
 #pragma unroll
     for (int r = 0; r < 4; ++r) v[r] += rv[r];
   }
@@ -497,10 +498,13 @@ extern "C" int udt_gemm(const udt_gemm_desc* d, void* workspace, size_t workspac
   p.out = d->out;
   p.M = d->M; p.N = d->N; p.K = d->K;
   p.lda = d->lda; p.ldo = d->ldo; p.ldr = d->ldr;
+  p.ldw = d->ldw > 0 ? d->ldw : d->K;
+  if (p.ldw < d->K || p.ldw % 8 != 0) return UDT_ERR_BAD_SHAPE;
   p.sA = d->stride_a; p.sW = d->stride_w; p.sO = d->stride_out; p.sR = d->stride_res;
   p.Hin = d->Hin; p.Win = d->Win; p.C1 = d->C1; p.C2 = d->C2; p.Hout = d->Hout; p.Wout = d->Wout;
   p.ksz = d->ksize; p.stride = d->stride; p.pad_t = d->pad_t; p.pad_l = d->pad_l; p.ups = d->upsample ? 1 : 0;
   p.rows_per_batch = d->rows_per_batch > 0 ? d->rows_per_batch : d->M;
+  p.ldrv = d->ld_rowvec > 0 ? d->ld_rowvec : d->N;
   p.flags = d->flags;
   p.alpha = d->alpha;
   p.tiles_m = (d->M + t.bm - 1) / t.bm;

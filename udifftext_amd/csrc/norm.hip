@@ -11,8 +11,10 @@ namespace {
 constexpr int GN_MAX_C = 4096;
 
 // grid (nchunks, B).  Thread layout: R row-groups x c8 channel-chunks (8 channels = 16 B each).
-__global__ void __launch_bounds__(256) gn_stats_kernel(const uint16_t* __restrict__ x, float* __restrict__ partials,
-                                                       long long HW, int C, int G, int nchunks) {
+__global__ void __launch_bounds__(256) gn_stats_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ x2,
+                                                       float* __restrict__ partials, long long HW, int C1, int C2,
+                                                       int G, int nchunks) {
+  const int C = C1 + C2;
   extern __shared__ __attribute__((aligned(16))) float gsm[];   // [R][C] sums, then [R][C] sumsq
   const int t = threadIdx.x;
   const int c8 = C >> 3;
@@ -35,13 +37,15 @@ __global__ void __launch_bounds__(256) gn_stats_kernel(const uint16_t* __restric
   }
   float* ssum = gsm;
   float* ssq = gsm + R * C;
-  const uint16_t* xb = x + (long long)b * HW * C;
   for (int cc = cc0; cc < c8; cc += cstep) {
     float s[8], q[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) s[j] = q[j] = 0.f;
+    const bool second = cc * 8 >= C1;
+    const int cs = second ? C2 : C1;
+    const uint16_t* xb = (second ? x2 : x) + (long long)b * HW * cs + (second ? cc * 8 - C1 : cc * 8);
     for (long long pix = p0 + rg; pix < p1; pix += R) {
-      const u32x4 v = *reinterpret_cast<const u32x4*>(xb + pix * C + cc * 8);
+      const u32x4 v = *reinterpret_cast<const u32x4*>(xb + pix * cs);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const float a = bf16_lo(v[j]), bb = bf16_hi(v[j]);
@@ -71,11 +75,13 @@ __global__ void __launch_bounds__(256) gn_stats_kernel(const uint16_t* __restric
 }
 
 // grid (blocks_per_sample, B); each workgroup normalises a contiguous span of one sample
-__global__ void __launch_bounds__(256) gn_apply_kernel(const uint16_t* __restrict__ x, uint16_t* __restrict__ y,
-                                                       const float* __restrict__ partials,
+__global__ void __launch_bounds__(256) gn_apply_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ x2,
+                                                       uint16_t* __restrict__ y, const float* __restrict__ partials,
                                                        const float* __restrict__ gamma,
-                                                       const float* __restrict__ beta, long long HW, int C, int G,
-                                                       int nchunks, float eps, int act, long long chunks_per_wg) {
+                                                       const float* __restrict__ beta, long long HW, int C1, int C2,
+                                                       int G, int nchunks, float eps, int act,
+                                                       long long chunks_per_wg) {
+  const int C = C1 + C2;
   extern __shared__ __attribute__((aligned(16))) float asm_[];   // [C] scale, [C] shift, [G] mean, [G] rstd
   float* sc = asm_;
   float* sh = asm_ + C;
@@ -111,11 +117,14 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const uint16_t* __restric
   const long long begin = (long long)blockIdx.x * chunks_per_wg;
   long long end = begin + chunks_per_wg;
   if (end > total) end = total;
-  const uint16_t* xb = x + (long long)b * HW * C;
+  const uint16_t* xb1 = x + (long long)b * HW * C1;
+  const uint16_t* xb2 = x2 ? (x2 + (long long)b * HW * C2) : nullptr;
   uint16_t* yb = y + (long long)b * HW * C;
   for (long long i = begin + t; i < end; i += 256) {
-    const int cc = (int)(i % c8);
-    const u32x4 v = *reinterpret_cast<const u32x4*>(xb + i * 8);
+    const long long pix = i / c8;
+    const int cc = (int)(i - pix * c8);
+    const uint16_t* src = (cc * 8 < C1) ? (xb1 + pix * C1 + cc * 8) : (xb2 + pix * C2 + (cc * 8 - C1));
+    const u32x4 v = *reinterpret_cast<const u32x4*>(src);
     u32x4 o;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -212,11 +221,12 @@ extern "C" int32_t udt_gn_nchunks(int64_t HW, int32_t C) {
   return (int32_t)n;
 }
 
-extern "C" int udt_gn_stats(const void* x, float* partials, int32_t B, int64_t HW, int32_t C, int32_t G,
-                            void* stream) {
-  if (!x || !partials) return UDT_ERR_BAD_ARG;
-  if (B <= 0 || HW <= 0 || C <= 0 || C % 8 != 0 || G <= 0 || G > 256 || C % G != 0 || C > GN_MAX_C)
-    return UDT_ERR_BAD_SHAPE;
+extern "C" int udt_gn_stats(const void* x, const void* x2, float* partials, int32_t B, int64_t HW, int32_t C1,
+                            int32_t C2, int32_t G, void* stream) {
+  if (!x || !partials || (C2 > 0 && !x2)) return UDT_ERR_BAD_ARG;
+  if (C2 < 0 || C1 <= 0 || C1 % 8 != 0 || C2 % 8 != 0) return UDT_ERR_BAD_SHAPE;
+  const int C = C1 + C2;
+  if (B <= 0 || HW <= 0 || G <= 0 || G > 256 || C % G != 0 || C > GN_MAX_C) return UDT_ERR_BAD_SHAPE;
   const int nchunks = udt_gn_nchunks(HW, C);
   const int c8 = C / 8;
   const int R = c8 <= 256 ? 256 / c8 : 1;
@@ -224,16 +234,18 @@ extern "C" int udt_gn_stats(const void* x, float* partials, int32_t B, int64_t H
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   UdtProfScope prof(4, s);
   hipLaunchKernelGGL(gn_stats_kernel, dim3(nchunks, B), dim3(256), smem, s, reinterpret_cast<const uint16_t*>(x),
-                     partials, (long long)HW, C, G, nchunks);
+                     reinterpret_cast<const uint16_t*>(x2), partials, (long long)HW, C1, C2, G, nchunks);
   UDT_CHECK_LAUNCH();
   return UDT_OK;
 }
 
-extern "C" int udt_gn_apply(const void* x, void* y, const float* partials, const float* gamma, const float* beta,
-                            int32_t B, int64_t HW, int32_t C, int32_t G, float eps, int32_t act, void* stream) {
-  if (!x || !y || !partials || !gamma || !beta) return UDT_ERR_BAD_ARG;
-  if (B <= 0 || HW <= 0 || C <= 0 || C % 8 != 0 || G <= 0 || G > 256 || C % G != 0 || C > GN_MAX_C)
-    return UDT_ERR_BAD_SHAPE;
+extern "C" int udt_gn_apply(const void* x, const void* x2, void* y, const float* partials, const float* gamma,
+                            const float* beta, int32_t B, int64_t HW, int32_t C1, int32_t C2, int32_t G, float eps,
+                            int32_t act, void* stream) {
+  if (!x || !y || !partials || !gamma || !beta || (C2 > 0 && !x2)) return UDT_ERR_BAD_ARG;
+  if (C2 < 0 || C1 <= 0 || C1 % 8 != 0 || C2 % 8 != 0) return UDT_ERR_BAD_SHAPE;
+  const int C = C1 + C2;
+  if (B <= 0 || HW <= 0 || G <= 0 || G > 256 || C % G != 0 || C > GN_MAX_C) return UDT_ERR_BAD_SHAPE;
   const int nchunks = udt_gn_nchunks(HW, C);
   const long long total = (long long)HW * (C / 8);
   const long long chunks_per_wg = 4096;   // 64 KiB of bf16 per workgroup
@@ -242,8 +254,8 @@ extern "C" int udt_gn_apply(const void* x, void* y, const float* partials, const
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   UdtProfScope prof(4, s);
   hipLaunchKernelGGL(gn_apply_kernel, dim3(blocks, B), dim3(256), smem, s, reinterpret_cast<const uint16_t*>(x),
-                     reinterpret_cast<uint16_t*>(y), partials, gamma, beta, (long long)HW, C, G, nchunks, eps, act,
-                     chunks_per_wg);
+                     reinterpret_cast<const uint16_t*>(x2), reinterpret_cast<uint16_t*>(y), partials, gamma, beta,
+                     (long long)HW, C1, C2, G, nchunks, eps, act, chunks_per_wg);
   UDT_CHECK_LAUNCH();
   return UDT_OK;
 }

@@ -27,13 +27,14 @@ class GemmDesc(C.Structure):
         ("a", C.c_void_p), ("a2", C.c_void_p), ("w", C.c_void_p), ("bias", C.c_void_p),
         ("residual", C.c_void_p), ("rowvec", C.c_void_p), ("out", C.c_void_p),
         ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
-        ("lda", C.c_int32), ("ldo", C.c_int32), ("ldr", C.c_int32),
+        ("lda", C.c_int32), ("ldo", C.c_int32), ("ldr", C.c_int32), ("ldw", C.c_int32),
         ("batch", C.c_int32),
         ("stride_a", C.c_int64), ("stride_w", C.c_int64), ("stride_out", C.c_int64), ("stride_res", C.c_int64),
         ("Hin", C.c_int32), ("Win", C.c_int32), ("C1", C.c_int32), ("C2", C.c_int32),
         ("Hout", C.c_int32), ("Wout", C.c_int32),
         ("ksize", C.c_int32), ("stride", C.c_int32), ("pad_t", C.c_int32), ("pad_l", C.c_int32),
-        ("upsample", C.c_int32), ("rows_per_batch", C.c_int32), ("flags", C.c_int32), ("alpha", C.c_float),
+        ("upsample", C.c_int32), ("rows_per_batch", C.c_int32), ("ld_rowvec", C.c_int32), ("flags", C.c_int32),
+        ("alpha", C.c_float),
     ]
 
 
@@ -47,11 +48,11 @@ SYMBOLS = {
     "udt_xattn_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _fp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp]),
     "udt_softmax_rows": (C.c_int, [_vp, _i64, _i32, _i32, _vp]),
     "udt_gn_nchunks": (_i32, [_i64, _i32]),
-    "udt_gn_stats": (C.c_int, [_vp, _fp, _i32, _i64, _i32, _i32, _vp]),
-    "udt_gn_apply": (C.c_int, [_vp, _vp, _fp, _fp, _fp, _i32, _i64, _i32, _i32, _f32, _i32, _vp]),
+    "udt_gn_stats": (C.c_int, [_vp, _vp, _fp, _i32, _i64, _i32, _i32, _i32, _vp]),
+    "udt_gn_apply": (C.c_int, [_vp, _vp, _vp, _fp, _fp, _fp, _i32, _i64, _i32, _i32, _i32, _f32, _i32, _vp]),
     "udt_layernorm": (C.c_int, [_vp, _vp, _fp, _fp, _i64, _i32, _f32, _vp]),
     "udt_unet_input": (C.c_int, [_fp, _vp, _i32, _i32, _i32, _f32, _vp]),
-    "udt_cfg_euler_step": (C.c_int, [_fp, _fp, _fp, _i32, _i32, _i32, _f32, _f32, _f32, _vp]),
+    "udt_cfg_euler_step": (C.c_int, [_fp, _fp, _fp, _i32, _i32, _i32, _f32, _f32, _f32, _f32, _vp]),
     "udt_posterior_sample": (C.c_int, [_fp, _fp, _fp, _i32, _i32, _i32, _f32, _vp]),
     "udt_nchw_to_nhwc": (C.c_int, [_fp, _vp, _i32, _i32, _i64, _i32, _f32, _vp]),
     "udt_nhwc_to_nchw": (C.c_int, [_vp, _fp, _i32, _i32, _i64, _i32, _i32, _vp]),

@@ -83,21 +83,23 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
     ldo = out.stride(0) if not (flags & L.GEMM_TRANSPOSED) else 0
     d = gemm_desc(a=_ptr(x2), w=_ptr(w), bias=_ptr(bias), residual=_ptr(residual), rowvec=_ptr(rowvec), out=_ptr(out),
                   M=M, N=N, K=K, lda=x2.stride(0), ldo=ldo, ldr=(residual.stride(0) if residual is not None else 0),
-                  rows_per_batch=rows_per_batch, flags=flags, alpha=alpha)
+                  rows_per_batch=rows_per_batch, ld_rowvec=(rowvec.stride(0) if rowvec is not None else 0), flags=flags,
+                  alpha=alpha)
     run_gemm(d, x.device)
     return out
 
 
 def bmm_nt(a: torch.Tensor, w: torch.Tensor, *, out: Optional[torch.Tensor] = None, alpha: float = 1.0) -> torch.Tensor:
-    """Batched out[b] = a[b] @ w[b]^T with a [B, M, K], w [B, N, K] (bf16, contiguous)."""
+    """Batched out[b] = a[b] @ w[b]^T with a [B, M, K], w [B, N, K] bf16 (row-strided views allowed)."""
     _bf16(a); _bf16(w)
     B, M, K = a.shape
     N = w.shape[1]
-    assert a.is_contiguous() and w.is_contiguous() and w.shape[0] == B and w.shape[2] == K
+    assert a.stride(2) == 1 and w.stride(2) == 1 and w.shape[0] == B and w.shape[2] == K
     if out is None:
         out = torch.empty((B, M, N), dtype=torch.bfloat16, device=a.device)
-    d = gemm_desc(a=_ptr(a), w=_ptr(w), out=_ptr(out), M=M, N=N, K=K, lda=K, ldo=N, batch=B,
-                  stride_a=M * K, stride_w=N * K, stride_out=M * N, alpha=alpha)
+    d = gemm_desc(a=_ptr(a), w=_ptr(w), out=_ptr(out), M=M, N=N, K=K, lda=a.stride(1), ldw=w.stride(1),
+                  ldo=out.stride(1), batch=B, stride_a=a.stride(0), stride_w=w.stride(0), stride_out=out.stride(0),
+                  alpha=alpha)
     run_gemm(d, a.device)
     return out
 
@@ -134,7 +136,8 @@ def conv2d(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
                   out=_ptr(out), M=M, N=N, K=K, lda=0, ldo=out.stride(2),
                   ldr=(residual.stride(2) if residual is not None else 0),
                   Hin=H, Win=W_, C1=C1, C2=C2, Hout=Ho, Wout=Wo, ksize=ksize, stride=stride, pad_t=pad[0], pad_l=pad[1],
-                  upsample=1 if upsample else 0, rows_per_batch=Ho * Wo, flags=flags | L.GEMM_CONV)
+                  upsample=1 if upsample else 0, rows_per_batch=Ho * Wo,
+                  ld_rowvec=(rowvec.stride(0) if rowvec is not None else 0), flags=flags | L.GEMM_CONV)
     run_gemm(d, x.device)
     return out
 
@@ -185,20 +188,26 @@ def softmax_rows_(x: torch.Tensor) -> torch.Tensor:
 
 # --------------------------------------------------------------------------------------- normalisation
 def group_norm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, groups: int, eps: float, silu: bool,
-               out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """x bf16 NHWC [B, ..., C] -> same shape; statistics in fp32 over (pixels, C/groups)."""
+               out: Optional[torch.Tensor] = None, x2: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """x bf16 NHWC [B, ..., C1] (+ optional x2 [B, ..., C2] concatenated on channels) -> [B, ..., C1+C2];
+    statistics in fp32 over (pixels, channels/groups)."""
     _bf16(x)
     assert x.is_contiguous()
-    B, Cc = x.shape[0], x.shape[-1]
-    HW = x.numel() // (B * Cc)
+    B, C1 = x.shape[0], x.shape[-1]
+    C2 = 0
+    if x2 is not None:
+        _bf16(x2)
+        assert x2.is_contiguous() and x2.shape[:-1] == x.shape[:-1]
+        C2 = x2.shape[-1]
+    HW = x.numel() // (B * C1)
     lib = L.load()
-    nch = lib.udt_gn_nchunks(HW, Cc)
+    nch = lib.udt_gn_nchunks(HW, C1 + C2)
     part = torch.empty((B, nch, groups, 2), dtype=torch.float32, device=x.device)
-    L.check(lib.udt_gn_stats(_ptr(x), _ptr(part), B, HW, Cc, groups, _stream()), "udt_gn_stats")
+    L.check(lib.udt_gn_stats(_ptr(x), _ptr(x2), _ptr(part), B, HW, C1, C2, groups, _stream()), "udt_gn_stats")
     if out is None:
-        out = torch.empty_like(x)
-    L.check(lib.udt_gn_apply(_ptr(x), _ptr(out), _ptr(part), _ptr(gamma), _ptr(beta), B, HW, Cc, groups, eps,
-                             1 if silu else 0, _stream()), "udt_gn_apply")
+        out = torch.empty(x.shape[:-1] + (C1 + C2,), dtype=torch.bfloat16, device=x.device)
+    L.check(lib.udt_gn_apply(_ptr(x), _ptr(x2), _ptr(out), _ptr(part), _ptr(gamma), _ptr(beta), B, HW, C1, C2, groups,
+                             eps, 1 if silu else 0, _stream()), "udt_gn_apply")
     return out
 
 
@@ -221,11 +230,13 @@ def unet_input(x: torch.Tensor, xin: torch.Tensor, c_in: float) -> None:
 
 
 def cfg_euler_step(x: torch.Tensor, eps: torch.Tensor, sigma: float, sigma_next: float, scale: float,
-                   denoised: Optional[torch.Tensor] = None) -> None:
+                   denoised: Optional[torch.Tensor] = None, c_out: Optional[float] = None) -> None:
+    """c_out defaults to -sigma (EpsScaling); pass the quantised value when it differs from sigma."""
     B, _, h, w = x.shape
     assert x.dtype == torch.float32 and eps.dtype == torch.float32 and x.is_contiguous() and eps.is_contiguous()
-    L.check(L.load().udt_cfg_euler_step(_ptr(x), _ptr(eps), _ptr(denoised), B, h * w, eps.shape[-1], sigma, sigma_next,
-                                        scale, _stream()), "udt_cfg_euler_step")
+    L.check(L.load().udt_cfg_euler_step(_ptr(x), _ptr(eps), _ptr(denoised), B, h * w, eps.shape[-1],
+                                        -sigma if c_out is None else c_out, sigma, sigma_next, scale, _stream()),
+            "udt_cfg_euler_step")
 
 
 def posterior_sample(moments: torch.Tensor, noise: torch.Tensor, scale: float) -> torch.Tensor:

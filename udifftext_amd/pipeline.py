@@ -1,0 +1,85 @@
+"""Inference driver: the reference's ``util.py`` (init_model / init_sampling / prepare_batch, :7-78) and
+``test.py:predict`` (:19-40) restated against the MI355X ``sgm`` package, for synthetic batches.
+
+The reference's own ``test.py`` needs datasets, checkpoints and packages that do not exist here
+(SURVEY.md §8b); this module is the shipped equivalent of its hot path and is what bench.py times.
+"""
+from __future__ import annotations
+
+import time
+from typing import Optional, Tuple
+
+import torch
+
+import udifftext_amd  # noqa: F401  (puts the sgm mirror on sys.path)
+from udifftext_amd import config as C
+from udifftext_amd import synth
+
+
+def build_engine(device: torch.device, synthetic_weights: bool = True, verbose: bool = False):
+    """instantiate the DiffusionEngine from the (code-built) model config, fill deterministic synthetic weights
+    (there are no checkpoints here), move it to the GPU, eval + freeze — reference util.py:7-22."""
+    from sgm.util import instantiate_from_config, skip_param_init
+    t0 = time.time()
+    cfg = C.default_model_config()
+    if synthetic_weights:
+        with skip_param_init():
+            model = instantiate_from_config(cfg.model)
+        synth.fill_module_(model)
+    else:
+        model = instantiate_from_config(cfg.model)
+    model.to(device)
+    model.eval()
+    model.freeze()
+    if verbose:
+        n = sum(p.numel() for p in model.parameters())
+        print(f"[pipeline] engine with {n / 1e6:.1f} M parameters ready in {time.time() - t0:.1f}s")
+    return model
+
+
+def init_sampling(steps: int, scale: float, device: torch.device, verbose: bool = False):
+    """reference util.py:24-47: EulerEDMSampler + LegacyDDPMDiscretization + VanillaCFG(scale)"""
+    from sgm.modules.diffusionmodules.sampling import EulerEDMSampler
+    return EulerEDMSampler(
+        num_steps=steps,
+        discretization_config={"target": "sgm.modules.diffusionmodules.discretizer.LegacyDDPMDiscretization"},
+        guider_config={"target": "sgm.modules.diffusionmodules.guiders.VanillaCFG", "params": {"scale": scale}},
+        s_churn=0.0, s_tmin=0.0, s_tmax=999.0, s_noise=1.0, verbose=verbose, device=device)
+
+
+def _copy_batch(batch: dict) -> dict:
+    out = {}
+    for k, v in batch.items():
+        if isinstance(v, torch.Tensor):
+            out[k] = v.clone()
+        elif isinstance(v, (tuple, list)):
+            out[k] = list(v)
+        else:
+            out[k] = v
+    return out
+
+
+def prepare_batch(batch: dict, device: torch.device) -> Tuple[dict, dict]:
+    """reference util.py:62-78: tensors to the device; the unconditional batch has empty labels / prompts"""
+    for k, v in batch.items():
+        if isinstance(v, torch.Tensor):
+            batch[k] = v.to(device)
+    buc = _copy_batch(batch)
+    buc["txt"] = batch["ntxt"] if "ntxt" in batch else ["" for _ in batch["txt"]]
+    if "label" in batch:
+        buc["label"] = ["" for _ in batch["label"]]
+    return batch, buc
+
+
+@torch.no_grad()
+def predict(cfgs, model, sampler, batch: dict, device: Optional[torch.device] = None):
+    """reference test.py:19-40 -> (samples in [0,1] fp32 NCHW, latent z)"""
+    device = device or next(model.parameters()).device
+    batch, batch_uc = prepare_batch(batch, device)
+    c, uc = model.conditioner.get_unconditional_conditioning(
+        batch, batch_uc=batch_uc, force_uc_zero_embeddings=cfgs.force_uc_zero_embeddings)
+    x = sampler.get_init_noise(cfgs, model, cond=c, batch=batch, uc=uc)
+    z = sampler(model, x, cond=c, batch=batch, uc=uc, init_step=cfgs.init_step, aae_enabled=cfgs.aae_enabled,
+                detailed=cfgs.detailed)
+    img = model.decode_first_stage(z)
+    return torch.clamp((img + 1.0) / 2.0, min=0.0, max=1.0), z

@@ -1,0 +1,179 @@
+"""Transformer blocks of the UNet on the gfx950 kernels (tokens are bf16 ``[B, N, C]``).
+
+State-dict names and semantics follow reference sgm/modules/attention.py:
+  GEGLU / FeedForward              :44-70    -> one GEMM with a fused x*gelu(gate) epilogue + one GEMM
+  CrossAttention (t_attn)          :111-174  -> q GEMM, hoistable k|v GEMM on the context, short-context kernel
+                                               that can emit the softmax probabilities (attn_map_cache)
+  MemoryEfficientCrossAttention    :177-262  -> fused q|k GEMM, V^T GEMM (transposed epilogue), flash attention
+  BasicTransformerBlock            :265-341  -> pre-LN residual blocks; residual adds fused in GEMM epilogues
+  SpatialTransformer               :344-415  -> GroupNorm(eps 1e-6), proj_in/proj_out linears; NHWC activations
+                                               make the reference's two permute copies (:405,:412) disappear
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import torch
+import torch.nn as nn
+
+from udifftext_amd import ops, packing
+
+from . import hipnn as H
+from .diffusionmodules.util import zero_module
+
+
+class GEGLU(H._Packed):
+    def __init__(self, dim_in: int, dim_out: int):
+        super().__init__()
+        self.proj = H.Linear(dim_in, dim_out * 2)
+
+    def _key(self):
+        return self.proj._key()
+
+    def _pack(self):
+        return packing.pack_geglu(self.proj.weight, self.proj.bias)
+
+    def forward(self, x):
+        w, b = self.packed()
+        return ops.linear(x, w, b, flags=H.GEMM_GEGLU)
+
+
+class FeedForward(nn.Module):
+    def __init__(self, dim, dim_out=None, mult=4, glu=True, dropout=0.0):
+        super().__init__()
+        if not glu:
+            raise NotImplementedError("only the gated (GEGLU) feed-forward is on the UDiffText path")
+        inner = int(dim * mult)
+        self.net = nn.Sequential(GEGLU(dim, inner), nn.Identity(), H.Linear(inner, dim_out or dim))
+
+    def forward(self, x, residual=None):
+        return self.net[2](self.net[0](x), residual=residual)
+
+
+class CrossAttention(H._Packed):
+    """text cross-attention over L <= 16 context tokens"""
+
+    def __init__(self, query_dim, context_dim=None, heads=8, dim_head=64, dropout=0.0):
+        super().__init__()
+        inner = dim_head * heads
+        context_dim = context_dim or query_dim
+        self.scale = dim_head ** -0.5
+        self.heads, self.dim_head = heads, dim_head
+        self.to_q = H.Linear(query_dim, inner, bias=False)
+        self.to_k = H.Linear(context_dim, inner, bias=False)
+        self.to_v = H.Linear(context_dim, inner, bias=False)
+        self.to_out = zero_module(nn.Sequential(H.Linear(inner, query_dim), nn.Identity()))
+        self.attn_map_cache = None
+
+    def _key(self):
+        return self.to_k._key() + self.to_v._key()
+
+    def _pack(self):
+        return H.fuse_rows(self.to_k.weight, self.to_v.weight)
+
+    def project_context(self, context_bf16: torch.Tensor) -> torch.Tensor:
+        """context [B, L, Dc] bf16 -> k|v [B, L, 2*inner]; step-invariant, hoisted by the sampler"""
+        B, Lc, Dc = context_bf16.shape
+        return ops.linear(context_bf16.reshape(B * Lc, Dc), self.packed()).reshape(B, Lc, -1)
+
+    def forward(self, x, context=None, kv=None, residual=None, emit_map: bool = False):
+        B, N, _ = x.shape
+        inner = self.heads * self.dim_head
+        if kv is None:
+            kv = self.project_context(context)
+        q = self.to_q(x.reshape(B * N, -1)).reshape(B, N, inner)
+        probs = None
+        if emit_map and self.attn_map_cache is not None:
+            probs = torch.empty((B * self.heads, N, kv.shape[1]), dtype=torch.float32, device=x.device)
+            self.attn_map_cache["size"] = int(N ** 0.5)
+            self.attn_map_cache["attn_map"] = probs
+        o = ops.xattention(q, kv[..., :inner], kv[..., inner:], self.heads, self.dim_head, self.scale, probs=probs)
+        res = residual.reshape(B * N, -1) if residual is not None else None
+        return self.to_out[0](o.reshape(B * N, inner), residual=res).reshape(B, N, -1)
+
+
+class MemoryEfficientCrossAttention(H._Packed):
+    """self-attention (flash kernel, head_dim 64)"""
+
+    def __init__(self, query_dim, context_dim=None, heads=8, dim_head=64, dropout=0.0, **kwargs):
+        super().__init__()
+        if dim_head != 64:
+            raise NotImplementedError("udt_attn_fwd is specialised for head_dim 64 (num_head_channels: 64)")
+        inner = dim_head * heads
+        context_dim = context_dim or query_dim
+        self.heads, self.dim_head = heads, dim_head
+        self.to_q = H.Linear(query_dim, inner, bias=False)
+        self.to_k = H.Linear(context_dim, inner, bias=False)
+        self.to_v = H.Linear(context_dim, inner, bias=False)
+        self.to_out = nn.Sequential(H.Linear(inner, query_dim), nn.Identity())
+
+    def _key(self):
+        return self.to_q._key() + self.to_k._key() + self.to_v._key()
+
+    def _pack(self):
+        return H.fuse_rows(self.to_q.weight, self.to_k.weight), packing.pack_linear(self.to_v.weight)
+
+    def forward(self, x, context=None, mask=None, residual=None):
+        if context is not None or mask is not None:
+            raise NotImplementedError("attn1 is pure self-attention on this path (reference attention.py:251-252)")
+        B, N, C = x.shape
+        inner = self.heads * self.dim_head
+        wqk, wv = self.packed()
+        x2 = x.reshape(B * N, C)
+        qk = ops.linear(x2, wqk).reshape(B, N, 2 * inner)
+        vt = ops.linear(x2, wv, flags=H.GEMM_TRANSPOSED, rows_per_batch=N)           # [B, inner, N]
+        o = ops.attention(qk[..., :inner], qk[..., inner:], vt, self.heads, self.dim_head ** -0.5)
+        res = residual.reshape(B * N, -1) if residual is not None else None
+        return self.to_out[0](o.reshape(B * N, inner), residual=res).reshape(B, N, -1)
+
+
+class BasicTransformerBlock(nn.Module):
+    def __init__(self, dim, n_heads, d_head, dropout=0.0, t_context_dim=None, v_context_dim=None, gated_ff=True):
+        super().__init__()
+        self.attn1 = MemoryEfficientCrossAttention(query_dim=dim, heads=n_heads, dim_head=d_head)
+        if t_context_dim is not None and t_context_dim > 0:
+            self.t_attn = CrossAttention(query_dim=dim, context_dim=t_context_dim, heads=n_heads, dim_head=d_head)
+            self.t_norm = H.LayerNorm(dim)
+        if v_context_dim is not None and v_context_dim > 0:
+            raise NotImplementedError("v_attn is not configured in UDiffText (v_context_dim unset)")
+        self.norm1 = H.LayerNorm(dim)
+        self.norm3 = H.LayerNorm(dim)
+        self.ff = FeedForward(dim, dropout=dropout, glu=gated_ff)
+
+    def forward(self, x, t_context=None, v_context=None, t_kv=None, emit_map: bool = False):
+        x = self.attn1(self.norm1(x), residual=x)
+        if hasattr(self, "t_attn"):
+            x = self.t_attn(self.t_norm(x), context=t_context, kv=t_kv, residual=x, emit_map=emit_map)
+        B, N, C = x.shape
+        x2 = x.reshape(B * N, C)
+        return self.ff(self.norm3(x2), residual=x2).reshape(B, N, C)
+
+
+class SpatialTransformer(nn.Module):
+    def __init__(self, in_channels, n_heads, d_head, depth=1, dropout=0.0, t_context_dim=None, v_context_dim=None,
+                 use_linear=False):
+        super().__init__()
+        if not use_linear:
+            raise NotImplementedError("use_linear_in_transformer: True is the UDiffText configuration")
+        self.in_channels = in_channels
+        inner = n_heads * d_head
+        self.norm = H.GroupNorm(32, in_channels, eps=1e-6)
+        self.proj_in = H.Linear(in_channels, inner)
+        self.transformer_blocks = nn.ModuleList(
+            [BasicTransformerBlock(inner, n_heads, d_head, dropout=dropout, t_context_dim=t_context_dim,
+                                   v_context_dim=v_context_dim) for _ in range(depth)])
+        self.proj_out = zero_module(H.Linear(inner, in_channels))
+        self.use_linear = use_linear
+
+    def project_context(self, context_bf16) -> List[torch.Tensor]:
+        return [blk.t_attn.project_context(context_bf16) for blk in self.transformer_blocks]
+
+    def forward(self, x, t_context=None, v_context=None, t_kv: Optional[list] = None, emit_map: bool = False):
+        """x: bf16 NHWC [B, H, W, C]"""
+        B, Hh, Ww, C = x.shape
+        N = Hh * Ww
+        t = self.proj_in(self.norm(x).reshape(B * N, C)).reshape(B, N, -1)
+        for i, blk in enumerate(self.transformer_blocks):
+            t = blk(t, t_context=t_context, t_kv=(t_kv[i] if t_kv is not None else None), emit_map=emit_map)
+        out = self.proj_out(t.reshape(B * N, -1), residual=x.reshape(B * N, C))
+        return out.reshape(B, Hh, Ww, C)

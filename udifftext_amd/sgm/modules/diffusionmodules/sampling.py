@@ -1,0 +1,205 @@
+"""Samplers.  ``EulerEDMSampler`` is the one UDiffText instantiates (reference util.py:35-45); with s_churn = 0 it
+is the deterministic Euler == DDIM(eta 0) integrator with classifier-free guidance.
+
+Reference: sgm/modules/diffusionmodules/sampling.py — BaseDiffusionSampler :28-78, EDMSampler :89-98,
+EulerEDMSampler :218-420 (get_init_noise :264-322, sampler_step :324-353, __call__ :355-420).
+
+MI355X execution of one step (``_Stepper.step``): all scalars (sigma, quantised sigma, timestep index,
+c_in, c_out) are computed on the host from the fp32 tables — no ``.item()`` sync in the loop; the device work is
+  udt_unet_input (x*c_in into the NHWC bf16 CFG pair) -> UNet kernels -> udt_cfg_euler_step (c_out, CFG, Euler),
+with the step-invariant pieces hoisted out of the loop (text k|v projections of all 16 transformers, the
+concat channels of the UNet input).  Attention maps are only emitted where they are consumed (noise search).
+The heavier side paths (attend-and-excite: needs autograd through the UNet; attention-map plots / GIFs) are
+out of scope and raise.
+"""
+from __future__ import annotations
+
+from typing import Dict, Union
+
+import numpy as np
+import torch
+
+from udifftext_amd import ops, packing
+
+from ...util import default, instantiate_from_config, require_gpu
+from .guiders import VanillaCFG
+from .sampling_utils import to_d
+
+DEFAULT_GUIDER = {"target": "sgm.modules.diffusionmodules.guiders.IdentityGuider"}
+
+
+class BaseDiffusionSampler:
+    def __init__(self, discretization_config, num_steps: Union[int, None] = None, guider_config=None,
+                 verbose: bool = False, device: str = "cuda"):
+        self.num_steps = num_steps
+        self.discretization = instantiate_from_config(discretization_config)
+        self.guider = instantiate_from_config(default(guider_config, DEFAULT_GUIDER))
+        self.verbose = verbose
+        self.device = device
+
+    def prepare_sampling_loop(self, x, cond, uc=None, num_steps=None):
+        sigmas = self.discretization(self.num_steps if num_steps is None else num_steps, device=self.device)
+        uc = default(uc, cond)
+        x *= torch.sqrt(1.0 + sigmas[0] ** 2.0)
+        s_in = x.new_ones([x.shape[0]])
+        return x, s_in, sigmas, len(sigmas), cond, uc
+
+    def denoise(self, x, model, sigma, cond, uc):
+        """generic (any denoiser / network) formulation, tensor math as in the reference :61-64"""
+        denoised = model.denoiser(model.model, *self.guider.prepare_inputs(x, sigma, cond, uc))
+        return self.guider(denoised, sigma)
+
+    def get_sigma_gen(self, num_sigmas, init_step=0):
+        gen = range(init_step, num_sigmas - 1)
+        if self.verbose:
+            try:
+                from tqdm import tqdm
+                gen = tqdm(gen, total=num_sigmas - 1 - init_step,
+                           desc=f"Sampling with {self.__class__.__name__} for {num_sigmas - 1 - init_step} steps")
+            except ImportError:
+                pass
+        return gen
+
+
+class SingleStepDiffusionSampler(BaseDiffusionSampler):
+    def sampler_step(self, sigma, next_sigma, denoiser, x, cond, uc, *args, **kwargs):
+        raise NotImplementedError
+
+    def euler_step(self, x, d, dt):
+        return x + dt * d
+
+
+class EDMSampler(SingleStepDiffusionSampler):
+    def __init__(self, s_churn=0.0, s_tmin=0.0, s_tmax=float("inf"), s_noise=1.0, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.s_churn, self.s_tmin, self.s_tmax, self.s_noise = s_churn, s_tmin, s_tmax, s_noise
+
+
+class _Stepper:
+    """Step-invariant device state of one sampling run + the fused per-step launch sequence."""
+
+    def __init__(self, model, cond: dict, uc: dict, batch_size: int, latent_hw, scale: float):
+        self.engine = model
+        self.unet = model.model.diffusion_model
+        self.scale = float(scale)
+        self.B = batch_size
+        h, w = latent_hw
+        dev = cond["concat"].device
+        self.table = model.denoiser.sigmas.detach().float().cpu()          # ascending 1000-entry table
+        ctx = torch.cat((uc["t_crossattn"], cond["t_crossattn"]), 0)
+        self.t_kv = self.unet.project_context(ctx)                        # hoisted k|v of all transformers
+        self.xin = torch.zeros((2 * batch_size, h, w, packing.KPAD), dtype=torch.bfloat16, device=dev)
+        concat = torch.cat((uc["concat"], cond["concat"]), 0).float().contiguous()
+        ops.nhwc_set_channels(concat, self.xin, 4)                         # channels 4..8: mask, masked latent
+        self._emb_cache: Dict[int, torch.Tensor] = {}
+        self.dev = dev
+
+    def quantise(self, sigma: float):
+        idx = int((self.table - sigma).abs().argmin())
+        return idx, float(self.table[idx])
+
+    def emb_rows(self, idx: int) -> torch.Tensor:
+        rows = self._emb_cache.get(idx)
+        if rows is None:
+            t = torch.full((2 * self.B,), float(idx), dtype=torch.float32, device=self.dev)
+            rows = self.unet.time_embedding_rows(t)
+            self._emb_cache[idx] = rows
+        return rows
+
+    def step(self, x: torch.Tensor, sigma: float, sigma_next: float, emit_maps: bool = False) -> None:
+        """in-place Euler update of x (fp32 NCHW [B,4,h,w])"""
+        idx, sq = self.quantise(sigma)
+        c_in = 1.0 / (sq * sq + 1.0) ** 0.5
+        ops.unet_input(x, self.xin, c_in)
+        if emit_maps:
+            self.unet.clear_attn_map()
+        eps = self.unet.forward_nhwc(self.xin, self.emb_rows(idx), self.t_kv, emit_maps=emit_maps)
+        ops.cfg_euler_step(x, eps, sigma, sigma_next, self.scale, c_out=-sq)
+
+
+class EulerEDMSampler(EDMSampler):
+    def possible_correction_step(self, euler_step, x, d, dt, next_sigma, denoiser, cond, uc):
+        return euler_step
+
+    # ----------------------------------------------------------------------------------------- helpers
+    def _host_sigmas(self, num_steps=None):
+        n = self.num_steps if num_steps is None else num_steps
+        return [float(s) for s in self.discretization(n, device="cpu")]
+
+    def _check_fast_path(self):
+        if not isinstance(self.guider, VanillaCFG):
+            raise NotImplementedError("the fused MI355X step implements VanillaCFG guidance")
+        if self.s_churn != 0.0:
+            raise NotImplementedError("s_churn > 0 (stochastic sampling) is not used by UDiffText (util.py:39)")
+
+    # -------------------------------------------------------------------------------------- noise search
+    def get_init_noise(self, cfgs, model, cond, batch, uc=None):
+        """noise_iters candidates, each scored by the text-attention local loss after the 2nd of 2 Euler steps;
+        the per-sample arg-min is kept (identical to the reference for batch 1; the reference is undefined for
+        larger batches).  All randn draws come from the CPU default generator, in the reference's order."""
+        self._check_fast_path()
+        H, W = batch["target_size_as_tuple"][0]
+        shape = (cfgs.batch_size, cfgs.channel, int(H) // cfgs.factor, int(W) // cfgs.factor)
+        dev = cond["concat"].device
+        randn = torch.randn(shape).to(dev)
+        if cfgs.noise_iters <= 0:
+            return randn
+        stepper = _Stepper(model, cond, default(uc, cond), shape[0], shape[2:], self.guider.scale)
+        sig = self._host_sigmas(2)
+        mask, seg = batch["mask"], batch["seg_mask"]
+        cands, scores = [], []
+        for _ in range(cfgs.noise_iters):
+            x = randn.clone()
+            x *= (1.0 + sig[0] ** 2.0) ** 0.5
+            ll = None
+            for i in range(2):
+                stepper.step(x, sig[i], sig[i + 1], emit_maps=True)
+                ll = model.loss_fn.get_min_local_loss(stepper.unet.attn_map_cache, mask, seg)
+            cands.append(randn)
+            scores.append(ll[ll.shape[0] // 2:])
+            randn = torch.randn(shape).to(dev)
+        stepper.unet.clear_attn_map()
+        score = torch.stack(scores, 0)                                   # [iters, B]
+        best = score.argmin(dim=0)                                        # first minimum, like the stable sort
+        print(f"Init local loss: Best {score.min().item()} Worst {score.max().item()}")
+        stack = torch.stack(cands, 0)                                     # [iters, B, 4, h, w]
+        return stack[best, torch.arange(shape[0], device=dev)].contiguous()
+
+    # ------------------------------------------------------------------------------------------- API step
+    def sampler_step(self, sigma, next_sigma, model, x, cond, batch=None, uc=None, gamma=0.0, alpha=0, iter_enabled=False,
+                     thres=None, update=False, name=None, save_loss=False, save_attn=False, save_inter=False):
+        """reference-shaped single step on tensors (sigma / next_sigma are [B] tensors); returns
+        (x_next, denoised_decode, local_loss).  Generic formulation via denoiser + guider."""
+        if gamma > 0 or update or save_attn:
+            raise NotImplementedError("churn / attend-and-excite / attention plots are out of scope (DESIGN.md)")
+        denoised = self.denoise(x, model, sigma, cond, uc)
+        inter = model.decode_first_stage(denoised) if save_inter else None
+        if save_loss:
+            ll = model.loss_fn.get_min_local_loss(model.model.diffusion_model.attn_map_cache, batch["mask"], batch["seg_mask"])
+            ll = ll[ll.shape[0] // 2:]
+        else:
+            ll = torch.zeros(1)
+        d = to_d(x, sigma, denoised)
+        dt = (next_sigma - sigma)[(...,) + (None,) * (x.ndim - 1)]
+        return self.euler_step(x, d, dt), inter, ll
+
+    # --------------------------------------------------------------------------------------------- loop
+    def __call__(self, model, x, cond, batch=None, uc=None, num_steps=None, init_step=0, name=None, aae_enabled=False,
+                 detailed=False):
+        if aae_enabled:
+            raise NotImplementedError("attend-and-excite needs a backward pass through the UNet — out of scope "
+                                      "(SURVEY.md §8f rank 4)")
+        if detailed:
+            raise NotImplementedError("attention-map / segment-map dumps are a visualisation side path (out of scope)")
+        self._check_fast_path()
+        require_gpu(x, "EulerEDMSampler")
+        uc = default(uc, cond)
+        sig = self._host_sigmas(num_steps)
+        x = x.float().contiguous()
+        x *= (1.0 + sig[0] ** 2.0) ** 0.5                                  # in place, like the reference :54
+        stepper = _Stepper(model, cond, uc, x.shape[0], x.shape[2:], self.guider.scale)
+        prev = stepper.unet.cache_attn_maps
+        for i in self.get_sigma_gen(len(sig), init_step=init_step):
+            stepper.step(x, sig[i], sig[i + 1], emit_maps=False)
+        stepper.unet.cache_attn_maps = prev
+        return x

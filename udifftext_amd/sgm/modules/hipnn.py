@@ -1,0 +1,131 @@
+"""Parameter containers whose forward is a launch into libudt_kernels.so.
+
+Each container keeps its parameters in the reference's checkpoint layout (fp32, same names/shapes) so that
+``load_state_dict`` of a reference ``.ckpt`` / ``.safetensors`` works unchanged, and lazily derives the
+device layout the kernels consume (bf16, K-contiguous, channel-padded) in ``packed()``.
+Activations between containers are bf16, channel-last: ``[B, H, W, C]`` (or ``[rows, C]`` for tokens).
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from udifftext_amd import lib as L
+from udifftext_amd import ops, packing
+
+from ..util import init_skipped
+
+
+def _init_uniform_(p: torch.Tensor, fan_in: int) -> None:
+    if init_skipped():
+        return
+    bound = 1.0 / math.sqrt(max(fan_in, 1))
+    with torch.no_grad():
+        p.uniform_(-bound, bound)
+
+
+class _Packed(nn.Module):
+    """mixin: cache of repacked device weights, invalidated when parameters move or change"""
+
+    def _key(self):
+        ps = list(self.parameters(recurse=False))
+        return tuple((p.data_ptr(), p._version, str(p.device)) for p in ps)
+
+    def packed(self):
+        key = self._key()
+        if getattr(self, "_pk_key", None) != key:
+            with torch.no_grad():
+                self._pk = self._pack()
+            self._pk_key = key
+        return self._pk
+
+    def _pack(self):
+        raise NotImplementedError
+
+
+class Linear(_Packed):
+    def __init__(self, in_features: int, out_features: int, bias: bool = True):
+        super().__init__()
+        self.in_features, self.out_features = in_features, out_features
+        self.weight = nn.Parameter(torch.empty(out_features, in_features))
+        _init_uniform_(self.weight, in_features)
+        if bias:
+            self.bias = nn.Parameter(torch.empty(out_features))
+            _init_uniform_(self.bias, in_features)
+        else:
+            self.register_parameter("bias", None)
+
+    def _pack(self):
+        return packing.pack_linear(self.weight), packing.pad_bias(self.bias)
+
+    def forward(self, x, residual=None, flags: int = 0, out=None, rowvec=None, rows_per_batch: int = 0):
+        w, b = self.packed()
+        return ops.linear(x, w, b, residual=residual, flags=flags, out=out, rowvec=rowvec, rows_per_batch=rows_per_batch)
+
+
+class Conv2d(_Packed):
+    """3x3 / 1x1 convolution evaluated as implicit GEMM on NHWC bf16 (``segments``: channel counts of the
+    concatenated sources this conv reads, for packing)."""
+
+    def __init__(self, in_channels: int, out_channels: int, kernel_size: int, stride: int = 1, padding: int = 0):
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.kernel_size, self.stride, self.padding = kernel_size, stride, padding
+        self.weight = nn.Parameter(torch.empty(out_channels, in_channels, kernel_size, kernel_size))
+        self.bias = nn.Parameter(torch.empty(out_channels))
+        fan_in = in_channels * kernel_size * kernel_size
+        _init_uniform_(self.weight, fan_in)
+        _init_uniform_(self.bias, fan_in)
+        self.segments = None
+        self.n_pad = 4          # output channels are padded to a multiple of this (64 when the consumer is a GEMM)
+
+    def _pack(self):
+        return packing.pack_conv(self.weight, self.segments, self.n_pad), packing.pad_bias(self.bias, self.n_pad)
+
+    def forward(self, x, x2=None, residual=None, rowvec=None, upsample: bool = False, flags: int = 0,
+                pad: Optional[tuple] = None, out_hw: Optional[tuple] = None):
+        if x2 is not None and self.segments is None:
+            self.segments = [x.shape[-1], x2.shape[-1]]
+            self._pk_key = None
+        w, b = self.packed()
+        if pad is None:
+            pad = (self.padding, self.padding)
+        return ops.conv2d(x, w, b, ksize=self.kernel_size, stride=self.stride, pad=pad, upsample=upsample, x2=x2,
+                          out_hw=out_hw, residual=residual, rowvec=rowvec, flags=flags, n_out=w.shape[0])
+
+
+class GroupNorm(nn.Module):
+    def __init__(self, num_groups: int, num_channels: int, eps: float = 1e-5):
+        super().__init__()
+        self.num_groups, self.num_channels, self.eps = num_groups, num_channels, eps
+        self.weight = nn.Parameter(torch.ones(num_channels))
+        self.bias = nn.Parameter(torch.zeros(num_channels))
+
+    def forward(self, x, x2=None, silu: bool = False):
+        return ops.group_norm(x, self.weight, self.bias, self.num_groups, self.eps, silu, x2=x2)
+
+
+class LayerNorm(nn.Module):
+    def __init__(self, dim: int, eps: float = 1e-5):
+        super().__init__()
+        self.dim, self.eps = dim, eps
+        self.weight = nn.Parameter(torch.ones(dim))
+        self.bias = nn.Parameter(torch.zeros(dim))
+
+    def forward(self, x):
+        return ops.layer_norm(x, self.weight, self.bias, self.eps)
+
+
+def fuse_rows(*weights: torch.Tensor) -> torch.Tensor:
+    """stack [Ni, K] matrices row-wise and pack to bf16 (fused q|k, k|v projections)"""
+    return packing.pack_linear(torch.cat(list(weights), dim=0))
+
+
+GEMM_GEGLU = L.GEMM_GEGLU
+GEMM_OUT_F32 = L.GEMM_OUT_F32
+GEMM_RELU = L.GEMM_RELU
+GEMM_TRANSPOSED = L.GEMM_TRANSPOSED
+GEMM_SILU_OUT = L.GEMM_SILU_OUT
