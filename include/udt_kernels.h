@@ -197,6 +197,9 @@ int udt_device_arch_ok(void);            /* 1 if device 0 reports gfx950        
 #define UDT_PROF_NCLASS 6
 int udt_prof_enable(uint32_t class_mask);
 int udt_prof_reset(void);
+/* per-launch trace (class, ms, shape tag) of the profiled classes; dump writes a CSV                  */
+int udt_prof_trace(int32_t on);
+int udt_prof_dump(const char* path);
 /* synchronises the recorded events and returns total ms / launch count for a class               */
 int udt_prof_get(int32_t op_class, double* total_ms, int64_t* launches);
 

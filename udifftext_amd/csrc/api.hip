@@ -3,6 +3,7 @@
 #include "common.h"
 
 #include <mutex>
+#include <stdio.h>
 #include <string.h>
 #include <vector>
 
@@ -15,7 +16,11 @@ uint16_t* g_zero_page = nullptr;
 struct ProfRec {
   hipEvent_t start, stop;
   int cls;
+  char tag[96];
 };
+struct TraceRow { int cls; float ms; char tag[96]; };
+std::vector<TraceRow> g_trace;
+bool g_trace_on = false;
 uint32_t g_prof_mask = 0;
 std::vector<ProfRec> g_recs;        // recorded, not yet folded
 std::vector<ProfRec> g_pool;        // reusable event pairs
@@ -44,6 +49,13 @@ const uint16_t* udt_zero_page() {
   return g_zero_page;
 }
 
+void udt_prof_tag(void* rec, const char* tag) {
+  if (!rec || !tag) return;
+  std::lock_guard<std::mutex> lk(g_mu);
+  const size_t idx = reinterpret_cast<size_t>(rec) - 1;
+  if (idx < g_recs.size()) { strncpy(g_recs[idx].tag, tag, sizeof(g_recs[idx].tag) - 1); }
+}
+
 UdtProfScope::UdtProfScope(int cls_, hipStream_t s_) : cls(cls_), s(s_), rec(nullptr) {
   if (!(g_prof_mask & (1u << cls))) return;
   std::lock_guard<std::mutex> lk(g_mu);
@@ -56,7 +68,8 @@ UdtProfScope::UdtProfScope(int cls_, hipStream_t s_) : cls(cls_), s(s_), rec(nul
     if (hipEventCreate(&r.stop) != hipSuccess) return;
   }
   r.cls = cls;
-  hipEventRecord(r.start, s);
+  r.tag[0] = 0;
+  (void)hipEventRecord(r.start, s);
   g_recs.push_back(r);
   rec = reinterpret_cast<void*>(g_recs.size());   // 1-based index
 }
@@ -65,16 +78,20 @@ UdtProfScope::~UdtProfScope() {
   if (!rec) return;
   std::lock_guard<std::mutex> lk(g_mu);
   const size_t idx = reinterpret_cast<size_t>(rec) - 1;
-  if (idx < g_recs.size()) hipEventRecord(g_recs[idx].stop, s);
+  if (idx < g_recs.size()) (void)hipEventRecord(g_recs[idx].stop, s);
 }
 
 static void fold_records_locked() {
   for (auto& r : g_recs) {
-    hipEventSynchronize(r.stop);
+    (void)hipEventSynchronize(r.stop);
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, r.start, r.stop) == hipSuccess) {
       g_total_ms[r.cls] += (double)ms;
       g_launches[r.cls] += 1;
+      if (g_trace_on) {
+        TraceRow t; t.cls = r.cls; t.ms = ms; memcpy(t.tag, r.tag, sizeof(t.tag));
+        g_trace.push_back(t);
+      }
     }
     g_pool.push_back(r);
   }
@@ -123,6 +140,25 @@ extern "C" int udt_prof_reset(void) {
     g_total_ms[i] = 0.0;
     g_launches[i] = 0;
   }
+  return UDT_OK;
+}
+
+extern "C" int udt_prof_trace(int32_t on) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  g_trace_on = on != 0;
+  if (!on) g_trace.clear();
+  return UDT_OK;
+}
+
+extern "C" int udt_prof_dump(const char* path) {
+  if (!path) return UDT_ERR_BAD_ARG;
+  std::lock_guard<std::mutex> lk(g_mu);
+  fold_records_locked();
+  FILE* f = fopen(path, "w");
+  if (!f) return UDT_ERR_BAD_ARG;
+  fprintf(f, "class,ms,tag\n");
+  for (auto& t : g_trace) fprintf(f, "%d,%.6f,%s\n", t.cls, t.ms, t.tag);
+  fclose(f);
   return UDT_OK;
 }
 

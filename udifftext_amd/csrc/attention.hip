@@ -19,6 +19,7 @@
 // udt_softmax_rows: in-place row softmax (VAE single-head attention, model.py:246, computed as
 //   GEMM -> softmax -> GEMM because head_dim = 512 does not fit a register-resident flash tile).
 #include "common.h"
+#include <stdio.h>
 
 namespace {
 
@@ -360,6 +361,11 @@ extern "C" int udt_attn_fwd(const void* q, const void* k, const void* vt, void* 
   p.scale_log2e = scale * 1.4426950408889634f;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   UdtProfScope prof(2, s);
+  if (prof.rec) {
+    char tag[96];
+    snprintf(tag, sizeof(tag), "attn B=%d H=%d nq=%d nk=%d", batch, heads, nq, nk);
+    udt_prof_tag(prof.rec, tag);
+  }
   dim3 grid((nq + 127) / 128, batch * heads);
   hipLaunchKernelGGL(attn_d64_kernel, grid, dim3(256), 0, s, p);
   UDT_CHECK_LAUNCH();

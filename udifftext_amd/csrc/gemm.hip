@@ -19,6 +19,7 @@
 //
 // Replaces: nn.Linear / nn.Conv2d call sites listed in include/udt_kernels.h.
 #include "common.h"
+#include <stdio.h>
 
 namespace {
 
@@ -521,6 +522,12 @@ extern "C" int udt_gemm(const udt_gemm_desc* d, void* workspace, size_t workspac
 
   const int cls = (conv && d->ksize == 3) ? 0 : 1;
   UdtProfScope prof(cls, s);
+  if (prof.rec) {
+    char tag[96];
+    snprintf(tag, sizeof(tag), "gemm M=%d N=%d K=%d conv=%d ks=%d fl=0x%x tile=%dx%d split=%d b=%d", d->M, d->N, d->K,
+             conv ? 1 : 0, d->ksize, d->flags, t.bm, t.bn, t.splits, batch);
+    udt_prof_tag(prof.rec, tag);
+  }
 
   dim3 grid(p.tiles_m * p.tiles_n, t.splits, batch);
   hipError_t e;

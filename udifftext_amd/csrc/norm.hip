@@ -5,6 +5,7 @@
 //   GroupNorm eps 1e-6 : sgm/modules/attention.py:82-85 ; sgm/modules/diffusionmodules/model.py:48-52
 //   LayerNorm          : sgm/modules/attention.py:297,310-311
 #include "common.h"
+#include <stdio.h>
 
 namespace {
 
@@ -44,15 +45,23 @@ __global__ void __launch_bounds__(256) gn_stats_kernel(const uint16_t* __restric
     const bool second = cc * 8 >= C1;
     const int cs = second ? C2 : C1;
     const uint16_t* xb = (second ? x2 : x) + (long long)b * HW * cs + (second ? cc * 8 - C1 : cc * 8);
-    for (long long pix = p0 + rg; pix < p1; pix += R) {
-      const u32x4 v = *reinterpret_cast<const u32x4*>(xb + pix * cs);
+    auto acc8 = [&](const u32x4 v) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const float a = bf16_lo(v[j]), bb = bf16_hi(v[j]);
         s[2 * j] += a; q[2 * j] += a * a;
         s[2 * j + 1] += bb; q[2 * j + 1] += bb * bb;
       }
+    };
+    long long pix = p0 + rg;
+    for (; pix + 3LL * R < p1; pix += 4LL * R) {          // 4 loads in flight per lane
+      const u32x4 v0 = *reinterpret_cast<const u32x4*>(xb + pix * cs);
+      const u32x4 v1 = *reinterpret_cast<const u32x4*>(xb + (pix + R) * cs);
+      const u32x4 v2 = *reinterpret_cast<const u32x4*>(xb + (pix + 2LL * R) * cs);
+      const u32x4 v3 = *reinterpret_cast<const u32x4*>(xb + (pix + 3LL * R) * cs);
+      acc8(v0); acc8(v1); acc8(v2); acc8(v3);
     }
+    for (; pix < p1; pix += R) acc8(*reinterpret_cast<const u32x4*>(xb + pix * cs));
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       ssum[rg * C + cc * 8 + j] = s[j];
@@ -90,19 +99,31 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const uint16_t* __restric
   const int t = threadIdx.x;
   const int b = blockIdx.y;
   const int cpg = C / G;
-  if (t < G) {
+  {
+    // 256 threads = G groups x (256/G) lanes; each lane sums a strided subset of the chunk partials
+    double* red = reinterpret_cast<double*>(gr + G);          // [2][256] doubles
+    const int lanes = 256 / G;
+    const int g = t % G, ln = t / G;
     double a = 0.0, q = 0.0;
-    for (int k = 0; k < nchunks; ++k) {
-      const float* src = partials + (((long long)b * nchunks + k) * G + t) * 2;
-      a += (double)src[0];
-      q += (double)src[1];
+    if (ln < lanes)
+      for (int k = ln; k < nchunks; k += lanes) {
+        const float* src = partials + (((long long)b * nchunks + k) * G + g) * 2;
+        a += (double)src[0];
+        q += (double)src[1];
+      }
+    red[t] = a;
+    red[256 + t] = q;
+    __syncthreads();
+    if (t < G) {
+      a = 0.0; q = 0.0;
+      for (int l = 0; l < lanes; ++l) { a += red[l * G + t]; q += red[256 + l * G + t]; }
+      const double n = (double)HW * (double)cpg;
+      const double mean = a / n;
+      double var = q / n - mean * mean;
+      if (var < 0.0) var = 0.0;
+      gm[t] = (float)mean;
+      gr[t] = (float)(1.0 / sqrt(var + (double)eps));
     }
-    const double n = (double)HW * (double)cpg;
-    const double mean = a / n;
-    double var = q / n - mean * mean;
-    if (var < 0.0) var = 0.0;
-    gm[t] = (float)mean;
-    gr[t] = (float)(1.0 / sqrt(var + (double)eps));
   }
   __syncthreads();
   for (int c = t; c < C; c += 256) {
@@ -120,11 +141,7 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const uint16_t* __restric
   const uint16_t* xb1 = x + (long long)b * HW * C1;
   const uint16_t* xb2 = x2 ? (x2 + (long long)b * HW * C2) : nullptr;
   uint16_t* yb = y + (long long)b * HW * C;
-  for (long long i = begin + t; i < end; i += 256) {
-    const long long pix = i / c8;
-    const int cc = (int)(i - pix * c8);
-    const uint16_t* src = (cc * 8 < C1) ? (xb1 + pix * C1 + cc * 8) : (xb2 + pix * C2 + (cc * 8 - C1));
-    const u32x4 v = *reinterpret_cast<const u32x4*>(src);
+  auto norm8 = [&](const u32x4 v, int cc) {
     u32x4 o;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -137,7 +154,29 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const uint16_t* __restric
       }
       o[j] = pack_bf16x2(a, bb);
     }
-    *reinterpret_cast<u32x4*>(yb + i * 8) = o;
+    return o;
+  };
+  auto src_of = [&](long long i, int& cc) -> const uint16_t* {
+    const long long pix = i / c8;
+    cc = (int)(i - pix * c8);
+    return (cc * 8 < C1) ? (xb1 + pix * C1 + cc * 8) : (xb2 + pix * C2 + (cc * 8 - C1));
+  };
+  long long i = begin + t;
+  for (; i + 768 < end; i += 1024) {                       // 4 independent 16-byte loads per lane
+    int c0, c1, c2, c3;
+    const u32x4 v0 = *reinterpret_cast<const u32x4*>(src_of(i, c0));
+    const u32x4 v1 = *reinterpret_cast<const u32x4*>(src_of(i + 256, c1));
+    const u32x4 v2 = *reinterpret_cast<const u32x4*>(src_of(i + 512, c2));
+    const u32x4 v3 = *reinterpret_cast<const u32x4*>(src_of(i + 768, c3));
+    *reinterpret_cast<u32x4*>(yb + i * 8) = norm8(v0, c0);
+    *reinterpret_cast<u32x4*>(yb + (i + 256) * 8) = norm8(v1, c1);
+    *reinterpret_cast<u32x4*>(yb + (i + 512) * 8) = norm8(v2, c2);
+    *reinterpret_cast<u32x4*>(yb + (i + 768) * 8) = norm8(v3, c3);
+  }
+  for (; i < end; i += 256) {
+    int cc;
+    const u32x4 v = *reinterpret_cast<const u32x4*>(src_of(i, cc));
+    *reinterpret_cast<u32x4*>(yb + i * 8) = norm8(v, cc);
   }
 }
 
@@ -215,9 +254,9 @@ __global__ void __launch_bounds__(256) layernorm_kernel(const uint16_t* __restri
 
 extern "C" int32_t udt_gn_nchunks(int64_t HW, int32_t C) {
   (void)C;
-  int64_t n = HW / 128;
+  int64_t n = HW / 16;            // >= 16 pixels per workgroup, up to 128 chunks per sample
   if (n < 1) n = 1;
-  if (n > 64) n = 64;
+  if (n > 128) n = 128;
   return (int32_t)n;
 }
 
@@ -233,6 +272,11 @@ extern "C" int udt_gn_stats(const void* x, const void* x2, float* partials, int3
   const size_t smem = (size_t)2 * R * C * sizeof(float);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   UdtProfScope prof(4, s);
+  if (prof.rec) {
+    char tag[96];
+    snprintf(tag, sizeof(tag), "gn_stats B=%d HW=%lld C=%d", B, (long long)HW, C);
+    udt_prof_tag(prof.rec, tag);
+  }
   hipLaunchKernelGGL(gn_stats_kernel, dim3(nchunks, B), dim3(256), smem, s, reinterpret_cast<const uint16_t*>(x),
                      reinterpret_cast<const uint16_t*>(x2), partials, (long long)HW, C1, C2, G, nchunks);
   UDT_CHECK_LAUNCH();
@@ -248,11 +292,17 @@ extern "C" int udt_gn_apply(const void* x, const void* x2, void* y, const float*
   if (B <= 0 || HW <= 0 || G <= 0 || G > 256 || C % G != 0 || C > GN_MAX_C) return UDT_ERR_BAD_SHAPE;
   const int nchunks = udt_gn_nchunks(HW, C);
   const long long total = (long long)HW * (C / 8);
-  const long long chunks_per_wg = 4096;   // 64 KiB of bf16 per workgroup
+  const long long chunks_per_wg = 2048;   // 32 KiB of bf16 per workgroup
   const int blocks = (int)((total + chunks_per_wg - 1) / chunks_per_wg);
-  const size_t smem = (size_t)(2 * C + 2 * G) * sizeof(float);
+  if (256 % G != 0) return UDT_ERR_BAD_SHAPE;
+  const size_t smem = (size_t)(2 * C + 2 * G) * sizeof(float) + 8 + 512 * sizeof(double);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   UdtProfScope prof(4, s);
+  if (prof.rec) {
+    char tag[96];
+    snprintf(tag, sizeof(tag), "gn_apply B=%d HW=%lld C=%d", B, (long long)HW, C);
+    udt_prof_tag(prof.rec, tag);
+  }
   hipLaunchKernelGGL(gn_apply_kernel, dim3(blocks, B), dim3(256), smem, s, reinterpret_cast<const uint16_t*>(x),
                      reinterpret_cast<const uint16_t*>(x2), reinterpret_cast<uint16_t*>(y), partials, gamma, beta,
                      (long long)HW, C1, C2, G, nchunks, eps, act, chunks_per_wg);

@@ -68,6 +68,8 @@ SYMBOLS = {
     "udt_device_arch_ok": (C.c_int, []),
     "udt_prof_enable": (C.c_int, [C.c_uint32]),
     "udt_prof_reset": (C.c_int, []),
+    "udt_prof_trace": (C.c_int, [_i32]),
+    "udt_prof_dump": (C.c_int, [C.c_char_p]),
     "udt_prof_get": (C.c_int, [_i32, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
 }
 
