@@ -1,4 +1,4 @@
-// gemm.hip — bf16 MFMA GEMM / implicit-GEMM convolution for gfx950.
+// gemm.hip — bf16 MFMA GEMM / implicit-GEMM convolution for gfx950, persistent "stream-K" scheduling.
 //
 //   out[M, N] = epilogue( A[M, K] · W[N, K]^T )          (fp32 accumulation)
 //
@@ -12,6 +12,13 @@
 // two NHWC sources (channel concat), optionally through a nearest x2 upsample, with stride 1/2 and
 // explicit top/left padding; out-of-image taps read a zero page.
 //
+// Scheduling.  The UNet's problems are mid-sized (40 .. 1300 output tiles on a 256-CU chip), so a
+// one-workgroup-per-tile launch wastes 20-40 % in partial waves.  Instead the (tile, K-tile) iteration space is
+// cut into G equal contiguous ranges, one per persistent workgroup (G = 2 per CU): a workgroup walks its range,
+// finishing whole tiles with the fused epilogue and parking the accumulators of the (at most two) tiles it only
+// partially covers in fp32 slabs; a small second kernel adds the slabs of each shared tile and runs the same epilogue.
+// That is split-K where it is needed (few tiles, deep K) and plain data-parallel where it is not, with one rule.
+//
 // The MFMA is issued with the WEIGHT fragment as the A operand and the ACTIVATION fragment as B, so a
 // lane ends up holding 4 consecutive output channels of one output row: 8-byte bf16 / 16-byte fp32
 // stores into the row-major (NHWC) output.  UDT_GEMM_TRANSPOSED swaps the operands and stores
@@ -20,6 +27,7 @@
 // Replaces: nn.Linear / nn.Conv2d call sites listed in include/udt_kernels.h.
 #include "common.h"
 #include <stdio.h>
+#include <stdlib.h>
 
 namespace {
 
@@ -32,6 +40,7 @@ struct GemmParams {
   const uint16_t* res;
   const float* rowvec;
   void* out;
+  float* slabs;          // [G][2][16][256] float4 accumulator parking space
   int M, N, K;
   int lda, ldo, ldr, ldw;
   long long sA, sW, sO, sR;
@@ -40,198 +49,25 @@ struct GemmParams {
   int ldrv;
   int flags;
   float alpha;
-  int tiles_m, tiles_n;
-  int kt_per_split, n_ktiles;
-  int split_mode;  // 1: write raw fp32 accumulators to slab blockIdx.y of `out`
+  int tiles_m, tiles_n, tiles_per_batch;
+  int n_ktiles;
+  long long total_iters;
+  int iters_per_wg;
+  int G;
 };
 
 constexpr int BK = 64;          // K elements per tile (128 bytes per row)
 constexpr int ROW_BYTES = 128;
+constexpr int SLAB_FLOATS = 16 * 256 * 4;   // one parked 4-wave accumulator set
 
-template <int BM, int BN, int WGM, int WGN, bool CONV, bool TRANS>
-__global__ void __launch_bounds__(256) gemm_kernel(const GemmParams p) {
-  static_assert(WGM * WGN == 4, "4 waves per workgroup");
-  static_assert(BM == WGM * 64 && BN == WGN * 64, "each wave owns a 64x64 output tile");
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int A_BYTES = BM * ROW_BYTES;
-  constexpr int B_BYTES = BN * ROW_BYTES;
-  constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
-  constexpr int A_INSTR = BM / 32;   // 1-KiB LDS-DMA pieces per wave for the A tile
-  constexpr int B_INSTR = BN / 32;
-
-  const int tid = threadIdx.x;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int lane = tid & 63;
+// ------------------------------------------------------------------------------------------------ epilogue
+// acc[tm][tn] is the wave's 64x64 block of the tile at (m0, n0); see the header comment for the layout.
+template <bool TRANS>
+UDT_DEVINL void epilogue(const GemmParams& p, f32x16 (&acc)[2][2], int m0, int n0, int batch, int wm, int wn,
+                         int lane) {
   const int l31 = lane & 31;
   const int hi = lane >> 5;
-
-  // block -> (row tile, column tile); M fastest so concurrently running blocks share weight tiles
-  const int bid = blockIdx.x;
-  const int tile_m = bid % p.tiles_m;
-  const int tile_n = bid / p.tiles_m;
-  const int m0 = tile_m * BM;
-  const int n0 = tile_n * BN;
-  const int split = blockIdx.y;
-  const int batch = blockIdx.z;
-
-  const uint16_t* __restrict__ A = p.a + (long long)batch * p.sA;
-  const uint16_t* __restrict__ A2 = p.a2;
-  const uint16_t* __restrict__ W = p.w + (long long)batch * p.sW;
-
-  // ---- per-lane staging state --------------------------------------------------------------------
-  // piece ci (8 rows x 128 B) of a tile: lane -> row ci*8 + (lane>>3), physical 16-B slot lane&7,
-  // logical k-slot = physical ^ ((row>>1)&7).
-  const int l3 = lane >> 3;
-  const int pslot = lane & 7;
-
-  // A rows
-  int a_koff[A_INSTR];                 // logical k-slot * 8 elements
-  long long a_rowoff[A_INSTR];         // plain: row * lda (or -1 when out of range)
-  int a_iy0[A_INSTR], a_ix0[A_INSTR], a_pixb[A_INSTR];   // conv
-#pragma unroll
-  for (int i = 0; i < A_INSTR; ++i) {
-    const int ci = wave * A_INSTR + i;
-    const int row = ci * 8 + l3;
-    a_koff[i] = (pslot ^ ((row >> 1) & 7)) * 8;
-    const int m = m0 + row;
-    if constexpr (CONV) {
-      const int hw = p.Hout * p.Wout;
-      const int b = m / hw;
-      const int rem = m - b * hw;
-      const int oy = rem / p.Wout;
-      const int ox = rem - oy * p.Wout;
-      a_pixb[i] = b * p.Hin * p.Win;
-      a_iy0[i] = (m < p.M) ? (oy * p.stride - p.pad_t) : -100000;
-      a_ix0[i] = ox * p.stride - p.pad_l;
-      a_rowoff[i] = 0;
-    } else {
-      a_rowoff[i] = (m < p.M) ? (long long)m * p.lda : -1;
-      a_iy0[i] = a_ix0[i] = a_pixb[i] = 0;
-    }
-  }
-  // W rows
-  long long w_rowoff[B_INSTR];
-  int w_koff[B_INSTR];
-#pragma unroll
-  for (int i = 0; i < B_INSTR; ++i) {
-    const int ci = wave * B_INSTR + i;
-    const int row = ci * 8 + l3;
-    w_koff[i] = (pslot ^ ((row >> 1) & 7)) * 8;
-    const int n = n0 + row;
-    w_rowoff[i] = (n < p.N) ? (long long)n * p.ldw : -1;
-  }
-
-  const int Ctot = p.C1 + p.C2;
-  const int Hv = p.Hin << p.ups;
-  const int Wv = p.Win << p.ups;
-
-  auto stage = [&](int buf, int kt) {
-    char* abuf = smem + buf * STAGE_BYTES;
-    char* bbuf = abuf + A_BYTES;
-    const int k0 = kt * BK;
-    if constexpr (CONV) {
-      const int tap = k0 / Ctot;
-      const int c0 = k0 - tap * Ctot;
-      const int ky = tap / p.ksz;
-      const int kx = tap - ky * p.ksz;
-      const bool second = c0 >= p.C1;
-      const uint16_t* src = second ? A2 : A;
-      const int cs = second ? p.C2 : p.C1;
-      const int cc = second ? (c0 - p.C1) : c0;
-#pragma unroll
-      for (int i = 0; i < A_INSTR; ++i) {
-        const int iy = a_iy0[i] + ky;
-        const int ix = a_ix0[i] + kx;
-        const bool ok = ((unsigned)iy < (unsigned)Hv) && ((unsigned)ix < (unsigned)Wv);
-        const long long pix = (long long)a_pixb[i] + (long long)(iy >> p.ups) * p.Win + (ix >> p.ups);
-        const uint16_t* g = ok ? (src + pix * cs + cc + a_koff[i]) : p.zero;
-        glds16(g, abuf + (wave * A_INSTR + i) * 1024);
-      }
-    } else {
-#pragma unroll
-      for (int i = 0; i < A_INSTR; ++i) {
-        const uint16_t* g = (a_rowoff[i] >= 0) ? (A + a_rowoff[i] + k0 + a_koff[i]) : p.zero;
-        glds16(g, abuf + (wave * A_INSTR + i) * 1024);
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < B_INSTR; ++i) {
-      const uint16_t* g = (w_rowoff[i] >= 0) ? (W + w_rowoff[i] + k0 + w_koff[i]) : p.zero;
-      glds16(g, bbuf + (wave * B_INSTR + i) * 1024);
-    }
-  };
-
-  // ---- main loop -----------------------------------------------------------------------------------
-  const int wm = (WGN == 1) ? wave : (wave >> 1);
-  const int wn = (WGN == 1) ? 0 : ((WGM == 1) ? wave : (wave & 1));
-  const int swz = (l31 >> 1) & 7;
-  const int a_frag_row = (wm * 64 + l31) * ROW_BYTES;
-  const int b_frag_row = (wn * 64 + l31) * ROW_BYTES;
-
-  f32x16 acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  const int kt_begin = split * p.kt_per_split;
-  int kt_end = kt_begin + p.kt_per_split;
-  if (kt_end > p.n_ktiles) kt_end = p.n_ktiles;
-
-  if (kt_begin < kt_end) stage(0, kt_begin);
-  for (int kt = kt_begin; kt < kt_end; ++kt) {
-    const int cur = (kt - kt_begin) & 1;
-    wait_vmcnt0();
-    __syncthreads();
-    if (kt + 1 < kt_end) stage(cur ^ 1, kt + 1);
-    const char* abuf = smem + cur * STAGE_BYTES;
-    const char* bbuf = abuf + A_BYTES;
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      const int slot = ((ks * 2 + hi) ^ swz) << 4;
-      bf16x8_t xf[2], wf[2];
-#pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        xf[t] = lds_read_frag(abuf + a_frag_row + t * 32 * ROW_BYTES + slot);
-        wf[t] = lds_read_frag(bbuf + b_frag_row + t * 32 * ROW_BYTES + slot);
-      }
-#pragma unroll
-      for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-        for (int tn = 0; tn < 2; ++tn) {
-          if constexpr (TRANS)
-            acc[tm][tn] = mfma32(xf[tm], wf[tn], acc[tm][tn]);
-          else
-            acc[tm][tn] = mfma32(wf[tn], xf[tm], acc[tm][tn]);
-        }
-    }
-  }
-
-  // ---- epilogue ----------------------------------------------------------------------------------------
   const int flags = p.flags;
-  if (p.split_mode) {
-    // raw fp32 partial sums -> slab [split][M][N]
-    float* slab = reinterpret_cast<float*>(p.out) + (long long)split * p.M * p.N;
-#pragma unroll
-    for (int tm = 0; tm < 2; ++tm) {
-      const int m = m0 + wm * 64 + tm * 32 + l31;
-#pragma unroll
-      for (int tn = 0; tn < 2; ++tn)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int n = n0 + wn * 64 + tn * 32 + q * 8 + hi * 4;
-          if (m < p.M && n < p.N) {
-            f32x4 v = {acc[tm][tn][q * 4 + 0], acc[tm][tn][q * 4 + 1], acc[tm][tn][q * 4 + 2],
-                       acc[tm][tn][q * 4 + 3]};
-            *reinterpret_cast<f32x4*>(slab + (long long)m * p.N + n) = v;
-          }
-        }
-    }
-    return;
-  }
-
   if constexpr (TRANS) {
     // D[row = activation row][col = output channel]: lane = channel, 4 consecutive rows per quad
     uint16_t* outT = reinterpret_cast<uint16_t*>(p.out);
@@ -257,7 +93,6 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmParams p) {
           }
         }
       }
-    return;
   } else {
     const uint16_t* __restrict__ R = p.res ? (p.res + (long long)batch * p.sR) : nullptr;
     if (flags & UDT_GEMM_GEGLU) {
@@ -268,7 +103,7 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmParams p) {
         const int m = m0 + wm * 64 + tm * 32 + l31;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const int nx = n0 + wn * 64 + q * 8 + hi * 4;        // packed index of x
+          const int nx = n0 + wn * 64 + q * 8 + hi * 4;           // packed index of x
           const int no = ((n0 + wn * 64) >> 1) + q * 8 + hi * 4;  // output column
           if (m < p.M && nx < p.N) {
             float o[4];
@@ -342,93 +177,342 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmParams p) {
   }
 }
 
-// split-K: sum the fp32 slabs and apply the epilogue (bias, rowvec, residual, activation, cast)
-__global__ void __launch_bounds__(256) splitk_finalize_kernel(const float* __restrict__ slabs, int nsplit,
-                                                              const GemmParams p) {
-  const long long idx4 = (long long)blockIdx.x * 256 + threadIdx.x;   // one thread per 4 columns
-  const int n4 = p.N >> 2;
-  const long long total = (long long)p.M * n4;
-  if (idx4 >= total) return;
-  const int m = (int)(idx4 / n4);
-  const int n = (int)(idx4 - (long long)m * n4) * 4;
-  const long long mn = (long long)p.M * p.N;
-  f32x4 s = *reinterpret_cast<const f32x4*>(slabs + (long long)m * p.N + n);
-  for (int k = 1; k < nsplit; ++k) {
-    const f32x4 t = *reinterpret_cast<const f32x4*>(slabs + k * mn + (long long)m * p.N + n);
-    s += t;
-  }
-  float v[4] = {s[0] * p.alpha, s[1] * p.alpha, s[2] * p.alpha, s[3] * p.alpha};
-  if (p.bias) {
-    const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + n);
+// tile id -> (batch, m0, n0); M fastest so that neighbouring workgroups share weight tiles
+template <int BM, int BN>
+UDT_DEVINL void decode_tile(const GemmParams& p, int tile, int& batch, int& m0, int& n0) {
+  batch = tile / p.tiles_per_batch;
+  const int t = tile - batch * p.tiles_per_batch;
+  const int tn = t / p.tiles_m;
+  const int tm = t - tn * p.tiles_m;
+  m0 = tm * BM;
+  n0 = tn * BN;
+}
+
+// workgroup -> iteration-range index.  Blocks are dispatched round-robin over the 8 XCDs (block b -> XCD b % 8,
+// speed heuristic only); give every XCD a contiguous slice of the iteration space so that its private L2 sees
+// neighbouring tiles (which share the weight column tile).
+UDT_DEVINL int range_index(int g, int G) {
+  if ((G & 7) != 0) return g;
+  return (g & 7) * (G >> 3) + (g >> 3);
+}
+
+template <int BM, int BN, int WGM, int WGN, bool CONV, bool TRANS>
+__global__ void __launch_bounds__(256) gemm_kernel(const GemmParams p) {
+  static_assert(WGM * WGN == 4, "4 waves per workgroup");
+  static_assert(BM == WGM * 64 && BN == WGN * 64, "each wave owns a 64x64 output tile");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int A_BYTES = BM * ROW_BYTES;
+  constexpr int B_BYTES = BN * ROW_BYTES;
+  constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
+  constexpr int A_INSTR = BM / 32;   // 1-KiB LDS-DMA pieces per wave for the A tile
+  constexpr int B_INSTR = BN / 32;
+
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = tid & 63;
+  const int l31 = lane & 31;
+  const int hi = lane >> 5;
+  const int l3 = lane >> 3;
+  const int pslot = lane & 7;
+  const int wm = (WGN == 1) ? wave : (wave >> 1);
+  const int wn = (WGN == 1) ? 0 : ((WGM == 1) ? wave : (wave & 1));
+  const int swz = (l31 >> 1) & 7;
+  const int a_frag_row = (wm * 64 + l31) * ROW_BYTES;
+  const int b_frag_row = (wn * 64 + l31) * ROW_BYTES;
+
+  const int g = range_index(blockIdx.x, p.G);
+  long long it = (long long)g * p.iters_per_wg;
+  long long it_end = it + p.iters_per_wg;
+  if (it_end > p.total_iters) it_end = p.total_iters;
+  if (it >= it_end) return;
+  const long long it_first = it;
+
+  const int Ctot = p.C1 + p.C2;
+  const int Hv = p.Hin << p.ups;
+  const int Wv = p.Win << p.ups;
+
+  // ---- per-lane staging state of the CURRENT segment -------------------------------------------------
+  // piece ci (8 rows x 128 B) of a tile: lane -> row ci*8 + (lane>>3), physical 16-B slot lane&7,
+  // logical k-slot = physical ^ ((row>>1)&7).
+  const uint16_t* A = nullptr;
+  const uint16_t* W = nullptr;
+  int a_koff[A_INSTR];
+  long long a_rowoff[A_INSTR];
+  int a_iy0[A_INSTR], a_ix0[A_INSTR], a_pixb[A_INSTR];
+  long long w_rowoff[B_INSTR];
+  int w_koff[B_INSTR];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) v[r] += bv[r];
+  for (int i = 0; i < A_INSTR; ++i) {
+    const int row = (wave * A_INSTR + i) * 8 + l3;
+    a_koff[i] = (pslot ^ ((row >> 1) & 7)) * 8;
   }
-  if (p.rowvec) {
-    const int b = m / p.rows_per_batch;
-    const f32x4 rv = *reinterpret_cast<const f32x4*>(p.rowvec + (long long)b * p.ldrv + n);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) v[r] += rv[r];
+  for (int i = 0; i < B_INSTR; ++i) {
+    const int row = (wave * B_INSTR + i) * 8 + l3;
+    w_koff[i] = (pslot ^ ((row >> 1) & 7)) * 8;
   }
-  if (p.res) {
-    const u32x2 rr = *reinterpret_cast<const u32x2*>(p.res + (long long)m * p.ldr + n);
-    v[0] += bf16_lo(rr[0]);
-    v[1] += bf16_hi(rr[0]);
-    v[2] += bf16_lo(rr[1]);
-    v[3] += bf16_hi(rr[1]);
-  }
-  if (p.flags & UDT_GEMM_RELU) {
+
+  auto prepare = [&](int batch, int m0, int n0) {
+    A = p.a + (long long)batch * p.sA;
+    W = p.w + (long long)batch * p.sW;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
-  }
-  if (p.flags & UDT_GEMM_SILU_OUT) {
+    for (int i = 0; i < A_INSTR; ++i) {
+      const int row = (wave * A_INSTR + i) * 8 + l3;
+      const int m = m0 + row;
+      if constexpr (CONV) {
+        const int hw = p.Hout * p.Wout;
+        const int b = m / hw;
+        const int rem = m - b * hw;
+        const int oy = rem / p.Wout;
+        const int ox = rem - oy * p.Wout;
+        a_pixb[i] = b * p.Hin * p.Win;
+        a_iy0[i] = (m < p.M) ? (oy * p.stride - p.pad_t) : -100000;
+        a_ix0[i] = ox * p.stride - p.pad_l;
+        a_rowoff[i] = 0;
+      } else {
+        a_rowoff[i] = (m < p.M) ? (long long)m * p.lda : -1;
+        a_iy0[i] = a_ix0[i] = a_pixb[i] = 0;
+      }
+    }
 #pragma unroll
-    for (int r = 0; r < 4; ++r) v[r] = silu_f(v[r]);
-  }
-  if (p.flags & UDT_GEMM_OUT_F32) {
-    f32x4 ov = {v[0], v[1], v[2], v[3]};
-    *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + (long long)m * p.ldo + n) = ov;
-  } else {
-    u32x2 pk = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
-    *reinterpret_cast<u32x2*>(reinterpret_cast<uint16_t*>(p.out) + (long long)m * p.ldo + n) = pk;
+    for (int i = 0; i < B_INSTR; ++i) {
+      const int row = (wave * B_INSTR + i) * 8 + l3;
+      const int n = n0 + row;
+      w_rowoff[i] = (n < p.N) ? (long long)n * p.ldw : -1;
+    }
+  };
+
+  auto stage = [&](int buf, int kt) {
+    char* abuf = smem + buf * STAGE_BYTES;
+    char* bbuf = abuf + A_BYTES;
+    const int k0 = kt * BK;
+    if constexpr (CONV) {
+      const int tap = k0 / Ctot;
+      const int c0 = k0 - tap * Ctot;
+      const int ky = tap / p.ksz;
+      const int kx = tap - ky * p.ksz;
+      const bool second = c0 >= p.C1;
+      const uint16_t* src = second ? p.a2 : A;
+      const int cs = second ? p.C2 : p.C1;
+      const int cc = second ? (c0 - p.C1) : c0;
+#pragma unroll
+      for (int i = 0; i < A_INSTR; ++i) {
+        const int iy = a_iy0[i] + ky;
+        const int ix = a_ix0[i] + kx;
+        const bool ok = ((unsigned)iy < (unsigned)Hv) && ((unsigned)ix < (unsigned)Wv);
+        const long long pix = (long long)a_pixb[i] + (long long)(iy >> p.ups) * p.Win + (ix >> p.ups);
+        const uint16_t* gp = ok ? (src + pix * cs + cc + a_koff[i]) : p.zero;
+        glds16(gp, abuf + (wave * A_INSTR + i) * 1024);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < A_INSTR; ++i) {
+        const uint16_t* gp = (a_rowoff[i] >= 0) ? (A + a_rowoff[i] + k0 + a_koff[i]) : p.zero;
+        glds16(gp, abuf + (wave * A_INSTR + i) * 1024);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < B_INSTR; ++i) {
+      const uint16_t* gp = (w_rowoff[i] >= 0) ? (W + w_rowoff[i] + k0 + w_koff[i]) : p.zero;
+      glds16(gp, bbuf + (wave * B_INSTR + i) * 1024);
+    }
+  };
+
+  // ---- walk the iteration range ---------------------------------------------------------------------------
+  int tile = (int)(it / p.n_ktiles);
+  int kt0 = (int)(it - (long long)tile * p.n_ktiles);
+  int batch, m0, n0;
+  decode_tile<BM, BN>(p, tile, batch, m0, n0);
+  prepare(batch, m0, n0);
+  stage(0, kt0);
+
+  while (true) {
+    int kt1 = p.n_ktiles;
+    if ((long long)(kt1 - kt0) > it_end - it) kt1 = kt0 + (int)(it_end - it);
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // K loop of this segment; the first tile's loads are already in flight (buffer 0)
+    for (int kt = kt0; kt < kt1; ++kt) {
+      const int cur = (kt - kt0) & 1;
+      wait_vmcnt0();
+      __syncthreads();
+      if (kt + 1 < kt1) stage(cur ^ 1, kt + 1);
+      const char* abuf = smem + cur * STAGE_BYTES;
+      const char* bbuf = abuf + A_BYTES;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const int slot = ((ks * 2 + hi) ^ swz) << 4;
+        bf16x8_t xf[2], wf[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          xf[t] = lds_read_frag(abuf + a_frag_row + t * 32 * ROW_BYTES + slot);
+          wf[t] = lds_read_frag(bbuf + b_frag_row + t * 32 * ROW_BYTES + slot);
+        }
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+          for (int tn = 0; tn < 2; ++tn) {
+            if constexpr (TRANS)
+              acc[tm][tn] = mfma32(xf[tm], wf[tn], acc[tm][tn]);
+            else
+              acc[tm][tn] = mfma32(wf[tn], xf[tm], acc[tm][tn]);
+          }
+      }
+    }
+
+    const bool full = (kt0 == 0) && (kt1 == p.n_ktiles);
+    const bool head = (it == it_first);          // segment starts at the beginning of this workgroup's range
+    const int cur_batch = batch, cur_m0 = m0, cur_n0 = n0;
+    it += kt1 - kt0;
+    const bool more = it < it_end;
+    if (more) {
+      // start the next segment's first K-tile before running this segment's epilogue
+      __syncthreads();                           // every wave is done reading both LDS buffers
+      tile = (int)(it / p.n_ktiles);
+      kt0 = (int)(it - (long long)tile * p.n_ktiles);
+      decode_tile<BM, BN>(p, tile, batch, m0, n0);
+      prepare(batch, m0, n0);
+      stage(0, kt0);
+    }
+    if (full) {
+      epilogue<TRANS>(p, acc, cur_m0, cur_n0, cur_batch, wm, wn, lane);
+    } else {
+      // park the partial accumulators: slab[g][head ? 0 : 1][i][tid] (float4), coalesced 4 KiB per i
+      f32x4* slab = reinterpret_cast<f32x4*>(p.slabs) + ((long long)g * 2 + (head ? 0 : 1)) * (16 * 256);
+#pragma unroll
+      for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            f32x4 v = {acc[tm][tn][q * 4 + 0], acc[tm][tn][q * 4 + 1], acc[tm][tn][q * 4 + 2],
+                       acc[tm][tn][q * 4 + 3]};
+            slab[(tm * 8 + tn * 4 + q) * 256 + tid] = v;
+          }
+    }
+    if (!more) break;
   }
 }
 
+// second pass of the stream-K schedule: one workgroup per output tile; tiles that were covered by a single
+// workgroup were already finished by it and exit here immediately
+template <int BM, int BN, int WGM, int WGN, bool TRANS>
+__global__ void __launch_bounds__(256) gemm_fixup_kernel(const GemmParams p) {
+  const int tile = blockIdx.x;
+  const long long it0 = (long long)tile * p.n_ktiles;
+  const long long it1 = it0 + p.n_ktiles;
+  const int g_first = (int)(it0 / p.iters_per_wg);
+  const int g_last = (int)((it1 - 1) / p.iters_per_wg);
+  if (g_first == g_last) return;
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6;
+  const int lane = tid & 63;
+  const int wm = (WGN == 1) ? wave : (wave >> 1);
+  const int wn = (WGN == 1) ? 0 : ((WGM == 1) ? wave : (wave & 1));
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  for (int g = g_first; g <= g_last; ++g) {
+    const long long gb = (long long)g * p.iters_per_wg;
+    const int slot = (it0 <= gb) ? 0 : 1;        // segment starts at the workgroup's range start -> slot 0
+    const f32x4* slab = reinterpret_cast<const f32x4*>(p.slabs) + ((long long)g * 2 + slot) * (16 * 256);
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 v = slab[(tm * 8 + tn * 4 + q) * 256 + tid];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[tm][tn][q * 4 + r] += v[r];
+        }
+  }
+  int batch, m0, n0;
+  decode_tile<BM, BN>(p, tile, batch, m0, n0);
+  epilogue<TRANS>(p, acc, m0, n0, batch, wm, wn, lane);
+}
+
+#include "gemm8.h"
+
 struct TilePlan {
-  int bm, bn;     // tile
-  int splits;     // split-K factor (1 = none)
-  int kt_per_split;
+  int bm, bn;
+  int tiles_m, tiles_n, tiles;
+  int nkt;
+  long long total;
+  int G, ipw;
+  bool fixup;
 };
 
-// Tile / split-K heuristic.  256 CUs; aim for >= ~2 workgroups per CU when the problem allows it.
+int g_slots = 0;    // resident workgroup slots: 2 per CU
+
+int resident_slots() {
+  if (g_slots == 0) {
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) {
+      int v = 0;
+      if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+    }
+    g_slots = 2 * cus;
+  }
+  return g_slots;
+}
+
 TilePlan plan_tiles(const udt_gemm_desc* d) {
   TilePlan t;
-  const int n_eff = d->N;
-  // narrow outputs (N <= 64, or N a multiple of 64 but not 128 with a tall M) -> 256x64 tiles
+  const int batch = d->batch > 0 ? d->batch : 1;
+  // narrow outputs (N <= 64, or a 64-wide remainder column with a tall M) -> 256x64 tiles
   const bool tall = d->M >= 1024;
-  if (n_eff <= 64 || (tall && (n_eff % 128) != 0 && (n_eff % 128) <= 64)) {
+  if (d->N <= 64 || (tall && (d->N % 128) != 0 && (d->N % 128) <= 64)) {
     t.bm = 256; t.bn = 64;
   } else {
     t.bm = 128; t.bn = 128;
   }
   if (d->flags & (UDT_GEMM_TRANSPOSED | UDT_GEMM_GEGLU)) { t.bm = 128; t.bn = 128; }
-  const int tiles = ((d->M + t.bm - 1) / t.bm) * ((d->N + t.bn - 1) / t.bn) * (d->batch > 0 ? d->batch : 1);
-  const int nkt = d->K / BK;
-  t.splits = 1;
-  const bool can_split = !(d->flags & (UDT_GEMM_TRANSPOSED | UDT_GEMM_GEGLU)) && d->batch <= 1 && (d->N % 4 == 0);
-  if (can_split && tiles < 256 && nkt >= 16) {
-    int want = (512 + tiles - 1) / tiles;          // reach ~512 workgroups
-    int max_by_k = nkt / 8;                         // keep >= 8 K-tiles per split
-    int s = want < max_by_k ? want : max_by_k;
-    if (s > 16) s = 16;
-    if (s >= 2) t.splits = s;
+  t.tiles_m = (d->M + t.bm - 1) / t.bm;
+  t.tiles_n = (d->N + t.bn - 1) / t.bn;
+  t.tiles = t.tiles_m * t.tiles_n * batch;
+  t.nkt = d->K / BK;
+  t.total = (long long)t.tiles * t.nkt;
+  const int slots = resident_slots();
+  // A parked partial tile costs a 64 KiB slab write + read (~4 K-tiles of operand traffic), so ranges are cut
+  // inside tiles only where it buys balance:
+  //   few tiles (< slots)            : stream-K, >= 4 K-tiles per workgroup (this is split-K for the deep 8x8 layers)
+  //   ragged mid-size, deep K        : stream-K over exactly `slots` workgroups
+  //   many tiles (>= 8 x slots)      : persistent, whole tiles per workgroup (tail imbalance < 1/8)
+  //   otherwise (shallow K)          : one workgroup per tile
+  //   (measured, MI355X round 1: the separate fix-up pass costs ~17 us per launch, so ranges are only cut inside
+  //    tiles when there are few tiles AND K is deep, or when the per-workgroup share is >= 160 K-tiles)
+  const long long share = (t.total + slots - 1) / slots;
+  if (t.tiles < slots / 2 && t.nkt >= 16) {
+    long long G = t.total / 8;
+    if (G < 1) G = 1;
+    if (G > slots) G = slots;
+    t.ipw = (int)((t.total + G - 1) / G);
+  } else if (t.tiles >= 8 * slots) {
+    t.ipw = ((t.tiles + slots - 1) / slots) * t.nkt;
+  } else if (share >= 160 && (t.tiles % slots) != 0) {
+    t.ipw = (int)share;
+  } else {
+    t.ipw = t.nkt;
   }
-  t.kt_per_split = (nkt + t.splits - 1) / t.splits;
-  t.splits = (nkt + t.kt_per_split - 1) / t.kt_per_split;
+  t.G = (int)((t.total + t.ipw - 1) / t.ipw);
+  t.fixup = (t.ipw % t.nkt) != 0;
   return t;
 }
 
 template <int BM, int BN, int WGM, int WGN, bool CONV, bool TRANS>
-hipError_t launch_cfg(const GemmParams& p, dim3 grid, hipStream_t s) {
+hipError_t launch_cfg(const GemmParams& p, const TilePlan& t, hipStream_t s) {
   constexpr int smem = 2 * (BM + BN) * ROW_BYTES;
   static bool attr_set = false;
   auto kern = gemm_kernel<BM, BN, WGM, WGN, CONV, TRANS>;
@@ -438,17 +522,83 @@ hipError_t launch_cfg(const GemmParams& p, dim3 grid, hipStream_t s) {
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, grid, dim3(256), smem, s, p);
+  hipLaunchKernelGGL(kern, dim3(t.G), dim3(256), smem, s, p);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  if (t.fixup) {
+    hipLaunchKernelGGL((gemm_fixup_kernel<BM, BN, WGM, WGN, TRANS>), dim3(t.tiles), dim3(256), 0, s, p);
+    e = hipGetLastError();
+  }
+  return e;
+}
+
+// ---- 8-wave kernel: host side ------------------------------------------------------------------------------
+constexpr size_t G8_HEADER_BYTES = 4096;     // flags[<=1023] + err word, ahead of the slabs
+
+int g_impl = -1;     // 8: deep-pipelined 8-wave kernel (default), 4: first-generation 4-wave kernel
+
+int gemm_impl() {
+  if (g_impl < 0) {
+    const char* e = getenv("UDT_GEMM_IMPL");
+    g_impl = (e && e[0] == '4') ? 4 : 8;
+  }
+  return g_impl;
+}
+
+bool use_gemm8(const udt_gemm_desc* d) { return gemm_impl() == 8 && d->N > 64; }
+
+TilePlan plan_tiles8(const udt_gemm_desc* d) {
+  TilePlan t;
+  const int batch = d->batch > 0 ? d->batch : 1;
+  const bool geglu_or_trans = (d->flags & (UDT_GEMM_TRANSPOSED | UDT_GEMM_GEGLU)) != 0;
+  t.bm = 256;
+  t.bn = (!geglu_or_trans && d->N % 160 == 0 && d->N % 128 != 0) ? 160 : 128;
+  t.tiles_m = (d->M + t.bm - 1) / t.bm;
+  t.tiles_n = (d->N + t.bn - 1) / t.bn;
+  t.tiles = t.tiles_m * t.tiles_n * batch;
+  t.nkt = d->K / BK;
+  t.total = (long long)t.tiles * t.nkt;
+  const int slots = resident_slots() / 2;          // one 8-wave workgroup per CU
+  long long G = t.total / 4;                       // >= 4 K-tiles per workgroup
+  if (G < 1) G = 1;
+  if (G > slots) G = slots;
+  t.ipw = (int)((t.total + G - 1) / G);
+  // shallow K (< 24 K-tiles): cutting a tile costs more (slab round trip + the finisher's wait) than the imbalance it
+  // removes — measured on MI355X: 2048x1280x1280 33.7 -> 28.6 us, 8192x640x640 32.4 -> 20.2 us with whole tiles
+  if (t.nkt < 24) t.ipw = ((t.ipw + t.nkt - 1) / t.nkt) * t.nkt;
+  t.G = (int)((t.total + t.ipw - 1) / t.ipw);
+  t.fixup = (t.ipw % t.nkt) != 0;
+  return t;
+}
+
+template <int WGM, int WGN, int TM, int TN, bool CONV, bool TRANS>
+hipError_t launch8(const g8::Params& pp, const TilePlan& t, hipStream_t s) {
+  constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
+  constexpr int smem = g8::NSTAGE * (BM + BN) * ROW_BYTES;
+  static bool attr_set = false;
+  auto kern = g8::gemm8_kernel<WGM, WGN, TM, TN, CONV, TRANS>;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(t.G), dim3(g8::NTHREADS), smem, s, pp);
   return hipGetLastError();
 }
 
 }  // namespace
 
 extern "C" size_t udt_gemm_workspace_bytes(const udt_gemm_desc* d) {
-  if (!d) return 0;
+  if (!d || d->K <= 0 || d->M <= 0 || d->N <= 0 || d->K % BK != 0) return 0;
+  if (use_gemm8(d)) {
+    TilePlan t8 = plan_tiles8(d);
+    if (!t8.fixup) return 0;
+    return G8_HEADER_BYTES + (size_t)t8.G * t8.bm * t8.bn * sizeof(float);
+  }
   TilePlan t = plan_tiles(d);
-  if (t.splits <= 1) return 0;
-  return (size_t)t.splits * (size_t)d->M * (size_t)d->N * sizeof(float);
+  if (!t.fixup) return 0;
+  return (size_t)t.G * 2 * SLAB_FLOATS * sizeof(float);
 }
 
 extern "C" int udt_gemm(const udt_gemm_desc* d, void* workspace, size_t workspace_bytes, void* stream) {
@@ -497,6 +647,7 @@ extern "C" int udt_gemm(const udt_gemm_desc* d, void* workspace, size_t workspac
   p.res = reinterpret_cast<const uint16_t*>(d->residual);
   p.rowvec = d->rowvec;
   p.out = d->out;
+  p.slabs = nullptr;
   p.M = d->M; p.N = d->N; p.K = d->K;
   p.lda = d->lda; p.ldo = d->ldo; p.ldr = d->ldr;
   p.ldw = d->ldw > 0 ? d->ldw : d->K;
@@ -508,46 +659,71 @@ extern "C" int udt_gemm(const udt_gemm_desc* d, void* workspace, size_t workspac
   p.ldrv = d->ld_rowvec > 0 ? d->ld_rowvec : d->N;
   p.flags = d->flags;
   p.alpha = d->alpha;
-  p.tiles_m = (d->M + t.bm - 1) / t.bm;
-  p.tiles_n = (d->N + t.bn - 1) / t.bn;
-  p.n_ktiles = d->K / BK;
-  p.kt_per_split = t.kt_per_split;
-  p.split_mode = t.splits > 1 ? 1 : 0;
-
-  if (p.split_mode) {
-    const size_t need = (size_t)t.splits * (size_t)d->M * (size_t)d->N * sizeof(float);
-    if (!workspace || workspace_bytes < need) return UDT_ERR_WORKSPACE;
-    p.out = workspace;
+  const int cls = (conv && d->ksize == 3) ? 0 : 1;
+  if (use_gemm8(d)) {
+    const TilePlan t8 = plan_tiles8(d);
+    p.tiles_m = t8.tiles_m; p.tiles_n = t8.tiles_n; p.tiles_per_batch = t8.tiles_m * t8.tiles_n;
+    p.n_ktiles = t8.nkt;
+    p.total_iters = t8.total;
+    p.iters_per_wg = t8.ipw;
+    p.G = t8.G;
+    g8::Params pp;
+    pp.g = p;
+    pp.flags = nullptr; pp.err = nullptr; pp.slab_base = nullptr;
+    if (t8.fixup) {
+      const size_t need = G8_HEADER_BYTES + (size_t)t8.G * t8.bm * t8.bn * sizeof(float);
+      if (!workspace || workspace_bytes < need) return UDT_ERR_WORKSPACE;
+      pp.flags = reinterpret_cast<int*>(workspace);
+      pp.err = pp.flags + 1023;
+      pp.slab_base = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + G8_HEADER_BYTES);
+    }
+    UdtProfScope prof8(cls, s);
+    if (prof8.rec) {
+      char tag[96];
+      snprintf(tag, sizeof(tag), "gemm8 M=%d N=%d K=%d conv=%d ks=%d fl=0x%x tile=%dx%d G=%d ipw=%d b=%d", d->M, d->N,
+               d->K, conv ? 1 : 0, d->ksize, d->flags, t8.bm, t8.bn, t8.G, t8.ipw, batch);
+      udt_prof_tag(prof8.rec, tag);
+    }
+    hipError_t e8;
+    if (t8.bn == 160) {
+      e8 = conv ? launch8<8, 1, 1, 5, true, false>(pp, t8, s) : launch8<8, 1, 1, 5, false, false>(pp, t8, s);
+    } else if (trans) {
+      e8 = launch8<4, 2, 2, 2, false, true>(pp, t8, s);
+    } else {
+      e8 = conv ? launch8<4, 2, 2, 2, true, false>(pp, t8, s) : launch8<4, 2, 2, 2, false, false>(pp, t8, s);
+    }
+    if (e8 != hipSuccess) return udt_set_hip_error(e8);
+    return UDT_OK;
   }
 
-  const int cls = (conv && d->ksize == 3) ? 0 : 1;
+  p.tiles_m = t.tiles_m; p.tiles_n = t.tiles_n; p.tiles_per_batch = t.tiles_m * t.tiles_n;
+  p.n_ktiles = t.nkt;
+  p.total_iters = t.total;
+  p.iters_per_wg = t.ipw;
+  p.G = t.G;
+
+  if (t.fixup) {
+    const size_t need = (size_t)t.G * 2 * SLAB_FLOATS * sizeof(float);
+    if (!workspace || workspace_bytes < need) return UDT_ERR_WORKSPACE;
+    p.slabs = reinterpret_cast<float*>(workspace);
+  }
+
   UdtProfScope prof(cls, s);
   if (prof.rec) {
     char tag[96];
-    snprintf(tag, sizeof(tag), "gemm M=%d N=%d K=%d conv=%d ks=%d fl=0x%x tile=%dx%d split=%d b=%d", d->M, d->N, d->K,
-             conv ? 1 : 0, d->ksize, d->flags, t.bm, t.bn, t.splits, batch);
+    snprintf(tag, sizeof(tag), "gemm M=%d N=%d K=%d conv=%d ks=%d fl=0x%x tile=%dx%d G=%d ipw=%d b=%d", d->M, d->N, d->K,
+             conv ? 1 : 0, d->ksize, d->flags, t.bm, t.bn, t.G, t.ipw, batch);
     udt_prof_tag(prof.rec, tag);
   }
 
-  dim3 grid(p.tiles_m * p.tiles_n, t.splits, batch);
   hipError_t e;
   if (t.bm == 256) {
-    e = conv ? launch_cfg<256, 64, 4, 1, true, false>(p, grid, s) : launch_cfg<256, 64, 4, 1, false, false>(p, grid, s);
+    e = conv ? launch_cfg<256, 64, 4, 1, true, false>(p, t, s) : launch_cfg<256, 64, 4, 1, false, false>(p, t, s);
   } else if (trans) {
-    e = launch_cfg<128, 128, 2, 2, false, true>(p, grid, s);
+    e = launch_cfg<128, 128, 2, 2, false, true>(p, t, s);
   } else {
-    e = conv ? launch_cfg<128, 128, 2, 2, true, false>(p, grid, s) : launch_cfg<128, 128, 2, 2, false, false>(p, grid, s);
+    e = conv ? launch_cfg<128, 128, 2, 2, true, false>(p, t, s) : launch_cfg<128, 128, 2, 2, false, false>(p, t, s);
   }
   if (e != hipSuccess) return udt_set_hip_error(e);
-
-  if (p.split_mode) {
-    GemmParams pf = p;
-    pf.out = d->out;
-    const long long total4 = (long long)d->M * (d->N / 4);
-    const int blocks = (int)((total4 + 255) / 256);
-    hipLaunchKernelGGL(splitk_finalize_kernel, dim3(blocks), dim3(256), 0, s,
-                       reinterpret_cast<const float*>(workspace), t.splits, pf);
-    UDT_CHECK_LAUNCH();
-  }
   return UDT_OK;
 }

@@ -1,0 +1,486 @@
+// gemm8.h — the 8-wave, deep-pipelined, persistent GEMM / implicit-conv kernel (included by gemm.hip).
+//
+// One workgroup = 512 threads = 8 waves owns a BM x BN output tile (256x128: waves 4x2, 64x64 each; or 256x160:
+// waves 8x1, 32x160 each — the latter tiles N = 320 without waste).  One workgroup per CU (G <= #CUs), all
+// co-resident, each walking an equal contiguous share of the (tile, K-tile) iteration space ("stream-K").
+//
+// Pipeline: a ring of THREE LDS stages (each BM+BN rows x 128 B, XOR-swizzled, filled by 16-byte LDS-DMA).  Loads run
+// two K-tiles ahead of the MFMAs and stay in flight across the workgroup barrier: the loop uses a raw s_barrier and a
+// COUNTED `s_waitcnt vmcnt(loads of one K-tile)` — never vmcnt(0) — so the only thing a K-tile waits for is data that
+// was requested two tiles ago (cdna_hip_programming.md §5 "Pipelining across barriers", T3+T4).  Two waves per SIMD
+// let one wave's ds_read / address work overlap the other's MFMAs.
+//
+// Stream-K finishing happens inside the launch: a workgroup whose range starts in the middle of a tile computes that
+// head segment FIRST, parks the fp32 accumulators in its slab and raises its flag (agent-scope release); the workgroup
+// that owns the START of the tile reaches it LAST in its range, polls the partner flags (relaxed poll, one agent-scope
+// acquire), adds the slabs and runs the fused epilogue.  Dependencies only point at work a partner does first, so
+// there is no wait chain; flags are reset by their consumer, the workspace is zero-initialised once by the caller.
+#pragma once
+
+namespace g8 {
+
+constexpr int NSTAGE = 3;
+constexpr int NTHREADS = 512;
+constexpr int SPIN_LIMIT = 1 << 24;
+constexpr bool USE_SETPRIO = false;
+
+struct Params {
+  GemmParams g;          // operand / epilogue description shared with the 4-wave kernel
+  int* flags;            // [G] slab-ready flags (0 / 1), zero between launches
+  int* err;              // [1] set to 1 if a spin timed out
+  float* slab_base;      // [G][BM*BN] fp32
+};
+
+template <int TM, int TN, bool TRANS>
+UDT_DEVINL void epilogue8(const GemmParams& p, f32x16 (&acc)[TM][TN], int m0, int n0, int batch, int row0, int col0,
+                          int lane) {
+  const int l31 = lane & 31;
+  const int hi = lane >> 5;
+  const int flags = p.flags;
+  if constexpr (TRANS) {
+    uint16_t* outT = reinterpret_cast<uint16_t*>(p.out);
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) {
+        const int n = n0 + col0 + tn * 32 + l31;
+        const float bias = (p.bias != nullptr && n < p.N) ? p.bias[n] : 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int m = m0 + row0 + tm * 32 + q * 8 + hi * 4;
+          if (m < p.M && n < p.N) {
+            const int b = m / p.rows_per_batch;
+            const int tok = m - b * p.rows_per_batch;
+            const float v0 = acc[tm][tn][q * 4 + 0] * p.alpha + bias;
+            const float v1 = acc[tm][tn][q * 4 + 1] * p.alpha + bias;
+            const float v2 = acc[tm][tn][q * 4 + 2] * p.alpha + bias;
+            const float v3 = acc[tm][tn][q * 4 + 3] * p.alpha + bias;
+            u32x2 pk = {pack_bf16x2(v0, v1), pack_bf16x2(v2, v3)};
+            const long long off = ((long long)b * p.N + n) * p.rows_per_batch + tok;
+            *reinterpret_cast<u32x2*>(outT + off) = pk;
+          }
+        }
+      }
+  } else {
+    const uint16_t* __restrict__ R = p.res ? (p.res + (long long)batch * p.sR) : nullptr;
+    if (flags & UDT_GEMM_GEGLU) {
+      if constexpr (TN == 2) {
+        uint16_t* out = reinterpret_cast<uint16_t*>(p.out) + (long long)batch * p.sO;
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) {
+          const int m = m0 + row0 + tm * 32 + l31;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int nx = n0 + col0 + q * 8 + hi * 4;
+            const int no = ((n0 + col0) >> 1) + q * 8 + hi * 4;
+            if (m < p.M && nx < p.N) {
+              float o[4];
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                float x = acc[tm][0][q * 4 + r] * p.alpha;
+                float gt = acc[tm][1][q * 4 + r] * p.alpha;
+                if (p.bias) {
+                  x += p.bias[nx + r];
+                  gt += p.bias[nx + 32 + r];
+                }
+                o[r] = x * gelu_erf_f(gt);
+              }
+              u32x2 pk = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
+              *reinterpret_cast<u32x2*>(out + (long long)m * p.ldo + no) = pk;
+            }
+          }
+        }
+      }
+      return;
+    }
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+      const int m = m0 + row0 + tm * 32 + l31;
+      const int b = (p.rowvec != nullptr) ? (m / p.rows_per_batch) : 0;
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int n = n0 + col0 + tn * 32 + q * 8 + hi * 4;
+          if (m < p.M && n < p.N) {
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = acc[tm][tn][q * 4 + r] * p.alpha;
+            if (p.bias) {
+              const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + n);
+#pragma unroll
+              for (int r = 0; r < 4; ++r) v[r] += bv[r];
+            }
+            if (p.rowvec) {
+              const f32x4 rv = *reinterpret_cast<const f32x4*>(p.rowvec + (long long)b * p.ldrv + n);
+#pragma unroll
+              for (int r = 0; r < 4; ++r) v[r] += rv[r];
+            }
+            if (R) {
+              const u32x2 rr = *reinterpret_cast<const u32x2*>(R + (long long)m * p.ldr + n);
+              v[0] += bf16_lo(rr[0]);
+              v[1] += bf16_hi(rr[0]);
+              v[2] += bf16_lo(rr[1]);
+              v[3] += bf16_hi(rr[1]);
+            }
+            if (flags & UDT_GEMM_RELU) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+            }
+            if (flags & UDT_GEMM_SILU_OUT) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) v[r] = silu_f(v[r]);
+            }
+            if (flags & UDT_GEMM_OUT_F32) {
+              float* out = reinterpret_cast<float*>(p.out) + (long long)batch * p.sO;
+              f32x4 ov = {v[0], v[1], v[2], v[3]};
+              *reinterpret_cast<f32x4*>(out + (long long)m * p.ldo + n) = ov;
+            } else {
+              uint16_t* out = reinterpret_cast<uint16_t*>(p.out) + (long long)batch * p.sO;
+              u32x2 pk = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+              *reinterpret_cast<u32x2*>(out + (long long)m * p.ldo + n) = pk;
+            }
+          }
+        }
+    }
+  }
+}
+
+UDT_DEVINL void raw_barrier() {
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
+template <int N>
+UDT_DEVINL void wait_vmcnt() {
+  if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+  else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  else if constexpr (N == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+  else static_assert(N == 0, "add the immediate");
+}
+
+// WGM x WGN waves, each TM x TN MFMA tiles of 32x32
+template <int WGM, int WGN, int TM, int TN, bool CONV, bool TRANS>
+__global__ void __launch_bounds__(NTHREADS) gemm8_kernel(const Params pp) {
+  static_assert(WGM * WGN == 8, "8 waves per workgroup");
+  constexpr int BM = WGM * TM * 32;
+  constexpr int BN = WGN * TN * 32;
+  static_assert(BM == 256, "A staging assumes 32 pieces");
+  constexpr int A_BYTES = BM * ROW_BYTES;
+  constexpr int B_BYTES = BN * ROW_BYTES;
+  constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
+  constexpr int A_INSTR = 4;                       // 32 pieces / 8 waves
+  constexpr int B_PIECES = BN / 8;                 // 16 or 20
+  constexpr int B_INSTR_MAX = (B_PIECES + 7) / 8;  // 2 or 3
+  constexpr bool B_UNEVEN = (B_PIECES % 8) != 0;   // waves < B_PIECES % 8 carry one piece more
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const GemmParams& p = pp.g;
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = tid & 63;
+  const int l31 = lane & 31;
+  const int hi = lane >> 5;
+  const int l3 = lane >> 3;
+  const int pslot = lane & 7;
+  const int wm = wave / WGN;
+  const int wn = wave - wm * WGN;
+  const int row0 = wm * TM * 32;
+  const int col0 = wn * TN * 32;
+  const int swz = (l31 >> 1) & 7;
+  const int a_frag_row = (row0 + l31) * ROW_BYTES;
+  const int b_frag_row = (col0 + l31) * ROW_BYTES;
+  const bool b_extra = B_UNEVEN && (wave < (B_PIECES % 8));      // wave-uniform
+  const bool lag = wave >= 4;                                    // second wave of each SIMD (wave-uniform)
+
+  const int g = range_index(blockIdx.x, p.G);
+  long long it = (long long)g * p.iters_per_wg;
+  long long it_end = it + p.iters_per_wg;
+  if (it_end > p.total_iters) it_end = p.total_iters;
+  if (it >= it_end) return;
+
+  const int Ctot = p.C1 + p.C2;
+  const int Hv = p.Hin << p.ups;
+  const int Wv = p.Win << p.ups;
+
+  // ---- per-lane staging state of the current segment ----------------------------------------------------
+  const uint16_t* A = nullptr;
+  const uint16_t* W = nullptr;
+  int a_koff[A_INSTR];
+  long long a_rowoff[A_INSTR];
+  int a_iy0[A_INSTR], a_ix0[A_INSTR], a_pixb[A_INSTR];
+  long long w_rowoff[B_INSTR_MAX];
+  int w_koff[B_INSTR_MAX];
+#pragma unroll
+  for (int i = 0; i < A_INSTR; ++i) {
+    const int row = (wave * A_INSTR + i) * 8 + l3;
+    a_koff[i] = (pslot ^ ((row >> 1) & 7)) * 8;
+  }
+#pragma unroll
+  for (int i = 0; i < B_INSTR_MAX; ++i) {
+    const int row = (wave + 8 * i) * 8 + l3;               // piece index wave + 8*i
+    w_koff[i] = (pslot ^ ((row >> 1) & 7)) * 8;
+  }
+
+  auto prepare = [&](int batch, int m0, int n0) {
+    A = p.a + (long long)batch * p.sA;
+    W = p.w + (long long)batch * p.sW;
+#pragma unroll
+    for (int i = 0; i < A_INSTR; ++i) {
+      const int m = m0 + (wave * A_INSTR + i) * 8 + l3;
+      if constexpr (CONV) {
+        const int hw = p.Hout * p.Wout;
+        const int b = m / hw;
+        const int rem = m - b * hw;
+        const int oy = rem / p.Wout;
+        const int ox = rem - oy * p.Wout;
+        a_pixb[i] = b * p.Hin * p.Win;
+        a_iy0[i] = (m < p.M) ? (oy * p.stride - p.pad_t) : -100000;
+        a_ix0[i] = ox * p.stride - p.pad_l;
+        a_rowoff[i] = 0;
+      } else {
+        a_rowoff[i] = (m < p.M) ? (long long)m * p.lda : -1;
+        a_iy0[i] = a_ix0[i] = a_pixb[i] = 0;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < B_INSTR_MAX; ++i) {
+      const int n = n0 + (wave + 8 * i) * 8 + l3;
+      w_rowoff[i] = (n < p.N) ? (long long)n * p.ldw : -1;
+    }
+  };
+
+  auto stage = [&](int st, int kt) {
+    char* abuf = smem + st * STAGE_BYTES;
+    char* bbuf = abuf + A_BYTES;
+    const int k0 = kt * BK;
+    if constexpr (CONV) {
+      const int tap = k0 / Ctot;
+      const int c0 = k0 - tap * Ctot;
+      const int ky = tap / p.ksz;
+      const int kx = tap - ky * p.ksz;
+      const bool second = c0 >= p.C1;
+      const uint16_t* src = second ? p.a2 : A;
+      const int cs = second ? p.C2 : p.C1;
+      const int cc = second ? (c0 - p.C1) : c0;
+#pragma unroll
+      for (int i = 0; i < A_INSTR; ++i) {
+        const int iy = a_iy0[i] + ky;
+        const int ix = a_ix0[i] + kx;
+        const bool ok = ((unsigned)iy < (unsigned)Hv) && ((unsigned)ix < (unsigned)Wv);
+        const long long pix = (long long)a_pixb[i] + (long long)(iy >> p.ups) * p.Win + (ix >> p.ups);
+        const uint16_t* gp = ok ? (src + pix * cs + cc + a_koff[i]) : p.zero;
+        glds16(gp, abuf + (wave * A_INSTR + i) * 1024);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < A_INSTR; ++i) {
+        const uint16_t* gp = (a_rowoff[i] >= 0) ? (A + a_rowoff[i] + k0 + a_koff[i]) : p.zero;
+        glds16(gp, abuf + (wave * A_INSTR + i) * 1024);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < B_INSTR_MAX; ++i) {
+      if (i < B_PIECES / 8 || b_extra) {                           // wave-uniform
+        const uint16_t* gp = (w_rowoff[i] >= 0) ? (W + w_rowoff[i] + k0 + w_koff[i]) : p.zero;
+        glds16(gp, bbuf + (wave + 8 * i) * 1024);
+      }
+    }
+  };
+
+  // wait until this wave's loads of the OLDEST in-flight K-tile have landed, leaving one K-tile in flight
+  auto wait_one_tile_left = [&]() {
+    if constexpr (B_UNEVEN) {
+      if (b_extra) wait_vmcnt<A_INSTR + B_INSTR_MAX>();
+      else wait_vmcnt<A_INSTR + B_INSTR_MAX - 1>();
+    } else {
+      wait_vmcnt<A_INSTR + B_INSTR_MAX>();
+    }
+  };
+
+  int tile = (int)(it / p.n_ktiles);
+  int kt0 = (int)(it - (long long)tile * p.n_ktiles);
+  int batch, m0, n0;
+  decode_tile<BM, BN>(p, tile, batch, m0, n0);
+  prepare(batch, m0, n0);
+  {
+    int kt1 = p.n_ktiles;
+    if ((long long)(kt1 - kt0) > it_end - it) kt1 = kt0 + (int)(it_end - it);
+    stage(0, kt0);
+    if (kt0 + 1 < kt1) stage(1, kt0 + 1);
+  }
+
+  while (true) {
+    int kt1 = p.n_ktiles;
+    if ((long long)(kt1 - kt0) > it_end - it) kt1 = kt0 + (int)(it_end - it);
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    bf16x8_t fx[4][TM], fw[4][TN];        // one K-tile of MFMA operands (4 k-steps)
+    auto read_all = [&](const char* abuf, const char* bbuf) {
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const int slot = ((ks * 2 + hi) ^ swz) << 4;
+#pragma unroll
+        for (int t = 0; t < TM; ++t) fx[ks][t] = lds_read_frag(abuf + a_frag_row + t * 32 * ROW_BYTES + slot);
+#pragma unroll
+        for (int t = 0; t < TN; ++t) fw[ks][t] = lds_read_frag(bbuf + b_frag_row + t * 32 * ROW_BYTES + slot);
+      }
+    };
+    auto mfma_all = [&]() {
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+          for (int tn = 0; tn < TN; ++tn) {
+            if constexpr (TRANS)
+              acc[tm][tn] = mfma32(fx[ks][tm], fw[ks][tn], acc[tm][tn]);
+            else
+              acc[tm][tn] = mfma32(fw[ks][tn], fx[ks][tm], acc[tm][tn]);
+          }
+    };
+    // ---- K loop: tiles kt and kt+1 are in flight on entry of iteration kt -------------------------------
+    // Role split between the two waves of a SIMD (waves w and w+4 share one): the "lead" half reads a K-tile's
+    // fragments and then issues its MFMAs; the "lag" half reads the same tile's fragments one MFMA block later,
+    // i.e. it issues the MFMAs of the PREVIOUS K-tile (operands held in registers across the barrier) while the
+    // lead half is reading.  On every SIMD one wave is in its LDS phase while the other is in its MFMA phase, so the
+    // matrix pipe does not wait for ds_read latency (the lock-step version lost ~60 % of its cycles there).
+    // Both halves execute exactly one barrier per K-tile; the two loops are kept separate so that each has
+    // straight-line control flow (a shared loop with a role branch made hipcc duplicate and spill accumulators).
+    int st = 0;
+    auto iter_head = [&](int kt) {
+      if (kt + 1 < kt1) wait_one_tile_left();
+      else wait_vmcnt<0>();
+      raw_barrier();                     // tile kt visible to all waves; stage (st+2)%3 no longer being read
+      int st2 = st + 2;
+      if (st2 >= NSTAGE) st2 -= NSTAGE;
+      if (kt + 2 < kt1) stage(st2, kt + 2);
+    };
+    auto advance = [&]() {
+      st = st + 1;
+      if (st >= NSTAGE) st = 0;
+    };
+    if (!lag) {
+      for (int kt = kt0; kt < kt1; ++kt) {
+        iter_head(kt);
+        const char* abuf = smem + st * STAGE_BYTES;
+        read_all(abuf, abuf + A_BYTES);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_all();
+        advance();
+      }
+    } else {
+      {
+        iter_head(kt0);
+        const char* abuf = smem + st * STAGE_BYTES;
+        read_all(abuf, abuf + A_BYTES);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // operands in registers before the stage is recycled
+        advance();
+      }
+      for (int kt = kt0 + 1; kt < kt1; ++kt) {
+        iter_head(kt);
+        mfma_all();                                          // previous K-tile
+        __builtin_amdgcn_sched_barrier(0);
+        const char* abuf = smem + st * STAGE_BYTES;
+        read_all(abuf, abuf + A_BYTES);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        advance();
+      }
+      mfma_all();
+    }
+
+    const bool full = (kt0 == 0) && (kt1 == p.n_ktiles);
+    const bool publish = (kt0 > 0);                       // head segment of a tile another workgroup started
+    const int cur_tile = tile, cur_batch = batch, cur_m0 = m0, cur_n0 = n0;
+    it += kt1 - kt0;
+    const bool more = it < it_end;
+    if (more) {
+      // prefetch the next segment's first two K-tiles before finishing this one
+      raw_barrier();                                      // every wave is done reading the ring
+      tile = (int)(it / p.n_ktiles);
+      kt0 = (int)(it - (long long)tile * p.n_ktiles);
+      decode_tile<BM, BN>(p, tile, batch, m0, n0);
+      prepare(batch, m0, n0);
+      int nk1 = p.n_ktiles;
+      if ((long long)(nk1 - kt0) > it_end - it) nk1 = kt0 + (int)(it_end - it);
+      stage(0, kt0);
+      if (kt0 + 1 < nk1) stage(1, kt0 + 1);
+    }
+
+    if (publish) {
+      // park the accumulators: slab[g][(tm*TN+tn)*4+q][tid] float4 (coalesced 8 KiB per unit), then raise the flag
+      f32x4* slab = reinterpret_cast<f32x4*>(pp.slab_base + (long long)g * (BM * BN));
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            f32x4 v = {acc[tm][tn][q * 4 + 0], acc[tm][tn][q * 4 + 1], acc[tm][tn][q * 4 + 2],
+                       acc[tm][tn][q * 4 + 3]};
+            slab[((tm * TN + tn) * 4 + q) * NTHREADS + tid] = v;
+          }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // every storing wave drains its stores
+      __syncthreads();
+      if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(pp.flags + g, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      if (more) {
+        // the drain above also retired the prefetch; nothing else to do (its data is simply already there)
+      }
+    } else {
+      if (!full) {
+        // this workgroup owns the start of the tile: collect the partners' slabs
+        const long long tile_end = ((long long)cur_tile + 1) * p.n_ktiles;
+        const int g_last = (int)((tile_end - 1) / p.iters_per_wg);
+        if (tid == 0) {
+          for (int pg = g + 1; pg <= g_last; ++pg) {
+            int spins = 0;
+            while (__hip_atomic_load(pp.flags + pg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+              __builtin_amdgcn_s_sleep(8);
+              if (++spins > SPIN_LIMIT) {
+                __hip_atomic_store(pp.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+              }
+            }
+          }
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        __syncthreads();
+        for (int pg = g + 1; pg <= g_last; ++pg) {
+          const f32x4* slab = reinterpret_cast<const f32x4*>(pp.slab_base + (long long)pg * (BM * BN));
+#pragma unroll
+          for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                const f32x4 v = slab[((tm * TN + tn) * 4 + q) * NTHREADS + tid];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[tm][tn][q * 4 + r] += v[r];
+              }
+        }
+        __syncthreads();
+        if (tid == 0)
+          for (int pg = g + 1; pg <= g_last; ++pg)
+            __hip_atomic_store(pp.flags + pg, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      epilogue8<TM, TN, TRANS>(p, acc, cur_m0, cur_n0, cur_batch, row0, col0, lane);
+    }
+    if (!more) break;
+  }
+}
+
+}  // namespace g8

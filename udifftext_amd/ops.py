@@ -31,7 +31,8 @@ def _ws(nbytes: int, device) -> torch.Tensor:
     key = (device.type, device.index)
     buf = _workspace.get(key)
     if buf is None or buf.numel() < nbytes:
-        buf = torch.empty(max(nbytes, 64 << 20), dtype=torch.uint8, device=device)
+        # zero-initialised: the stream-K kernels keep 'slab ready' flags in the first 4 KiB and restore them to 0
+        buf = torch.zeros(max(nbytes, 96 << 20), dtype=torch.uint8, device=device)
         _workspace[key] = buf
     return buf
 
