@@ -131,6 +131,15 @@ CONV_CASES = [
     (2, 8, 8, 1280, 1280, 1280, 3, 1, (1, 1), False),    # deep, split-K
     (2, 16, 16, 640, 320, 320, 1, 1, (0, 0), False),     # 1x1 skip on a concat
     (1, 24, 40, 128, 0, 4, 3, 1, (1, 1), False),         # narrow output, non-square
+    # patch-staged kernel (conv3p): 32x8, 16x16 and 4x(8x8) spatial tiles, bn 128 / 160, stream-K splits
+    (2, 8, 8, 1280, 0, 1280, 3, 1, (1, 1), False),       # 8x8 maps, image group only half full (B=2 of 4)
+    (8, 8, 8, 640, 0, 1280, 3, 1, (1, 1), False),
+    (5, 8, 8, 128, 0, 320, 3, 1, (1, 1), False),         # ragged image groups, bn 160
+    (1, 64, 64, 320, 0, 320, 3, 1, (1, 1), False),
+    (2, 32, 32, 640, 0, 640, 3, 1, (1, 1), False),
+    (3, 16, 16, 1280, 0, 1280, 3, 1, (1, 1), False),
+    (1, 32, 64, 128, 0, 128, 3, 1, (1, 1), False),       # non-square, VAE-like
+    (1, 16, 32, 192, 0, 256, 3, 1, (1, 1), False),       # 3 chunks
 ]
 
 

@@ -1,0 +1,428 @@
+// conv3p.h — 3x3 / stride-1 / pad-1 convolution with LDS-staged input patches (included by gemm.hip).
+//
+// Why: the implicit-GEMM kernels are bound by the global->LDS fill rate (PMC: MFMA busy 46 %, zero bank conflicts,
+// ~42 GB/s of LDS-DMA per CU), and a 3x3 convolution streams the SAME activation rows through LDS nine times, once per
+// tap.  Here a workgroup owns a spatial block of 256 output pixels (32x8, 16x16 or four 8x8 images) x BN output
+// channels and, per 64-channel chunk, stages the input patch INCLUDING ITS HALO once (<= 400 pixel rows x 128 B);
+// the nine taps are nine K-tiles that read their A fragments from that patch at shifted row offsets, so only the
+// weight tile (BN x 128 B) is fetched per K-tile: ~2.3x less LDS fill per MFMA than the gather formulation.
+//
+// Everything else is the 8-wave machinery of gemm8.h: 3-stage weight ring + double-buffered patch, counted vmcnt
+// across raw barriers, lead/lag wave roles, persistent stream-K ranges over (tile, chunk, tap) with in-kernel finishing.
+// K order inside a tile is (chunk, tap); the packed weight layout k = tap*C + c is unchanged.
+#pragma once
+#include <type_traits>
+
+namespace c3p {
+
+using g8::NSTAGE;
+using g8::NTHREADS;
+using g8::Params;
+using g8::raw_barrier;
+
+constexpr int PATCH_ROWS = 400;                    // max pixel rows of a staged patch (4 x 10 x 10)
+constexpr int PATCH_BYTES = PATCH_ROWS * ROW_BYTES;
+constexpr int MAX_PATCH_PIECES = PATCH_ROWS / 8;   // 50 pieces of 8 rows -> at most 7 per wave
+
+struct Geo {            // spatial tiling of the output (= input) map
+  int TW, TH, NI;       // tile width / height in pixels, images per tile (TW*TH*NI == 256)
+  int tiles_x, tiles_y; // tiles per image row / column
+  int img_groups;       // ceil(B / NI)
+  int B, H, W, C;
+  int prow_w;           // TW + 2
+  int prows_img;        // (TH + 2) * (TW + 2)
+  int n_pieces;         // ceil(NI * prows_img / 8)
+  int chunks;           // C / 64
+};
+
+struct CParams {
+  Params base;
+  Geo geo;
+  unsigned a_bytes, w_bytes;     // buffer-descriptor extents of the activation tensor / weight matrix
+};
+
+UDT_DEVINL void wait_vmcnt_dyn(int n) {          // n is wave-uniform
+  switch (n) {
+    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+    case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+    case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+    case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+    case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+    case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+    case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+    case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+    case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+    case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+  }
+}
+
+// epilogue with an explicit output-row table: mrow[tm] = global NHWC pixel index of this lane's row, or -1
+template <int TM, int TN>
+UDT_DEVINL void epilogue_rows(const GemmParams& p, f32x16 (&acc)[TM][TN], const long long (&mrow)[TM], int n0, int col0,
+                              int lane) {
+  const int hi = lane >> 5;
+  const int flags = p.flags;
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm) {
+    const long long m = mrow[tm];
+    if (m < 0) continue;
+    const int b = (p.rowvec != nullptr) ? (int)(m / p.rows_per_batch) : 0;
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int n = n0 + col0 + tn * 32 + q * 8 + hi * 4;
+        if (n < p.N) {
+          float v[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = acc[tm][tn][q * 4 + r] * p.alpha;
+          if (p.bias) {
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + n);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] += bv[r];
+          }
+          if (p.rowvec) {
+            const f32x4 rv = *reinterpret_cast<const f32x4*>(p.rowvec + (long long)b * p.ldrv + n);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] += rv[r];
+          }
+          if (p.res) {
+            const u32x2 rr = *reinterpret_cast<const u32x2*>(p.res + m * p.ldr + n);
+            v[0] += bf16_lo(rr[0]);
+            v[1] += bf16_hi(rr[0]);
+            v[2] += bf16_lo(rr[1]);
+            v[3] += bf16_hi(rr[1]);
+          }
+          if (flags & UDT_GEMM_RELU) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+          }
+          if (flags & UDT_GEMM_SILU_OUT) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = silu_f(v[r]);
+          }
+          if (flags & UDT_GEMM_OUT_F32) {
+            f32x4 ov = {v[0], v[1], v[2], v[3]};
+            *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + m * p.ldo + n) = ov;
+          } else {
+            u32x2 pk = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+            *reinterpret_cast<u32x2*>(reinterpret_cast<uint16_t*>(p.out) + m * p.ldo + n) = pk;
+          }
+        }
+      }
+  }
+}
+
+template <int N>
+UDT_DEVINL void wait_vm() {
+  static_assert(N >= 0 && N <= 10, "immediate");
+  if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if constexpr (N == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+  if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+  if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+  if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  if constexpr (N == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+  if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  if constexpr (N == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+  if constexpr (N == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+}
+
+UDT_DEVINL void buf_lds16(__amdgpu_buffer_rsrc_t rsrc, void* lds_wave_base, unsigned voff, int soff) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voff, soff,
+                                           0, 0);
+}
+
+constexpr unsigned OOB = 0x80000000u;      // voffset beyond num_records: the buffer load returns zeros (padding)
+constexpr int PP = 7;                      // patch pieces per wave and chunk (padded with duplicate pieces)
+
+// WGM x WGN waves, each TM x TN MFMA tiles of 32x32; BM = 256 output pixels.
+// The stream-K iteration unit is one 64-channel CHUNK (= 9 K-tiles, one per tap): ranges never cut a chunk, so the tap
+// loop is fully unrolled — stage indices, tap offsets and every s_waitcnt immediate are compile-time constants, and the
+// per-K-tile address work is one scalar offset per load (buffer descriptors: uniform base + per-lane voffset fixed for
+// the whole tile + scalar soffset per K-tile; out-of-image halo pixels use an out-of-range voffset and read zeros).
+template <int WGM, int WGN, int TM, int TN>
+__global__ void __launch_bounds__(NTHREADS) conv3p_kernel(const CParams cp) {
+  static_assert(WGM * WGN == 8 && WGM * TM * 32 == 256, "8 waves, 256 output pixels");
+  constexpr int BN = WGN * TN * 32;
+  constexpr int W_BYTES = BN * ROW_BYTES;
+  constexpr int W_PIECES = BN / 8;                  // 16 or 20
+  constexpr int NWP = (W_PIECES + 7) / 8;           // weight pieces per wave and K-tile (2 or 3, padded with duplicates)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const wring = smem;                              // NSTAGE weight stages
+  char* const patches = smem + NSTAGE * W_BYTES;         // 2 patch stages
+
+  const GemmParams& p = cp.base.g;
+  const Geo& ge = cp.geo;
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = tid & 63;
+  const int l31 = lane & 31;
+  const int hi = lane >> 5;
+  const int l3 = lane >> 3;
+  const int pslot = lane & 7;
+  const int wm = wave / WGN;
+  const int wn = wave - wm * WGN;
+  const int row0 = wm * TM * 32;
+  const int col0 = wn * TN * 32;
+  const int swz_w = (l31 >> 1) & 7;
+  const int w_frag_row = (col0 + l31) * ROW_BYTES;
+  const int chunks = p.n_ktiles;                         // iteration unit: chunk
+
+  const int g = range_index(blockIdx.x, p.G);
+  long long it = (long long)g * p.iters_per_wg;
+  long long it_end = it + p.iters_per_wg;
+  if (it_end > p.total_iters) it_end = p.total_iters;
+  if (it >= it_end) return;
+
+  const __amdgpu_buffer_rsrc_t rsrc_w =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.w), 0, cp.w_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_a =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.a), 0, cp.a_bytes, 0x00020000);
+
+  // ---- per-lane state of the current tile ------------------------------------------------------------------
+  // piece index of load i of this wave: wave + 8*i, wrapped back by multiples of 8 when past the last piece (the
+  // duplicate re-writes identical bytes; it keeps the number of loads per wave uniform = compile-time wait counts)
+  int w_piece[NWP];
+  unsigned w_voff[NWP];
+#pragma unroll
+  for (int i = 0; i < NWP; ++i) {
+    int idx = wave + 8 * i;
+    while (idx >= W_PIECES) idx -= 8;
+    w_piece[i] = idx;
+  }
+  int p_piece[PP];
+  unsigned p_voff[PP];
+#pragma unroll
+  for (int i = 0; i < PP; ++i) {
+    int idx = wave + 8 * i;
+    while (idx >= ge.n_pieces) idx -= 8;
+    p_piece[i] = idx;
+  }
+  int a_prow[TM];                      // patch row of this lane's output pixel at tap (0,0)
+  long long mrow[TM];                  // global output pixel index of this lane's rows (epilogue)
+
+  auto prepare = [&](int tile_m, int n0) {
+    const int per_img = ge.tiles_x * ge.tiles_y;
+    const int ig = tile_m / per_img;
+    const int r = tile_m - ig * per_img;
+    const int ty = r / ge.tiles_x;
+    const int tx = r - ty * ge.tiles_x;
+    const int y0 = ty * ge.TH, x0 = tx * ge.TW, b0 = ig * ge.NI;
+#pragma unroll
+    for (int i = 0; i < NWP; ++i) {
+      const int row = w_piece[i] * 8 + l3;
+      const int koff = (pslot ^ ((row >> 1) & 7)) * 8;
+      const int n = n0 + row;
+      w_voff[i] = (n < p.N) ? (unsigned)(((long long)n * p.ldw + koff) * 2) : OOB;
+    }
+#pragma unroll
+    for (int i = 0; i < PP; ++i) {
+      const int prow = p_piece[i] * 8 + l3;
+      const int koff = (pslot ^ ((prow >> 1) & 7)) * 8;
+      const int img = prow / ge.prows_img;
+      const int rem = prow - img * ge.prows_img;
+      const int yy = rem / ge.prow_w;
+      const int xx = rem - yy * ge.prow_w;
+      const int gy = y0 + yy - 1, gx = x0 + xx - 1, b = b0 + img;
+      const bool ok = (img < ge.NI) && (b < ge.B) && ((unsigned)gy < (unsigned)ge.H) && ((unsigned)gx < (unsigned)ge.W);
+      p_voff[i] = ok ? (unsigned)(((((long long)b * ge.H + gy) * ge.W + gx) * ge.C + koff) * 2) : OOB;
+    }
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+      const int ml = row0 + tm * 32 + l31;
+      const int per = ge.TW * ge.TH;
+      const int img = ml / per;
+      const int rem = ml - img * per;
+      const int py = rem / ge.TW;
+      const int px = rem - py * ge.TW;
+      a_prow[tm] = img * ge.prows_img + py * ge.prow_w + px;
+      const int b = b0 + img;
+      mrow[tm] = (b < ge.B) ? (((long long)b * ge.H + (y0 + py)) * ge.W + (x0 + px)) : -1;
+    }
+  };
+
+  auto issue_w = [&](int st, int c, int tap) {
+    const int soff = (tap * ge.C + c * 64) * 2;
+    char* wbuf = wring + st * W_BYTES;
+#pragma unroll
+    for (int i = 0; i < NWP; ++i) buf_lds16(rsrc_w, wbuf + w_piece[i] * 1024, w_voff[i], soff);
+  };
+  auto issue_patch = [&](int c) {
+    char* pbuf = patches + (c & 1) * PATCH_BYTES;
+    const int soff = c * 128;
+#pragma unroll
+    for (int i = 0; i < PP; ++i) buf_lds16(rsrc_a, pbuf + p_piece[i] * 1024, p_voff[i], soff);
+  };
+
+  int tile = (int)(it / chunks);
+  int c0 = (int)(it - (long long)tile * chunks);
+  int tile_n = tile / p.tiles_m;
+  int tile_m = tile - tile_n * p.tiles_m;
+  int n0 = tile_n * BN;
+  prepare(tile_m, n0);
+  issue_patch(c0);
+  issue_w(0, c0, 0);
+  issue_w(1, c0, 1);
+
+  while (true) {
+    int c1 = chunks;
+    if ((long long)(c1 - c0) > it_end - it) c1 = c0 + (int)(it_end - it);
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int k = 0; k < TN; ++k)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][k][r] = 0.f;
+
+    bf16x8_t fx[4][TM], fw[4][TN];
+    auto mfma_all = [&]() {
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+          for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = mfma32(fw[ks][tn], fx[ks][tm], acc[tm][tn]);
+    };
+
+    // One K-tile step.  DX (= tap % 3 = weight-ring stage) is compile time, dy (tap / 3) is a run-time loop index:
+    // wait for W(c,tap) [+ the patch at tap 0], barrier, keep two K-tiles of weights in flight, request the next
+    // chunk's patch at tap 0.
+    auto head = [&](auto dx_c, int c, int dy, bool nxt) {
+      constexpr int DX = decltype(dx_c)::value;
+      const int tap = dy * 3 + DX;
+      if (DX == 2 && dy == 2) {                                   // tap 8: next weights belong to the next chunk
+        if (nxt) wait_vm<NWP>(); else wait_vm<0>();
+      } else if (DX != 0 && dy == 0 && nxt) {                     // taps 1, 2: the patch requested at tap 0 may be in flight
+        wait_vm<NWP + PP>();
+      } else {
+        wait_vm<NWP>();
+      }
+      raw_barrier();
+      if (tap <= 6) issue_w((DX + 2) % 3, c, tap + 2);
+      else if (nxt) issue_w((DX + 2) % 3, c + 1, tap + 2 - 9);
+      if (DX == 0 && dy == 0 && nxt) issue_patch(c + 1);
+    };
+    auto read_all = [&](auto dx_c, int c, int dy) {
+      constexpr int DX = decltype(dx_c)::value;
+      const char* pbuf = patches + (c & 1) * PATCH_BYTES;
+      const char* wbuf = wring + DX * W_BYTES;
+      int arow[TM], aswz[TM];
+#pragma unroll
+      for (int t = 0; t < TM; ++t) {
+        const int prow = a_prow[t] + dy * ge.prow_w + DX;
+        arow[t] = prow * ROW_BYTES;
+        aswz[t] = (prow >> 1) & 7;
+      }
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+        for (int t = 0; t < TM; ++t) fx[ks][t] = lds_read_frag(pbuf + arow[t] + (((ks * 2 + hi) ^ aswz[t]) << 4));
+        const int slot = ((ks * 2 + hi) ^ swz_w) << 4;
+#pragma unroll
+        for (int t = 0; t < TN; ++t) fw[ks][t] = lds_read_frag(wbuf + w_frag_row + t * 32 * ROW_BYTES + slot);
+      }
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+    // (the lead/lag wave-role split of gemm8.h measured no gain once the per-K-tile instruction overhead was gone, and
+    //  holding a K-tile of operands across the barrier cost spills here — all waves run the same straight loop)
+    for (int c = c0; c < c1; ++c) {
+      const bool nxt = (c + 1 < c1);
+      for (int dy = 0; dy < 3; ++dy) {
+        head(I0{}, c, dy, nxt); read_all(I0{}, c, dy); mfma_all();
+        head(I1{}, c, dy, nxt); read_all(I1{}, c, dy); mfma_all();
+        head(I2{}, c, dy, nxt); read_all(I2{}, c, dy); mfma_all();
+      }
+    }
+
+    const int j0 = c0, j1 = c1;       // (names used by the finishing code below: units are chunks)
+    const bool full = (j0 == 0) && (j1 == p.n_ktiles);
+    const bool publish = (j0 > 0);
+    const int cur_tile = tile, cur_n0 = n0;
+    long long cur_mrow[TM];
+#pragma unroll
+    for (int t = 0; t < TM; ++t) cur_mrow[t] = mrow[t];
+    it += j1 - j0;
+    const bool more = it < it_end;
+    if (more) {
+      raw_barrier();
+      tile = (int)(it / chunks);
+      c0 = (int)(it - (long long)tile * chunks);
+      tile_n = tile / p.tiles_m;
+      tile_m = tile - tile_n * p.tiles_m;
+      n0 = tile_n * BN;
+      prepare(tile_m, n0);
+      issue_patch(c0);
+      issue_w(0, c0, 0);
+      issue_w(1, c0, 1);
+    }
+
+    if (publish) {
+      f32x4* slab = reinterpret_cast<f32x4*>(cp.base.slab_base + (long long)g * (256 * BN));
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            f32x4 v = {acc[tm][tn][q * 4 + 0], acc[tm][tn][q * 4 + 1], acc[tm][tn][q * 4 + 2],
+                       acc[tm][tn][q * 4 + 3]};
+            slab[((tm * TN + tn) * 4 + q) * NTHREADS + tid] = v;
+          }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(cp.base.flags + g, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    } else {
+      if (!full) {
+        const long long tile_end = ((long long)cur_tile + 1) * p.n_ktiles;
+        const int g_last = (int)((tile_end - 1) / p.iters_per_wg);
+        if (tid == 0) {
+          for (int pg = g + 1; pg <= g_last; ++pg) {
+            int spins = 0;
+            while (__hip_atomic_load(cp.base.flags + pg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+              __builtin_amdgcn_s_sleep(8);
+              if (++spins > g8::SPIN_LIMIT) {
+                __hip_atomic_store(cp.base.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+              }
+            }
+          }
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        __syncthreads();
+        for (int pg = g + 1; pg <= g_last; ++pg) {
+          const f32x4* slab = reinterpret_cast<const f32x4*>(cp.base.slab_base + (long long)pg * (256 * BN));
+#pragma unroll
+          for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                const f32x4 v = slab[((tm * TN + tn) * 4 + q) * NTHREADS + tid];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[tm][tn][q * 4 + r] += v[r];
+              }
+        }
+        __syncthreads();
+        if (tid == 0)
+          for (int pg = g + 1; pg <= g_last; ++pg)
+            __hip_atomic_store(cp.base.flags + pg, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      epilogue_rows<TM, TN>(p, acc, cur_mrow, cur_n0, col0, lane);
+    }
+    if (!more) break;
+  }
+}
+
+}  // namespace c3p

@@ -444,6 +444,7 @@ __global__ void __launch_bounds__(256) gemm_fixup_kernel(const GemmParams p) {
 }
 
 #include "gemm8.h"
+#include "conv3p.h"
 
 struct TilePlan {
   int bm, bn;
@@ -587,10 +588,84 @@ hipError_t launch8(const g8::Params& pp, const TilePlan& t, hipStream_t s) {
   return hipGetLastError();
 }
 
+// ---- patch-staged 3x3 convolution: host side -------------------------------------------------------------------
+int g_conv3p = -1;
+
+bool conv3p_geometry(const udt_gemm_desc* d, c3p::Geo& ge) {
+  if (g_conv3p < 0) {
+    const char* e = getenv("UDT_CONV3P");
+    g_conv3p = (e && e[0] == '0') ? 0 : 1;
+  }
+  if (!g_conv3p || gemm_impl() != 8) return false;
+  if (!(d->flags & UDT_GEMM_CONV) || d->ksize != 3 || d->stride != 1 || d->upsample || d->C2 != 0) return false;
+  if (d->pad_t != 1 || d->pad_l != 1 || d->Hout != d->Hin || d->Wout != d->Win || d->N <= 64) return false;
+  if (d->flags & (UDT_GEMM_GEGLU | UDT_GEMM_TRANSPOSED)) return false;
+  const int H = d->Hin, W = d->Win;
+  if (W % 32 == 0 && H % 8 == 0) { ge.TW = 32; ge.TH = 8; ge.NI = 1; }
+  else if (W == 16 && H % 16 == 0) { ge.TW = 16; ge.TH = 16; ge.NI = 1; }
+  else if (W == 8 && H == 8) { ge.TW = 8; ge.TH = 8; ge.NI = 4; }
+  else return false;
+  ge.B = d->M / (H * W);
+  ge.H = H; ge.W = W; ge.C = d->C1;
+  ge.tiles_x = W / ge.TW;
+  ge.tiles_y = H / ge.TH;
+  ge.img_groups = (ge.B + ge.NI - 1) / ge.NI;
+  ge.prow_w = ge.TW + 2;
+  ge.prows_img = (ge.TH + 2) * (ge.TW + 2);
+  ge.n_pieces = (ge.NI * ge.prows_img + 7) / 8;
+  ge.chunks = d->C1 / 64;
+  // buffer-descriptor addressing: 31-bit byte offsets (bit 31 marks zero padding)
+  if ((long long)d->M * d->C1 * 2 >= (1LL << 31) || (long long)d->N * (d->ldw > 0 ? d->ldw : d->K) * 2 >= (1LL << 31)) return false;
+  return ge.n_pieces * 8 <= c3p::PATCH_ROWS && ge.n_pieces >= 8;
+}
+
+TilePlan plan_tiles3p(const udt_gemm_desc* d, const c3p::Geo& ge) {
+  TilePlan t;
+  t.bm = 256;
+  t.bn = (d->N % 160 == 0 && d->N % 128 != 0) ? 160 : 128;
+  t.tiles_m = ge.img_groups * ge.tiles_y * ge.tiles_x;
+  t.tiles_n = (d->N + t.bn - 1) / t.bn;
+  t.tiles = t.tiles_m * t.tiles_n;
+  t.nkt = ge.chunks;                               // iteration unit of this kernel: one 64-channel chunk (9 K-tiles)
+  t.total = (long long)t.tiles * t.nkt;
+  const int slots = resident_slots() / 2;
+  long long G = t.total;                           // >= one chunk per workgroup
+  if (G > slots) G = slots;
+  t.ipw = (int)((t.total + G - 1) / G);
+  if (t.nkt * 9 < 24) t.ipw = ((t.ipw + t.nkt - 1) / t.nkt) * t.nkt;   // shallow K: whole tiles
+  t.G = (int)((t.total + t.ipw - 1) / t.ipw);
+  t.fixup = (t.ipw % t.nkt) != 0;
+  return t;
+}
+
+template <int WGM, int WGN, int TM, int TN>
+hipError_t launch3p(const c3p::CParams& cp, const TilePlan& t, hipStream_t s) {
+  constexpr int BN = WGN * TN * 32;
+  constexpr int smem = g8::NSTAGE * BN * ROW_BYTES + 2 * c3p::PATCH_BYTES;
+  static bool attr_set = false;
+  auto kern = c3p::conv3p_kernel<WGM, WGN, TM, TN>;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(t.G), dim3(g8::NTHREADS), smem, s, cp);
+  return hipGetLastError();
+}
+
 }  // namespace
 
 extern "C" size_t udt_gemm_workspace_bytes(const udt_gemm_desc* d) {
   if (!d || d->K <= 0 || d->M <= 0 || d->N <= 0 || d->K % BK != 0) return 0;
+  {
+    c3p::Geo ge;
+    if (conv3p_geometry(d, ge)) {
+      TilePlan t3 = plan_tiles3p(d, ge);
+      if (!t3.fixup) return 0;
+      return G8_HEADER_BYTES + (size_t)t3.G * t3.bm * t3.bn * sizeof(float);
+    }
+  }
   if (use_gemm8(d)) {
     TilePlan t8 = plan_tiles8(d);
     if (!t8.fixup) return 0;
@@ -598,7 +673,8 @@ extern "C" size_t udt_gemm_workspace_bytes(const udt_gemm_desc* d) {
   }
   TilePlan t = plan_tiles(d);
   if (!t.fixup) return 0;
-  return (size_t)t.G * 2 * SLAB_FLOATS * sizeof(float);
+  // the first G8_HEADER_BYTES of the workspace hold the 8-wave kernels' flags and are never used for slabs
+  return G8_HEADER_BYTES + (size_t)t.G * 2 * SLAB_FLOATS * sizeof(float);
 }
 
 extern "C" int udt_gemm(const udt_gemm_desc* d, void* workspace, size_t workspace_bytes, void* stream) {
@@ -660,6 +736,38 @@ extern "C" int udt_gemm(const udt_gemm_desc* d, void* workspace, size_t workspac
   p.flags = d->flags;
   p.alpha = d->alpha;
   const int cls = (conv && d->ksize == 3) ? 0 : 1;
+  {
+    c3p::CParams cp;
+    if (conv3p_geometry(d, cp.geo)) {
+      const TilePlan t3 = plan_tiles3p(d, cp.geo);
+      p.tiles_m = t3.tiles_m; p.tiles_n = t3.tiles_n; p.tiles_per_batch = t3.tiles_m * t3.tiles_n;
+      p.n_ktiles = t3.nkt;
+      p.total_iters = t3.total;
+      p.iters_per_wg = t3.ipw;
+      p.G = t3.G;
+      cp.a_bytes = (unsigned)((long long)d->M * d->C1 * 2);
+      cp.w_bytes = (unsigned)((long long)d->N * p.ldw * 2);
+      cp.base.g = p;
+      cp.base.flags = nullptr; cp.base.err = nullptr; cp.base.slab_base = nullptr;
+      if (t3.fixup) {
+        const size_t need = G8_HEADER_BYTES + (size_t)t3.G * t3.bm * t3.bn * sizeof(float);
+        if (!workspace || workspace_bytes < need) return UDT_ERR_WORKSPACE;
+        cp.base.flags = reinterpret_cast<int*>(workspace);
+        cp.base.err = cp.base.flags + 1023;
+        cp.base.slab_base = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + G8_HEADER_BYTES);
+      }
+      UdtProfScope prof3(cls, s);
+      if (prof3.rec) {
+        char tag[96];
+        snprintf(tag, sizeof(tag), "conv3p M=%d N=%d K=%d %dx%d tile=%dx%dx%d bn=%d G=%d ipw=%d", d->M, d->N, d->K, d->Hin,
+                 d->Win, cp.geo.TW, cp.geo.TH, cp.geo.NI, t3.bn, t3.G, t3.ipw);
+        udt_prof_tag(prof3.rec, tag);
+      }
+      hipError_t e3 = (t3.bn == 160) ? launch3p<8, 1, 1, 5>(cp, t3, s) : launch3p<4, 2, 2, 2>(cp, t3, s);
+      if (e3 != hipSuccess) return udt_set_hip_error(e3);
+      return UDT_OK;
+    }
+  }
   if (use_gemm8(d)) {
     const TilePlan t8 = plan_tiles8(d);
     p.tiles_m = t8.tiles_m; p.tiles_n = t8.tiles_n; p.tiles_per_batch = t8.tiles_m * t8.tiles_n;
@@ -703,9 +811,9 @@ extern "C" int udt_gemm(const udt_gemm_desc* d, void* workspace, size_t workspac
   p.G = t.G;
 
   if (t.fixup) {
-    const size_t need = (size_t)t.G * 2 * SLAB_FLOATS * sizeof(float);
+    const size_t need = G8_HEADER_BYTES + (size_t)t.G * 2 * SLAB_FLOATS * sizeof(float);
     if (!workspace || workspace_bytes < need) return UDT_ERR_WORKSPACE;
-    p.slabs = reinterpret_cast<float*>(workspace);
+    p.slabs = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + G8_HEADER_BYTES);
   }
 
   UdtProfScope prof(cls, s);
