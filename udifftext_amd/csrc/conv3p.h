@@ -36,9 +36,8 @@ struct Geo {            // spatial tiling of the output (= input) map
 };
 
 struct CParams {
-  Params base;
+  Params base;              // base.a_bytes / base.w_bytes: buffer-descriptor extents
   Geo geo;
-  unsigned a_bytes, w_bytes;     // buffer-descriptor extents of the activation tensor / weight matrix
 };
 
 UDT_DEVINL void wait_vmcnt_dyn(int n) {          // n is wave-uniform
@@ -115,28 +114,9 @@ UDT_DEVINL void epilogue_rows(const GemmParams& p, f32x16 (&acc)[TM][TN], const 
   }
 }
 
-template <int N>
-UDT_DEVINL void wait_vm() {
-  static_assert(N >= 0 && N <= 10, "immediate");
-  if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  if constexpr (N == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-  if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-  if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-  if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-  if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-  if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-  if constexpr (N == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
-  if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-  if constexpr (N == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
-  if constexpr (N == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-}
-
-UDT_DEVINL void buf_lds16(__amdgpu_buffer_rsrc_t rsrc, void* lds_wave_base, unsigned voff, int soff) {
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voff, soff,
-                                           0, 0);
-}
-
-constexpr unsigned OOB = 0x80000000u;      // voffset beyond num_records: the buffer load returns zeros (padding)
+using g8::wait_vm;
+using g8::buf_lds16;
+using g8::OOB;
 constexpr int PP = 7;                      // patch pieces per wave and chunk (padded with duplicate pieces)
 
 // WGM x WGN waves, each TM x TN MFMA tiles of 32x32; BM = 256 output pixels.
@@ -179,9 +159,9 @@ __global__ void __launch_bounds__(NTHREADS) conv3p_kernel(const CParams cp) {
   if (it >= it_end) return;
 
   const __amdgpu_buffer_rsrc_t rsrc_w =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.w), 0, cp.w_bytes, 0x00020000);
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.w), 0, cp.base.w_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsrc_a =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.a), 0, cp.a_bytes, 0x00020000);
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.a), 0, cp.base.a_bytes, 0x00020000);
 
   // ---- per-lane state of the current tile ------------------------------------------------------------------
   // piece index of load i of this wave: wave + 8*i, wrapped back by multiples of 8 when past the last piece (the

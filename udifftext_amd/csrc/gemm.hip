@@ -546,7 +546,13 @@ int gemm_impl() {
   return g_impl;
 }
 
-bool use_gemm8(const udt_gemm_desc* d) { return gemm_impl() == 8 && d->N > 64; }
+bool use_gemm8(const udt_gemm_desc* d) {
+  if (gemm_impl() != 8 || d->N <= 64) return false;
+  const long long ldw = d->ldw > 0 ? d->ldw : d->K;
+  // buffer-descriptor addressing uses 31-bit byte offsets per batch element
+  if (!(d->flags & UDT_GEMM_CONV) && (long long)d->M * d->lda * 2 >= (1LL << 31)) return false;
+  return (long long)d->N * ldw * 2 < (1LL << 31);
+}
 
 TilePlan plan_tiles8(const udt_gemm_desc* d) {
   TilePlan t;
@@ -745,8 +751,8 @@ extern "C" int udt_gemm(const udt_gemm_desc* d, void* workspace, size_t workspac
       p.total_iters = t3.total;
       p.iters_per_wg = t3.ipw;
       p.G = t3.G;
-      cp.a_bytes = (unsigned)((long long)d->M * d->C1 * 2);
-      cp.w_bytes = (unsigned)((long long)d->N * p.ldw * 2);
+      cp.base.a_bytes = (unsigned)((long long)d->M * d->C1 * 2);
+      cp.base.w_bytes = (unsigned)((long long)d->N * p.ldw * 2);
       cp.base.g = p;
       cp.base.flags = nullptr; cp.base.err = nullptr; cp.base.slab_base = nullptr;
       if (t3.fixup) {
@@ -778,6 +784,8 @@ extern "C" int udt_gemm(const udt_gemm_desc* d, void* workspace, size_t workspac
     g8::Params pp;
     pp.g = p;
     pp.flags = nullptr; pp.err = nullptr; pp.slab_base = nullptr;
+    pp.a_bytes = conv ? 0u : (unsigned)((long long)d->M * d->lda * 2);
+    pp.w_bytes = (unsigned)((long long)d->N * p.ldw * 2);
     if (t8.fixup) {
       const size_t need = G8_HEADER_BYTES + (size_t)t8.G * t8.bm * t8.bn * sizeof(float);
       if (!workspace || workspace_bytes < need) return UDT_ERR_WORKSPACE;

@@ -22,13 +22,13 @@ namespace g8 {
 constexpr int NSTAGE = 3;
 constexpr int NTHREADS = 512;
 constexpr int SPIN_LIMIT = 1 << 24;
-constexpr bool USE_SETPRIO = false;
 
 struct Params {
   GemmParams g;          // operand / epilogue description shared with the 4-wave kernel
   int* flags;            // [G] slab-ready flags (0 / 1), zero between launches
   int* err;              // [1] set to 1 if a spin timed out
   float* slab_base;      // [G][BM*BN] fp32
+  unsigned a_bytes, w_bytes;   // buffer-descriptor extents (per batch element) of A and W
 };
 
 template <int TM, int TN, bool TRANS>
@@ -153,14 +153,28 @@ UDT_DEVINL void raw_barrier() {
 }
 
 template <int N>
-UDT_DEVINL void wait_vmcnt() {
+UDT_DEVINL void wait_vm() {
+  static_assert(N >= 0 && N <= 10, "immediate");
   if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-  else if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-  else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-  else if constexpr (N == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
-  else static_assert(N == 0, "add the immediate");
+  if constexpr (N == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+  if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+  if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+  if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  if constexpr (N == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+  if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  if constexpr (N == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+  if constexpr (N == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
 }
+
+// 16-byte LDS-DMA through a buffer descriptor: uniform base (SGPRs) + per-lane byte offset + scalar byte offset.
+// A per-lane offset >= num_records (OOB) makes the load return zeros — used for rows past M / N and conv padding.
+UDT_DEVINL void buf_lds16(__amdgpu_buffer_rsrc_t rsrc, void* lds_wave_base, unsigned voff, int soff) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voff, soff,
+                                           0, 0);
+}
+constexpr unsigned OOB = 0x80000000u;
 
 // WGM x WGN waves, each TM x TN MFMA tiles of 32x32
 template <int WGM, int WGN, int TM, int TN, bool CONV, bool TRANS>
@@ -174,8 +188,8 @@ __global__ void __launch_bounds__(NTHREADS) gemm8_kernel(const Params pp) {
   constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
   constexpr int A_INSTR = 4;                       // 32 pieces / 8 waves
   constexpr int B_PIECES = BN / 8;                 // 16 or 20
-  constexpr int B_INSTR_MAX = (B_PIECES + 7) / 8;  // 2 or 3
-  constexpr bool B_UNEVEN = (B_PIECES % 8) != 0;   // waves < B_PIECES % 8 carry one piece more
+  constexpr int B_INSTR = (B_PIECES + 7) / 8;      // 2 or 3 per wave (padded with duplicate pieces -> uniform count)
+  constexpr int LPT = A_INSTR + B_INSTR;           // loads per K-tile and wave
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const GemmParams& p = pp.g;
@@ -193,8 +207,6 @@ __global__ void __launch_bounds__(NTHREADS) gemm8_kernel(const Params pp) {
   const int swz = (l31 >> 1) & 7;
   const int a_frag_row = (row0 + l31) * ROW_BYTES;
   const int b_frag_row = (col0 + l31) * ROW_BYTES;
-  const bool b_extra = B_UNEVEN && (wave < (B_PIECES % 8));      // wave-uniform
-  const bool lag = wave >= 4;                                    // second wave of each SIMD (wave-uniform)
 
   const int g = range_index(blockIdx.x, p.G);
   long long it = (long long)g * p.iters_per_wg;
@@ -207,27 +219,34 @@ __global__ void __launch_bounds__(NTHREADS) gemm8_kernel(const Params pp) {
   const int Wv = p.Win << p.ups;
 
   // ---- per-lane staging state of the current segment ----------------------------------------------------
-  const uint16_t* A = nullptr;
-  const uint16_t* W = nullptr;
+  // plain GEMM: every load is (descriptor, fixed per-lane voffset, scalar k-offset) -> no per-K-tile vector math.
+  // conv gather: the per-lane source pixel changes with the tap, so A keeps 64-bit pointers + a zero page.
+  __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.a), 0, pp.a_bytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.w), 0, pp.w_bytes, 0x00020000);
+  unsigned a_voff[A_INSTR];
+  unsigned w_voff[B_INSTR];
+  int w_piece[B_INSTR];
   int a_koff[A_INSTR];
-  long long a_rowoff[A_INSTR];
   int a_iy0[A_INSTR], a_ix0[A_INSTR], a_pixb[A_INSTR];
-  long long w_rowoff[B_INSTR_MAX];
-  int w_koff[B_INSTR_MAX];
 #pragma unroll
   for (int i = 0; i < A_INSTR; ++i) {
     const int row = (wave * A_INSTR + i) * 8 + l3;
     a_koff[i] = (pslot ^ ((row >> 1) & 7)) * 8;
   }
 #pragma unroll
-  for (int i = 0; i < B_INSTR_MAX; ++i) {
-    const int row = (wave + 8 * i) * 8 + l3;               // piece index wave + 8*i
-    w_koff[i] = (pslot ^ ((row >> 1) & 7)) * 8;
+  for (int i = 0; i < B_INSTR; ++i) {
+    int idx = wave + 8 * i;
+    while (idx >= B_PIECES) idx -= 8;                      // duplicate piece (re-writes identical bytes)
+    w_piece[i] = idx;
   }
 
   auto prepare = [&](int batch, int m0, int n0) {
-    A = p.a + (long long)batch * p.sA;
-    W = p.w + (long long)batch * p.sW;
+    if constexpr (!CONV) {
+      rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.a + (long long)batch * p.sA), 0, pp.a_bytes,
+                                                 0x00020000);
+      rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.w + (long long)batch * p.sW), 0, pp.w_bytes,
+                                                 0x00020000);
+    }
 #pragma unroll
     for (int i = 0; i < A_INSTR; ++i) {
       const int m = m0 + (wave * A_INSTR + i) * 8 + l3;
@@ -240,16 +259,18 @@ __global__ void __launch_bounds__(NTHREADS) gemm8_kernel(const Params pp) {
         a_pixb[i] = b * p.Hin * p.Win;
         a_iy0[i] = (m < p.M) ? (oy * p.stride - p.pad_t) : -100000;
         a_ix0[i] = ox * p.stride - p.pad_l;
-        a_rowoff[i] = 0;
+        a_voff[i] = 0;
       } else {
-        a_rowoff[i] = (m < p.M) ? (long long)m * p.lda : -1;
+        a_voff[i] = (m < p.M) ? (unsigned)(((long long)m * p.lda + a_koff[i]) * 2) : OOB;
         a_iy0[i] = a_ix0[i] = a_pixb[i] = 0;
       }
     }
 #pragma unroll
-    for (int i = 0; i < B_INSTR_MAX; ++i) {
-      const int n = n0 + (wave + 8 * i) * 8 + l3;
-      w_rowoff[i] = (n < p.N) ? (long long)n * p.ldw : -1;
+    for (int i = 0; i < B_INSTR; ++i) {
+      const int row = w_piece[i] * 8 + l3;
+      const int koff = (pslot ^ ((row >> 1) & 7)) * 8;
+      const int n = n0 + row;
+      w_voff[i] = (n < p.N) ? (unsigned)(((long long)n * p.ldw + koff) * 2) : OOB;
     }
   };
 
@@ -263,7 +284,7 @@ __global__ void __launch_bounds__(NTHREADS) gemm8_kernel(const Params pp) {
       const int ky = tap / p.ksz;
       const int kx = tap - ky * p.ksz;
       const bool second = c0 >= p.C1;
-      const uint16_t* src = second ? p.a2 : A;
+      const uint16_t* src = second ? p.a2 : p.a;
       const int cs = second ? p.C2 : p.C1;
       const int cc = second ? (c0 - p.C1) : c0;
 #pragma unroll
@@ -277,28 +298,10 @@ __global__ void __launch_bounds__(NTHREADS) gemm8_kernel(const Params pp) {
       }
     } else {
 #pragma unroll
-      for (int i = 0; i < A_INSTR; ++i) {
-        const uint16_t* gp = (a_rowoff[i] >= 0) ? (A + a_rowoff[i] + k0 + a_koff[i]) : p.zero;
-        glds16(gp, abuf + (wave * A_INSTR + i) * 1024);
-      }
+      for (int i = 0; i < A_INSTR; ++i) buf_lds16(rsrc_a, abuf + (wave * A_INSTR + i) * 1024, a_voff[i], k0 * 2);
     }
 #pragma unroll
-    for (int i = 0; i < B_INSTR_MAX; ++i) {
-      if (i < B_PIECES / 8 || b_extra) {                           // wave-uniform
-        const uint16_t* gp = (w_rowoff[i] >= 0) ? (W + w_rowoff[i] + k0 + w_koff[i]) : p.zero;
-        glds16(gp, bbuf + (wave + 8 * i) * 1024);
-      }
-    }
-  };
-
-  // wait until this wave's loads of the OLDEST in-flight K-tile have landed, leaving one K-tile in flight
-  auto wait_one_tile_left = [&]() {
-    if constexpr (B_UNEVEN) {
-      if (b_extra) wait_vmcnt<A_INSTR + B_INSTR_MAX>();
-      else wait_vmcnt<A_INSTR + B_INSTR_MAX - 1>();
-    } else {
-      wait_vmcnt<A_INSTR + B_INSTR_MAX>();
-    }
+    for (int i = 0; i < B_INSTR; ++i) buf_lds16(rsrc_w, bbuf + w_piece[i] * 1024, w_voff[i], k0 * 2);
   };
 
   int tile = (int)(it / p.n_ktiles);
@@ -325,78 +328,38 @@ __global__ void __launch_bounds__(NTHREADS) gemm8_kernel(const Params pp) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    bf16x8_t fx[4][TM], fw[4][TN];        // one K-tile of MFMA operands (4 k-steps)
-    auto read_all = [&](const char* abuf, const char* bbuf) {
+    // ---- K loop: tiles kt and kt+1 are in flight on entry of iteration kt -------------------------------
+    // (a lead/lag role split between the two waves of a SIMD was measured: no gain over this straight loop)
+    int st = 0;
+    for (int kt = kt0; kt < kt1; ++kt) {
+      if (kt + 1 < kt1) wait_vm<LPT>();            // leaves exactly one K-tile in flight
+      else wait_vm<0>();
+      raw_barrier();                               // tile kt visible to all waves; stage (st+2)%3 no longer being read
+      int st2 = st + 2;
+      if (st2 >= NSTAGE) st2 -= NSTAGE;
+      if (kt + 2 < kt1) stage(st2, kt + 2);
+      const char* abuf = smem + st * STAGE_BYTES;
+      const char* bbuf = abuf + A_BYTES;
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
         const int slot = ((ks * 2 + hi) ^ swz) << 4;
+        bf16x8_t xf[TM], wf[TN];
 #pragma unroll
-        for (int t = 0; t < TM; ++t) fx[ks][t] = lds_read_frag(abuf + a_frag_row + t * 32 * ROW_BYTES + slot);
+        for (int t = 0; t < TM; ++t) xf[t] = lds_read_frag(abuf + a_frag_row + t * 32 * ROW_BYTES + slot);
 #pragma unroll
-        for (int t = 0; t < TN; ++t) fw[ks][t] = lds_read_frag(bbuf + b_frag_row + t * 32 * ROW_BYTES + slot);
-      }
-    };
-    auto mfma_all = [&]() {
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks)
+        for (int t = 0; t < TN; ++t) wf[t] = lds_read_frag(bbuf + b_frag_row + t * 32 * ROW_BYTES + slot);
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
           for (int tn = 0; tn < TN; ++tn) {
             if constexpr (TRANS)
-              acc[tm][tn] = mfma32(fx[ks][tm], fw[ks][tn], acc[tm][tn]);
+              acc[tm][tn] = mfma32(xf[tm], wf[tn], acc[tm][tn]);
             else
-              acc[tm][tn] = mfma32(fw[ks][tn], fx[ks][tm], acc[tm][tn]);
+              acc[tm][tn] = mfma32(wf[tn], xf[tm], acc[tm][tn]);
           }
-    };
-    // ---- K loop: tiles kt and kt+1 are in flight on entry of iteration kt -------------------------------
-    // Role split between the two waves of a SIMD (waves w and w+4 share one): the "lead" half reads a K-tile's
-    // fragments and then issues its MFMAs; the "lag" half reads the same tile's fragments one MFMA block later,
-    // i.e. it issues the MFMAs of the PREVIOUS K-tile (operands held in registers across the barrier) while the
-    // lead half is reading.  On every SIMD one wave is in its LDS phase while the other is in its MFMA phase, so the
-    // matrix pipe does not wait for ds_read latency (the lock-step version lost ~60 % of its cycles there).
-    // Both halves execute exactly one barrier per K-tile; the two loops are kept separate so that each has
-    // straight-line control flow (a shared loop with a role branch made hipcc duplicate and spill accumulators).
-    int st = 0;
-    auto iter_head = [&](int kt) {
-      if (kt + 1 < kt1) wait_one_tile_left();
-      else wait_vmcnt<0>();
-      raw_barrier();                     // tile kt visible to all waves; stage (st+2)%3 no longer being read
-      int st2 = st + 2;
-      if (st2 >= NSTAGE) st2 -= NSTAGE;
-      if (kt + 2 < kt1) stage(st2, kt + 2);
-    };
-    auto advance = [&]() {
+      }
       st = st + 1;
       if (st >= NSTAGE) st = 0;
-    };
-    if (!lag) {
-      for (int kt = kt0; kt < kt1; ++kt) {
-        iter_head(kt);
-        const char* abuf = smem + st * STAGE_BYTES;
-        read_all(abuf, abuf + A_BYTES);
-        __builtin_amdgcn_sched_barrier(0);
-        mfma_all();
-        advance();
-      }
-    } else {
-      {
-        iter_head(kt0);
-        const char* abuf = smem + st * STAGE_BYTES;
-        read_all(abuf, abuf + A_BYTES);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // operands in registers before the stage is recycled
-        advance();
-      }
-      for (int kt = kt0 + 1; kt < kt1; ++kt) {
-        iter_head(kt);
-        mfma_all();                                          // previous K-tile
-        __builtin_amdgcn_sched_barrier(0);
-        const char* abuf = smem + st * STAGE_BYTES;
-        read_all(abuf, abuf + A_BYTES);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        advance();
-      }
-      mfma_all();
     }
 
     const bool full = (kt0 == 0) && (kt1 == p.n_ktiles);
