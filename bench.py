@@ -46,6 +46,21 @@ def parse():
     return ap.parse_args()
 
 
+def measured_traffic():
+    """HBM bytes per launch of the 3x3-conv kernels, from the committed rocprofv3 PMC passes of this same command
+    (profiles/r01_traffic.json, produced by tools/pmc_traffic.py: FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE,
+    separate passes).  PMC collection cannot run inside the timed region, hence the file; None if absent."""
+    path = os.path.join(ROOT, "profiles", "r01_traffic.json")
+    if not os.path.exists(path):
+        return None
+    try:
+        t = json.load(open(path))
+        n = sum(v["launches"] for v in t.values())
+        return sum(v["hbm_bytes_per_launch"] * v["launches"] for v in t.values()) / max(n, 1)
+    except Exception:
+        return None
+
+
 def cpu_baseline(model, size: int, chars: int, sampler_steps: int) -> dict:
     """time the CPU oracle on a bounded sample of the same workload: 2 UNet calls on one CFG pair at the bench
     resolution + LabelEncoder + 1 VAE encode + 1 VAE decode; extrapolate to sampler_steps UNet calls per image"""
@@ -135,6 +150,7 @@ def main():
     ops.prof_enable(0)
     conv_ms, conv_launches = ops.prof_get(L.PROF_CONV3X3)
     conv_flops = H.FLOP_COUNTER.get("conv3x3", 0.0)
+    conv_bytes = H.FLOP_COUNTER.get("conv3x3_bytes", 0.0)
     H.FLOP_COUNTER = None
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -178,10 +194,13 @@ def main():
                                    "labels, noise_iters 0; BASELINE.json configs[1]",
                        "global_batch": args.batch * world, "parallelism": f"dp{world} (images sharded, one all-gather of frames)",
                        "weights": "synthetic (name-keyed recipe), 1361.2 M parameters"},
-            "roofline": {"kernel": "gemm_kernel<CONV> (3x3 implicit-GEMM convolution, UNet + VAE)", "bound": "mfma",
+            "roofline": {"kernel": "3x3 convolution: c3p::conv3p_kernel (LDS-staged patches) + g8::gemm8_kernel<CONV> "
+                                   "(stride-2 / upsampling gathers), UNet + VAE", "bound": "mfma",
                          "achieved": achieved, "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s", "frac": achieved / (PEAK_BF16 / 1e12),
-                         "traffic": None, "launches": conv_launches, "avg_launch_us": conv_ms * 1e3 / max(conv_launches, 1),
+                         "traffic": measured_traffic(), "launches": conv_launches,
+                         "avg_launch_us": conv_ms * 1e3 / max(conv_launches, 1),
                          "algorithmic_gflop_per_launch": conv_flops / max(conv_launches, 1) / 1e9,
+                         "algorithmic_bytes_per_launch": conv_bytes / max(conv_launches, 1),
                          "whole_path_frac_of_peak": value * FLOP_PER_IMAGE / (world * PEAK_BF16)},
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -75,14 +75,15 @@ UDT_DEVINL void epilogue8(const GemmParams& p, f32x16 (&acc)[TM][TN], int m0, in
             const int no = ((n0 + col0) >> 1) + q * 8 + hi * 4;
             if (m < p.M && nx < p.N) {
               float o[4];
+              f32x4 bx = {0.f, 0.f, 0.f, 0.f}, bg = {0.f, 0.f, 0.f, 0.f};
+              if (p.bias) {
+                bx = *reinterpret_cast<const f32x4*>(p.bias + nx);
+                bg = *reinterpret_cast<const f32x4*>(p.bias + nx + 32);
+              }
 #pragma unroll
               for (int r = 0; r < 4; ++r) {
-                float x = acc[tm][0][q * 4 + r] * p.alpha;
-                float gt = acc[tm][1][q * 4 + r] * p.alpha;
-                if (p.bias) {
-                  x += p.bias[nx + r];
-                  gt += p.bias[nx + 32 + r];
-                }
+                const float x = acc[tm][0][q * 4 + r] * p.alpha + bx[r];
+                const float gt = acc[tm][1][q * 4 + r] * p.alpha + bg[r];
                 o[r] = x * gelu_erf_f(gt);
               }
               u32x2 pk = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};

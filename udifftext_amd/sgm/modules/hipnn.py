@@ -106,8 +106,15 @@ class Conv2d(_Packed):
                          out_hw=out_hw, residual=residual, rowvec=rowvec, flags=flags, n_out=w.shape[0])
         if FLOP_COUNTER is not None:   # algorithmic (un-padded) multiply-adds x 2
             k = self.kernel_size
-            count_flops("conv3x3" if k == 3 else "conv1x1",
-                        2.0 * out.shape[0] * out.shape[1] * out.shape[2] * self.out_channels * self.in_channels * k * k)
+            kind = "conv3x3" if k == 3 else "conv1x1"
+            npix_out = out.shape[0] * out.shape[1] * out.shape[2]
+            count_flops(kind, 2.0 * npix_out * self.out_channels * self.in_channels * k * k)
+            # algorithmic HBM bytes: read the input(s) once, the weights once, write the output once (+ residual read)
+            nbytes = 2.0 * x.numel() / x.shape[-1] * self.in_channels + 2.0 * self.weight.numel() \
+                + npix_out * self.out_channels * (4.0 if (flags & L.GEMM_OUT_F32) else 2.0)
+            if residual is not None:
+                nbytes += 2.0 * npix_out * self.out_channels
+            count_flops(kind + "_bytes", nbytes)
         return out
 
 
