@@ -16,11 +16,11 @@ OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libudt_kernels.so")
 SOURCES = ["api.hip", "gemm.hip", "attention.hip", "norm.hip", "elementwise.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"] + os.environ.get("UDT_EXTRA_FLAGS", "").split()
 
 
 def _deps_mtime() -> float:
-    hdrs = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "gemm8.h"), os.path.join(CSRC, "conv3p.h"), os.path.join(HERE, "..", "include", "udt_kernels.h")]
+    hdrs = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "gemm8.h"), os.path.join(CSRC, "gemm9.h"), os.path.join(CSRC, "conv3p.h"), os.path.join(HERE, "..", "include", "udt_kernels.h")]
     return max(os.path.getmtime(h) for h in hdrs)
 
 

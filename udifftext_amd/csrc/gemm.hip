@@ -444,6 +444,7 @@ __global__ void __launch_bounds__(256) gemm_fixup_kernel(const GemmParams p) {
 }
 
 #include "gemm8.h"
+#include "gemm9.h"
 #include "conv3p.h"
 
 struct TilePlan {
@@ -541,13 +542,13 @@ int g_impl = -1;     // 8: deep-pipelined 8-wave kernel (default), 4: first-gene
 int gemm_impl() {
   if (g_impl < 0) {
     const char* e = getenv("UDT_GEMM_IMPL");
-    g_impl = (e && e[0] == '4') ? 4 : 8;
+    g_impl = (e && e[0] == '4') ? 4 : (e && e[0] == '9') ? 9 : 8;
   }
   return g_impl;
 }
 
 bool use_gemm8(const udt_gemm_desc* d) {
-  if (gemm_impl() != 8 || d->N <= 64) return false;
+  if (gemm_impl() == 4 || d->N <= 64) return false;
   const long long ldw = d->ldw > 0 ? d->ldw : d->K;
   // buffer-descriptor addressing uses 31-bit byte offsets per batch element
   if (!(d->flags & UDT_GEMM_CONV) && (long long)d->M * d->lda * 2 >= (1LL << 31)) return false;
@@ -594,6 +595,46 @@ hipError_t launch8(const g8::Params& pp, const TilePlan& t, hipStream_t s) {
   return hipGetLastError();
 }
 
+// ---- 256x256 phase-interleaved kernel: host side ---------------------------------------------------------------
+bool use_gemm9(const udt_gemm_desc* d) {
+  return gemm_impl() == 9 && use_gemm8(d);
+}
+
+TilePlan plan_tiles9(const udt_gemm_desc* d) {
+  TilePlan t;
+  const int batch = d->batch > 0 ? d->batch : 1;
+  t.bm = 256;
+  t.bn = 256;
+  t.tiles_m = (d->M + t.bm - 1) / t.bm;
+  t.tiles_n = (d->N + t.bn - 1) / t.bn;
+  t.tiles = t.tiles_m * t.tiles_n * batch;
+  t.nkt = d->K / BK;
+  t.total = (long long)t.tiles * t.nkt;
+  const int slots = resident_slots() / 2;          // one 8-wave workgroup per CU
+  long long G = t.total / 4;
+  if (G < 1) G = 1;
+  if (G > slots) G = slots;
+  t.ipw = (int)((t.total + G - 1) / G);
+  if (t.nkt < 24) t.ipw = ((t.ipw + t.nkt - 1) / t.nkt) * t.nkt;
+  t.G = (int)((t.total + t.ipw - 1) / t.ipw);
+  t.fixup = (t.ipw % t.nkt) != 0;
+  return t;
+}
+
+template <bool CONV, bool TRANS>
+hipError_t launch9(const g8::Params& pp, const TilePlan& t, hipStream_t s) {
+  static bool attr_set = false;
+  auto kern = g9::gemm9_kernel<CONV, TRANS>;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, g9::SMEM_BYTES);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(t.G), dim3(g9::NTHREADS), g9::SMEM_BYTES, s, pp);
+  return hipGetLastError();
+}
+
 // ---- patch-staged 3x3 convolution: host side -------------------------------------------------------------------
 int g_conv3p = -1;
 
@@ -602,7 +643,7 @@ bool conv3p_geometry(const udt_gemm_desc* d, c3p::Geo& ge) {
     const char* e = getenv("UDT_CONV3P");
     g_conv3p = (e && e[0] == '0') ? 0 : 1;
   }
-  if (!g_conv3p || gemm_impl() != 8) return false;
+  if (!g_conv3p || gemm_impl() == 4) return false;
   if (!(d->flags & UDT_GEMM_CONV) || d->ksize != 3 || d->stride != 1 || d->upsample || d->C2 != 0) return false;
   if (d->pad_t != 1 || d->pad_l != 1 || d->Hout != d->Hin || d->Wout != d->Win || d->N <= 64) return false;
   if (d->flags & (UDT_GEMM_GEGLU | UDT_GEMM_TRANSPOSED)) return false;
@@ -673,9 +714,10 @@ extern "C" size_t udt_gemm_workspace_bytes(const udt_gemm_desc* d) {
     }
   }
   if (use_gemm8(d)) {
-    TilePlan t8 = plan_tiles8(d);
+    const bool nine = use_gemm9(d);
+    TilePlan t8 = nine ? plan_tiles9(d) : plan_tiles8(d);
     if (!t8.fixup) return 0;
-    return G8_HEADER_BYTES + (size_t)t8.G * t8.bm * t8.bn * sizeof(float);
+    return G8_HEADER_BYTES + (size_t)(nine ? 2 : 1) * t8.G * t8.bm * t8.bn * sizeof(float);
   }
   TilePlan t = plan_tiles(d);
   if (!t.fixup) return 0;
@@ -775,7 +817,8 @@ extern "C" int udt_gemm(const udt_gemm_desc* d, void* workspace, size_t workspac
     }
   }
   if (use_gemm8(d)) {
-    const TilePlan t8 = plan_tiles8(d);
+    const bool nine = use_gemm9(d);
+    const TilePlan t8 = nine ? plan_tiles9(d) : plan_tiles8(d);
     p.tiles_m = t8.tiles_m; p.tiles_n = t8.tiles_n; p.tiles_per_batch = t8.tiles_m * t8.tiles_n;
     p.n_ktiles = t8.nkt;
     p.total_iters = t8.total;
@@ -787,7 +830,7 @@ extern "C" int udt_gemm(const udt_gemm_desc* d, void* workspace, size_t workspac
     pp.a_bytes = conv ? 0u : (unsigned)((long long)d->M * d->lda * 2);
     pp.w_bytes = (unsigned)((long long)d->N * p.ldw * 2);
     if (t8.fixup) {
-      const size_t need = G8_HEADER_BYTES + (size_t)t8.G * t8.bm * t8.bn * sizeof(float);
+      const size_t need = G8_HEADER_BYTES + (size_t)(nine ? 2 : 1) * t8.G * t8.bm * t8.bn * sizeof(float);
       if (!workspace || workspace_bytes < need) return UDT_ERR_WORKSPACE;
       pp.flags = reinterpret_cast<int*>(workspace);
       pp.err = pp.flags + 1023;
@@ -796,12 +839,15 @@ extern "C" int udt_gemm(const udt_gemm_desc* d, void* workspace, size_t workspac
     UdtProfScope prof8(cls, s);
     if (prof8.rec) {
       char tag[96];
-      snprintf(tag, sizeof(tag), "gemm8 M=%d N=%d K=%d conv=%d ks=%d fl=0x%x tile=%dx%d G=%d ipw=%d b=%d", d->M, d->N,
-               d->K, conv ? 1 : 0, d->ksize, d->flags, t8.bm, t8.bn, t8.G, t8.ipw, batch);
+      snprintf(tag, sizeof(tag), "gemm%d M=%d N=%d K=%d conv=%d ks=%d fl=0x%x tile=%dx%d G=%d ipw=%d b=%d", nine ? 9 : 8,
+               d->M, d->N, d->K, conv ? 1 : 0, d->ksize, d->flags, t8.bm, t8.bn, t8.G, t8.ipw, batch);
       udt_prof_tag(prof8.rec, tag);
     }
     hipError_t e8;
-    if (t8.bn == 160) {
+    if (nine) {
+      if (trans) e8 = launch9<false, true>(pp, t8, s);
+      else e8 = conv ? launch9<true, false>(pp, t8, s) : launch9<false, false>(pp, t8, s);
+    } else if (t8.bn == 160) {
       e8 = conv ? launch8<8, 1, 1, 5, true, false>(pp, t8, s) : launch8<8, 1, 1, 5, false, false>(pp, t8, s);
     } else if (trans) {
       e8 = launch8<4, 2, 2, 2, false, true>(pp, t8, s);
