@@ -145,6 +145,16 @@ int udt_gn_stats(const void* x, const void* x2, float* partials, int32_t B, int6
 int udt_gn_apply(const void* x, const void* x2, void* y, const float* partials, const float* gamma,
                  const float* beta, int32_t B, int64_t HW, int32_t C, int32_t C2, int32_t G, float eps, int32_t act,
                  void* stream);
+/* Single-pass GroupNorm (+ optional SiLU): same result as udt_gn_stats + udt_gn_apply with ONE read of x.  Every
+ * workgroup keeps its slab of the sample in LDS across a per-sample arrival counter, so the launch must be fully
+ * resident: udt_gn_fused_nchunks() returns the number of slabs per sample (partials must hold B * nchunks * G * 2
+ * floats) or 0 when the shape does not qualify (slab > 128 KiB, B > 256, ...) — callers then use the two-kernel
+ * pair.  One launch at a time per device (the counters live in a library-owned page); replaces the same reference
+ * modules as udt_gn_stats/udt_gn_apply (sgm/modules/diffusionmodules/util.py:258-275, attention.py:82-85). */
+int32_t udt_gn_fused_nchunks(int32_t B, int64_t HW, int32_t C, int32_t G);
+int udt_gn_fused(const void* x, const void* x2, void* y, float* partials, const float* gamma, const float* beta,
+                 int32_t B, int64_t HW, int32_t C1, int32_t C2, int32_t G, float eps, int32_t act, void* stream);
+
 /* LayerNorm over the last dim of bf16 [rows, C] (C % 8 == 0, C <= 4096). */
 int udt_layernorm(const void* x, void* y, const float* gamma, const float* beta,
                   int64_t rows, int32_t C, float eps, void* stream);
@@ -185,6 +195,12 @@ int udt_local_loss(const float* probs, const float* mask, const float* seg_mask,
                    int32_t Hm, int32_t Wm, void* stream);
 /* x bf16 += y bf16 (n elements, n % 8 == 0) ; utility for residuals outside GEMM epilogues */
 int udt_add_bf16(void* x, const void* y, int64_t n, void* stream);
+
+/* out[r][c] = bf16(x[r][c] + bias[c]); x/out bf16 [rows, C] (may alias), bias fp32 [C], C % 8 == 0.
+ * Used where a projection's GEMM input is identically zero (cross-attention over an all-zero context — the
+ * unconditional half under force_uc_zero_embeddings, reference sgm/modules/attention.py:150-174 with k = v = 0 — so
+ * to_out(...) + x reduces to bias + x). */
+int udt_bias_add_bf16(const void* x, const float* bias, void* out, int64_t rows, int32_t C, void* stream);
 
 /* ---- library services -------------------------------------------------------------------------- */
 const char* udt_version(void);

@@ -114,6 +114,27 @@ def test_unet_call_vs_reference_golden(engine, cond256, eg, cuda):
     _check("get_min_local_loss vs reference", ll.cpu(), eg["g8_local_loss"], 3e-2)
 
 
+def test_zero_context_shortcut_is_bit_exact(engine, cond256, cuda):
+    """the sampler skips the t_attn GEMMs of the unconditional half (context == 0 -> x + to_out.bias); the eps must
+    be bit-identical to running the full cross-attention on the zero context"""
+    from udifftext_amd import ops, packing
+    _, c, uc = cond256
+    assert not bool(uc["t_crossattn"].any()), "force_uc_zero_embeddings must zero the label context"
+    unet = engine.model.diffusion_model
+    torch.manual_seed(7)
+    xin = torch.zeros((2, 32, 32, packing.KPAD), dtype=torch.bfloat16, device=cuda)
+    xin[..., :9] = torch.randn((2, 32, 32, 9), device=cuda).bfloat16()
+    emb = unet.time_embedding_rows(torch.tensor([500.0, 500.0], device=cuda))
+    t_kv = unet.project_context(torch.cat((uc["t_crossattn"], c["t_crossattn"]), 0))
+    full = unet.forward_nhwc(xin, emb, t_kv, zero_ctx_rows=0)
+    fast = unet.forward_nhwc(xin, emb, t_kv, zero_ctx_rows=1)
+    assert torch.equal(full, fast)
+    # and the bias_add kernel on its own
+    x = torch.randn((64, 320), device=cuda).bfloat16()
+    b = torch.randn((320,), device=cuda)
+    assert torch.equal(ops.bias_add(x, b), (x.float() + b).bfloat16())
+
+
 def test_per_block_activations_vs_oracle(engine, cond256, eg, cuda):
     """per-block parity inside the UNet (taps of the oracle == reference goldens, see test_oracle_golden)"""
     from udifftext_amd import ops

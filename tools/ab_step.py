@@ -1,0 +1,41 @@
+"""A/B timing of one sampler step (CFG pair, 512x512, batch 4) inside ONE process: toggles given as name=values."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import udifftext_amd
+from udifftext_amd import pipeline, synth
+from sgm.modules.diffusionmodules.sampling import _Stepper
+dev = torch.device("cuda", 0)
+torch.set_grad_enabled(False)
+B, size = 4, 512
+model = pipeline.build_engine(dev)
+sampler = pipeline.init_sampling(50, 5.0, dev)
+b = synth.synthetic_batch(B, size, size, 9, seed=0)
+b = {k: (v.to(dev) if isinstance(v, torch.Tensor) else v) for k, v in b.items()}
+batch, buc = pipeline.prepare_batch(b, dev)
+c, uc = model.conditioner.get_unconditional_conditioning(batch, batch_uc=buc, force_uc_zero_embeddings=["label"])
+st = _Stepper(model, c, uc, B, (size // 8, size // 8), 5.0)
+sig = sampler._host_sigmas()
+x = torch.randn((B, 4, size // 8, size // 8), device=dev) * 14.0
+
+def run(n):
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for i in range(n):
+        st.step(x, sig[5 + i], sig[6 + i])
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n
+
+import udifftext_amd.ops as O
+which = sys.argv[1] if len(sys.argv) > 1 else "gn"
+if which == "zero":
+    variants = {"zero_rows=B": lambda: setattr(st, "zero_ctx_rows", B), "zero_rows=0": lambda: setattr(st, "zero_ctx_rows", 0)}
+else:
+    variants = {"gn_fused=1": lambda: setattr(O, "GN_FUSED", True), "gn_fused=0": lambda: setattr(O, "GN_FUSED", False)}
+for name, fn in variants.items():
+    fn(); run(3)
+for rnd in range(4):
+    for name, fn in variants.items():
+        fn()
+        print(f"round {rnd} {name:14s} {run(10):.3f} ms/step", flush=True)

@@ -49,6 +49,20 @@ const uint16_t* udt_zero_page() {
   return g_zero_page;
 }
 
+int* udt_sync_page() {
+  static int* page = nullptr;
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (!page) {
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, 4096);
+    if (e != hipSuccess) { g_last_hip_error = (int)e; return nullptr; }
+    e = hipMemset(p, 0, 4096);
+    if (e != hipSuccess) { g_last_hip_error = (int)e; return nullptr; }
+    page = reinterpret_cast<int*>(p);
+  }
+  return page;
+}
+
 void udt_prof_tag(void* rec, const char* tag) {
   if (!rec || !tag) return;
   std::lock_guard<std::mutex> lk(g_mu);

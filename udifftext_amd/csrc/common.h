@@ -50,6 +50,13 @@ UDT_DEVINL void glds16(const void* gsrc, void* lds_wave_base) {
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
+// 16-byte write-through (sc1) store: the data is visible at agent scope (other XCDs' L2s) once the wave's vmcnt
+// drains, so a flag can be raised after it WITHOUT a release fence — the fence's buffer_wbl2 writes back the whole
+// L2 and was measured at 4-5 us per episode (cdna_hip_programming.md, split-K recipe, "sc1 slab stores").
+UDT_DEVINL void store16_sc1(void* p, f32x4 v) {
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+}
+
 UDT_DEVINL void wait_vmcnt0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 UDT_DEVINL bf16x8_t lds_read_frag(const char* p) { return *reinterpret_cast<const bf16x8_t*>(p); }
@@ -61,6 +68,7 @@ UDT_DEVINL f32x16 mfma32(bf16x8_t a, bf16x8_t b, f32x16 c) {
 // ---- host-side helpers -------------------------------------------------------------------------
 int udt_set_hip_error(hipError_t e);   // records e, returns UDT_ERR_HIP (or UDT_OK when e == success)
 const uint16_t* udt_zero_page();       // >= 4 KiB of zeroed device memory (lazily allocated once)
+int* udt_sync_page();                  // 4 KiB of device ints, zero at rest: arrival counters of cooperative kernels
 
 struct UdtProfScope {                  // brackets a launch with events when profiling is enabled
   int cls; hipStream_t s; void* rec;

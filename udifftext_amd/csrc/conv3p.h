@@ -354,13 +354,12 @@ __global__ void __launch_bounds__(NTHREADS) conv3p_kernel(const CParams cp) {
           for (int q = 0; q < 4; ++q) {
             f32x4 v = {acc[tm][tn][q * 4 + 0], acc[tm][tn][q * 4 + 1], acc[tm][tn][q * 4 + 2],
                        acc[tm][tn][q * 4 + 3]};
-            slab[((tm * TN + tn) * 4 + q) * NTHREADS + tid] = v;
+            store16_sc1(slab + ((tm * TN + tn) * 4 + q) * NTHREADS + tid, v);
           }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       if (tid == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // slab stores were write-through (sc1) and are drained: no L2 write-back fence needed
         __hip_atomic_store(cp.base.flags + g, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     } else {

@@ -210,6 +210,22 @@ __global__ void add_bf16_kernel(uint16_t* __restrict__ x, const uint16_t* __rest
   *reinterpret_cast<u32x4*>(x + i * 8) = a;
 }
 
+// out[r][c] = x[r][c] + bias[c]  (bf16 rows, fp32 bias, 8 channels per thread)
+__global__ void bias_add_kernel(const uint16_t* __restrict__ x, const float* __restrict__ bias, uint16_t* __restrict__ out,
+                                long long n8, int c8) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n8) return;
+  const int c = (int)(i % c8) * 8;
+  u32x4 a = *reinterpret_cast<const u32x4*>(x + i * 8);
+  const f32x4 b0 = *reinterpret_cast<const f32x4*>(bias + c);
+  const f32x4 b1 = *reinterpret_cast<const f32x4*>(bias + c + 4);
+  a[0] = pack_bf16x2(bf16_lo(a[0]) + b0[0], bf16_hi(a[0]) + b0[1]);
+  a[1] = pack_bf16x2(bf16_lo(a[1]) + b0[2], bf16_hi(a[1]) + b0[3]);
+  a[2] = pack_bf16x2(bf16_lo(a[2]) + b1[0], bf16_hi(a[2]) + b1[1]);
+  a[3] = pack_bf16x2(bf16_lo(a[3]) + b1[2], bf16_hi(a[3]) + b1[3]);
+  *reinterpret_cast<u32x4*>(out + i * 8) = a;
+}
+
 inline unsigned nblk(long long n, int bs = 256) { return (unsigned)((n + bs - 1) / bs); }
 
 }  // namespace
@@ -321,6 +337,17 @@ extern "C" int udt_local_loss(const float* probs, const float* mask, const float
   UDT_STREAM;
   hipLaunchKernelGGL(local_loss_kernel, dim3(B), dim3(256), 0, s, probs, mask, seg_mask, gkernel9, loss_accum, heads,
                      size, L, seg_l, Hm, Wm);
+  UDT_CHECK_LAUNCH();
+  return UDT_OK;
+}
+
+extern "C" int udt_bias_add_bf16(const void* x, const float* bias, void* out, int64_t rows, int32_t C, void* stream) {
+  if (!x || !bias || !out) return UDT_ERR_BAD_ARG;
+  if (rows <= 0 || C <= 0 || C % 8 != 0) return UDT_ERR_BAD_SHAPE;
+  UDT_STREAM;
+  const long long n8 = rows * (C / 8);
+  hipLaunchKernelGGL(bias_add_kernel, dim3(nblk(n8)), dim3(256), 0, s, reinterpret_cast<const uint16_t*>(x), bias,
+                     reinterpret_cast<uint16_t*>(out), n8, C / 8);
   UDT_CHECK_LAUNCH();
   return UDT_OK;
 }

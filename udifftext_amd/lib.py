@@ -50,6 +50,8 @@ SYMBOLS = {
     "udt_gn_nchunks": (_i32, [_i64, _i32]),
     "udt_gn_stats": (C.c_int, [_vp, _vp, _fp, _i32, _i64, _i32, _i32, _i32, _vp]),
     "udt_gn_apply": (C.c_int, [_vp, _vp, _vp, _fp, _fp, _fp, _i32, _i64, _i32, _i32, _i32, _f32, _i32, _vp]),
+    "udt_gn_fused_nchunks": (C.c_int32, [_i32, _i64, _i32, _i32]),
+    "udt_gn_fused": (C.c_int, [_vp, _vp, _vp, _fp, _fp, _fp, _i32, _i64, _i32, _i32, _i32, _f32, _i32, _vp]),
     "udt_layernorm": (C.c_int, [_vp, _vp, _fp, _fp, _i64, _i32, _f32, _vp]),
     "udt_unet_input": (C.c_int, [_fp, _vp, _i32, _i32, _i32, _f32, _vp]),
     "udt_cfg_euler_step": (C.c_int, [_fp, _fp, _fp, _i32, _i32, _i32, _f32, _f32, _f32, _f32, _vp]),
@@ -62,6 +64,7 @@ SYMBOLS = {
     "udt_mask_downsample": (C.c_int, [_fp, _fp, _i32, _i32, _i32, _vp]),
     "udt_local_loss": (C.c_int, [_fp, _fp, _fp, _fp, _fp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "udt_add_bf16": (C.c_int, [_vp, _vp, _i64, _vp]),
+    "udt_bias_add_bf16": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _vp]),
     "udt_version": (C.c_char_p, []),
     "udt_status_string": (C.c_char_p, [C.c_int]),
     "udt_last_hip_error": (C.c_int, []),

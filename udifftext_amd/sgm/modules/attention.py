@@ -76,7 +76,7 @@ class CrossAttention(H._Packed):
         B, Lc, Dc = context_bf16.shape
         return ops.linear(context_bf16.reshape(B * Lc, Dc), self.packed()).reshape(B, Lc, -1)
 
-    def forward(self, x, context=None, kv=None, residual=None, emit_map: bool = False):
+    def forward(self, x, context=None, kv=None, residual=None, emit_map: bool = False, out=None):
         B, N, _ = x.shape
         inner = self.heads * self.dim_head
         if kv is None:
@@ -89,7 +89,14 @@ class CrossAttention(H._Packed):
             self.attn_map_cache["attn_map"] = probs
         o = ops.xattention(q, kv[..., :inner], kv[..., inner:], self.heads, self.dim_head, self.scale, probs=probs)
         res = residual.reshape(B * N, -1) if residual is not None else None
-        return self.to_out[0](o.reshape(B * N, inner), residual=res).reshape(B, N, -1)
+        out2 = out.reshape(B * N, -1) if out is not None else None
+        return self.to_out[0](o.reshape(B * N, inner), residual=res, out=out2).reshape(B, N, -1)
+
+    def zero_context_residual(self, x, out):
+        """x + t_attn(anything, context == 0): with k = v = 0 (to_k / to_v have no bias) the attention output is 0
+        and to_out reduces to its bias — bit-identical to running the projections on zeros."""
+        _, b = self.to_out[0].packed()
+        return ops.bias_add(x, b, out=out)
 
 
 class MemoryEfficientCrossAttention(H._Packed):
@@ -140,10 +147,21 @@ class BasicTransformerBlock(nn.Module):
         self.norm3 = H.LayerNorm(dim)
         self.ff = FeedForward(dim, dropout=dropout, glu=gated_ff)
 
-    def forward(self, x, t_context=None, v_context=None, t_kv=None, emit_map: bool = False):
+    def forward(self, x, t_context=None, v_context=None, t_kv=None, emit_map: bool = False, zero_ctx_rows: int = 0):
+        """zero_ctx_rows: the first n samples of the batch attend to an all-zero text context (the unconditional
+        half of a CFG pair under force_uc_zero_embeddings) — their t_attn branch is x + to_out.bias, no GEMMs."""
         x = self.attn1(self.norm1(x), residual=x)
         if hasattr(self, "t_attn"):
-            x = self.t_attn(self.t_norm(x), context=t_context, kv=t_kv, residual=x, emit_map=emit_map)
+            n0 = 0 if emit_map else min(int(zero_ctx_rows), x.shape[0])
+            if n0 > 0 and t_kv is not None:
+                y = torch.empty_like(x)
+                self.t_attn.zero_context_residual(x[:n0], y[:n0])
+                if n0 < x.shape[0]:
+                    xc = x[n0:]
+                    self.t_attn(self.t_norm(xc), kv=t_kv[n0:], residual=xc, out=y[n0:])
+                x = y
+            else:
+                x = self.t_attn(self.t_norm(x), context=t_context, kv=t_kv, residual=x, emit_map=emit_map)
         B, N, C = x.shape
         x2 = x.reshape(B * N, C)
         return self.ff(self.norm3(x2), residual=x2).reshape(B, N, C)
@@ -168,12 +186,14 @@ class SpatialTransformer(nn.Module):
     def project_context(self, context_bf16) -> List[torch.Tensor]:
         return [blk.t_attn.project_context(context_bf16) for blk in self.transformer_blocks]
 
-    def forward(self, x, t_context=None, v_context=None, t_kv: Optional[list] = None, emit_map: bool = False):
+    def forward(self, x, t_context=None, v_context=None, t_kv: Optional[list] = None, emit_map: bool = False,
+                zero_ctx_rows: int = 0):
         """x: bf16 NHWC [B, H, W, C]"""
         B, Hh, Ww, C = x.shape
         N = Hh * Ww
         t = self.proj_in(self.norm(x).reshape(B * N, C)).reshape(B, N, -1)
         for i, blk in enumerate(self.transformer_blocks):
-            t = blk(t, t_context=t_context, t_kv=(t_kv[i] if t_kv is not None else None), emit_map=emit_map)
+            t = blk(t, t_context=t_context, t_kv=(t_kv[i] if t_kv is not None else None), emit_map=emit_map,
+                    zero_ctx_rows=zero_ctx_rows)
         out = self.proj_out(t.reshape(B * N, -1), residual=x.reshape(B * N, C))
         return out.reshape(B, Hh, Ww, C)

@@ -102,14 +102,15 @@ class ResBlock(TimestepBlock):
 
 
 class TimestepEmbedSequential(nn.Sequential, TimestepBlock):
-    def forward(self, x, emb_rows=None, t_context=None, v_context=None, x2=None, t_kv=None, emit_map=False):
+    def forward(self, x, emb_rows=None, t_context=None, v_context=None, x2=None, t_kv=None, emit_map=False,
+                zero_ctx_rows=0):
         for layer in self:
             if isinstance(layer, ResBlock):
                 x = layer(x, emb_rows, x2=x2)
                 x2 = None
             elif isinstance(layer, SpatialTransformer):
                 kv = t_kv[layer.st_index] if t_kv is not None else None
-                x = layer(x, t_context, v_context, t_kv=kv, emit_map=emit_map)
+                x = layer(x, t_context, v_context, t_kv=kv, emit_map=emit_map, zero_ctx_rows=zero_ctx_rows)
             else:
                 x = layer(x)
         return x
@@ -232,16 +233,19 @@ class UnifiedUNetModel(nn.Module):
         ctx = t_context.to(torch.bfloat16).contiguous()
         return [st.project_context(ctx) for st in self._transformers]
 
-    def forward_nhwc(self, xin: torch.Tensor, emb_rows: torch.Tensor, t_kv: List[list], emit_maps: bool = False) -> torch.Tensor:
-        """xin: bf16 [B, h, w, 64] (9 real channels); returns eps fp32 [B, h, w, 4]."""
+    def forward_nhwc(self, xin: torch.Tensor, emb_rows: torch.Tensor, t_kv: List[list], emit_maps: bool = False,
+                     zero_ctx_rows: int = 0) -> torch.Tensor:
+        """xin: bf16 [B, h, w, 64] (9 real channels); returns eps fp32 [B, h, w, 4].
+        zero_ctx_rows: leading samples whose text context is exactly zero (see BasicTransformerBlock.forward)."""
         hs = []
         h = xin
+        kw = dict(t_kv=t_kv, emit_map=emit_maps, zero_ctx_rows=zero_ctx_rows)
         for block in self.input_blocks:
-            h = block(h, emb_rows, t_kv=t_kv, emit_map=emit_maps)
+            h = block(h, emb_rows, **kw)
             hs.append(h)
-        h = self.middle_block(h, emb_rows, t_kv=t_kv, emit_map=emit_maps)
+        h = self.middle_block(h, emb_rows, **kw)
         for block in self.output_blocks:
-            h = block(h, emb_rows, x2=hs.pop(), t_kv=t_kv, emit_map=emit_maps)
+            h = block(h, emb_rows, x2=hs.pop(), **kw)
         hn = self.out[0](h, silu=True)
         return self.out[2](hn, flags=H.GEMM_OUT_F32)
 
