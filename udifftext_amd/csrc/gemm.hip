@@ -582,7 +582,8 @@ TilePlan plan_tiles8(const udt_gemm_desc* d) {
 template <int WGM, int WGN, int TM, int TN, bool CONV, bool TRANS>
 hipError_t launch8(const g8::Params& pp, const TilePlan& t, hipStream_t s) {
   constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
-  constexpr int smem = g8::NSTAGE * (BM + BN) * ROW_BYTES;
+  // the 256x128 configuration transposes its output through LDS: stage 2 plus 16 KiB above the ring (160 KiB total)
+  constexpr int smem = (TM == 2 && TN == 2 && !TRANS) ? 160 * 1024 : g8::NSTAGE * (BM + BN) * ROW_BYTES;
   static bool attr_set = false;
   auto kern = g8::gemm8_kernel<WGM, WGN, TM, TN, CONV, TRANS>;
   if (!attr_set) {

@@ -147,6 +147,137 @@ UDT_DEVINL void epilogue8(const GemmParams& p, f32x16 (&acc)[TM][TN], int m0, in
   }
 }
 
+// ---- row-coalesced epilogue (bf16 output, TN == 2, not transposed) ----------------------------------------------
+// The MFMA accumulator layout gives a lane 4 consecutive columns of ONE row, so a direct store instruction touches 32
+// rows with 16 bytes each: 512 partial-line write requests per wave and tile, and the launch becomes L2-request
+// bound (a K=64 GEMM wrote its output at 2.4 TB/s).  Instead every wave transposes its 64-row block through 8 KiB of
+// LDS of its own (XOR-swizzled 16-byte chunks) and stores 16 bytes per lane with 8 lanes covering one full 128-byte
+// row: whole cache lines, half the store instructions.  Residual rows are fetched the same way (whole lines) and
+// added in fp32 BEFORE the single bf16 rounding.  `wlds` = this wave's 8 KiB scratch (free ring stage).
+template <int TM>
+UDT_DEVINL void epilogue8_rows(const GemmParams& p, f32x16 (&acc)[TM][2], int m0, int n0, int batch, int row0, int col0,
+                               int lane, char* wlds) {
+  const int l31 = lane & 31;
+  const int hi = lane >> 5;
+  const int flags = p.flags;
+  const int mw = m0 + row0;
+  uint16_t* out = reinterpret_cast<uint16_t*>(p.out) + (long long)batch * p.sO;
+  if (flags & UDT_GEMM_GEGLU) {
+    // 32 output columns per wave: rows of 64 bytes, 4 chunks; lane -> (row = 16 i + lane/4, chunk = lane%4)
+    const int nx0 = n0 + col0;
+    const int no0 = (n0 + col0) >> 1;
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+      const int row = tm * 32 + l31;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int nx = nx0 + q * 8 + hi * 4;
+        f32x4 bx = {0.f, 0.f, 0.f, 0.f}, bg = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias && nx < p.N) {
+          bx = *reinterpret_cast<const f32x4*>(p.bias + nx);
+          bg = *reinterpret_cast<const f32x4*>(p.bias + nx + 32);
+        }
+        float o[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          o[r] = (acc[tm][0][q * 4 + r] * p.alpha + bx[r]) * gelu_erf_f(acc[tm][1][q * 4 + r] * p.alpha + bg[r]);
+        u32x2 pk = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
+        *reinterpret_cast<u32x2*>(wlds + row * 64 + ((q ^ (row & 3)) << 4) + hi * 8) = pk;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < TM * 2; ++i) {
+      const int row = i * 16 + (lane >> 2);
+      const int ch = lane & 3;
+      const u32x4 v = *reinterpret_cast<const u32x4*>(wlds + row * 64 + ((ch ^ (row & 3)) << 4));
+      const int m = mw + row;
+      const int no = no0 + ch * 8;
+      if (m < p.M && (nx0 + ch * 8) < p.N) *reinterpret_cast<u32x4*>(out + (long long)m * p.ldo + no) = v;
+    }
+    return;
+  }
+  const int nw = n0 + col0;
+  const uint16_t* __restrict__ R = p.res ? (p.res + (long long)batch * p.sR) : nullptr;
+  if (R) {
+    // residual block -> LDS in whole rows (8 lanes x 16 B = one 128-byte line), read back in accumulator order below
+#pragma unroll
+    for (int i = 0; i < TM * 4; ++i) {
+      const int row = i * 8 + (lane >> 3);
+      const int ch = lane & 7;
+      const int m = mw + row;
+      const int n = nw + ch * 8;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (m < p.M && n + 8 <= p.N) {
+        v = *reinterpret_cast<const u32x4*>(R + (long long)m * p.ldr + n);
+      } else if (m < p.M && n < p.N) {                     // N % 8 == 4 tail: 4 columns
+        const u32x2 h = *reinterpret_cast<const u32x2*>(R + (long long)m * p.ldr + n);
+        v[0] = h[0];
+        v[1] = h[1];
+      }
+      *reinterpret_cast<u32x4*>(wlds + row * 128 + ((ch ^ (row & 7)) << 4)) = v;
+    }
+  }
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm) {
+    const int row = tm * 32 + l31;
+    const int m = mw + row;
+    const int b = (p.rowvec != nullptr) ? ((m < p.M ? m : p.M - 1) / p.rows_per_batch) : 0;
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int n = nw + tn * 32 + q * 8 + hi * 4;
+        char* cell = wlds + row * 128 + (((tn * 4 + q) ^ (row & 7)) << 4) + hi * 8;
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = acc[tm][tn][q * 4 + r] * p.alpha;
+        if (n < p.N) {
+          if (p.bias) {
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + n);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] += bv[r];
+          }
+          if (p.rowvec) {
+            const f32x4 rv = *reinterpret_cast<const f32x4*>(p.rowvec + (long long)b * p.ldrv + n);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] += rv[r];
+          }
+        }
+        if (R) {
+          const u32x2 rr = *reinterpret_cast<const u32x2*>(cell);
+          v[0] += bf16_lo(rr[0]);
+          v[1] += bf16_hi(rr[0]);
+          v[2] += bf16_lo(rr[1]);
+          v[3] += bf16_hi(rr[1]);
+        }
+        if (flags & UDT_GEMM_RELU) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+        }
+        if (flags & UDT_GEMM_SILU_OUT) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = silu_f(v[r]);
+        }
+        u32x2 pk = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+        *reinterpret_cast<u32x2*>(cell) = pk;
+      }
+  }
+#pragma unroll
+  for (int i = 0; i < TM * 4; ++i) {
+    const int row = i * 8 + (lane >> 3);
+    const int ch = lane & 7;
+    const u32x4 v = *reinterpret_cast<const u32x4*>(wlds + row * 128 + ((ch ^ (row & 7)) << 4));
+    const int m = mw + row;
+    const int n = nw + ch * 8;
+    if (m < p.M && n + 8 <= p.N) {
+      *reinterpret_cast<u32x4*>(out + (long long)m * p.ldo + n) = v;
+    } else if (m < p.M && n < p.N) {
+      u32x2 h = {v[0], v[1]};
+      *reinterpret_cast<u32x2*>(out + (long long)m * p.ldo + n) = h;
+    }
+  }
+}
+
 UDT_DEVINL void raw_barrier() {
   asm volatile("" ::: "memory");
   __builtin_amdgcn_s_barrier();
@@ -155,18 +286,8 @@ UDT_DEVINL void raw_barrier() {
 
 template <int N>
 UDT_DEVINL void wait_vm() {
-  static_assert(N >= 0 && N <= 10, "immediate");
-  if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  if constexpr (N == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-  if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-  if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-  if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-  if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-  if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-  if constexpr (N == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
-  if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-  if constexpr (N == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
-  if constexpr (N == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+  static_assert(N >= 0 && N <= 63, "vmcnt is a 6-bit immediate");
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
 // 16-byte LDS-DMA through a buffer descriptor: uniform base (SGPRs) + per-lane byte offset + scalar byte offset.
@@ -191,6 +312,8 @@ __global__ void __launch_bounds__(NTHREADS) gemm8_kernel(const Params pp) {
   constexpr int B_PIECES = BN / 8;                 // 16 or 20
   constexpr int B_INSTR = (B_PIECES + 7) / 8;      // 2 or 3 per wave (padded with duplicate pieces -> uniform count)
   constexpr int LPT = A_INSTR + B_INSTR;           // loads per K-tile and wave
+  constexpr bool ROWS_EPI = (TN == 2) && (TM == 2) && !TRANS;    // row-coalesced epilogue through LDS (256x128 tile)
+  constexpr int EPI_WAVE_BYTES = TM * 32 * 128;    // 8 KiB per wave; 8 waves = stage 2 (48 KiB) + 16 KiB above the ring
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const GemmParams& p = pp.g;
@@ -317,6 +440,10 @@ __global__ void __launch_bounds__(NTHREADS) gemm8_kernel(const Params pp) {
     if (kt0 + 1 < kt1) stage(1, kt0 + 1);
   }
 
+  // after a register epilogue of an interior tile exactly `nst` stores per wave are YOUNGER than the next segment's
+  // two prefetched K-tiles: vmcnt retires in order, so leaving them in flight (LPT + nst) lets the store drain
+  // overlap the first two K-tiles instead of stalling them
+  int boost = 0, nst = 0;
   while (true) {
     int kt1 = p.n_ktiles;
     if ((long long)(kt1 - kt0) > it_end - it) kt1 = kt0 + (int)(it_end - it);
@@ -333,8 +460,17 @@ __global__ void __launch_bounds__(NTHREADS) gemm8_kernel(const Params pp) {
     // (a lead/lag role split between the two waves of a SIMD was measured: no gain over this straight loop)
     int st = 0;
     for (int kt = kt0; kt < kt1; ++kt) {
-      if (kt + 1 < kt1) wait_vm<LPT>();            // leaves exactly one K-tile in flight
-      else wait_vm<0>();
+      if (kt + 1 < kt1) {                          // leaves exactly one K-tile in flight
+        if (boost > 0) {
+          --boost;
+          if (nst == TM * TN * 4) wait_vm<LPT + TM * TN * 4>();
+          else wait_vm<LPT + TM * 4>();
+        } else {
+          wait_vm<LPT>();
+        }
+      } else {
+        wait_vm<0>();
+      }
       raw_barrier();                               // tile kt visible to all waves; stage (st+2)%3 no longer being read
       int st2 = st + 2;
       if (st2 >= NSTAGE) st2 -= NSTAGE;
@@ -366,6 +502,7 @@ __global__ void __launch_bounds__(NTHREADS) gemm8_kernel(const Params pp) {
     const bool full = (kt0 == 0) && (kt1 == p.n_ktiles);
     const bool publish = (kt0 > 0);                       // head segment of a tile another workgroup started
     const int cur_tile = tile, cur_batch = batch, cur_m0 = m0, cur_n0 = n0;
+    boost = 0;
     it += kt1 - kt0;
     const bool more = it < it_end;
     if (more) {
@@ -440,7 +577,22 @@ __global__ void __launch_bounds__(NTHREADS) gemm8_kernel(const Params pp) {
           for (int pg = g + 1; pg <= g_last; ++pg)
             __hip_atomic_store(pp.flags + pg, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
-      epilogue8<TM, TN, TRANS>(p, acc, cur_m0, cur_n0, cur_batch, row0, col0, lane);
+      if constexpr (ROWS_EPI) {
+        if (!(p.flags & UDT_GEMM_OUT_F32)) {
+          if (!more) raw_barrier();     // (with `more` the barrier ahead of the prefetch already closed the ring)
+          // ring stage 2 (+ the 16 KiB above the ring) is idle here: the next segment's prefetch went to stages 0, 1
+          epilogue8_rows<TM>(p, acc, cur_m0, cur_n0, cur_batch, row0, col0, lane,
+                             smem + 2 * STAGE_BYTES + wave * EPI_WAVE_BYTES);
+        } else {
+          epilogue8<TM, TN, TRANS>(p, acc, cur_m0, cur_n0, cur_batch, row0, col0, lane);
+        }
+      } else {
+        epilogue8<TM, TN, TRANS>(p, acc, cur_m0, cur_n0, cur_batch, row0, col0, lane);
+      }
+      if (!ROWS_EPI && full && cur_m0 + BM <= p.M && cur_n0 + BN <= p.N) {
+        boost = 2;
+        nst = (p.flags & UDT_GEMM_GEGLU) ? TM * 4 : TM * TN * 4;
+      }
     }
     if (!more) break;
   }
