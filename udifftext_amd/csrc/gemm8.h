@@ -278,6 +278,108 @@ UDT_DEVINL void epilogue8_rows(const GemmParams& p, f32x16 (&acc)[TM][2], int m0
   }
 }
 
+// the same for the 256x160 configuration (TM = 1, TN = 5: a wave owns 32 rows x 160 columns = 320-byte rows).  The
+// free ring stage holds 52 KiB, so the block goes through LDS in two passes of 16 rows (rows padded to 336 bytes:
+// 84-dword stride spreads the 16 rows over the banks without a swizzle); 20 lanes cover one row, 3 rows per
+// instruction.
+template <int TN>
+UDT_DEVINL void epilogue8_rows16(const GemmParams& p, f32x16 (&acc)[1][TN], int m0, int n0, int batch, int row0, int col0,
+                                 int lane, char* wlds) {
+  constexpr int NC = TN * 4;                   // 16-byte chunks per row
+  constexpr int RS = TN * 64 + 16;             // padded row stride
+  const int l31 = lane & 31;
+  const int hi = lane >> 5;
+  const int flags = p.flags;
+  const int mw = m0 + row0;
+  const int nw = n0 + col0;
+  uint16_t* out = reinterpret_cast<uint16_t*>(p.out) + (long long)batch * p.sO;
+  const uint16_t* __restrict__ R = p.res ? (p.res + (long long)batch * p.sR) : nullptr;
+  const int rl = lane / NC;                    // 0..2 (lane 60..63: idle)
+  const int ch = lane - rl * NC;
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    const bool mine = (l31 >> 4) == pass;
+    const int lrow = l31 & 15;
+    if (R) {
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        const int row = i * 3 + rl;
+        if (rl < 3 && row < 16) {
+          const int m = mw + pass * 16 + row;
+          const int n = nw + ch * 8;
+          u32x4 v = {0u, 0u, 0u, 0u};
+          if (m < p.M && n + 8 <= p.N) {
+            v = *reinterpret_cast<const u32x4*>(R + (long long)m * p.ldr + n);
+          } else if (m < p.M && n < p.N) {
+            const u32x2 h = *reinterpret_cast<const u32x2*>(R + (long long)m * p.ldr + n);
+            v[0] = h[0];
+            v[1] = h[1];
+          }
+          *reinterpret_cast<u32x4*>(wlds + row * RS + ch * 16) = v;
+        }
+      }
+    }
+    if (mine) {
+      const int m = mw + pass * 16 + lrow;
+      const int b = (p.rowvec != nullptr) ? ((m < p.M ? m : p.M - 1) / p.rows_per_batch) : 0;
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int n = nw + tn * 32 + q * 8 + hi * 4;
+          char* cell = wlds + lrow * RS + (tn * 4 + q) * 16 + hi * 8;
+          float v[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = acc[0][tn][q * 4 + r] * p.alpha;
+          if (n < p.N) {
+            if (p.bias) {
+              const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + n);
+#pragma unroll
+              for (int r = 0; r < 4; ++r) v[r] += bv[r];
+            }
+            if (p.rowvec) {
+              const f32x4 rv = *reinterpret_cast<const f32x4*>(p.rowvec + (long long)b * p.ldrv + n);
+#pragma unroll
+              for (int r = 0; r < 4; ++r) v[r] += rv[r];
+            }
+          }
+          if (R) {
+            const u32x2 rr = *reinterpret_cast<const u32x2*>(cell);
+            v[0] += bf16_lo(rr[0]);
+            v[1] += bf16_hi(rr[0]);
+            v[2] += bf16_lo(rr[1]);
+            v[3] += bf16_hi(rr[1]);
+          }
+          if (flags & UDT_GEMM_RELU) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+          }
+          if (flags & UDT_GEMM_SILU_OUT) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = silu_f(v[r]);
+          }
+          u32x2 pk = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+          *reinterpret_cast<u32x2*>(cell) = pk;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const int row = i * 3 + rl;
+      if (rl < 3 && row < 16) {
+        const u32x4 v = *reinterpret_cast<const u32x4*>(wlds + row * RS + ch * 16);
+        const int m = mw + pass * 16 + row;
+        const int n = nw + ch * 8;
+        if (m < p.M && n + 8 <= p.N) {
+          *reinterpret_cast<u32x4*>(out + (long long)m * p.ldo + n) = v;
+        } else if (m < p.M && n < p.N) {
+          u32x2 h = {v[0], v[1]};
+          *reinterpret_cast<u32x2*>(out + (long long)m * p.ldo + n) = h;
+        }
+      }
+    }
+  }
+}
+
 UDT_DEVINL void raw_barrier() {
   asm volatile("" ::: "memory");
   __builtin_amdgcn_s_barrier();
@@ -313,7 +415,9 @@ __global__ void __launch_bounds__(NTHREADS) gemm8_kernel(const Params pp) {
   constexpr int B_INSTR = (B_PIECES + 7) / 8;      // 2 or 3 per wave (padded with duplicate pieces -> uniform count)
   constexpr int LPT = A_INSTR + B_INSTR;           // loads per K-tile and wave
   constexpr bool ROWS_EPI = (TN == 2) && (TM == 2) && !TRANS;    // row-coalesced epilogue through LDS (256x128 tile)
-  constexpr int EPI_WAVE_BYTES = TM * 32 * 128;    // 8 KiB per wave; 8 waves = stage 2 (48 KiB) + 16 KiB above the ring
+  constexpr bool ROWS16_EPI = (TM == 1) && !TRANS;               // two 16-row passes (256x160 tile)
+  // 256x128: 8 KiB per wave = stage 2 (48 KiB) + 16 KiB above the ring; 256x160: 16 rows x 336 B per wave, in stage 2
+  constexpr int EPI_WAVE_BYTES = ROWS16_EPI ? 16 * (TN * 64 + 16) : TM * 32 * 128;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const GemmParams& p = pp.g;
@@ -577,7 +681,15 @@ __global__ void __launch_bounds__(NTHREADS) gemm8_kernel(const Params pp) {
           for (int pg = g + 1; pg <= g_last; ++pg)
             __hip_atomic_store(pp.flags + pg, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
-      if constexpr (ROWS_EPI) {
+      if constexpr (ROWS16_EPI) {
+        if (!(p.flags & (UDT_GEMM_OUT_F32 | UDT_GEMM_GEGLU))) {
+          if (!more) raw_barrier();
+          epilogue8_rows16<TN>(p, acc, cur_m0, cur_n0, cur_batch, row0, col0, lane,
+                               smem + 2 * STAGE_BYTES + wave * EPI_WAVE_BYTES);
+        } else {
+          epilogue8<TM, TN, TRANS>(p, acc, cur_m0, cur_n0, cur_batch, row0, col0, lane);
+        }
+      } else if constexpr (ROWS_EPI) {
         if (!(p.flags & UDT_GEMM_OUT_F32)) {
           if (!more) raw_barrier();     // (with `more` the barrier ahead of the prefetch already closed the ring)
           // ring stage 2 (+ the 16 KiB above the ring) is idle here: the next segment's prefetch went to stages 0, 1
@@ -589,7 +701,7 @@ __global__ void __launch_bounds__(NTHREADS) gemm8_kernel(const Params pp) {
       } else {
         epilogue8<TM, TN, TRANS>(p, acc, cur_m0, cur_n0, cur_batch, row0, col0, lane);
       }
-      if (!ROWS_EPI && full && cur_m0 + BM <= p.M && cur_n0 + BN <= p.N) {
+      if (!ROWS_EPI && !ROWS16_EPI && full && cur_m0 + BM <= p.M && cur_n0 + BN <= p.N) {
         boost = 2;
         nst = (p.flags & UDT_GEMM_GEGLU) ? TM * 4 : TM * TN * 4;
       }
