@@ -196,6 +196,10 @@ int udt_local_loss(const float* probs, const float* mask, const float* seg_mask,
 /* x bf16 += y bf16 (n elements, n % 8 == 0) ; utility for residuals outside GEMM epilogues */
 int udt_add_bf16(void* x, const void* y, int64_t n, void* stream);
 
+/* Measurement switch (A/B runs inside one process; no reference counterpart): key "gemm_impl" (4, 8, 9),
+ * "conv3p" (0/1: patch-staged 3x3 convolution), "rows_epi" (0/1: row-coalesced epilogues). */
+int udt_debug_set(const char* key, int32_t value);
+
 /* out[r][c] = bf16(x[r][c] + bias[c]); x/out bf16 [rows, C] (may alias), bias fp32 [C], C % 8 == 0.
  * Used where a projection's GEMM input is identically zero (cross-attention over an all-zero context — the
  * unconditional half under force_uc_zero_embeddings, reference sgm/modules/attention.py:150-174 with k = v = 0 — so

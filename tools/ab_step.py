@@ -31,6 +31,24 @@ import udifftext_amd.ops as O
 which = sys.argv[1] if len(sys.argv) > 1 else "gn"
 if which == "zero":
     variants = {"zero_rows=B": lambda: setattr(st, "zero_ctx_rows", B), "zero_rows=0": lambda: setattr(st, "zero_ctx_rows", 0)}
+elif which == "multi":
+    from udifftext_amd import lib as L
+    def setall(**kw):
+        for k, v in kw.items():
+            L.check(L.load().udt_debug_set(k.encode(), v), "dbg")
+    base = dict(skip_k=0, no_xchg=0, no_epi=0, no_store=0, no_res=0, no_bias=0, no_fast=0)
+    variants = {}
+    for spec in sys.argv[2:]:
+        kv = dict(base)
+        for item in spec.split(","):
+            if item:
+                k, v = item.split("="); kv[k] = int(v)
+        variants[spec or "base"] = (lambda kv=kv: setall(**kv))
+elif which.startswith("dbg:"):
+    key = which[4:]
+    from udifftext_amd import lib as L
+    vals = [int(v) for v in (sys.argv[2:] or ["1", "0"])]
+    variants = {f"{key}={v}": (lambda v=v: L.check(L.load().udt_debug_set(key.encode(), v), "dbg")) for v in vals}
 else:
     variants = {"gn_fused=1": lambda: setattr(O, "GN_FUSED", True), "gn_fused=0": lambda: setattr(O, "GN_FUSED", False)}
 for name, fn in variants.items():

@@ -28,6 +28,7 @@
 #include "common.h"
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 
 namespace {
 
@@ -538,6 +539,9 @@ hipError_t launch_cfg(const GemmParams& p, const TilePlan& t, hipStream_t s) {
 constexpr size_t G8_HEADER_BYTES = 4096;     // flags[<=1023] + err word, ahead of the slabs
 
 int g_impl = -1;     // 8: deep-pipelined 8-wave kernel (default), 4: first-generation 4-wave kernel
+int g_dbg_bits = 0;  // measurement modes: bit 28 no stream-K exchange, bit 27 no epilogue (results are wrong)
+int g_rows_epi = 1;  // row-coalesced (LDS-transposed) epilogues; 0 = direct accumulator-layout stores (A/B runs)
+constexpr int INTERNAL_DIRECT_EPI = 1 << 30;   // kernel-side flag bit, never part of the public flag set
 
 int gemm_impl() {
   if (g_impl < 0) {
@@ -704,6 +708,21 @@ hipError_t launch3p(const c3p::CParams& cp, const TilePlan& t, hipStream_t s) {
 
 }  // namespace
 
+extern "C" int udt_debug_set(const char* key, int32_t value) {
+  if (!key) return UDT_ERR_BAD_ARG;
+  if (!strcmp(key, "gemm_impl")) { g_impl = value; return UDT_OK; }
+  if (!strcmp(key, "conv3p")) { g_conv3p = value; return UDT_OK; }
+  if (!strcmp(key, "rows_epi")) { g_rows_epi = value; return UDT_OK; }
+  if (!strcmp(key, "no_xchg")) { g_dbg_bits = (g_dbg_bits & ~(1 << 28)) | (value ? (1 << 28) : 0); return UDT_OK; }
+  if (!strcmp(key, "no_store")) { g_dbg_bits = (g_dbg_bits & ~(1 << 26)) | (value ? (1 << 26) : 0); return UDT_OK; }
+  if (!strcmp(key, "no_res")) { g_dbg_bits = (g_dbg_bits & ~(1 << 25)) | (value ? (1 << 25) : 0); return UDT_OK; }
+  if (!strcmp(key, "no_bias")) { g_dbg_bits = (g_dbg_bits & ~(1 << 24)) | (value ? (1 << 24) : 0); return UDT_OK; }
+  if (!strcmp(key, "no_fast")) { g_dbg_bits = (g_dbg_bits & ~(1 << 22)) | (value ? (1 << 22) : 0); return UDT_OK; }
+  if (!strcmp(key, "epi_x4")) { g_dbg_bits = (g_dbg_bits & ~(1 << 23)) | (value ? (1 << 23) : 0); return UDT_OK; }
+  if (!strcmp(key, "no_epi")) { g_dbg_bits = (g_dbg_bits & ~(1 << 27)) | (value ? (1 << 27) : 0); return UDT_OK; }
+  return UDT_ERR_BAD_ARG;
+}
+
 extern "C" size_t udt_gemm_workspace_bytes(const udt_gemm_desc* d) {
   if (!d || d->K <= 0 || d->M <= 0 || d->N <= 0 || d->K % BK != 0) return 0;
   {
@@ -782,7 +801,7 @@ extern "C" int udt_gemm(const udt_gemm_desc* d, void* workspace, size_t workspac
   p.ksz = d->ksize; p.stride = d->stride; p.pad_t = d->pad_t; p.pad_l = d->pad_l; p.ups = d->upsample ? 1 : 0;
   p.rows_per_batch = d->rows_per_batch > 0 ? d->rows_per_batch : d->M;
   p.ldrv = d->ld_rowvec > 0 ? d->ld_rowvec : d->N;
-  p.flags = d->flags;
+  p.flags = d->flags | (g_rows_epi ? 0 : INTERNAL_DIRECT_EPI) | g_dbg_bits;
   p.alpha = d->alpha;
   const int cls = (conv && d->ksize == 3) ? 0 : 1;
   {

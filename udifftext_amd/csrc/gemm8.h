@@ -154,18 +154,19 @@ UDT_DEVINL void epilogue8(const GemmParams& p, f32x16 (&acc)[TM][TN], int m0, in
 // LDS of its own (XOR-swizzled 16-byte chunks) and stores 16 bytes per lane with 8 lanes covering one full 128-byte
 // row: whole cache lines, half the store instructions.  Residual rows are fetched the same way (whole lines) and
 // added in fp32 BEFORE the single bf16 rounding.  `wlds` = this wave's 8 KiB scratch (free ring stage).
-template <int TM>
-UDT_DEVINL void epilogue8_rows(const GemmParams& p, f32x16 (&acc)[TM][2], int m0, int n0, int batch, int row0, int col0,
-                               int lane, char* wlds) {
+// `mof(row)` maps a wave-local row (0 .. TM*32-1) to the global output row, or -1 (GEMM: m0 + row0 + row; the
+// patch-staged convolution: the NHWC pixel of that tile position); `nw` = first output column of the wave.
+template <int TM, class MOF>
+UDT_DEVINL void epilogue8_rows(const GemmParams& p, f32x16 (&acc)[TM][2], MOF mof, int nw, int batch, int lane,
+                               char* wlds) {
   const int l31 = lane & 31;
   const int hi = lane >> 5;
   const int flags = p.flags;
-  const int mw = m0 + row0;
   uint16_t* out = reinterpret_cast<uint16_t*>(p.out) + (long long)batch * p.sO;
   if (flags & UDT_GEMM_GEGLU) {
     // 32 output columns per wave: rows of 64 bytes, 4 chunks; lane -> (row = 16 i + lane/4, chunk = lane%4)
-    const int nx0 = n0 + col0;
-    const int no0 = (n0 + col0) >> 1;
+    const int nx0 = nw;
+    const int no0 = nw >> 1;
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm) {
       const int row = tm * 32 + l31;
@@ -173,7 +174,7 @@ UDT_DEVINL void epilogue8_rows(const GemmParams& p, f32x16 (&acc)[TM][2], int m0
       for (int q = 0; q < 4; ++q) {
         const int nx = nx0 + q * 8 + hi * 4;
         f32x4 bx = {0.f, 0.f, 0.f, 0.f}, bg = {0.f, 0.f, 0.f, 0.f};
-        if (p.bias && nx < p.N) {
+        if (p.bias && nx < p.N && !(p.flags & (1 << 24))) {
           bx = *reinterpret_cast<const f32x4*>(p.bias + nx);
           bg = *reinterpret_cast<const f32x4*>(p.bias + nx + 32);
         }
@@ -190,27 +191,26 @@ UDT_DEVINL void epilogue8_rows(const GemmParams& p, f32x16 (&acc)[TM][2], int m0
       const int row = i * 16 + (lane >> 2);
       const int ch = lane & 3;
       const u32x4 v = *reinterpret_cast<const u32x4*>(wlds + row * 64 + ((ch ^ (row & 3)) << 4));
-      const int m = mw + row;
+      const long long m = mof(row);
       const int no = no0 + ch * 8;
-      if (m < p.M && (nx0 + ch * 8) < p.N) *reinterpret_cast<u32x4*>(out + (long long)m * p.ldo + no) = v;
+      if (m >= 0 && (nx0 + ch * 8) < p.N && !(flags & (1 << 26))) *reinterpret_cast<u32x4*>(out + m * p.ldo + no) = v;
     }
     return;
   }
-  const int nw = n0 + col0;
-  const uint16_t* __restrict__ R = p.res ? (p.res + (long long)batch * p.sR) : nullptr;
+  const uint16_t* __restrict__ R = (p.res && !(p.flags & (1 << 25))) ? (p.res + (long long)batch * p.sR) : nullptr;
   if (R) {
     // residual block -> LDS in whole rows (8 lanes x 16 B = one 128-byte line), read back in accumulator order below
 #pragma unroll
     for (int i = 0; i < TM * 4; ++i) {
       const int row = i * 8 + (lane >> 3);
       const int ch = lane & 7;
-      const int m = mw + row;
+      const long long m = mof(row);
       const int n = nw + ch * 8;
       u32x4 v = {0u, 0u, 0u, 0u};
-      if (m < p.M && n + 8 <= p.N) {
-        v = *reinterpret_cast<const u32x4*>(R + (long long)m * p.ldr + n);
-      } else if (m < p.M && n < p.N) {                     // N % 8 == 4 tail: 4 columns
-        const u32x2 h = *reinterpret_cast<const u32x2*>(R + (long long)m * p.ldr + n);
+      if (m >= 0 && n + 8 <= p.N) {
+        v = *reinterpret_cast<const u32x4*>(R + m * p.ldr + n);
+      } else if (m >= 0 && n < p.N) {                      // N % 8 == 4 tail: 4 columns
+        const u32x2 h = *reinterpret_cast<const u32x2*>(R + m * p.ldr + n);
         v[0] = h[0];
         v[1] = h[1];
       }
@@ -220,8 +220,8 @@ UDT_DEVINL void epilogue8_rows(const GemmParams& p, f32x16 (&acc)[TM][2], int m0
 #pragma unroll
   for (int tm = 0; tm < TM; ++tm) {
     const int row = tm * 32 + l31;
-    const int m = mw + row;
-    const int b = (p.rowvec != nullptr) ? ((m < p.M ? m : p.M - 1) / p.rows_per_batch) : 0;
+    const long long mo = mof(row);
+    const int b = (p.rowvec != nullptr) ? (int)((mo >= 0 ? mo : 0) / p.rows_per_batch) : 0;
 #pragma unroll
     for (int tn = 0; tn < 2; ++tn)
 #pragma unroll
@@ -232,12 +232,12 @@ UDT_DEVINL void epilogue8_rows(const GemmParams& p, f32x16 (&acc)[TM][2], int m0
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = acc[tm][tn][q * 4 + r] * p.alpha;
         if (n < p.N) {
-          if (p.bias) {
+          if (p.bias && !(p.flags & (1 << 24))) {
             const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + n);
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] += bv[r];
           }
-          if (p.rowvec) {
+          if (p.rowvec && !(p.flags & (1 << 24))) {
             const f32x4 rv = *reinterpret_cast<const f32x4*>(p.rowvec + (long long)b * p.ldrv + n);
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] += rv[r];
@@ -267,13 +267,13 @@ UDT_DEVINL void epilogue8_rows(const GemmParams& p, f32x16 (&acc)[TM][2], int m0
     const int row = i * 8 + (lane >> 3);
     const int ch = lane & 7;
     const u32x4 v = *reinterpret_cast<const u32x4*>(wlds + row * 128 + ((ch ^ (row & 7)) << 4));
-    const int m = mw + row;
+    const long long m = mof(row);
     const int n = nw + ch * 8;
-    if (m < p.M && n + 8 <= p.N) {
-      *reinterpret_cast<u32x4*>(out + (long long)m * p.ldo + n) = v;
-    } else if (m < p.M && n < p.N) {
+    if (m >= 0 && n + 8 <= p.N && !(flags & (1 << 26))) {
+      *reinterpret_cast<u32x4*>(out + m * p.ldo + n) = v;
+    } else if (m >= 0 && n < p.N) {
       u32x2 h = {v[0], v[1]};
-      *reinterpret_cast<u32x2*>(out + (long long)m * p.ldo + n) = h;
+      *reinterpret_cast<u32x2*>(out + m * p.ldo + n) = h;
     }
   }
 }
@@ -282,18 +282,16 @@ UDT_DEVINL void epilogue8_rows(const GemmParams& p, f32x16 (&acc)[TM][2], int m0
 // free ring stage holds 52 KiB, so the block goes through LDS in two passes of 16 rows (rows padded to 336 bytes:
 // 84-dword stride spreads the 16 rows over the banks without a swizzle); 20 lanes cover one row, 3 rows per
 // instruction.
-template <int TN>
-UDT_DEVINL void epilogue8_rows16(const GemmParams& p, f32x16 (&acc)[1][TN], int m0, int n0, int batch, int row0, int col0,
-                                 int lane, char* wlds) {
+template <int TN, class MOF>
+UDT_DEVINL void epilogue8_rows16(const GemmParams& p, f32x16 (&acc)[1][TN], MOF mof, int nw, int batch, int lane,
+                                 char* wlds) {
   constexpr int NC = TN * 4;                   // 16-byte chunks per row
   constexpr int RS = TN * 64 + 16;             // padded row stride
   const int l31 = lane & 31;
   const int hi = lane >> 5;
   const int flags = p.flags;
-  const int mw = m0 + row0;
-  const int nw = n0 + col0;
   uint16_t* out = reinterpret_cast<uint16_t*>(p.out) + (long long)batch * p.sO;
-  const uint16_t* __restrict__ R = p.res ? (p.res + (long long)batch * p.sR) : nullptr;
+  const uint16_t* __restrict__ R = (p.res && !(p.flags & (1 << 25))) ? (p.res + (long long)batch * p.sR) : nullptr;
   const int rl = lane / NC;                    // 0..2 (lane 60..63: idle)
   const int ch = lane - rl * NC;
 #pragma unroll
@@ -304,14 +302,14 @@ UDT_DEVINL void epilogue8_rows16(const GemmParams& p, f32x16 (&acc)[1][TN], int 
 #pragma unroll
       for (int i = 0; i < 6; ++i) {
         const int row = i * 3 + rl;
+        const long long m = mof(pass * 16 + (row < 16 ? row : 15));   // outside the branch: mof may read another lane
         if (rl < 3 && row < 16) {
-          const int m = mw + pass * 16 + row;
           const int n = nw + ch * 8;
           u32x4 v = {0u, 0u, 0u, 0u};
-          if (m < p.M && n + 8 <= p.N) {
-            v = *reinterpret_cast<const u32x4*>(R + (long long)m * p.ldr + n);
-          } else if (m < p.M && n < p.N) {
-            const u32x2 h = *reinterpret_cast<const u32x2*>(R + (long long)m * p.ldr + n);
+          if (m >= 0 && n + 8 <= p.N) {
+            v = *reinterpret_cast<const u32x4*>(R + m * p.ldr + n);
+          } else if (m >= 0 && n < p.N) {
+            const u32x2 h = *reinterpret_cast<const u32x2*>(R + m * p.ldr + n);
             v[0] = h[0];
             v[1] = h[1];
           }
@@ -319,9 +317,9 @@ UDT_DEVINL void epilogue8_rows16(const GemmParams& p, f32x16 (&acc)[1][TN], int 
         }
       }
     }
+    const long long mo = mof(l31);          // (all lanes: mof may be a cross-lane read)
     if (mine) {
-      const int m = mw + pass * 16 + lrow;
-      const int b = (p.rowvec != nullptr) ? ((m < p.M ? m : p.M - 1) / p.rows_per_batch) : 0;
+      const int b = (p.rowvec != nullptr) ? (int)((mo >= 0 ? mo : 0) / p.rows_per_batch) : 0;
 #pragma unroll
       for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
@@ -332,12 +330,12 @@ UDT_DEVINL void epilogue8_rows16(const GemmParams& p, f32x16 (&acc)[1][TN], int 
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[r] = acc[0][tn][q * 4 + r] * p.alpha;
           if (n < p.N) {
-            if (p.bias) {
+            if (p.bias && !(p.flags & (1 << 24))) {
               const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + n);
 #pragma unroll
               for (int r = 0; r < 4; ++r) v[r] += bv[r];
             }
-            if (p.rowvec) {
+            if (p.rowvec && !(p.flags & (1 << 24))) {
               const f32x4 rv = *reinterpret_cast<const f32x4*>(p.rowvec + (long long)b * p.ldrv + n);
 #pragma unroll
               for (int r = 0; r < 4; ++r) v[r] += rv[r];
@@ -365,17 +363,260 @@ UDT_DEVINL void epilogue8_rows16(const GemmParams& p, f32x16 (&acc)[1][TN], int 
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
       const int row = i * 3 + rl;
+      const long long m = mof(pass * 16 + (row < 16 ? row : 15));
       if (rl < 3 && row < 16) {
         const u32x4 v = *reinterpret_cast<const u32x4*>(wlds + row * RS + ch * 16);
-        const int m = mw + pass * 16 + row;
         const int n = nw + ch * 8;
-        if (m < p.M && n + 8 <= p.N) {
-          *reinterpret_cast<u32x4*>(out + (long long)m * p.ldo + n) = v;
-        } else if (m < p.M && n < p.N) {
+        if (m >= 0 && n + 8 <= p.N && !(flags & (1 << 26))) {
+          *reinterpret_cast<u32x4*>(out + m * p.ldo + n) = v;
+        } else if (m >= 0 && n < p.N) {
           u32x2 h = {v[0], v[1]};
-          *reinterpret_cast<u32x2*>(out + (long long)m * p.ldo + n) = h;
+          *reinterpret_cast<u32x2*>(out + m * p.ldo + n) = h;
         }
       }
+    }
+  }
+}
+
+// ---- fast variants of the row-coalesced epilogues ----------------------------------------------------------------
+// Measured on MI355X: the generic epilogues above spend ~9 us per tile on NOTHING BUT control flow — every 4-value
+// group re-tests the runtime feature flags and its lane predicates, and every bias / time-embedding load sits behind
+// such a branch, so the loads are issued one latency at a time (another ~8 us).  The fast variants are compiled per
+// feature set (bias / per-sample row vector / residual), assume an INTERIOR tile (every row and column valid, one
+// sample per wave block) and issue all their loads up front; anything else takes the generic path.
+template <int TM, bool BIAS, bool ROWVEC, bool RES, class MOF>
+UDT_DEVINL void epilogue8_rows_fast(const GemmParams& p, f32x16 (&acc)[TM][2], MOF mof, int nw, int batch, int lane,
+                                    char* wlds) {
+  const int l31 = lane & 31;
+  const int hi = lane >> 5;
+  uint16_t* out = reinterpret_cast<uint16_t*>(p.out) + (long long)batch * p.sO;
+  long long mrow[TM * 4];
+#pragma unroll
+  for (int i = 0; i < TM * 4; ++i) mrow[i] = mof(i * 8 + (lane >> 3));
+  const int ch = lane & 7;
+  if constexpr (RES) {
+    const uint16_t* __restrict__ R = p.res + (long long)batch * p.sR;
+    u32x4 rv[TM * 4];
+#pragma unroll
+    for (int i = 0; i < TM * 4; ++i) rv[i] = *reinterpret_cast<const u32x4*>(R + mrow[i] * p.ldr + nw + ch * 8);
+#pragma unroll
+    for (int i = 0; i < TM * 4; ++i) {
+      const int row = i * 8 + (lane >> 3);
+      *reinterpret_cast<u32x4*>(wlds + row * 128 + ((ch ^ (row & 7)) << 4)) = rv[i];
+    }
+  }
+  f32x4 cv[2][4];
+  int b = 0;
+  if constexpr (ROWVEC) b = (int)(mof(0) / p.rows_per_batch);    // one sample per wave block (caller checked)
+#pragma unroll
+  for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int n = nw + tn * 32 + q * 8 + hi * 4;
+      f32x4 c = {0.f, 0.f, 0.f, 0.f};
+      if constexpr (BIAS) c = *reinterpret_cast<const f32x4*>(p.bias + n);
+      if constexpr (ROWVEC) {
+        const f32x4 r = *reinterpret_cast<const f32x4*>(p.rowvec + (long long)b * p.ldrv + n);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) c[k] += r[k];
+      }
+      cv[tn][q] = c;
+    }
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm) {
+    const int row = tm * 32 + l31;
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        char* cell = wlds + row * 128 + (((tn * 4 + q) ^ (row & 7)) << 4) + hi * 8;
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = acc[tm][tn][q * 4 + r] * p.alpha + cv[tn][q][r];
+        if constexpr (RES) {
+          const u32x2 rr = *reinterpret_cast<const u32x2*>(cell);
+          v[0] += bf16_lo(rr[0]);
+          v[1] += bf16_hi(rr[0]);
+          v[2] += bf16_lo(rr[1]);
+          v[3] += bf16_hi(rr[1]);
+        }
+        u32x2 pk = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+        *reinterpret_cast<u32x2*>(cell) = pk;
+      }
+  }
+#pragma unroll
+  for (int i = 0; i < TM * 4; ++i) {
+    const int row = i * 8 + (lane >> 3);
+    const u32x4 v = *reinterpret_cast<const u32x4*>(wlds + row * 128 + ((ch ^ (row & 7)) << 4));
+    *reinterpret_cast<u32x4*>(out + mrow[i] * p.ldo + nw + ch * 8) = v;
+  }
+}
+
+// GEGLU, interior tile, bias present
+template <int TM, class MOF>
+UDT_DEVINL void epilogue8_geglu_fast(const GemmParams& p, f32x16 (&acc)[TM][2], MOF mof, int nw, int batch, int lane,
+                                     char* wlds) {
+  const int l31 = lane & 31;
+  const int hi = lane >> 5;
+  uint16_t* out = reinterpret_cast<uint16_t*>(p.out) + (long long)batch * p.sO;
+  f32x4 bx[4], bg[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    bx[q] = *reinterpret_cast<const f32x4*>(p.bias + nw + q * 8 + hi * 4);
+    bg[q] = *reinterpret_cast<const f32x4*>(p.bias + nw + q * 8 + hi * 4 + 32);
+  }
+  long long mrow[TM * 2];
+#pragma unroll
+  for (int i = 0; i < TM * 2; ++i) mrow[i] = mof(i * 16 + (lane >> 2));
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm) {
+    const int row = tm * 32 + l31;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float o[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        o[r] = (acc[tm][0][q * 4 + r] * p.alpha + bx[q][r]) * gelu_erf_f(acc[tm][1][q * 4 + r] * p.alpha + bg[q][r]);
+      u32x2 pk = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
+      *reinterpret_cast<u32x2*>(wlds + row * 64 + ((q ^ (row & 3)) << 4) + hi * 8) = pk;
+    }
+  }
+  const int no0 = nw >> 1;
+#pragma unroll
+  for (int i = 0; i < TM * 2; ++i) {
+    const int row = i * 16 + (lane >> 2);
+    const int ch = lane & 3;
+    const u32x4 v = *reinterpret_cast<const u32x4*>(wlds + row * 64 + ((ch ^ (row & 3)) << 4));
+    *reinterpret_cast<u32x4*>(out + mrow[i] * p.ldo + no0 + ch * 8) = v;
+  }
+}
+
+// 256x160 configuration (TM = 1): per-column constants (bias + row vector) staged once in LDS behind the 16-row block
+template <int TN, bool BIAS, bool ROWVEC, bool RES, class MOF>
+UDT_DEVINL void epilogue8_rows16_fast(const GemmParams& p, f32x16 (&acc)[1][TN], MOF mof, int nw, int batch, int lane,
+                                      char* wlds) {
+  constexpr int NC = TN * 4;
+  constexpr int RS = TN * 64 + 16;
+  const int l31 = lane & 31;
+  const int hi = lane >> 5;
+  uint16_t* out = reinterpret_cast<uint16_t*>(p.out) + (long long)batch * p.sO;
+  float* cvec = reinterpret_cast<float*>(wlds + 16 * RS);          // [TN * 32] floats
+  int b = 0;
+  if constexpr (ROWVEC) b = (int)(mof(0) / p.rows_per_batch);
+  if constexpr (BIAS || ROWVEC) {
+    if (lane < TN * 8) {
+      f32x4 c = {0.f, 0.f, 0.f, 0.f};
+      if constexpr (BIAS) c = *reinterpret_cast<const f32x4*>(p.bias + nw + lane * 4);
+      if constexpr (ROWVEC) {
+        const f32x4 r = *reinterpret_cast<const f32x4*>(p.rowvec + (long long)b * p.ldrv + nw + lane * 4);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) c[k] += r[k];
+      }
+      *reinterpret_cast<f32x4*>(cvec + lane * 4) = c;
+    }
+  }
+  const int rl = lane / NC;
+  const int ch = lane - rl * NC;
+  long long mrow[2][6];
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass)
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const int row = i * 3 + rl;
+      mrow[pass][i] = mof(pass * 16 + (row < 16 ? row : 15));
+    }
+  u32x4 rv[2][6];
+  if constexpr (RES) {
+    const uint16_t* __restrict__ R = p.res + (long long)batch * p.sR;
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass)
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        const int row = i * 3 + rl;
+        if (rl < 3 && row < 16) rv[pass][i] = *reinterpret_cast<const u32x4*>(R + mrow[pass][i] * p.ldr + nw + ch * 8);
+      }
+  }
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    const bool mine = (l31 >> 4) == pass;
+    const int lrow = l31 & 15;
+    if constexpr (RES) {
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        const int row = i * 3 + rl;
+        if (rl < 3 && row < 16) *reinterpret_cast<u32x4*>(wlds + row * RS + ch * 16) = rv[pass][i];
+      }
+    }
+    if (mine) {
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          char* cell = wlds + lrow * RS + (tn * 4 + q) * 16 + hi * 8;
+          float v[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = acc[0][tn][q * 4 + r] * p.alpha;
+          if constexpr (BIAS || ROWVEC) {
+            const f32x4 c = *reinterpret_cast<const f32x4*>(cvec + tn * 32 + q * 8 + hi * 4);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] += c[r];
+          }
+          if constexpr (RES) {
+            const u32x2 rr = *reinterpret_cast<const u32x2*>(cell);
+            v[0] += bf16_lo(rr[0]);
+            v[1] += bf16_hi(rr[0]);
+            v[2] += bf16_lo(rr[1]);
+            v[3] += bf16_hi(rr[1]);
+          }
+          u32x2 pk = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+          *reinterpret_cast<u32x2*>(cell) = pk;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const int row = i * 3 + rl;
+      if (rl < 3 && row < 16) {
+        const u32x4 v = *reinterpret_cast<const u32x4*>(wlds + row * RS + ch * 16);
+        *reinterpret_cast<u32x4*>(out + mrow[pass][i] * p.ldo + nw + ch * 8) = v;
+      }
+    }
+  }
+}
+
+// feature-set dispatch shared by the GEMM and the patch-staged convolution.  `interior`: every row of the wave block
+// and every column of its span is valid; `wave_rows`: rows per wave block (one sample per block is required for the
+// row vector).  Returns false when the generic epilogue has to run.
+template <int TM, int TN, class MOF>
+UDT_DEVINL bool epilogue8_fast_dispatch(const GemmParams& p, f32x16 (&acc)[TM][TN], MOF mof, int nw, int batch, int lane,
+                                        char* wlds, bool interior) {
+  constexpr int PUB = UDT_GEMM_OUT_F32 | UDT_GEMM_GEGLU | UDT_GEMM_RELU | UDT_GEMM_SILU_OUT | (1 << 30) | (1 << 24) |
+                      (1 << 25) | (1 << 26);
+  if (!interior || (p.flags & (1 << 22))) return false;
+  const int f = p.flags & PUB;
+  if constexpr (TN == 2) {
+    if (f == UDT_GEMM_GEGLU && p.bias && !p.res && !p.rowvec) {
+      epilogue8_geglu_fast<TM>(p, acc, mof, nw, batch, lane, wlds);
+      return true;
+    }
+  }
+  if (f != 0) return false;
+  if (p.rowvec && (p.rows_per_batch % (TM * 32)) != 0) return false;
+  const int code = (p.bias ? 1 : 0) | (p.rowvec ? 2 : 0) | (p.res ? 4 : 0);
+  if constexpr (TN == 2) {
+    switch (code) {
+      case 0: epilogue8_rows_fast<TM, false, false, false>(p, acc, mof, nw, batch, lane, wlds); return true;
+      case 1: epilogue8_rows_fast<TM, true, false, false>(p, acc, mof, nw, batch, lane, wlds); return true;
+      case 3: epilogue8_rows_fast<TM, true, true, false>(p, acc, mof, nw, batch, lane, wlds); return true;
+      case 5: epilogue8_rows_fast<TM, true, false, true>(p, acc, mof, nw, batch, lane, wlds); return true;
+      default: return false;
+    }
+  } else {
+    switch (code) {
+      case 0: epilogue8_rows16_fast<TN, false, false, false>(p, acc, mof, nw, batch, lane, wlds); return true;
+      case 1: epilogue8_rows16_fast<TN, true, false, false>(p, acc, mof, nw, batch, lane, wlds); return true;
+      case 3: epilogue8_rows16_fast<TN, true, true, false>(p, acc, mof, nw, batch, lane, wlds); return true;
+      case 5: epilogue8_rows16_fast<TN, true, false, true>(p, acc, mof, nw, batch, lane, wlds); return true;
+      default: return false;
     }
   }
 }
@@ -417,7 +658,7 @@ __global__ void __launch_bounds__(NTHREADS) gemm8_kernel(const Params pp) {
   constexpr bool ROWS_EPI = (TN == 2) && (TM == 2) && !TRANS;    // row-coalesced epilogue through LDS (256x128 tile)
   constexpr bool ROWS16_EPI = (TM == 1) && !TRANS;               // two 16-row passes (256x160 tile)
   // 256x128: 8 KiB per wave = stage 2 (48 KiB) + 16 KiB above the ring; 256x160: 16 rows x 336 B per wave, in stage 2
-  constexpr int EPI_WAVE_BYTES = ROWS16_EPI ? 16 * (TN * 64 + 16) : TM * 32 * 128;
+  constexpr int EPI_WAVE_BYTES = ROWS16_EPI ? 16 * (TN * 64 + 16) + TN * 128 : TM * 32 * 128;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const GemmParams& p = pp.g;
@@ -603,8 +844,10 @@ __global__ void __launch_bounds__(NTHREADS) gemm8_kernel(const Params pp) {
       if (st >= NSTAGE) st = 0;
     }
 
-    const bool full = (kt0 == 0) && (kt1 == p.n_ktiles);
-    const bool publish = (kt0 > 0);                       // head segment of a tile another workgroup started
+    // (bits 28 / 27 of flags: measurement modes of udt_debug_set — no slab exchange / no epilogue; wrong results)
+    const bool noxchg = (p.flags & (1 << 28)) != 0;
+    const bool full = noxchg || ((kt0 == 0) && (kt1 == p.n_ktiles));
+    const bool publish = !noxchg && (kt0 > 0);            // head segment of a tile another workgroup started
     const int cur_tile = tile, cur_batch = batch, cur_m0 = m0, cur_n0 = n0;
     boost = 0;
     it += kt1 - kt0;
@@ -644,7 +887,7 @@ __global__ void __launch_bounds__(NTHREADS) gemm8_kernel(const Params pp) {
       if (more) {
         // the drain above also retired the prefetch; nothing else to do (its data is simply already there)
       }
-    } else {
+    } else if (!(p.flags & (1 << 27))) {
       if (!full) {
         // this workgroup owns the start of the tile: collect the partners' slabs
         const long long tile_end = ((long long)cur_tile + 1) * p.n_ktiles;
@@ -682,19 +925,27 @@ __global__ void __launch_bounds__(NTHREADS) gemm8_kernel(const Params pp) {
             __hip_atomic_store(pp.flags + pg, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
       if constexpr (ROWS16_EPI) {
-        if (!(p.flags & (UDT_GEMM_OUT_F32 | UDT_GEMM_GEGLU))) {
+        if (!(p.flags & (UDT_GEMM_OUT_F32 | UDT_GEMM_GEGLU | (1 << 30)))) {
           if (!more) raw_barrier();
-          epilogue8_rows16<TN>(p, acc, cur_m0, cur_n0, cur_batch, row0, col0, lane,
-                               smem + 2 * STAGE_BYTES + wave * EPI_WAVE_BYTES);
+          const int mwv = cur_m0 + row0;
+          auto mof = [&](int row) -> long long { return (mwv + row < p.M) ? (long long)(mwv + row) : -1LL; };
+          char* wl = smem + 2 * STAGE_BYTES + wave * EPI_WAVE_BYTES;
+          const bool interior = (cur_m0 + BM <= p.M) && (cur_n0 + BN <= p.N);
+          if (!epilogue8_fast_dispatch<TM, TN>(p, acc, mof, cur_n0 + col0, cur_batch, lane, wl, interior))
+            epilogue8_rows16<TN>(p, acc, mof, cur_n0 + col0, cur_batch, lane, wl);
         } else {
           epilogue8<TM, TN, TRANS>(p, acc, cur_m0, cur_n0, cur_batch, row0, col0, lane);
         }
       } else if constexpr (ROWS_EPI) {
-        if (!(p.flags & UDT_GEMM_OUT_F32)) {
+        if (!(p.flags & (UDT_GEMM_OUT_F32 | (1 << 30)))) {
           if (!more) raw_barrier();     // (with `more` the barrier ahead of the prefetch already closed the ring)
           // ring stage 2 (+ the 16 KiB above the ring) is idle here: the next segment's prefetch went to stages 0, 1
-          epilogue8_rows<TM>(p, acc, cur_m0, cur_n0, cur_batch, row0, col0, lane,
-                             smem + 2 * STAGE_BYTES + wave * EPI_WAVE_BYTES);
+          const int mwv = cur_m0 + row0;
+          auto mof = [&](int row) -> long long { return (mwv + row < p.M) ? (long long)(mwv + row) : -1LL; };
+          char* wl = smem + 2 * STAGE_BYTES + wave * EPI_WAVE_BYTES;
+          const bool interior = (cur_m0 + BM <= p.M) && (cur_n0 + BN <= p.N);
+          if (!epilogue8_fast_dispatch<TM, TN>(p, acc, mof, cur_n0 + col0, cur_batch, lane, wl, interior))
+            epilogue8_rows<TM>(p, acc, mof, cur_n0 + col0, cur_batch, lane, wl);
         } else {
           epilogue8<TM, TN, TRANS>(p, acc, cur_m0, cur_n0, cur_batch, row0, col0, lane);
         }
