@@ -12,8 +12,9 @@ timed region starts.  For N > 1 (launched by torch.distributed.run, one rank per
 samples its own 4 images (weak scaling) and the decoded frames are all-gathered once per step.
 
 Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel class (3x3 implicit-GEMM convolution):
-algorithmic FLOPs of the launches in the timed region / their summed duration, measured live with HIP events on
-the launch stream (udt_prof_*).  `cpu_baseline` times the CPU oracle (oracle/, a port pinned against the real
+algorithmic FLOPs of its launches / their summed duration, measured live with HIP events on the launch stream
+(udt_prof_*) — on one extra eager pass of the same batch right after the timed region, because the timed region
+replays hipGraphs (no per-launch host calls to bracket).  `cpu_baseline` times the CPU oracle (oracle/, a port pinned against the real
 reference) on the host cores for a bounded sample and extrapolates (rank 0, N = 1 only).
 """
 from __future__ import annotations
@@ -137,9 +138,7 @@ def main():
         one_step(batches[i])
 
     # ---- timed region ------------------------------------------------------------------------------------
-    H.FLOP_COUNTER = {}
-    ops.prof_reset()
-    ops.prof_enable(1 << L.PROF_CONV3X3)
+    # (the sampling loop replays hipGraphs captured during warm-up, or on the first timed step when --warmup 0)
     barrier()
     t0 = time.perf_counter()
     frames = None
@@ -147,11 +146,23 @@ def main():
         frames = one_step(batches[args.warmup + i])
     barrier()
     elapsed = time.perf_counter() - t0
+
+    # ---- roofline pass: graph replay issues no per-launch host calls, so the per-kernel HIP events (udt_prof_*,
+    # recorded on the launch stream around every 3x3-convolution launch) are taken on ONE extra pass of the same
+    # workload with eager launches, right after the timed region
+    graphs_on = bool(getattr(sampler, "use_graphs", False))
+    sampler.use_graphs = False
+    H.FLOP_COUNTER = {}
+    ops.prof_reset()
+    ops.prof_enable(1 << L.PROF_CONV3X3)
+    one_step(batches[-1])
+    torch.cuda.synchronize()
     ops.prof_enable(0)
     conv_ms, conv_launches = ops.prof_get(L.PROF_CONV3X3)
     conv_flops = H.FLOP_COUNTER.get("conv3x3", 0.0)
     conv_bytes = H.FLOP_COUNTER.get("conv3x3_bytes", 0.0)
     H.FLOP_COUNTER = None
+    sampler.use_graphs = graphs_on
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if dist is not None:
@@ -161,21 +172,29 @@ def main():
 
     # per-step UNet time (second half of BASELINE's metric): one sampler step on the CFG pair, averaged
     if rank == 0:
-        batch, buc = pipeline.prepare_batch(batches[0], dev)
-        c, uc = model.conditioner.get_unconditional_conditioning(batch, batch_uc=buc, force_uc_zero_embeddings=["label"])
-        from sgm.modules.diffusionmodules.sampling import _Stepper
-        st = _Stepper(model, c, uc, args.batch, (args.size // 8, args.size // 8), 5.0)
-        x = torch.randn((args.batch, 4, args.size // 8, args.size // 8), device=dev) * 14.0
-        sig = sampler._host_sigmas()
-        for i in range(3):
-            st.step(x, sig[i], sig[i + 1])
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
+        gs = next(iter(getattr(sampler, "_graphed", {}).values()), None) if graphs_on else None
         n_meas = 10
-        for i in range(n_meas):
-            st.step(x, sig[3 + i], sig[4 + i])
-        e1.record()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        if gs is not None and all(i in gs.graphs for i in range(3, 3 + n_meas)):
+            torch.cuda.synchronize()
+            e0.record()
+            for i in range(3, 3 + n_meas):
+                gs.graphs[i].replay()
+            e1.record()
+        else:
+            batch, buc = pipeline.prepare_batch(batches[0], dev)
+            c, uc = model.conditioner.get_unconditional_conditioning(batch, batch_uc=buc, force_uc_zero_embeddings=["label"])
+            from sgm.modules.diffusionmodules.sampling import _Stepper
+            st = _Stepper(model, c, uc, args.batch, (args.size // 8, args.size // 8), 5.0)
+            x = torch.randn((args.batch, 4, args.size // 8, args.size // 8), device=dev) * 14.0
+            sig = sampler._host_sigmas()
+            for i in range(3):
+                st.step(x, sig[i], sig[i + 1])
+            torch.cuda.synchronize()
+            e0.record()
+            for i in range(n_meas):
+                st.step(x, sig[3 + i], sig[4 + i])
+            e1.record()
         torch.cuda.synchronize()
         unet_ms = e0.elapsed_time(e1) / n_meas
 
@@ -193,11 +212,14 @@ def main():
                                    f"batch {args.batch} per GPU ({2 * args.batch} samples per UNet call), {args.chars}-char "
                                    "labels, noise_iters 0; BASELINE.json configs[1]",
                        "global_batch": args.batch * world, "parallelism": f"dp{world} (images sharded, one all-gather of frames)",
-                       "weights": "synthetic (name-keyed recipe), 1361.2 M parameters"},
+                       "weights": "synthetic (name-keyed recipe), 1361.2 M parameters",
+                       "launch": "hipGraph replay of the 50 sampler steps" if graphs_on else "eager kernel launches"},
             "roofline": {"kernel": "3x3 convolution: c3p::conv3p_kernel (LDS-staged patches) + g8::gemm8_kernel<CONV> "
                                    "(stride-2 / upsampling gathers), UNet + VAE", "bound": "mfma",
                          "achieved": achieved, "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s", "frac": achieved / (PEAK_BF16 / 1e12),
                          "traffic": measured_traffic(), "launches": conv_launches,
+                         "measured_on": "one eager pass of the same batch right after the timed region (HIP events per "
+                                        "launch; the timed region replays hipGraphs)" if graphs_on else "eager pass",
                          "avg_launch_us": conv_ms * 1e3 / max(conv_launches, 1),
                          "algorithmic_gflop_per_launch": conv_flops / max(conv_launches, 1) / 1e9,
                          "algorithmic_bytes_per_launch": conv_bytes / max(conv_launches, 1),

@@ -178,6 +178,34 @@ def test_ten_step_sampling_vs_reference_golden(engine, cond256, eg, cuda):
     _check("decoded image of the 10-step latent vs reference", dec[:, :, ::8, ::8].cpu(), eg["g9_decoded_sub"], 1e-1)
 
 
+def test_graph_replay_matches_eager_launches(engine, cond256, cuda):
+    """the sampler's hipGraph path (capture once per step index, replay; static conditioning buffers refreshed by
+    rebind for the next batch) must give exactly the eager launch sequence's latent"""
+    from udifftext_amd import pipeline, synth
+    batch, c, uc = cond256
+    torch.manual_seed(5)
+    x0 = torch.randn((1, 4, 32, 32), device=cuda)
+    eager = pipeline.init_sampling(4, 5.0, cuda)
+    eager.use_graphs = False
+    graphed = pipeline.init_sampling(4, 5.0, cuda)
+    graphed.use_graphs = True
+    ze = eager(engine, x0.clone(), cond=c, batch=batch, uc=uc)
+    zg = graphed(engine, x0.clone(), cond=c, batch=batch, uc=uc)
+    assert graphed.use_graphs and len(graphed._graphed) == 1, "graph capture fell back to eager launches"
+    assert torch.equal(ze, zg)
+    # a second batch with other conditioning re-uses the captured graphs through rebind()
+    b2 = synth.synthetic_batch(1, 256, 256, 4, seed=3)
+    b2, buc2 = pipeline.prepare_batch(b2, cuda)
+    c2, uc2 = engine.conditioner.get_unconditional_conditioning(b2, batch_uc=buc2, force_uc_zero_embeddings=["label"])
+    gs = next(iter(graphed._graphed.values()))
+    n_graphs = len(gs.graphs)
+    ze2 = eager(engine, x0.clone(), cond=c2, batch=b2, uc=uc2)
+    zg2 = graphed(engine, x0.clone(), cond=c2, batch=b2, uc=uc2)
+    assert next(iter(graphed._graphed.values())) is gs and len(gs.graphs) == n_graphs
+    assert torch.equal(ze2, zg2)
+    assert not torch.equal(ze, ze2)
+
+
 def test_noise_search_vs_reference_golden(engine, cond256, eg, cuda):
     from udifftext_amd import config as C, pipeline
     batch, c, uc = cond256
