@@ -196,8 +196,10 @@ int udt_local_loss(const float* probs, const float* mask, const float* seg_mask,
 /* x bf16 += y bf16 (n elements, n % 8 == 0) ; utility for residuals outside GEMM epilogues */
 int udt_add_bf16(void* x, const void* y, int64_t n, void* stream);
 
-/* Measurement switch (A/B runs inside one process; no reference counterpart): key "gemm_impl" (4, 8, 9),
- * "conv3p" (0/1: patch-staged 3x3 convolution), "rows_epi" (0/1: row-coalesced epilogues). */
+/* Runtime switches (no reference counterpart).  "cu_share" (n >= 1): number of concurrent launch streams — the
+ * cooperative stream-K kernels keep all their workgroups resident, so each stream plans for 1/n of the CUs.
+ * Measurement keys for A/B runs inside one process: "gemm_impl" (4, 8, 9), "conv3p" (0/1), "rows_epi" (0/1),
+ * "no_fast", "no_xchg", "no_epi", "no_store", "no_res", "no_bias" (the last five produce WRONG results). */
 int udt_debug_set(const char* key, int32_t value);
 
 /* out[r][c] = bf16(x[r][c] + bias[c]); x/out bf16 [rows, C] (may alias), bias fp32 [C], C % 8 == 0.

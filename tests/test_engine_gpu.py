@@ -206,6 +206,27 @@ def test_graph_replay_matches_eager_launches(engine, cond256, cuda):
     assert not torch.equal(ze, ze2)
 
 
+def test_batches_in_flight_match_sequential(engine, cond256, cuda):
+    """two batches sampled concurrently (two launch streams, each planned for half the CUs) against the same two
+    batches one after the other; the stream-K split points differ, so agreement is to fp32-accumulation order"""
+    from udifftext_amd import pipeline, synth
+    _, c, uc = cond256
+    b2 = synth.synthetic_batch(1, 256, 256, 4, seed=3)
+    b2, buc2 = pipeline.prepare_batch(b2, cuda)
+    c2, uc2 = engine.conditioner.get_unconditional_conditioning(b2, batch_uc=buc2, force_uc_zero_embeddings=["label"])
+    torch.manual_seed(11)
+    xa, xb = torch.randn((1, 4, 32, 32), device=cuda), torch.randn((1, 4, 32, 32), device=cuda)
+    seq = pipeline.init_sampling(4, 5.0, cuda)
+    seq.use_graphs = False
+    za, zb = seq(engine, xa.clone(), cond=c, uc=uc), seq(engine, xb.clone(), cond=c2, uc=uc2)
+    par = pipeline.init_sampling(4, 5.0, cuda)
+    for _ in range(2):                                  # second round replays the captured graphs through rebind()
+        ya, yb = par.sample_in_flight(engine, [xa.clone(), xb.clone()], [c, c2], [uc, uc2])
+        _check("2 batches in flight, batch A vs sequential", ya.cpu(), za.cpu(), 2e-2)
+        _check("2 batches in flight, batch B vs sequential", yb.cpu(), zb.cpu(), 2e-2)
+    assert len(par._in_flight) == 2 and par.use_graphs
+
+
 def test_noise_search_vs_reference_golden(engine, cond256, eg, cuda):
     from udifftext_amd import config as C, pipeline
     batch, c, uc = cond256

@@ -458,8 +458,10 @@ struct TilePlan {
 };
 
 int g_slots = 0;    // resident workgroup slots: 2 per CU
+int g_cu_share = 1; // concurrent launch streams sharing the device: the cooperative (stream-K) kernels spin on partner
+                    // workgroups, so ALL their workgroups must be resident — each stream plans for 1/share of the CUs
 
-int resident_slots() {
+int resident_slots_all() {
   if (g_slots == 0) {
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) {
@@ -469,6 +471,11 @@ int resident_slots() {
     g_slots = 2 * cus;
   }
   return g_slots;
+}
+
+int resident_slots() {
+  int s = resident_slots_all() / (g_cu_share > 0 ? g_cu_share : 1);
+  return s < 2 ? 2 : s;
 }
 
 TilePlan plan_tiles(const udt_gemm_desc* d) {
@@ -712,6 +719,7 @@ extern "C" int udt_debug_set(const char* key, int32_t value) {
   if (!key) return UDT_ERR_BAD_ARG;
   if (!strcmp(key, "gemm_impl")) { g_impl = value; return UDT_OK; }
   if (!strcmp(key, "conv3p")) { g_conv3p = value; return UDT_OK; }
+  if (!strcmp(key, "cu_share")) { g_cu_share = value > 0 ? value : 1; return UDT_OK; }
   if (!strcmp(key, "rows_epi")) { g_rows_epi = value; return UDT_OK; }
   if (!strcmp(key, "no_xchg")) { g_dbg_bits = (g_dbg_bits & ~(1 << 28)) | (value ? (1 << 28) : 0); return UDT_OK; }
   if (!strcmp(key, "no_store")) { g_dbg_bits = (g_dbg_bits & ~(1 << 26)) | (value ? (1 << 26) : 0); return UDT_OK; }

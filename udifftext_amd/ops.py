@@ -31,7 +31,8 @@ def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
 
 
 def _ws(nbytes: int, device) -> torch.Tensor:
-    key = (device.type, device.index)
+    # one workspace per (device, stream): concurrent streams must not share the stream-K flags and slabs
+    key = (device.type, device.index, _stream())
     buf = _workspace.get(key)
     if buf is None or buf.numel() < nbytes:
         # zero-initialised: the stream-K kernels keep 'slab ready' flags in the first 4 KiB and restore them to 0
@@ -332,6 +333,11 @@ def bias_add(x: torch.Tensor, bias: torch.Tensor, out: Optional[torch.Tensor] = 
     assert x.is_contiguous() and out.is_contiguous() and bias.dtype == torch.float32 and bias.numel() >= Cc
     L.check(L.load().udt_bias_add_bf16(_ptr(x), _ptr(bias), _ptr(out), x.numel() // Cc, Cc, _stream()), "udt_bias_add_bf16")
     return out
+
+
+def set_cu_share(n: int) -> None:
+    """number of concurrent launch streams the cooperative (stream-K) kernels have to share the CUs with"""
+    L.check(L.load().udt_debug_set(b"cu_share", int(n)), "udt_debug_set")
 
 
 # ------------------------------------------------------------------------------------------ profiling

@@ -83,3 +83,32 @@ def predict(cfgs, model, sampler, batch: dict, device: Optional[torch.device] = 
                 detailed=cfgs.detailed)
     img = model.decode_first_stage(z)
     return torch.clamp((img + 1.0) / 2.0, min=0.0, max=1.0), z
+
+
+IN_FLIGHT = 2      # batches sampled concurrently by predict_many (measured optimum on MI355X; 1 = one after the other)
+
+
+def predict_many(cfgs, model, sampler, batches, device: Optional[torch.device] = None, in_flight: Optional[int] = None):
+    """``predict`` over a list of batches with up to ``in_flight`` of them sampled concurrently on separate launch
+    streams (EulerEDMSampler.sample_in_flight).  Conditioning, noise draws (CPU RNG, same order as calling predict
+    batch by batch) and decoding stay per batch.  Returns [(samples, z), ...] in input order."""
+    device = device or next(model.parameters()).device
+    n = max(1, int(in_flight if in_flight is not None else IN_FLIGHT))
+    if cfgs.aae_enabled or cfgs.detailed:
+        raise NotImplementedError("attend-and-excite / detailed dumps are out of scope (see EulerEDMSampler.__call__)")
+    out = []
+    for k in range(0, len(batches), n):
+        group = batches[k:k + n]
+        xs, cs, ucs = [], [], []
+        for b in group:
+            b, buc = prepare_batch(b, device)
+            c, uc = model.conditioner.get_unconditional_conditioning(
+                b, batch_uc=buc, force_uc_zero_embeddings=cfgs.force_uc_zero_embeddings)
+            xs.append(sampler.get_init_noise(cfgs, model, cond=c, batch=b, uc=uc))
+            cs.append(c)
+            ucs.append(uc)
+        zs = sampler.sample_in_flight(model, xs, cs, ucs, init_step=cfgs.init_step)
+        for z in zs:
+            img = model.decode_first_stage(z)
+            out.append((torch.clamp((img + 1.0) / 2.0, min=0.0, max=1.0), z))
+    return out
