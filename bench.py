@@ -49,16 +49,15 @@ def parse():
 
 
 def measured_traffic():
-    """HBM bytes per launch of the 3x3-conv kernels, from the committed rocprofv3 PMC passes of this same command
-    (profiles/r01_traffic.json, produced by tools/pmc_traffic.py: FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE,
-    separate passes).  PMC collection cannot run inside the timed region, hence the file; None if absent."""
+    """HBM bytes per launch of c3p::conv3p_kernel (the dominant kernel) over one batch of this workload, from the
+    committed rocprofv3 PMC passes (profiles/r01_traffic.json, tools/collect_profiles.sh + tools/pmc_extrapolate.py:
+    FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, separate passes).  Counter collection cannot run inside the
+    timed region, hence the file; None if absent."""
     path = os.path.join(ROOT, "profiles", "r01_traffic.json")
     if not os.path.exists(path):
         return None
     try:
-        t = json.load(open(path))
-        n = sum(v["launches"] for v in t.values())
-        return sum(v["hbm_bytes_per_launch"] * v["launches"] for v in t.values()) / max(n, 1)
+        return float(json.load(open(path))["conv3p"]["hbm_bytes_per_launch"])
     except Exception:
         return None
 
@@ -171,6 +170,7 @@ def main():
     conv_ms, conv_launches = ops.prof_get(L.PROF_CONV3X3)
     conv_flops = H.FLOP_COUNTER.get("conv3x3", 0.0)
     conv_bytes = H.FLOP_COUNTER.get("conv3x3_bytes", 0.0)
+    c3p_bytes, c3p_launches = H.FLOP_COUNTER.get("conv3p_bytes", 0.0), H.FLOP_COUNTER.get("conv3p_launches", 0.0)
     H.FLOP_COUNTER = None
     sampler.use_graphs = graphs_on
     S.DUAL_STREAM = dual_prev
@@ -240,6 +240,8 @@ def main():
                          "avg_launch_us": conv_ms * 1e3 / max(conv_launches, 1),
                          "algorithmic_gflop_per_launch": conv_flops / max(conv_launches, 1) / 1e9,
                          "algorithmic_bytes_per_launch": conv_bytes / max(conv_launches, 1),
+                         "traffic_scope": "c3p::conv3p_kernel launches only (%d of the %d launches of the class): algorithmic "
+                                          "%.1f MB per launch" % (int(c3p_launches), conv_launches, c3p_bytes / max(c3p_launches, 1) / 1e6),
                          "whole_path_frac_of_peak": value * FLOP_PER_IMAGE / (world * PEAK_BF16)},
         }
         if world == 1 and not args.no_cpu_baseline:

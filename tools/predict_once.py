@@ -1,0 +1,18 @@
+"""one predict() of the bench workload (conditioner + sampler steps + VAE decode), for counter collection"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import udifftext_amd
+from udifftext_amd import config as C, pipeline, synth
+dev = torch.device("cuda", 0)
+torch.set_grad_enabled(False)
+steps = int(sys.argv[1]) if len(sys.argv) > 1 else 50
+model = pipeline.build_engine(dev)
+sampler = pipeline.init_sampling(steps, 5.0, dev)
+cfgs = C.default_runtime_config(steps=steps, batch_size=4, noise_iters=0, gpu=0)
+b = synth.synthetic_batch(4, 512, 512, 9, seed=0)
+b = {k: (v.to(dev) if isinstance(v, torch.Tensor) else v) for k, v in b.items()}
+print("stage: predict", flush=True)
+out, z = pipeline.predict(cfgs, model, sampler, b, dev)
+torch.cuda.synchronize()
+print("done", out.shape, flush=True)

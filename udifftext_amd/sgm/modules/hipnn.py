@@ -115,6 +115,13 @@ class Conv2d(_Packed):
             if residual is not None:
                 nbytes += 2.0 * npix_out * self.out_channels
             count_flops(kind + "_bytes", nbytes)
+            Hh, Ww = x.shape[1], x.shape[2]
+            if (k == 3 and self.stride == 1 and x2 is None and not upsample and tuple(pad) == (1, 1)
+                    and self.out_channels > 64 and not (flags & L.GEMM_OUT_F32)
+                    and ((Ww % 32 == 0 and Hh % 8 == 0) or (Ww == 16 and Hh % 16 == 0) or (Ww == 8 and Hh == 8))):
+                # the launches udt_gemm routes to c3p::conv3p_kernel (same test as conv3p_geometry in gemm.hip)
+                count_flops("conv3p_bytes", nbytes)
+                count_flops("conv3p_launches", 1.0)
         return out
 
 
