@@ -215,7 +215,8 @@ def main():
         value = images / elapsed
         achieved = conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
         line = {
-            "metric": "512x512 50-step denoised images/sec (UDiffText hot path: conditioner + 50 CFG Euler steps + VAE decode)",
+            "metric": f"{args.size}x{args.size} {args.sampler_steps}-step denoised images/sec (UDiffText hot path: conditioner + "
+                      f"{args.sampler_steps} CFG Euler steps + VAE decode)",
             "value": value, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
@@ -223,7 +224,9 @@ def main():
             "unet_ms_note": "one batch alone on the whole GPU (latency); with batches in flight the per-batch cost is lower",
             "config": {"workload": f"{args.size}x{args.size}, {args.sampler_steps} Euler/DDIM(eta 0) steps, CFG 5.0, "
                                    f"batch {args.batch} per GPU ({2 * args.batch} samples per UNet call), {args.chars}-char "
-                                   "labels, noise_iters 0; BASELINE.json configs[1]",
+                                   "labels, noise_iters 0; " + ("BASELINE.json configs[1]" if (args.size, args.batch, args.chars,
+                                   args.sampler_steps) == (512, 4, 9, 50) else "BASELINE.json configs[3]" if (args.size, args.batch,
+                                   args.chars) == (768, 8, 12) else "non-baseline shape"),
                        "global_batch": args.batch * world, "parallelism": f"dp{world} (images sharded, one all-gather of frames)",
                        "weights": "synthetic (name-keyed recipe), 1361.2 M parameters",
                        "launch": "hipGraph replay of the 50 sampler steps" if graphs_on else "eager kernel launches",

@@ -42,10 +42,12 @@ def run_multi(sets):
             with torch.cuda.stream(st): gs.graphs[i].replay()
     torch.cuda.synchronize(); return (time.perf_counter() - t0) / NS * 1e3
 print(f"whole GPU, one batch at a time: {run_single(full, streams[0]):.2f} {run_single(full, streams[0]):.2f} ms/step", flush=True)
-for n in (2, 3, 4):
-    sets = [build(10 + k, n, streams[k]) for k in range(n)]
+for n, share in ((2, 2), (2, 3), (2, 4), (2, 1)):
+    if share == 1:
+        print("(share 1 with 2 streams oversubscribes the cooperative kernels: skipped)"); continue
+    sets = [build(10 + k, share, streams[k]) for k in range(n)]
     for rep in range(2):
         d = run_multi(sets)
-        print(f"{n} batches in flight (each planned for 1/{n} of the CUs): {d:.2f} ms per round = {d/n:.2f} ms/step/batch", flush=True)
+        print(f"{n} batches in flight, each planned for 1/{share} of the CUs: {d:.2f} ms per round = {d/n:.2f} ms/step/batch", flush=True)
     del sets
     torch.cuda.empty_cache()
