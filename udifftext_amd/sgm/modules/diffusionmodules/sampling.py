@@ -213,7 +213,9 @@ class _GraphedSteps:
         if self.cu_share > 1:
             ops.set_cu_share(self.cu_share)
         try:
-            with torch.cuda.graph(g, pool=self.pool, stream=self.capture_stream):
+            # thread_local: other threads of the process (the RCCL watchdog under torch.distributed) may touch the
+            # HIP runtime while this thread captures
+            with torch.cuda.graph(g, pool=self.pool, stream=self.capture_stream, capture_error_mode="thread_local"):
                 st.step(self.x, self.sig[i], self.sig[i + 1])
         finally:
             if self.cu_share > 1:
