@@ -579,14 +579,17 @@ TilePlan plan_tiles8(const udt_gemm_desc* d) {
   t.tiles = t.tiles_m * t.tiles_n * batch;
   t.nkt = d->K / BK;
   t.total = (long long)t.tiles * t.nkt;
-  const int slots = resident_slots() / 2;          // one 8-wave workgroup per CU
+  // one 8-wave workgroup per CU.  Whole-tile plans (shallow K, below) have no waits between workgroups, so they may
+  // use every CU even when other launch streams share the device (cu_share): excess workgroups simply queue
+  const bool whole = t.nkt < 24;
+  int slots = (whole ? resident_slots_all() : resident_slots()) / 2;
   long long G = t.total / 4;                       // >= 4 K-tiles per workgroup
   if (G < 1) G = 1;
   if (G > slots) G = slots;
   t.ipw = (int)((t.total + G - 1) / G);
   // shallow K (< 24 K-tiles): cutting a tile costs more (slab round trip + the finisher's wait) than the imbalance it
   // removes — measured on MI355X: 2048x1280x1280 33.7 -> 28.6 us, 8192x640x640 32.4 -> 20.2 us with whole tiles
-  if (t.nkt < 24) t.ipw = ((t.ipw + t.nkt - 1) / t.nkt) * t.nkt;
+  if (whole) t.ipw = ((t.ipw + t.nkt - 1) / t.nkt) * t.nkt;
   t.G = (int)((t.total + t.ipw - 1) / t.ipw);
   t.fixup = (t.ipw % t.nkt) != 0;
   return t;
@@ -689,20 +692,22 @@ TilePlan plan_tiles3p(const udt_gemm_desc* d, const c3p::Geo& ge) {
   t.tiles = t.tiles_m * t.tiles_n;
   t.nkt = ge.chunks;                               // iteration unit of this kernel: one 64-channel chunk (9 K-tiles)
   t.total = (long long)t.tiles * t.nkt;
-  const int slots = resident_slots() / 2;
+  const bool whole = t.nkt * 9 < 24;
+  const int slots = (whole ? resident_slots_all() : resident_slots()) / 2;
   long long G = t.total;                           // >= one chunk per workgroup
   if (G > slots) G = slots;
   t.ipw = (int)((t.total + G - 1) / G);
-  if (t.nkt * 9 < 24) t.ipw = ((t.ipw + t.nkt - 1) / t.nkt) * t.nkt;   // shallow K: whole tiles
+  if (whole) t.ipw = ((t.ipw + t.nkt - 1) / t.nkt) * t.nkt;             // shallow K: whole tiles
   t.G = (int)((t.total + t.ipw - 1) / t.ipw);
   t.fixup = (t.ipw % t.nkt) != 0;
   t.coop_S = 0;
   // few tiles, each cut >= 3 ways: equal cuts (ipw divides the chunk count) and a cooperative finish, where the S
   // partners of a tile reduce and store it together instead of one owner reading S-1 slabs through a single CU
-  if (g_coop && t.tiles <= 250 && t.tiles * 3 <= slots && t.nkt >= 3) {
+  const int cslots = resident_slots() / 2;          // cooperative: this stream's share of the CUs
+  if (g_coop && !whole && t.tiles <= 250 && t.tiles * 3 <= cslots && t.nkt >= 3) {
     int best = 0;
     for (int ipw = 1; ipw <= t.nkt; ++ipw)
-      if (t.nkt % ipw == 0 && (long long)t.tiles * (t.nkt / ipw) <= slots && t.nkt / ipw >= 3) { best = ipw; break; }
+      if (t.nkt % ipw == 0 && (long long)t.tiles * (t.nkt / ipw) <= cslots && t.nkt / ipw >= 3) { best = ipw; break; }
     if (best > 0) {
       t.ipw = best;
       t.G = t.tiles * (t.nkt / best);
