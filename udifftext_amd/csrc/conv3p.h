@@ -33,8 +33,6 @@ struct Geo {            // spatial tiling of the output (= input) map
   int prows_img;        // (TH + 2) * (TW + 2)
   int n_pieces;         // ceil(NI * prows_img / 8)
   int chunks;           // C / 64
-  int coop_S;           // > 0: every tile is cut into coop_S equal chunk ranges, one workgroup each, and the partners
-                        //      reduce + store the tile TOGETHER (see "cooperative finish" in the kernel)
 };
 
 struct CParams {
@@ -322,77 +320,6 @@ __global__ void __launch_bounds__(NTHREADS) conv3p_kernel(const CParams cp) {
         head(I1{}, c, dy, nxt); read_all(I1{}, c, dy); mfma_all();
         head(I2{}, c, dy, nxt); read_all(I2{}, c, dy); mfma_all();
       }
-    }
-
-    if (ge.coop_S > 0) {
-      // ---- cooperative finish (deep splits: few tiles, e.g. the 8x8-resolution layers cut 5-10 ways) ----------------
-      // With one owner per tile the owner reads every partner's 128 KiB slab alone (measured: 1.15 MB through one CU
-      // = 50 of the launch's 60 us).  Here all S partners park their partial, meet at a per-tile arrival counter and
-      // each reduces + stores 1/S of the tile's accumulator groups: 128 KiB of slab reads per workgroup, in parallel.
-      const int S = ge.coop_S;
-      const int g_first = tile * S;
-      const int rank = g - g_first;
-      f32x4* slab = reinterpret_cast<f32x4*>(cp.base.slab_base + (long long)g * (256 * BN));
-#pragma unroll
-      for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-        for (int tn = 0; tn < TN; ++tn)
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            f32x4 v = {acc[tm][tn][q * 4 + 0], acc[tm][tn][q * 4 + 1], acc[tm][tn][q * 4 + 2],
-                       acc[tm][tn][q * 4 + 3]};
-            store16_sc1(slab + ((tm * TN + tn) * 4 + q) * NTHREADS + tid, v);
-          }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      int* arrive = cp.base.flags + 512 + 2 * tile;
-      if (tid == 0) {
-        __hip_atomic_fetch_add(arrive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        int spins = 0;
-        while (__hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < S) {
-          __builtin_amdgcn_s_sleep(4);
-          if (++spins > g8::SPIN_LIMIT) {
-            __hip_atomic_store(cp.base.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            break;
-          }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      }
-      __syncthreads();
-      constexpr int NG = TM * TN * 4;
-      const f32x4* base = reinterpret_cast<const f32x4*>(cp.base.slab_base + (long long)g_first * (256 * BN)) + tid;
-      const long long gstride = (long long)(256 * BN) / 4;
-      for (int grp = rank; grp < NG; grp += S) {
-        const f32x4* sp = base + (long long)grp * NTHREADS;
-        f32x4 a = sp[0];
-        int i = 1;
-        for (; i + 1 < S; i += 2) {
-          const f32x4 b0 = sp[(long long)i * gstride];
-          const f32x4 b1 = sp[(long long)(i + 1) * gstride];
-#pragma unroll
-          for (int r = 0; r < 4; ++r) a[r] += b0[r] + b1[r];
-        }
-        if (i < S) {
-          const f32x4 b0 = sp[(long long)i * gstride];
-#pragma unroll
-          for (int r = 0; r < 4; ++r) a[r] += b0[r];
-        }
-        const int q = grp & 3;
-        const int tn = (grp >> 2) % TN;
-        const int tm = (grp >> 2) / TN;
-        long long m = mrow[0];
-        if constexpr (TM == 2) m = tm ? mrow[1] : mrow[0];
-        if (m >= 0) g9::epi_store(p, 0, (int)m, n0 + col0 + tn * 32 + q * 8 + hi * 4, a);
-      }
-      __syncthreads();
-      if (tid == 0) {
-        // the last partner to leave re-arms the tile's counters for the next launch
-        if (__hip_atomic_fetch_add(arrive + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == S - 1) {
-          __hip_atomic_store(arrive, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          __hip_atomic_store(arrive + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-      }
-      return;
     }
 
     const int j0 = c0, j1 = c1;       // (names used by the finishing code below: units are chunks)

@@ -455,7 +455,6 @@ struct TilePlan {
   long long total;
   int G, ipw;
   bool fixup;
-  int coop_S = 0;
 };
 
 int g_slots = 0;    // resident workgroup slots: 2 per CU
@@ -548,7 +547,6 @@ constexpr size_t G8_HEADER_BYTES = 4096;     // flags[<=1023] + err word, ahead 
 
 int g_impl = -1;     // 8: deep-pipelined 8-wave kernel (default), 4: first-generation 4-wave kernel
 int g_dbg_bits = 0;  // measurement modes: bit 28 no stream-K exchange, bit 27 no epilogue (results are wrong)
-int g_coop = 1;      // cooperative finish of deep-split convolution tiles (conv3p.h)
 int g_rows_epi = 1;  // row-coalesced (LDS-transposed) epilogues; 0 = direct accumulator-layout stores (A/B runs)
 constexpr int INTERNAL_DIRECT_EPI = 1 << 30;   // kernel-side flag bit, never part of the public flag set
 
@@ -700,21 +698,6 @@ TilePlan plan_tiles3p(const udt_gemm_desc* d, const c3p::Geo& ge) {
   if (whole) t.ipw = ((t.ipw + t.nkt - 1) / t.nkt) * t.nkt;             // shallow K: whole tiles
   t.G = (int)((t.total + t.ipw - 1) / t.ipw);
   t.fixup = (t.ipw % t.nkt) != 0;
-  t.coop_S = 0;
-  // few tiles, each cut >= 3 ways: equal cuts (ipw divides the chunk count) and a cooperative finish, where the S
-  // partners of a tile reduce and store it together instead of one owner reading S-1 slabs through a single CU
-  const int cslots = resident_slots() / 2;          // cooperative: this stream's share of the CUs
-  if (g_coop && !whole && t.tiles <= 250 && t.tiles * 3 <= cslots && t.nkt >= 3) {
-    int best = 0;
-    for (int ipw = 1; ipw <= t.nkt; ++ipw)
-      if (t.nkt % ipw == 0 && (long long)t.tiles * (t.nkt / ipw) <= cslots && t.nkt / ipw >= 3) { best = ipw; break; }
-    if (best > 0) {
-      t.ipw = best;
-      t.G = t.tiles * (t.nkt / best);
-      t.fixup = true;
-      t.coop_S = t.nkt / best;
-    }
-  }
   return t;
 }
 
@@ -741,7 +724,6 @@ extern "C" int udt_debug_set(const char* key, int32_t value) {
   if (!strcmp(key, "gemm_impl")) { g_impl = value; return UDT_OK; }
   if (!strcmp(key, "conv3p")) { g_conv3p = value; return UDT_OK; }
   if (!strcmp(key, "cu_share")) { g_cu_share = value > 0 ? value : 1; return UDT_OK; }
-  if (!strcmp(key, "coop")) { g_coop = value; return UDT_OK; }
   if (!strcmp(key, "rows_epi")) { g_rows_epi = value; return UDT_OK; }
   if (!strcmp(key, "no_xchg")) { g_dbg_bits = (g_dbg_bits & ~(1 << 28)) | (value ? (1 << 28) : 0); return UDT_OK; }
   if (!strcmp(key, "no_store")) { g_dbg_bits = (g_dbg_bits & ~(1 << 26)) | (value ? (1 << 26) : 0); return UDT_OK; }
@@ -843,7 +825,6 @@ extern "C" int udt_gemm(const udt_gemm_desc* d, void* workspace, size_t workspac
       p.total_iters = t3.total;
       p.iters_per_wg = t3.ipw;
       p.G = t3.G;
-      cp.geo.coop_S = t3.coop_S;
       cp.base.a_bytes = (unsigned)((long long)d->M * d->C1 * 2);
       cp.base.w_bytes = (unsigned)((long long)d->N * p.ldw * 2);
       cp.base.g = p;
