@@ -51,6 +51,7 @@ struct GemmParams {
   int flags;
   float alpha;
   int tiles_m, tiles_n, tiles_per_batch;
+  int n_block;           // N-tiles per block of the tile order (decode_tile)
   int n_ktiles;
   long long total_iters;
   int iters_per_wg;
@@ -179,12 +180,21 @@ UDT_DEVINL void epilogue(const GemmParams& p, f32x16 (&acc)[2][2], int m0, int n
 }
 
 // tile id -> (batch, m0, n0); M fastest so that neighbouring workgroups share weight tiles
+// Blocked order: the N-tiles are taken in blocks of p.n_block; inside a block the tile index runs N-fastest within an
+// M-tile, then over the M-tiles.  A workgroup's consecutive tiles (and its XCD neighbours') then re-use one activation
+// tile for n_block weight tiles out of L2, while the block's weight tiles (<= ~2 MiB) stay L2-resident across the
+// M-tiles.  n_block = 1 is the plain M-fastest order (deep K: the weight tile alone fills the L2).
 template <int BM, int BN>
 UDT_DEVINL void decode_tile(const GemmParams& p, int tile, int& batch, int& m0, int& n0) {
   batch = tile / p.tiles_per_batch;
   const int t = tile - batch * p.tiles_per_batch;
-  const int tn = t / p.tiles_m;
-  const int tm = t - tn * p.tiles_m;
+  const int per_block = p.tiles_m * p.n_block;
+  const int blk = t / per_block;
+  const int r = t - blk * per_block;
+  int nbw = p.tiles_n - blk * p.n_block;
+  if (nbw > p.n_block) nbw = p.n_block;
+  const int tm = r / nbw;
+  const int tn = blk * p.n_block + (r - tm * nbw);
   m0 = tm * BM;
   n0 = tn * BN;
 }
@@ -547,6 +557,7 @@ constexpr size_t G8_HEADER_BYTES = 4096;     // flags[<=1023] + err word, ahead 
 
 int g_impl = -1;     // 8: deep-pipelined 8-wave kernel (default), 4: first-generation 4-wave kernel
 int g_dbg_bits = 0;  // measurement modes: bit 28 no stream-K exchange, bit 27 no epilogue (results are wrong)
+int g_n_block = -1;  // tile order of plain GEMMs: -1 automatic (~2 MiB weight blocks), 0 off (M-fastest), n forced
 int g_rows_epi = 1;  // row-coalesced (LDS-transposed) epilogues; 0 = direct accumulator-layout stores (A/B runs)
 constexpr int INTERNAL_DIRECT_EPI = 1 << 30;   // kernel-side flag bit, never part of the public flag set
 
@@ -724,6 +735,7 @@ extern "C" int udt_debug_set(const char* key, int32_t value) {
   if (!strcmp(key, "gemm_impl")) { g_impl = value; return UDT_OK; }
   if (!strcmp(key, "conv3p")) { g_conv3p = value; return UDT_OK; }
   if (!strcmp(key, "cu_share")) { g_cu_share = value > 0 ? value : 1; return UDT_OK; }
+  if (!strcmp(key, "n_block")) { g_n_block = value; return UDT_OK; }
   if (!strcmp(key, "rows_epi")) { g_rows_epi = value; return UDT_OK; }
   if (!strcmp(key, "no_xchg")) { g_dbg_bits = (g_dbg_bits & ~(1 << 28)) | (value ? (1 << 28) : 0); return UDT_OK; }
   if (!strcmp(key, "no_store")) { g_dbg_bits = (g_dbg_bits & ~(1 << 26)) | (value ? (1 << 26) : 0); return UDT_OK; }
@@ -814,6 +826,7 @@ extern "C" int udt_gemm(const udt_gemm_desc* d, void* workspace, size_t workspac
   p.rows_per_batch = d->rows_per_batch > 0 ? d->rows_per_batch : d->M;
   p.ldrv = d->ld_rowvec > 0 ? d->ld_rowvec : d->N;
   p.flags = d->flags | (g_rows_epi ? 0 : INTERNAL_DIRECT_EPI) | g_dbg_bits;
+  p.n_block = 1;
   p.alpha = d->alpha;
   const int cls = (conv && d->ksize == 3) ? 0 : 1;
   {
@@ -852,6 +865,14 @@ extern "C" int udt_gemm(const udt_gemm_desc* d, void* workspace, size_t workspac
     const bool nine = use_gemm9(d);
     const TilePlan t8 = nine ? plan_tiles9(d) : plan_tiles8(d);
     p.tiles_m = t8.tiles_m; p.tiles_n = t8.tiles_n; p.tiles_per_batch = t8.tiles_m * t8.tiles_n;
+    if (g_n_block != 0 && !conv && (g_n_block > 0 || t8.tiles_n >= 8)) {    // wide outputs only (measured: N = 640 loses)
+      // weight block of ~2 MiB: bn * K * 2 bytes per N-tile
+      const long long wt = (long long)t8.bn * d->K * 2;
+      long long nb = g_n_block > 0 ? g_n_block : (2LL << 20) / (wt > 0 ? wt : 1);
+      if (nb < 1) nb = 1;
+      if (nb > t8.tiles_n) nb = t8.tiles_n;
+      p.n_block = (int)nb;
+    }
     p.n_ktiles = t8.nkt;
     p.total_iters = t8.total;
     p.iters_per_wg = t8.ipw;
