@@ -265,3 +265,39 @@ def test_full_size_properties(engine, cuda):
     r, _ = _metrics(z_one.cpu(), z1[:1].cpu())
     # different batch => different tile / split-K plans => bf16-rounding-level differences, amplified over 3 steps
     assert r < 5e-2, f"batch dependence: {r}"
+
+
+def test_unet_call_at_768_vs_oracle(engine, cuda):
+    """BASELINE config #4 geometry (768x768 -> 96x96 latents, 12-character context): one UNet call on a CFG pair
+    against the fp32 CPU oracle with the same synthetic weights.  96 is not a power of two: other convolution
+    tilings (3 patch tiles per row), 9216-token self-attention, ragged stream-K shares."""
+    from oracle import nets, spec
+    from udifftext_amd import synth
+    torch.manual_seed(21)
+    le = engine.conditioner.embedders[0]
+    batch = synth.synthetic_batch(1, 768, 768, 12, seed=5)
+    ctx = le(batch["label"])
+    tctx = torch.cat([torch.zeros_like(ctx), ctx])
+    x = torch.randn((2, 9, 96, 96), device=cuda)
+    ts = torch.tensor([601, 601], device=cuda)
+    eps = engine.model.diffusion_model(x, timesteps=ts, t_context=tctx)
+    assert eps.shape == (2, 4, 96, 96)
+    sd = {k: v.detach().float().cpu() for k, v in engine.state_dict().items()}
+    with torch.no_grad():
+        ref = nets.unet_forward(sd, x.cpu(), ts.cpu(), tctx.float().cpu(), spec.EngineConfig().unet)
+    _check("UNet eps at 96x96 latents (config #4) vs oracle", eps.cpu(), ref, 2e-2, 8e-2)
+
+
+def test_768_path_properties(engine, cuda):
+    """config #4 end to end (768x768, 12 characters, batch 2, 2 steps): shapes, range, determinism"""
+    from udifftext_amd import config as C, pipeline, synth
+    sampler = pipeline.init_sampling(2, 5.0, cuda)
+    cfgs = C.default_runtime_config(steps=2, batch_size=2, noise_iters=0)
+    outs = []
+    for _ in range(2):
+        torch.manual_seed(4)
+        outs.append(pipeline.predict(cfgs, engine, sampler, synth.synthetic_batch(2, 768, 768, 12, seed=2)))
+    (s1, z1), (s2, z2) = outs
+    assert s1.shape == (2, 3, 768, 768) and z1.shape == (2, 4, 96, 96)
+    assert torch.isfinite(s1).all() and float(s1.min()) >= 0.0 and float(s1.max()) <= 1.0
+    assert torch.equal(z1, z2) and torch.equal(s1, s2)
