@@ -19,4 +19,8 @@ for n in 2 10; do for c in FETCH_SIZE WRITE_SIZE; do
   UDT_GRAPHS=0 UDT_DUAL_STREAM=0 timeout 600 rocprofv3 --pmc $c --output-format csv -d /tmp/pmc_${c}_$n -o p -- python $R/tools/predict_once.py $n > /dev/null 2>&1
 done; done
 python $R/tools/pmc_extrapolate.py /tmp/pmc_FETCH_SIZE_2/p_counter_collection.csv /tmp/pmc_WRITE_SIZE_2/p_counter_collection.csv /tmp/pmc_FETCH_SIZE_10/p_counter_collection.csv /tmp/pmc_WRITE_SIZE_10/p_counter_collection.csv > $O/traffic.json
-ls -la $O; cat $O/bench.json | cut -c1-600; cat $O/traffic.json
+# 5. MFMA utilisation per kernel (one PMC pass over a 4-step batch)
+rm -rf /tmp/pmc_mfma
+UDT_GRAPHS=0 UDT_DUAL_STREAM=0 timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d /tmp/pmc_mfma -o p -- python $R/tools/predict_once.py 4 > /dev/null 2>&1
+python $R/tools/pmc_mfma.py /tmp/pmc_mfma/p_counter_collection.csv > $O/mfma_util.json
+ls -la $O; cat $O/bench.json | cut -c1-600; cat $O/traffic.json; head -40 $O/mfma_util.json
