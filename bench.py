@@ -44,7 +44,8 @@ def parse():
     ap.add_argument("--sampler-steps", type=int, default=50)
     ap.add_argument("--chars", type=int, default=9)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--in-flight", type=int, default=2, help="batches sampled concurrently per GPU (1 = one at a time)")
+    ap.add_argument("--in-flight", type=int, default=2, help="launch streams sampling concurrently per GPU (1 = one at a time)")
+    ap.add_argument("--fuse", type=int, default=2, help="batches concatenated into one sampling batch per stream")
     return ap.parse_args()
 
 
@@ -134,15 +135,15 @@ def main():
 
     def run_steps(blist):
         """K steps = K batches; up to --in-flight of them are sampled concurrently on separate launch streams"""
-        outs = pipeline.predict_many(cfgs, model, sampler, blist, dev, in_flight=args.in_flight)
+        outs = pipeline.predict_many(cfgs, model, sampler, blist, dev, in_flight=args.in_flight, fuse=args.fuse)
         return [gather_frames(smp, dist) for smp, _ in outs]
 
     torch.manual_seed(1234 + rank)
     batches = [make_batch(i) for i in range(args.warmup + args.steps)]
     if args.warmup > 0:
-        # untimed: W batches, topped up so that BOTH launch plans (a full group in flight, and a single left-over
-        # batch) have captured their hipGraphs before the clock starts
-        warm = [batches[i % args.warmup] for i in range(max(args.warmup, args.in_flight + 1))]
+        # untimed: W batches, topped up to the number of timed steps so that the same grouping (full groups in flight
+        # plus whatever is left over) has captured its hipGraphs before the clock starts
+        warm = [batches[i % args.warmup] for i in range(max(args.warmup, args.steps))]
         run_steps(warm)
 
     # ---- timed region ------------------------------------------------------------------------------------
@@ -223,16 +224,17 @@ def main():
             "unet_ms_per_sampler_step": unet_ms,
             "unet_ms_note": "one batch alone on the whole GPU (latency); with batches in flight the per-batch cost is lower",
             "config": {"workload": f"{args.size}x{args.size}, {args.sampler_steps} Euler/DDIM(eta 0) steps, CFG 5.0, "
-                                   f"batch {args.batch} per GPU ({2 * args.batch} samples per UNet call), {args.chars}-char "
+                                   f"batch {args.batch} per step ({2 * args.batch * max(args.fuse, 1)} samples per UNet call), {args.chars}-char "
                                    "labels, noise_iters 0; " + ("BASELINE.json configs[1]" if (args.size, args.batch, args.chars,
                                    args.sampler_steps) == (512, 4, 9, 50) else "BASELINE.json configs[3]" if (args.size, args.batch,
                                    args.chars) == (768, 8, 12) else "non-baseline shape"),
                        "global_batch": args.batch * world, "parallelism": f"dp{world} (images sharded, one all-gather of frames)",
                        "weights": "synthetic (name-keyed recipe), 1361.2 M parameters",
                        "launch": "hipGraph replay of the 50 sampler steps" if graphs_on else "eager kernel launches",
-                       "in_flight": f"{args.in_flight} batches sampled concurrently per GPU (one launch stream each, planned "
-                                    f"for 1/{args.in_flight} of the CUs); a left-over batch runs alone" if args.in_flight > 1
-                                    else "one batch at a time"},
+                       "in_flight": (f"throughput mode of pipeline.predict_many: {args.fuse} consecutive batches concatenated per "
+                                     f"sampling batch, {args.in_flight} sampling batches concurrently per GPU (one launch stream "
+                                     f"each, planned for 1/{args.in_flight} of the CUs); left-overs run in smaller groups")
+                                    if (args.in_flight > 1 or args.fuse > 1) else "one batch at a time"},
             "roofline": {"kernel": "3x3 convolution: c3p::conv3p_kernel (LDS-staged patches) + g8::gemm8_kernel<CONV> "
                                    "(stride-2 / upsampling gathers), UNet + VAE", "bound": "mfma",
                          "achieved": achieved, "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s", "frac": achieved / (PEAK_BF16 / 1e12),

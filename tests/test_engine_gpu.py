@@ -301,3 +301,23 @@ def test_768_path_properties(engine, cuda):
     assert s1.shape == (2, 3, 768, 768) and z1.shape == (2, 4, 96, 96)
     assert torch.isfinite(s1).all() and float(s1.min()) >= 0.0 and float(s1.max()) <= 1.0
     assert torch.equal(z1, z2) and torch.equal(s1, s2)
+
+
+def test_predict_many_matches_predict(engine, cuda):
+    """throughput mode (2 batches fused per sampling batch x 2 launch streams) against predict() batch by batch:
+    same CPU noise draws in the same order, per-image results equal up to the launch plans' summation order; also a
+    ragged tail (5 batches -> group of 4 + single)"""
+    from udifftext_amd import config as C, pipeline, synth
+    cfgs = C.default_runtime_config(steps=3, batch_size=1, noise_iters=0)
+    batches = [synth.synthetic_batch(1, 256, 256, 4, seed=40 + i) for i in range(5)]
+    seq = pipeline.init_sampling(3, 5.0, cuda)
+    torch.manual_seed(8)
+    ref = [pipeline.predict(cfgs, engine, seq, b) for b in batches]
+    par = pipeline.init_sampling(3, 5.0, cuda)
+    torch.manual_seed(8)
+    got = pipeline.predict_many(cfgs, engine, par, batches, in_flight=2, fuse=2)
+    assert len(got) == len(ref)
+    for i, ((s_ref, z_ref), (s_got, z_got)) in enumerate(zip(ref, got)):
+        assert s_got.shape == s_ref.shape and z_got.shape == z_ref.shape
+        _check(f"predict_many latent of batch {i} vs predict", z_got.cpu(), z_ref.cpu(), 3e-2)
+        _check(f"predict_many image of batch {i} vs predict", s_got.cpu(), s_ref.cpu(), 3e-2)

@@ -85,21 +85,36 @@ def predict(cfgs, model, sampler, batch: dict, device: Optional[torch.device] = 
     return torch.clamp((img + 1.0) / 2.0, min=0.0, max=1.0), z
 
 
-IN_FLIGHT = 2      # batches sampled concurrently by predict_many (measured optimum on MI355X; 1 = one after the other)
+IN_FLIGHT = 2      # launch streams sampling concurrently in predict_many (measured optimum on MI355X; 1 = one at a time)
+FUSE = 2           # batches concatenated into one sampling batch per stream (dynamic batching: 8 images per UNet call
+#                    cost 2.87 ms per step and image against 3.6 ms for 4, MI355X; per-sample statistics only, so every
+#                    image's result depends on its own inputs alone)
 
 
-def predict_many(cfgs, model, sampler, batches, device: Optional[torch.device] = None, in_flight: Optional[int] = None):
-    """``predict`` over a list of batches with up to ``in_flight`` of them sampled concurrently on separate launch
-    streams (EulerEDMSampler.sample_in_flight).  Conditioning, noise draws (CPU RNG, same order as calling predict
-    batch by batch) and decoding stay per batch.  Returns [(samples, z), ...] in input order."""
+def _cat_cond(conds):
+    out = {}
+    for k in conds[0]:
+        v = conds[0][k]
+        out[k] = torch.cat([c[k] for c in conds], 0) if isinstance(v, torch.Tensor) else v
+    return out
+
+
+def predict_many(cfgs, model, sampler, batches, device: Optional[torch.device] = None, in_flight: Optional[int] = None,
+                 fuse: Optional[int] = None):
+    """``predict`` over a list of batches in throughput mode: ``fuse`` consecutive batches are concatenated into one
+    sampling batch, and up to ``in_flight`` such batches are sampled concurrently on separate launch streams
+    (EulerEDMSampler.sample_in_flight).  Conditioning and noise draws stay per input batch, in the order and from the
+    CPU generator that calling ``predict`` batch by batch would use; decoding runs on the fused batch.  Returns
+    [(samples, z), ...] in input order."""
     device = device or next(model.parameters()).device
     n = max(1, int(in_flight if in_flight is not None else IN_FLIGHT))
+    f = max(1, int(fuse if fuse is not None else FUSE))
     if cfgs.aae_enabled or cfgs.detailed:
         raise NotImplementedError("attend-and-excite / detailed dumps are out of scope (see EulerEDMSampler.__call__)")
     out = []
-    for k in range(0, len(batches), n):
-        group = batches[k:k + n]
-        xs, cs, ucs = [], [], []
+    for k in range(0, len(batches), n * f):
+        group = batches[k:k + n * f]
+        xs, cs, ucs, sizes = [], [], [], []
         for b in group:
             b, buc = prepare_batch(b, device)
             c, uc = model.conditioner.get_unconditional_conditioning(
@@ -107,8 +122,24 @@ def predict_many(cfgs, model, sampler, batches, device: Optional[torch.device] =
             xs.append(sampler.get_init_noise(cfgs, model, cond=c, batch=b, uc=uc))
             cs.append(c)
             ucs.append(uc)
-        zs = sampler.sample_in_flight(model, xs, cs, ucs, init_step=cfgs.init_step)
-        for z in zs:
-            img = model.decode_first_stage(z)
-            out.append((torch.clamp((img + 1.0) / 2.0, min=0.0, max=1.0), z))
+            sizes.append(xs[-1].shape[0])
+        # fuse consecutive batches (same latent shape) into one sampling batch per stream
+        fx, fc, fuc, spans = [], [], [], []
+        i = 0
+        while i < len(group):
+            j = i + 1
+            while j < len(group) and j - i < f and xs[j].shape[1:] == xs[i].shape[1:]:
+                j += 1
+            fx.append(torch.cat(xs[i:j], 0) if j - i > 1 else xs[i])
+            fc.append(_cat_cond(cs[i:j]) if j - i > 1 else cs[i])
+            fuc.append(_cat_cond(ucs[i:j]) if j - i > 1 else ucs[i])
+            spans.append(sizes[i:j])
+            i = j
+        zs = sampler.sample_in_flight(model, fx, fc, fuc, init_step=cfgs.init_step)
+        for z, span in zip(zs, spans):
+            img = torch.clamp((model.decode_first_stage(z) + 1.0) / 2.0, min=0.0, max=1.0)
+            o = 0
+            for nb in span:
+                out.append((img[o:o + nb], z[o:o + nb]))
+                o += nb
     return out
