@@ -182,25 +182,29 @@ def main():
     elapsed = float(t.item())
     assert frames.shape[0] == args.batch * world and bool(torch.isfinite(frames).all())
 
-    # per-step UNet time (second half of BASELINE's metric): one sampler step on the CFG pair, averaged
+    # per-step UNet time (second half of BASELINE's metric): ONE batch alone on the GPU, one sampler step on its CFG
+    # pair, hipGraph replay (eager launches if graphs are off), averaged over 10 steps
     if rank == 0:
-        single = list(getattr(sampler, "_graphed", {}).values())
-        gs = single[0] if (graphs_on and single) else None
         n_meas = 10
+        batch, buc = pipeline.prepare_batch(batches[0], dev)
+        c, uc = model.conditioner.get_unconditional_conditioning(batch, batch_uc=buc, force_uc_zero_embeddings=["label"])
+        sig = sampler._host_sigmas()
+        hw = (args.size // 8, args.size // 8)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        if gs is not None and all(i in gs.graphs for i in range(3, 3 + n_meas)):
-            torch.cuda.synchronize()
-            e0.record()
+        if graphs_on:
+            gs = S._GraphedSteps(model, c, uc, args.batch, hw, 5.0, sig)
+            gs.x.copy_(torch.randn_like(gs.x) * 14.0)
             for i in range(3, 3 + n_meas):
-                gs.graphs[i].replay()
-            e1.record()
+                gs._capture(i)
+            with torch.cuda.stream(gs.capture_stream):
+                gs.graphs[3].replay()
+                e0.record()
+                for i in range(3, 3 + n_meas):
+                    gs.graphs[i].replay()
+                e1.record()
         else:
-            batch, buc = pipeline.prepare_batch(batches[0], dev)
-            c, uc = model.conditioner.get_unconditional_conditioning(batch, batch_uc=buc, force_uc_zero_embeddings=["label"])
-            from sgm.modules.diffusionmodules.sampling import _Stepper
-            st = _Stepper(model, c, uc, args.batch, (args.size // 8, args.size // 8), 5.0)
-            x = torch.randn((args.batch, 4, args.size // 8, args.size // 8), device=dev) * 14.0
-            sig = sampler._host_sigmas()
+            st = S._Stepper(model, c, uc, args.batch, hw, 5.0)
+            x = torch.randn((args.batch, 4) + hw, device=dev) * 14.0
             for i in range(3):
                 st.step(x, sig[i], sig[i + 1])
             torch.cuda.synchronize()
