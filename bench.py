@@ -45,7 +45,8 @@ def parse():
     ap.add_argument("--chars", type=int, default=9)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--in-flight", type=int, default=2, help="launch streams sampling concurrently per GPU (1 = one at a time)")
-    ap.add_argument("--fuse", type=int, default=2, help="batches concatenated into one sampling batch per stream")
+    ap.add_argument("--fuse", type=int, default=0, help="batches concatenated into one sampling batch per stream "
+                    "(0 = automatic: the timed steps are spread over the streams, at most 4 per sampling batch)")
     return ap.parse_args()
 
 
@@ -215,6 +216,7 @@ def main():
         torch.cuda.synchronize()
         unet_ms = e0.elapsed_time(e1) / n_meas
 
+    fuse_eff = args.fuse if args.fuse > 0 else min(4, max(1, -(-args.steps // max(args.in_flight, 1))))
     if rank == 0:
         images = args.steps * args.batch * world
         value = images / elapsed
@@ -228,17 +230,17 @@ def main():
             "unet_ms_per_sampler_step": unet_ms,
             "unet_ms_note": "one batch alone on the whole GPU (latency); with batches in flight the per-batch cost is lower",
             "config": {"workload": f"{args.size}x{args.size}, {args.sampler_steps} Euler/DDIM(eta 0) steps, CFG 5.0, "
-                                   f"batch {args.batch} per step ({2 * args.batch * max(args.fuse, 1)} samples per UNet call), {args.chars}-char "
+                                   f"batch {args.batch} per step ({2 * args.batch * fuse_eff} samples per UNet call), {args.chars}-char "
                                    "labels, noise_iters 0; " + ("BASELINE.json configs[1]" if (args.size, args.batch, args.chars,
                                    args.sampler_steps) == (512, 4, 9, 50) else "BASELINE.json configs[3]" if (args.size, args.batch,
                                    args.chars) == (768, 8, 12) else "non-baseline shape"),
                        "global_batch": args.batch * world, "parallelism": f"dp{world} (images sharded, one all-gather of frames)",
                        "weights": "synthetic (name-keyed recipe), 1361.2 M parameters",
                        "launch": "hipGraph replay of the 50 sampler steps" if graphs_on else "eager kernel launches",
-                       "in_flight": (f"throughput mode of pipeline.predict_many: {args.fuse} consecutive batches concatenated per "
+                       "in_flight": (f"throughput mode of pipeline.predict_many: {fuse_eff} consecutive batches concatenated per "
                                      f"sampling batch, {args.in_flight} sampling batches concurrently per GPU (one launch stream "
                                      f"each, planned for 1/{args.in_flight} of the CUs); left-overs run in smaller groups")
-                                    if (args.in_flight > 1 or args.fuse > 1) else "one batch at a time"},
+                                    if (args.in_flight > 1 or fuse_eff > 1) else "one batch at a time"},
             "roofline": {"kernel": "3x3 convolution: c3p::conv3p_kernel (LDS-staged patches) + g8::gemm8_kernel<CONV> "
                                    "(stride-2 / upsampling gathers), UNet + VAE", "bound": "mfma",
                          "achieved": achieved, "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s", "frac": achieved / (PEAK_BF16 / 1e12),
