@@ -350,6 +350,9 @@ class EulerEDMSampler(EDMSampler):
             gs = cache.get(key)
             if gs is None or not gs.rebind(c, u):
                 gs = _GraphedSteps(model, c, u, x.shape[0], x.shape[2:], self.guider.scale, sig, cu_share=n)
+                cache.pop(key, None)
+                while len(cache) >= 6:                      # every runner owns a memory pool: keep the newest few
+                    cache.pop(next(iter(cache)))
                 cache[key] = gs
             gs.x.copy_(x.float())
             gs.x.mul_((1.0 + sig[0] ** 2.0) ** 0.5)
