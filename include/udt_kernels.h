@@ -199,7 +199,9 @@ int udt_add_bf16(void* x, const void* y, int64_t n, void* stream);
 /* Runtime switches (no reference counterpart).  "cu_share" (n >= 1): number of concurrent launch streams — the
  * cooperative stream-K kernels keep all their workgroups resident, so each stream plans for 1/n of the CUs.
  * Measurement keys for A/B runs inside one process: "gemm_impl" (4, 8, 9), "conv3p" (0/1), "rows_epi" (0/1),
- * "no_fast", "no_xchg", "no_epi", "no_store", "no_res", "no_bias" (the last five produce WRONG results). */
+ * "n_block" (-1 automatic, 0 off, n: N-tiles per block of the GEMM tile order), "no_fast" (generic epilogues only);
+ * "no_xchg", "no_epi", "no_store", "no_res", "no_bias" switch parts of the finishing code off and produce WRONG
+ * results (cost attribution only). */
 int udt_debug_set(const char* key, int32_t value);
 
 /* out[r][c] = bf16(x[r][c] + bias[c]); x/out bf16 [rows, C] (may alias), bias fp32 [C], C % 8 == 0.

@@ -742,7 +742,6 @@ extern "C" int udt_debug_set(const char* key, int32_t value) {
   if (!strcmp(key, "no_res")) { g_dbg_bits = (g_dbg_bits & ~(1 << 25)) | (value ? (1 << 25) : 0); return UDT_OK; }
   if (!strcmp(key, "no_bias")) { g_dbg_bits = (g_dbg_bits & ~(1 << 24)) | (value ? (1 << 24) : 0); return UDT_OK; }
   if (!strcmp(key, "no_fast")) { g_dbg_bits = (g_dbg_bits & ~(1 << 22)) | (value ? (1 << 22) : 0); return UDT_OK; }
-  if (!strcmp(key, "epi_x4")) { g_dbg_bits = (g_dbg_bits & ~(1 << 23)) | (value ? (1 << 23) : 0); return UDT_OK; }
   if (!strcmp(key, "no_epi")) { g_dbg_bits = (g_dbg_bits & ~(1 << 27)) | (value ? (1 << 27) : 0); return UDT_OK; }
   return UDT_ERR_BAD_ARG;
 }
