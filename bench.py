@@ -44,6 +44,7 @@ def parse():
     ap.add_argument("--sampler-steps", type=int, default=50)
     ap.add_argument("--chars", type=int, default=9)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-mode-table", action="store_true", help="skip the extra passes in the stricter launch modes")
     ap.add_argument("--in-flight", type=int, default=2, help="launch streams sampling concurrently per GPU (1 = one at a time)")
     ap.add_argument("--fuse", type=int, default=0, help="batches concatenated into one sampling batch per stream "
                     "(0 = automatic: the timed steps are spread over the streams, at most 4 per sampling batch)")
@@ -134,9 +135,10 @@ def main():
         samples, _ = pipeline.predict(cfgs, model, sampler, batch, dev)
         return gather_frames(samples, dist)
 
-    def run_steps(blist):
+    def run_steps(blist, in_flight=None, fuse=None):
         """K steps = K batches; up to --in-flight of them are sampled concurrently on separate launch streams"""
-        outs = pipeline.predict_many(cfgs, model, sampler, blist, dev, in_flight=args.in_flight, fuse=args.fuse)
+        outs = pipeline.predict_many(cfgs, model, sampler, blist, dev, in_flight=args.in_flight if in_flight is None else in_flight,
+                                     fuse=args.fuse if fuse is None else fuse)
         return [gather_frames(smp, dist) for smp, _ in outs]
 
     torch.manual_seed(1234 + rank)
@@ -181,6 +183,27 @@ def main():
     if dist is not None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
+
+    # ---- the same K steps in the stricter launch modes, for reference next to `value` (same barriers / max over ranks)
+    def timed_mode(in_flight, fuse):
+        blist = batches[args.warmup:args.warmup + args.steps]
+        if args.warmup > 0:
+            run_steps(blist, in_flight, fuse)                    # captures this mode's hipGraphs
+        barrier()
+        t1 = time.perf_counter()
+        run_steps(blist, in_flight, fuse)
+        barrier()
+        tt = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev)
+        if dist is not None:
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        return args.steps * args.batch * world / float(tt.item())
+
+    other_modes = {}
+    if not args.no_mode_table:
+        if args.in_flight > 1 or args.fuse != 1:
+            other_modes["one_batch_at_a_time"] = timed_mode(1, 1)
+        if args.in_flight > 1 and args.fuse != 1:
+            other_modes[f"{args.in_flight}_batches_in_flight_unfused"] = timed_mode(args.in_flight, 1)
     assert frames.shape[0] == args.batch * world and bool(torch.isfinite(frames).all())
 
     # per-step UNet time (second half of BASELINE's metric): ONE batch alone on the GPU, one sampler step on its CFG
@@ -227,6 +250,7 @@ def main():
             "value": value, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "images_per_s_by_launch_mode": dict(other_modes, **{"throughput_mode (value)": value}),
             "unet_ms_per_sampler_step": unet_ms,
             "unet_ms_note": "one batch alone on the whole GPU (latency); with batches in flight the per-batch cost is lower",
             "config": {"workload": f"{args.size}x{args.size}, {args.sampler_steps} Euler/DDIM(eta 0) steps, CFG 5.0, "

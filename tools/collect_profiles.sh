@@ -6,10 +6,10 @@ cd /tmp && export TMPDIR=/tmp
 # 1. the bench line (default flags)
 (cd $R && python bench.py 2>$O/bench.err | tail -1 > $O/bench.json)
 # 2. kernel trace + stats of the bench command (graphs, 2 batches in flight)
-rm -rf /tmp/rpA; rocprofv3 --kernel-trace --stats -d /tmp/rpA -o t -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_under_rocprof_inflight.json
+rm -rf /tmp/rpA; rocprofv3 --kernel-trace --stats -d /tmp/rpA -o t -- python $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-mode-table 2>/dev/null | tail -1 > $O/bench_under_rocprof_inflight.json
 python $R/tools/rocpd_summary.py $(find /tmp/rpA -name "*.db" | head -1) > $O/kernel_stats_inflight.csv
 # 3. the regime the roofline events are taken in: eager launches, one stream, one batch at a time
-rm -rf /tmp/rpB; UDT_GRAPHS=0 UDT_DUAL_STREAM=0 rocprofv3 --kernel-trace --stats -d /tmp/rpB -o t -- python $R/bench.py --steps 1 --warmup 1 --in-flight 1 --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_under_rocprof_single.json
+rm -rf /tmp/rpB; UDT_GRAPHS=0 UDT_DUAL_STREAM=0 rocprofv3 --kernel-trace --stats -d /tmp/rpB -o t -- python $R/bench.py --steps 1 --warmup 1 --in-flight 1 --fuse 1 --no-cpu-baseline --no-mode-table 2>/dev/null | tail -1 > $O/bench_under_rocprof_single.json
 python $R/tools/rocpd_summary.py $(find /tmp/rpB -name "*.db" | head -1) > $O/kernel_stats_single.csv
 # 4. HBM traffic of the 3x3-conv kernels: PMC passes (no tracing domains) over one batch of the bench workload.
 #    rocprofv3's counter collection dies after ~6000 dispatches on this image, so a 2-step and a 10-step batch are
