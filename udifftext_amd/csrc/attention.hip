@@ -38,7 +38,7 @@ struct AttnParams {
 constexpr int KV_TILE = 64;
 constexpr int TILE_BYTES = 64 * 128;   // 64 rows x 128 B (K tile, and V^T tile)
 
-__global__ void __launch_bounds__(256) attn_d64_kernel(const AttnParams p) {
+__global__ void __launch_bounds__(256, 4) attn_d64_kernel(const AttnParams p) {
   __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];   // [buf][K | VT]
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
