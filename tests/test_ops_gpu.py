@@ -52,6 +52,24 @@ def test_linear_plain(ops, cuda, M, N, K):
     _close(out, ref, what=f"linear {M}x{N}x{K}")
 
 
+@pytest.mark.parametrize("n_block", [-1, 0, 3, 4, 64])
+def test_linear_blocked_tile_order(ops, cuda, n_block):
+    """wide outputs walk their tiles in blocks of N-tiles (decode_tile): automatic, off, forced widths that do not
+    divide the 11 N-tiles (ragged last block) and one wider than the matrix — all must give the same product"""
+    from udifftext_amd import lib as L, packing
+    M, N, K = 520, 1408, 3072            # 3 x 11 tiles of 256x128, partial last M-tile
+    x = _rand((M, K), cuda, seed=1).bfloat16()
+    w = _rand((N, K), cuda, 1.0 / math.sqrt(K), seed=2) * (1.0 + torch.arange(N, device=cuda)[:, None] / N)
+    wp = packing.pack_linear(w)
+    lib = L.load()
+    try:
+        L.check(lib.udt_debug_set(b"n_block", n_block), "udt_debug_set")
+        out = ops.linear(x, wp, n_out=N)
+    finally:
+        L.check(lib.udt_debug_set(b"n_block", -1), "udt_debug_set")
+    _close(out, x.float() @ wp[:, :K].float().t(), what=f"linear blocked order n_block={n_block}")
+
+
 def test_linear_epilogues(ops, cuda):
     from udifftext_amd import lib as L, packing
     M, N, K, rpb = 512, 640, 640, 128
