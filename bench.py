@@ -117,7 +117,9 @@ def main():
     import sgm.modules.hipnn as H
 
     torch.set_grad_enabled(False)
-    model = pipeline.build_engine(dev)
+    import contextlib
+    with contextlib.redirect_stdout(sys.stderr):          # the conditioner announces its embedders like the reference does;
+        model = pipeline.build_engine(dev)                # stdout carries the ONE JSON line only
     sampler = pipeline.init_sampling(args.sampler_steps, 5.0, dev)
     cfgs = C.default_runtime_config(steps=args.sampler_steps, batch_size=args.batch, noise_iters=0, gpu=local_rank)
 

@@ -15,6 +15,7 @@ out of scope and raise.
 from __future__ import annotations
 
 import os
+import sys
 from typing import Dict, Union
 
 import numpy as np
@@ -384,7 +385,7 @@ class EulerEDMSampler(EDMSampler):
             return gs.run(x, self.get_sigma_gen(len(sig), init_step=init_step))
         except RuntimeError as e:                               # capture not possible here: keep launching eagerly
             if not self.__dict__.get("_graph_warned"):
-                print(f"[udifftext_amd] hipGraph capture unavailable ({e}); using eager launches")
+                print(f"[udifftext_amd] hipGraph capture unavailable ({e}); using eager launches", file=sys.stderr)
                 self._graph_warned = True
             self.use_graphs = False
             cache.clear()
