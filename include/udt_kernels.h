@@ -63,7 +63,9 @@ typedef enum {
   UDT_ERR_BAD_ARG = -2,       /* null pointer / inconsistent flags                                */
   UDT_ERR_WORKSPACE = -3,     /* workspace too small (see udt_gemm_workspace_bytes)               */
   UDT_ERR_HIP = -4,           /* a HIP runtime call failed; see udt_last_hip_error                */
-  UDT_ERR_NO_DEVICE = -5      /* no gfx950 device visible                                         */
+  UDT_ERR_NO_DEVICE = -5,     /* no gfx950 device visible                                         */
+  UDT_ERR_ASYNC = -6          /* a stream-K launch timed out waiting for a partner workgroup (its output
+                                 tile is NaN-poisoned); reported by udt_check_async_error                */
 } udt_status;
 
 /* ---- epilogue / mode flags for udt_gemm ------------------------------------------------------- */
@@ -100,11 +102,21 @@ typedef struct {
   int32_t ld_rowvec;    /* elements between rows of rowvec (0 = N)                                 */
   int32_t flags;
   float alpha;          /* acc * alpha before bias (softmax scale for QK^T GEMMs); 1.0 default    */
+  int32_t cu_share;     /* number of launch streams that share the device with this call (0 / 1: none).
+                           The persistent stream-K kernels wait on partner workgroups, so all their
+                           workgroups must be resident: the launch is planned for 1/cu_share of the CUs.
+                           udt_gemm_workspace_bytes must be asked with the same value.                  */
 } udt_gemm_desc;
 
-/* workspace (bytes) udt_gemm needs for this problem (split-K slabs); 0 if none */
+/* workspace (bytes) udt_gemm needs for this problem (split-K slabs); 0 if none.  The first 4 KiB of a workspace are
+ * the kernels' slab flags + error word: zero them once when the buffer is allocated (they are zero again after
+ * every successful launch) and give concurrent streams separate workspaces. */
 size_t udt_gemm_workspace_bytes(const udt_gemm_desc* d);
 int udt_gemm(const udt_gemm_desc* d, void* workspace, size_t workspace_bytes, void* stream);
+/* Synchronises `stream` and reports (UDT_ERR_ASYNC) whether any udt_gemm launch that used `workspace` gave up waiting
+ * for a partner workgroup since the last check; in that case the header is re-zeroed so the workspace stays usable.
+ * Callers check at their natural sync points (the sampler: once per sampling loop). */
+int udt_check_async_error(void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- attention -------------------------------------------------------------------------------- */
 /* Flash attention forward, head_dim 64, no mask:  O = softmax(Q K^T * scale) V
@@ -145,16 +157,6 @@ int udt_gn_stats(const void* x, const void* x2, float* partials, int32_t B, int6
 int udt_gn_apply(const void* x, const void* x2, void* y, const float* partials, const float* gamma,
                  const float* beta, int32_t B, int64_t HW, int32_t C, int32_t C2, int32_t G, float eps, int32_t act,
                  void* stream);
-/* Single-pass GroupNorm (+ optional SiLU): same result as udt_gn_stats + udt_gn_apply with ONE read of x.  Every
- * workgroup keeps its slab of the sample in LDS across a per-sample arrival counter, so the launch must be fully
- * resident: udt_gn_fused_nchunks() returns the number of slabs per sample (partials must hold B * nchunks * G * 2
- * floats) or 0 when the shape does not qualify (slab > 128 KiB, B > 256, ...) — callers then use the two-kernel
- * pair.  One launch at a time per device (the counters live in a library-owned page); replaces the same reference
- * modules as udt_gn_stats/udt_gn_apply (sgm/modules/diffusionmodules/util.py:258-275, attention.py:82-85). */
-int32_t udt_gn_fused_nchunks(int32_t B, int64_t HW, int32_t C, int32_t G);
-int udt_gn_fused(const void* x, const void* x2, void* y, float* partials, const float* gamma, const float* beta,
-                 int32_t B, int64_t HW, int32_t C1, int32_t C2, int32_t G, float eps, int32_t act, void* stream);
-
 /* LayerNorm over the last dim of bf16 [rows, C] (C % 8 == 0, C <= 4096). */
 int udt_layernorm(const void* x, void* y, const float* gamma, const float* beta,
                   int64_t rows, int32_t C, float eps, void* stream);
@@ -196,12 +198,11 @@ int udt_local_loss(const float* probs, const float* mask, const float* seg_mask,
 /* x bf16 += y bf16 (n elements, n % 8 == 0) ; utility for residuals outside GEMM epilogues */
 int udt_add_bf16(void* x, const void* y, int64_t n, void* stream);
 
-/* Runtime switches (no reference counterpart).  "cu_share" (n >= 1): number of concurrent launch streams — the
- * cooperative stream-K kernels keep all their workgroups resident, so each stream plans for 1/n of the CUs.
- * Measurement keys for A/B runs inside one process: "gemm_impl" (4, 8, 9), "conv3p" (0/1), "rows_epi" (0/1),
- * "n_block" (-1 automatic, 0 off, n: N-tiles per block of the GEMM tile order), "no_fast" (generic epilogues only);
- * "no_xchg", "no_epi", "no_store", "no_res", "no_bias" switch parts of the finishing code off and produce WRONG
- * results (cost attribution only). */
+/* Tuning knobs (no reference counterpart); every setting computes the same results: "gemm_impl" (4 or 8: kernel
+ * generation), "conv3p" (0/1: patch-staged 3x3 convolution), "rows_epi" (0/1: row-coalesced epilogues), "n_block"
+ * (-1 automatic, 0 off, n: N-tiles per block of the GEMM tile order).  Measurement builds of the library
+ * (-DUDT_MEASURE) additionally accept the cost-attribution keys "no_xchg", "no_epi", "no_store", "no_res", "no_bias",
+ * "no_fast", which switch parts of the finishing code off and give WRONG results; the product library rejects them. */
 int udt_debug_set(const char* key, int32_t value);
 
 /* out[r][c] = bf16(x[r][c] + bias[c]); x/out bf16 [rows, C] (may alias), bias fp32 [C], C % 8 == 0.

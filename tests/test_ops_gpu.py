@@ -290,34 +290,6 @@ def test_group_norm_concat(ops, cuda, C1, C2):
     _close(out, ref, what=f"gn concat {C1}+{C2}")
 
 
-@pytest.mark.parametrize("B,HW,C1,C2", [(8, 4096, 320, 0), (8, 1024, 640, 640), (8, 256, 1280, 0), (8, 64, 1280, 1280),
-                                        (4, 4096, 640, 0), (5, 1024, 320, 0)])
-def test_group_norm_single_pass_matches_two_kernel_path(ops, cuda, B, HW, C1, C2):
-    """the cooperative single-pass kernel (slabs resident in LDS across a per-sample arrival counter) against the
-    stats + apply pair, launched repeatedly so that the counters' re-arming is exercised"""
-    import udifftext_amd.ops as O
-    x1 = (_rand((B, HW, C1), cuda, 2.0, seed=1) + 0.7).bfloat16()
-    x2 = (_rand((B, HW, C2), cuda, 0.5, seed=4) - 0.3).bfloat16() if C2 else None
-    g = _rand((C1 + C2,), cuda, seed=2) * 0.2 + 1.0
-    b = _rand((C1 + C2,), cuda, seed=3) * 0.2
-    prev = O.GN_FUSED
-    try:
-        O.GN_FUSED = False
-        two = ops.group_norm(x1, g, b, 32, 1e-5, True, x2=x2)
-        O.GN_FUSED = True
-        assert O.L.load().udt_gn_fused_nchunks(B, HW, C1 + C2, 32) > 0
-        for _ in range(3):
-            one = ops.group_norm(x1, g, b, 32, 1e-5, True, x2=x2)
-            # same fp32 element math; the statistics differ only in summation order
-            assert (one.float() - two.float()).abs().max().item() <= 2e-2
-            assert (one != two).float().mean().item() < 0.02
-    finally:
-        O.GN_FUSED = prev
-    cat = x1.float() if x2 is None else torch.cat([x1, x2], dim=-1).float()
-    ref = F.silu(F.group_norm(cat.permute(0, 2, 1), 32, g, b, 1e-5)).permute(0, 2, 1)
-    _close(one, ref, what=f"gn single pass {B,HW,C1,C2}")
-
-
 @pytest.mark.parametrize("rows,Cc", [(1000, 320), (513, 640), (64, 1280), (36, 2048)])
 def test_layer_norm(ops, cuda, rows, Cc):
     x = (_rand((rows, Cc), cuda, 2.0, seed=1) + 0.3).bfloat16()
@@ -396,12 +368,14 @@ def test_layout_and_misc(ops, cuda):
     _close(ops.add_(a, b), ref, what="add")
 
 
-def test_local_loss(ops, cuda):
-    B, heads, size, Lc, seg_l = 2, 5, 16, 12, 12
+@pytest.mark.parametrize("size,Hm", [(16, 64), (64, 512), (96, 768)])
+def test_local_loss(ops, cuda, size, Hm):
+    """96x96 maps are what the 768x768 noise search scores (t_attn at the first UNet level)"""
+    B, heads, Lc, seg_l = 2, 5, 12, 12
     n = size * size
     probs = torch.softmax(_rand((B * heads, n, Lc), cuda, 2.0, seed=1), dim=-1).contiguous()
-    mask = torch.zeros((B, 1, 64, 64), device=cuda)
-    mask[:, :, 20:40, 8:56] = 1
+    mask = torch.zeros((B, 1, Hm, Hm), device=cuda)
+    mask[:, :, (5 * Hm) // 16:(5 * Hm) // 8, Hm // 8:(7 * Hm) // 8] = 1
     seg = torch.zeros((B, seg_l), device=cuda)
     seg[0, :4] = 1
     seg[1, :9] = 1
@@ -417,6 +391,38 @@ def test_local_loss(ops, cuda):
     pl = (mm * am).max(-1)[0] + (1 - seg)
     ref = -pl.min(-1)[0]
     assert torch.allclose(loss, ref, atol=1e-5, rtol=1e-4), (loss, ref)
+
+
+def test_async_error_word_and_launch_context(ops, cuda):
+    """the stream-K kernels report a partner time-out through the workspace's error word: the host check must see it,
+    raise, and leave the workspace usable; cu_share travels in the descriptor (no process-global state)"""
+    import math
+    from udifftext_amd import lib as L, packing
+    ws = ops.Workspace(cuda)
+    ws.check()                                                   # clean workspace: no error
+    ws.buf[4 * 1023:4 * 1024].view(torch.int32).fill_(1)         # what a timed-out finisher stores
+    with pytest.raises(L.UdtError, match="timed out"):
+        ws.check()
+    ws.check()                                                   # header re-zeroed by the failed check
+    assert int(ws.buf[:4096].view(torch.int32).abs().sum()) == 0
+    # a deep-K GEMM (stream-K plan: slabs + flags) on an owned workspace, whole device and half the CUs
+    M, N, K = 512, 1280, 11520
+    x = _rand((M, K), cuda, seed=1).bfloat16()
+    wp = packing.pack_linear(_rand((N, K), cuda, 1.0 / math.sqrt(K), seed=2))
+    ref = x.float() @ wp.float().t()
+    for share in (1, 2, 4):
+        with ops.launch_context(cu_share=share, workspace=ws):
+            d = ops.gemm_desc()
+            assert d.cu_share == share
+            out = ops.linear(x, wp)
+        ws.check()
+        _close(out, ref, what=f"stream-K linear cu_share={share}")
+    assert ops.gemm_desc().cu_share == 1                          # context restored
+    small = ops.Workspace(cuda, 8192)
+    with pytest.raises(L.UdtError, match="too small"), ops.launch_context(workspace=small):
+        ops.linear(x, wp)
+    # wrong-result measurement switches are not part of the product library
+    assert L.load().udt_debug_set(b"no_epi", 1) != 0 and L.load().udt_debug_set(b"cu_share", 2) != 0
 
 
 def test_error_codes(ops, cuda):

@@ -1,4 +1,10 @@
-"""A/B timing of one sampler step (CFG pair, 512x512, batch 4) inside ONE process: toggles given as name=values."""
+"""A/B timing of one sampler step (CFG pair, 512x512, batch 4) inside ONE process: toggles given as name=values.
+
+    python tools/ab_step.py zero                      # zero-context shortcut on / off
+    python tools/ab_step.py dbg:rows_epi 1 0          # a tuning knob of udt_debug_set
+    python tools/ab_step.py multi "" no_epi=1 ...     # cost attribution: needs a MEASUREMENT build of the library
+                                                      # (UDT_EXTRA_FLAGS=-DUDT_MEASURE python -m udifftext_amd.build --force)
+"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -28,7 +34,7 @@ def run(n):
     return e0.elapsed_time(e1) / n
 
 import udifftext_amd.ops as O
-which = sys.argv[1] if len(sys.argv) > 1 else "gn"
+which = sys.argv[1] if len(sys.argv) > 1 else "zero"
 if which == "zero":
     variants = {"zero_rows=B": lambda: setattr(st, "zero_ctx_rows", B), "zero_rows=0": lambda: setattr(st, "zero_ctx_rows", 0)}
 elif which == "multi":
@@ -36,7 +42,7 @@ elif which == "multi":
     def setall(**kw):
         for k, v in kw.items():
             L.check(L.load().udt_debug_set(k.encode(), v), "dbg")
-    base = dict(skip_k=0, no_xchg=0, no_epi=0, no_store=0, no_res=0, no_bias=0, no_fast=0)
+    base = dict(no_xchg=0, no_epi=0, no_store=0, no_res=0, no_bias=0, no_fast=0)
     variants = {}
     for spec in sys.argv[2:]:
         kv = dict(base)
@@ -50,7 +56,7 @@ elif which.startswith("dbg:"):
     vals = [int(v) for v in (sys.argv[2:] or ["1", "0"])]
     variants = {f"{key}={v}": (lambda v=v: L.check(L.load().udt_debug_set(key.encode(), v), "dbg")) for v in vals}
 else:
-    variants = {"gn_fused=1": lambda: setattr(O, "GN_FUSED", True), "gn_fused=0": lambda: setattr(O, "GN_FUSED", False)}
+    raise SystemExit(__doc__)
 for name, fn in variants.items():
     fn(); run(3)
 for rnd in range(4):

@@ -11,7 +11,6 @@ namespace {
 
 std::mutex g_mu;
 int g_last_hip_error = 0;
-uint16_t* g_zero_page = nullptr;
 
 struct ProfRec {
   hipEvent_t start, stop;
@@ -36,31 +35,21 @@ int udt_set_hip_error(hipError_t e) {
   return UDT_ERR_HIP;
 }
 
+// one zero page per device (the library is used one process per GPU, but nothing here assumes it)
 const uint16_t* udt_zero_page() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+  static uint16_t* pages[16] = {nullptr};
   std::lock_guard<std::mutex> lk(g_mu);
-  if (!g_zero_page) {
+  if (!pages[dev]) {
     void* p = nullptr;
     hipError_t e = hipMalloc(&p, 4096);
     if (e != hipSuccess) { g_last_hip_error = (int)e; return nullptr; }
     e = hipMemset(p, 0, 4096);
     if (e != hipSuccess) { g_last_hip_error = (int)e; return nullptr; }
-    g_zero_page = reinterpret_cast<uint16_t*>(p);
+    pages[dev] = reinterpret_cast<uint16_t*>(p);
   }
-  return g_zero_page;
-}
-
-int* udt_sync_page() {
-  static int* page = nullptr;
-  std::lock_guard<std::mutex> lk(g_mu);
-  if (!page) {
-    void* p = nullptr;
-    hipError_t e = hipMalloc(&p, 4096);
-    if (e != hipSuccess) { g_last_hip_error = (int)e; return nullptr; }
-    e = hipMemset(p, 0, 4096);
-    if (e != hipSuccess) { g_last_hip_error = (int)e; return nullptr; }
-    page = reinterpret_cast<int*>(p);
-  }
-  return page;
+  return pages[dev];
 }
 
 void udt_prof_tag(void* rec, const char* tag) {
@@ -122,6 +111,7 @@ extern "C" const char* udt_status_string(int status) {
     case UDT_ERR_WORKSPACE: return "workspace too small";
     case UDT_ERR_HIP: return "HIP runtime error (see udt_last_hip_error)";
     case UDT_ERR_NO_DEVICE: return "no gfx950 device";
+    case UDT_ERR_ASYNC: return "a stream-K launch timed out waiting for a partner workgroup (not co-resident)";
     default: return "unknown status";
   }
 }

@@ -14,6 +14,14 @@ typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
 
 #define UDT_DEVINL __device__ __forceinline__
 
+// cost-attribution switches of the GEMM finishing code (udt_debug_set "no_*"): they produce WRONG results and exist
+// only in measurement builds (hipcc -DUDT_MEASURE); in the product library every test folds to 0
+#ifdef UDT_MEASURE
+#define UDT_DBG(flags, bit) ((((flags) >> (bit)) & 1) != 0)
+#else
+#define UDT_DBG(flags, bit) false
+#endif
+
 UDT_DEVINL float bf16_bits_to_f32(uint32_t v) { return __uint_as_float(v << 16); }
 UDT_DEVINL float bf16_lo(uint32_t packed) { return __uint_as_float(packed << 16); }
 UDT_DEVINL float bf16_hi(uint32_t packed) { return __uint_as_float(packed & 0xffff0000u); }
@@ -70,8 +78,7 @@ UDT_DEVINL f32x16 mfma32(bf16x8_t a, bf16x8_t b, f32x16 c) {
 
 // ---- host-side helpers -------------------------------------------------------------------------
 int udt_set_hip_error(hipError_t e);   // records e, returns UDT_ERR_HIP (or UDT_OK when e == success)
-const uint16_t* udt_zero_page();       // >= 4 KiB of zeroed device memory (lazily allocated once)
-int* udt_sync_page();                  // 4 KiB of device ints, zero at rest: arrival counters of cooperative kernels
+const uint16_t* udt_zero_page();       // >= 4 KiB of zeroed memory on the current device (lazily allocated once per device)
 
 struct UdtProfScope {                  // brackets a launch with events when profiling is enabled
   int cls; hipStream_t s; void* rec;

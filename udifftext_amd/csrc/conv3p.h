@@ -323,7 +323,7 @@ __global__ void __launch_bounds__(NTHREADS) conv3p_kernel(const CParams cp) {
     }
 
     const int j0 = c0, j1 = c1;       // (names used by the finishing code below: units are chunks)
-    const bool noxchg = (p.flags & (1 << 28)) != 0;       // measurement modes (udt_debug_set): wrong results
+    const bool noxchg = UDT_DBG(p.flags, 28);       // measurement modes (udt_debug_set): wrong results
     const bool full = noxchg || ((j0 == 0) && (j1 == p.n_ktiles));
     const bool publish = !noxchg && (j0 > 0);
     const int cur_tile = tile, cur_n0 = n0;
@@ -363,39 +363,54 @@ __global__ void __launch_bounds__(NTHREADS) conv3p_kernel(const CParams cp) {
         // slab stores were write-through (sc1) and are drained: no L2 write-back fence needed
         __hip_atomic_store(cp.base.flags + g, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
-    } else if (!(p.flags & (1 << 27))) {
+    } else if (!UDT_DBG(p.flags, 27)) {
       if (!full) {
         const long long tile_end = ((long long)cur_tile + 1) * p.n_ktiles;
         const int g_last = (int)((tile_end - 1) / p.iters_per_wg);
+        int* const bcast = reinterpret_cast<int*>(wring + 2 * W_BYTES);      // weight-ring stage 2 is idle here
+        if (!more) __syncthreads();        // (with `more` the barrier ahead of the prefetch already closed the ring)
         if (tid == 0) {
-          for (int pg = g + 1; pg <= g_last; ++pg) {
+          int ok = 1;
+          for (int pg = g + 1; pg <= g_last && ok; ++pg) {
             int spins = 0;
             while (__hip_atomic_load(cp.base.flags + pg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
               __builtin_amdgcn_s_sleep(8);
-              if (++spins > g8::SPIN_LIMIT) {
+              if (++spins > g8::SPIN_LIMIT) {      // partner not resident: flag the workspace, poison the tile (gemm8.h)
                 __hip_atomic_store(cp.base.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ok = 0;
                 break;
               }
             }
           }
           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+          *bcast = ok;
         }
         __syncthreads();
-        for (int pg = g + 1; pg <= g_last; ++pg) {
-          const f32x4* slab = reinterpret_cast<const f32x4*>(cp.base.slab_base + (long long)pg * (256 * BN));
+        const bool partners_ok = *bcast != 0;
+        if (partners_ok) {
+          for (int pg = g + 1; pg <= g_last; ++pg) {
+            const f32x4* slab = reinterpret_cast<const f32x4*>(cp.base.slab_base + (long long)pg * (256 * BN));
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+              for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                  const f32x4 v = slab[((tm * TN + tn) * 4 + q) * NTHREADS + tid];
+#pragma unroll
+                  for (int r = 0; r < 4; ++r) acc[tm][tn][q * 4 + r] += v[r];
+                }
+          }
+        } else {
 #pragma unroll
           for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
             for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
-              for (int q = 0; q < 4; ++q) {
-                const f32x4 v = slab[((tm * TN + tn) * 4 + q) * NTHREADS + tid];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) acc[tm][tn][q * 4 + r] += v[r];
-              }
+              for (int r = 0; r < 16; ++r) acc[tm][tn][r] = __builtin_nanf("");
         }
         __syncthreads();
-        if (tid == 0)
+        if (tid == 0 && partners_ok)
           for (int pg = g + 1; pg <= g_last; ++pg)
             __hip_atomic_store(cp.base.flags + pg, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }

@@ -150,14 +150,15 @@ __global__ void mask_downsample_kernel(const float* __restrict__ m, float* __res
   out[i] = 0.25f * (src[y0 * W + x0] + src[y0 * W + x0 + 1] + src[(y0 + 1) * W + x0] + src[(y0 + 1) * W + x0 + 1]);
 }
 
-// one workgroup per sample; n = size*size <= 4096
+// one workgroup per sample; the head-averaged map of one token (size x size floats, size <= 128) lives in LDS
 __global__ void __launch_bounds__(256) local_loss_kernel(const float* __restrict__ probs, const float* __restrict__ mask,
                                                          const float* __restrict__ seg, const float* __restrict__ gk,
                                                          float* __restrict__ loss, int heads, int size, int L,
                                                          int seg_l, int Hm, int Wm) {
-  __shared__ float amap[4096];
-  __shared__ float red[4];
-  __shared__ float best;
+  extern __shared__ __attribute__((aligned(16))) float llsm[];   // [size*size] map, [4] wave maxima, [1] best
+  float* amap = llsm;
+  float* red = llsm + size * size;
+  float& best = red[4];
   const int b = blockIdx.x;
   const int t = threadIdx.x;
   const int n = size * size;
@@ -333,9 +334,11 @@ extern "C" int udt_local_loss(const float* probs, const float* mask, const float
                               float* loss_accum, int32_t B, int32_t heads, int32_t size, int32_t L, int32_t seg_l,
                               int32_t Hm, int32_t Wm, void* stream) {
   if (!probs || !mask || !seg_mask || !gkernel9 || !loss_accum) return UDT_ERR_BAD_ARG;
-  if (B <= 0 || heads <= 0 || size <= 0 || size > 64 || L <= 0 || seg_l <= 0 || seg_l > L) return UDT_ERR_BAD_SHAPE;
+  if (B <= 0 || heads <= 0 || size <= 0 || size > 120 || L <= 0 || seg_l <= 0 || seg_l > L) return UDT_ERR_BAD_SHAPE;
   UDT_STREAM;
-  hipLaunchKernelGGL(local_loss_kernel, dim3(B), dim3(256), 0, s, probs, mask, seg_mask, gkernel9, loss_accum, heads,
+  // 96x96 maps (768x768 inputs) need 36 KiB; the default dynamic-LDS limit is 64 KiB (120x120 floats + 32 B fit)
+  const size_t smem = ((size_t)size * size + 8) * sizeof(float);
+  hipLaunchKernelGGL(local_loss_kernel, dim3(B), dim3(256), smem, s, probs, mask, seg_mask, gkernel9, loss_accum, heads,
                      size, L, seg_l, Hm, Wm);
   UDT_CHECK_LAUNCH();
   return UDT_OK;

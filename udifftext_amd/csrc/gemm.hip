@@ -29,6 +29,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <atomic>
 
 namespace {
 
@@ -455,7 +456,6 @@ __global__ void __launch_bounds__(256) gemm_fixup_kernel(const GemmParams p) {
 }
 
 #include "gemm8.h"
-#include "gemm9.h"
 #include "conv3p.h"
 
 struct TilePlan {
@@ -467,26 +467,48 @@ struct TilePlan {
   bool fixup;
 };
 
-int g_slots = 0;    // resident workgroup slots: 2 per CU
-int g_cu_share = 1; // concurrent launch streams sharing the device: the cooperative (stream-K) kernels spin on partner
-                    // workgroups, so ALL their workgroups must be resident — each stream plans for 1/share of the CUs
+// Resident workgroup slots of the CURRENT device (2 four-wave workgroups or 1 eight-wave workgroup per CU).  The
+// cooperative (stream-K) kernels spin on partner workgroups, so ALL their workgroups must be resident: a launch that
+// shares the device with other launch streams plans for 1/cu_share of the CUs (udt_gemm_desc.cu_share — a field of the
+// call, not process state, so concurrent callers with different shares do not interfere).
+constexpr int MAX_DEVICES = 16;
+std::atomic<int> g_dev_cus[MAX_DEVICES];
 
-int resident_slots_all() {
-  if (g_slots == 0) {
-    int dev = 0, cus = 256;
-    if (hipGetDevice(&dev) == hipSuccess) {
-      int v = 0;
-      if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
-    }
-    g_slots = 2 * cus;
+int device_cus() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEVICES) return 256;
+  int v = g_dev_cus[dev].load(std::memory_order_relaxed);
+  if (v == 0) {
+    v = 256;
+    int q = 0;
+    if (hipDeviceGetAttribute(&q, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && q > 0) v = q;
+    g_dev_cus[dev].store(v, std::memory_order_relaxed);
   }
-  return g_slots;
+  return v;
 }
 
-int resident_slots() {
-  int s = resident_slots_all() / (g_cu_share > 0 ? g_cu_share : 1);
+int resident_slots_all() { return 2 * device_cus(); }
+
+int resident_slots(const udt_gemm_desc* d) {
+  const int share = d->cu_share > 0 ? d->cu_share : 1;
+  const int s = resident_slots_all() / share;
   return s < 2 ? 2 : s;
 }
+
+// hipFuncSetAttribute(max dynamic LDS) once per (kernel, device); thread-safe
+struct AttrOnce {
+  std::atomic<unsigned> done{0};
+  hipError_t ensure(const void* fn, int bytes) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) dev = 0;
+    if (done.load(std::memory_order_acquire) & (1u << dev)) return hipSuccess;
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) return e;
+    // the persistent kernels assume >= 1 resident workgroup per CU with this much LDS; ask the runtime once
+    done.fetch_or(1u << dev, std::memory_order_release);
+    return hipSuccess;
+  }
+};
 
 TilePlan plan_tiles(const udt_gemm_desc* d) {
   TilePlan t;
@@ -504,7 +526,7 @@ TilePlan plan_tiles(const udt_gemm_desc* d) {
   t.tiles = t.tiles_m * t.tiles_n * batch;
   t.nkt = d->K / BK;
   t.total = (long long)t.tiles * t.nkt;
-  const int slots = resident_slots();
+  const int slots = resident_slots(d);
   // A parked partial tile costs a 64 KiB slab write + read (~4 K-tiles of operand traffic), so ranges are cut
   // inside tiles only where it buys balance:
   //   few tiles (< slots)            : stream-K, >= 4 K-tiles per workgroup (this is split-K for the deep 8x8 layers)
@@ -534,16 +556,12 @@ TilePlan plan_tiles(const udt_gemm_desc* d) {
 template <int BM, int BN, int WGM, int WGN, bool CONV, bool TRANS>
 hipError_t launch_cfg(const GemmParams& p, const TilePlan& t, hipStream_t s) {
   constexpr int smem = 2 * (BM + BN) * ROW_BYTES;
-  static bool attr_set = false;
+  static AttrOnce once;
   auto kern = gemm_kernel<BM, BN, WGM, WGN, CONV, TRANS>;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
+  hipError_t e = once.ensure(reinterpret_cast<const void*>(kern), smem);
+  if (e != hipSuccess) return e;
   hipLaunchKernelGGL(kern, dim3(t.G), dim3(256), smem, s, p);
-  hipError_t e = hipGetLastError();
+  e = hipGetLastError();
   if (e != hipSuccess) return e;
   if (t.fixup) {
     hipLaunchKernelGGL((gemm_fixup_kernel<BM, BN, WGM, WGN, TRANS>), dim3(t.tiles), dim3(256), 0, s, p);
@@ -555,18 +573,27 @@ hipError_t launch_cfg(const GemmParams& p, const TilePlan& t, hipStream_t s) {
 // ---- 8-wave kernel: host side ------------------------------------------------------------------------------
 constexpr size_t G8_HEADER_BYTES = 4096;     // flags[<=1023] + err word, ahead of the slabs
 
-int g_impl = -1;     // 8: deep-pipelined 8-wave kernel (default), 4: first-generation 4-wave kernel
-int g_dbg_bits = 0;  // measurement modes: bit 28 no stream-K exchange, bit 27 no epilogue (results are wrong)
-int g_n_block = -1;  // tile order of plain GEMMs: -1 automatic (~2 MiB weight blocks), 0 off (M-fastest), n forced
-int g_rows_epi = 1;  // row-coalesced (LDS-transposed) epilogues; 0 = direct accumulator-layout stores (A/B runs)
+// Tuning knobs (udt_debug_set; every setting gives correct results): kernel generation, tile order, epilogue form.
+std::atomic<int> g_impl{-1};     // 8: deep-pipelined 8-wave kernel (default), 4: first-generation 4-wave kernel
+std::atomic<int> g_n_block{-1};  // tile order of plain GEMMs: -1 automatic (~2 MiB weight blocks), 0 off (M-fastest), n forced
+std::atomic<int> g_rows_epi{1};  // row-coalesced (LDS-transposed) epilogues; 0 = direct accumulator-layout stores
+std::atomic<int> g_conv3p{-1};   // patch-staged 3x3 convolution kernel on (1) / off (0)
+#ifdef UDT_MEASURE
+std::atomic<int> g_dbg_bits{0};  // cost-attribution modes that switch parts of the finishing code OFF (wrong results):
+                                 // compiled only into measurement builds (-DUDT_MEASURE), never into the product library
+#endif
 constexpr int INTERNAL_DIRECT_EPI = 1 << 30;   // kernel-side flag bit, never part of the public flag set
+constexpr int PUBLIC_FLAGS = UDT_GEMM_OUT_F32 | UDT_GEMM_GEGLU | UDT_GEMM_RELU | UDT_GEMM_TRANSPOSED | UDT_GEMM_CONV |
+                             UDT_GEMM_SILU_OUT;
 
 int gemm_impl() {
-  if (g_impl < 0) {
+  int v = g_impl.load(std::memory_order_relaxed);
+  if (v < 0) {
     const char* e = getenv("UDT_GEMM_IMPL");
-    g_impl = (e && e[0] == '4') ? 4 : (e && e[0] == '9') ? 9 : 8;
+    v = (e && e[0] == '4') ? 4 : 8;
+    g_impl.store(v, std::memory_order_relaxed);
   }
-  return g_impl;
+  return v;
 }
 
 bool use_gemm8(const udt_gemm_desc* d) {
@@ -591,7 +618,7 @@ TilePlan plan_tiles8(const udt_gemm_desc* d) {
   // one 8-wave workgroup per CU.  Whole-tile plans (shallow K, below) have no waits between workgroups, so they may
   // use every CU even when other launch streams share the device (cu_share): excess workgroups simply queue
   const bool whole = t.nkt < 24;
-  int slots = (whole ? resident_slots_all() : resident_slots()) / 2;
+  int slots = (whole ? resident_slots_all() : resident_slots(d)) / 2;
   long long G = t.total / 4;                       // >= 4 K-tiles per workgroup
   if (G < 1) G = 1;
   if (G > slots) G = slots;
@@ -609,67 +636,23 @@ hipError_t launch8(const g8::Params& pp, const TilePlan& t, hipStream_t s) {
   constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
   // the 256x128 configuration transposes its output through LDS: stage 2 plus 16 KiB above the ring (160 KiB total)
   constexpr int smem = (TM == 2 && TN == 2 && !TRANS) ? 160 * 1024 : g8::NSTAGE * (BM + BN) * ROW_BYTES;
-  static bool attr_set = false;
+  static AttrOnce once;
   auto kern = g8::gemm8_kernel<WGM, WGN, TM, TN, CONV, TRANS>;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
+  hipError_t e = once.ensure(reinterpret_cast<const void*>(kern), smem);
+  if (e != hipSuccess) return e;
   hipLaunchKernelGGL(kern, dim3(t.G), dim3(g8::NTHREADS), smem, s, pp);
   return hipGetLastError();
 }
 
-// ---- 256x256 phase-interleaved kernel: host side ---------------------------------------------------------------
-bool use_gemm9(const udt_gemm_desc* d) {
-  return gemm_impl() == 9 && use_gemm8(d);
-}
-
-TilePlan plan_tiles9(const udt_gemm_desc* d) {
-  TilePlan t;
-  const int batch = d->batch > 0 ? d->batch : 1;
-  t.bm = 256;
-  t.bn = 256;
-  t.tiles_m = (d->M + t.bm - 1) / t.bm;
-  t.tiles_n = (d->N + t.bn - 1) / t.bn;
-  t.tiles = t.tiles_m * t.tiles_n * batch;
-  t.nkt = d->K / BK;
-  t.total = (long long)t.tiles * t.nkt;
-  const int slots = resident_slots() / 2;          // one 8-wave workgroup per CU
-  long long G = t.total / 4;
-  if (G < 1) G = 1;
-  if (G > slots) G = slots;
-  t.ipw = (int)((t.total + G - 1) / G);
-  if (t.nkt < 24) t.ipw = ((t.ipw + t.nkt - 1) / t.nkt) * t.nkt;
-  t.G = (int)((t.total + t.ipw - 1) / t.ipw);
-  t.fixup = (t.ipw % t.nkt) != 0;
-  return t;
-}
-
-template <bool CONV, bool TRANS>
-hipError_t launch9(const g8::Params& pp, const TilePlan& t, hipStream_t s) {
-  static bool attr_set = false;
-  auto kern = g9::gemm9_kernel<CONV, TRANS>;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, g9::SMEM_BYTES);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
-  hipLaunchKernelGGL(kern, dim3(t.G), dim3(g9::NTHREADS), g9::SMEM_BYTES, s, pp);
-  return hipGetLastError();
-}
-
 // ---- patch-staged 3x3 convolution: host side -------------------------------------------------------------------
-int g_conv3p = -1;
-
 bool conv3p_geometry(const udt_gemm_desc* d, c3p::Geo& ge) {
-  if (g_conv3p < 0) {
+  int on = g_conv3p.load(std::memory_order_relaxed);
+  if (on < 0) {
     const char* e = getenv("UDT_CONV3P");
-    g_conv3p = (e && e[0] == '0') ? 0 : 1;
+    on = (e && e[0] == '0') ? 0 : 1;
+    g_conv3p.store(on, std::memory_order_relaxed);
   }
-  if (!g_conv3p || gemm_impl() == 4) return false;
+  if (!on || gemm_impl() == 4) return false;
   if (!(d->flags & UDT_GEMM_CONV) || d->ksize != 3 || d->stride != 1 || d->upsample || d->C2 != 0) return false;
   if (d->pad_t != 1 || d->pad_l != 1 || d->Hout != d->Hin || d->Wout != d->Win || d->N <= 64) return false;
   if (d->flags & (UDT_GEMM_GEGLU | UDT_GEMM_TRANSPOSED)) return false;
@@ -702,7 +685,7 @@ TilePlan plan_tiles3p(const udt_gemm_desc* d, const c3p::Geo& ge) {
   t.nkt = ge.chunks;                               // iteration unit of this kernel: one 64-channel chunk (9 K-tiles)
   t.total = (long long)t.tiles * t.nkt;
   const bool whole = t.nkt * 9 < 24;
-  const int slots = (whole ? resident_slots_all() : resident_slots()) / 2;
+  const int slots = (whole ? resident_slots_all() : resident_slots(d)) / 2;
   long long G = t.total;                           // >= one chunk per workgroup
   if (G > slots) G = slots;
   t.ipw = (int)((t.total + G - 1) / G);
@@ -716,14 +699,10 @@ template <int WGM, int WGN, int TM, int TN>
 hipError_t launch3p(const c3p::CParams& cp, const TilePlan& t, hipStream_t s) {
   constexpr int BN = WGN * TN * 32;
   constexpr int smem = g8::NSTAGE * BN * ROW_BYTES + 2 * c3p::PATCH_BYTES;
-  static bool attr_set = false;
+  static AttrOnce once;
   auto kern = c3p::conv3p_kernel<WGM, WGN, TM, TN>;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
+  hipError_t e = once.ensure(reinterpret_cast<const void*>(kern), smem);
+  if (e != hipSuccess) return e;
   hipLaunchKernelGGL(kern, dim3(t.G), dim3(g8::NTHREADS), smem, s, cp);
   return hipGetLastError();
 }
@@ -732,18 +711,39 @@ hipError_t launch3p(const c3p::CParams& cp, const TilePlan& t, hipStream_t s) {
 
 extern "C" int udt_debug_set(const char* key, int32_t value) {
   if (!key) return UDT_ERR_BAD_ARG;
-  if (!strcmp(key, "gemm_impl")) { g_impl = value; return UDT_OK; }
-  if (!strcmp(key, "conv3p")) { g_conv3p = value; return UDT_OK; }
-  if (!strcmp(key, "cu_share")) { g_cu_share = value > 0 ? value : 1; return UDT_OK; }
-  if (!strcmp(key, "n_block")) { g_n_block = value; return UDT_OK; }
-  if (!strcmp(key, "rows_epi")) { g_rows_epi = value; return UDT_OK; }
-  if (!strcmp(key, "no_xchg")) { g_dbg_bits = (g_dbg_bits & ~(1 << 28)) | (value ? (1 << 28) : 0); return UDT_OK; }
-  if (!strcmp(key, "no_store")) { g_dbg_bits = (g_dbg_bits & ~(1 << 26)) | (value ? (1 << 26) : 0); return UDT_OK; }
-  if (!strcmp(key, "no_res")) { g_dbg_bits = (g_dbg_bits & ~(1 << 25)) | (value ? (1 << 25) : 0); return UDT_OK; }
-  if (!strcmp(key, "no_bias")) { g_dbg_bits = (g_dbg_bits & ~(1 << 24)) | (value ? (1 << 24) : 0); return UDT_OK; }
-  if (!strcmp(key, "no_fast")) { g_dbg_bits = (g_dbg_bits & ~(1 << 22)) | (value ? (1 << 22) : 0); return UDT_OK; }
-  if (!strcmp(key, "no_epi")) { g_dbg_bits = (g_dbg_bits & ~(1 << 27)) | (value ? (1 << 27) : 0); return UDT_OK; }
+  if (!strcmp(key, "gemm_impl")) { if (value != 4 && value != 8) return UDT_ERR_BAD_ARG; g_impl.store(value); return UDT_OK; }
+  if (!strcmp(key, "conv3p")) { g_conv3p.store(value ? 1 : 0); return UDT_OK; }
+  if (!strcmp(key, "n_block")) { g_n_block.store(value); return UDT_OK; }
+  if (!strcmp(key, "rows_epi")) { g_rows_epi.store(value ? 1 : 0); return UDT_OK; }
+#ifdef UDT_MEASURE
+  static const struct { const char* k; int bit; } bits[] = {{"no_xchg", 28}, {"no_epi", 27}, {"no_store", 26}, {"no_res", 25},
+                                                            {"no_bias", 24}, {"no_fast", 22}};
+  for (const auto& b : bits)
+    if (!strcmp(key, b.k)) {
+      int cur = g_dbg_bits.load();
+      g_dbg_bits.store((cur & ~(1 << b.bit)) | (value ? (1 << b.bit) : 0));
+      return UDT_OK;
+    }
+#endif
   return UDT_ERR_BAD_ARG;
+}
+
+// Stream-K kernels that time out waiting for a partner workgroup (a launch that was not co-resident: wrong cu_share,
+// foreign long-running kernels holding the CUs) poison their output tile with NaN, leave the flags alone and set the
+// workspace's err word.  Synchronises `stream`, reads the word back and, if set, re-zeroes the header so the workspace
+// is usable again.  Call at natural sync points (end of a sampling loop, tests).
+extern "C" int udt_check_async_error(void* workspace, size_t workspace_bytes, void* stream) {
+  if (!workspace || workspace_bytes < G8_HEADER_BYTES) return UDT_ERR_BAD_ARG;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  int err = 0;
+  hipError_t e = hipMemcpyAsync(&err, reinterpret_cast<int*>(workspace) + 1023, sizeof(int), hipMemcpyDeviceToHost, s);
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  if (e != hipSuccess) return udt_set_hip_error(e);
+  if (err == 0) return UDT_OK;
+  e = hipMemsetAsync(workspace, 0, G8_HEADER_BYTES, s);
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  if (e != hipSuccess) return udt_set_hip_error(e);
+  return UDT_ERR_ASYNC;
 }
 
 extern "C" size_t udt_gemm_workspace_bytes(const udt_gemm_desc* d) {
@@ -757,10 +757,9 @@ extern "C" size_t udt_gemm_workspace_bytes(const udt_gemm_desc* d) {
     }
   }
   if (use_gemm8(d)) {
-    const bool nine = use_gemm9(d);
-    TilePlan t8 = nine ? plan_tiles9(d) : plan_tiles8(d);
+    TilePlan t8 = plan_tiles8(d);
     if (!t8.fixup) return 0;
-    return G8_HEADER_BYTES + (size_t)(nine ? 2 : 1) * t8.G * t8.bm * t8.bn * sizeof(float);
+    return G8_HEADER_BYTES + (size_t)t8.G * t8.bm * t8.bn * sizeof(float);
   }
   TilePlan t = plan_tiles(d);
   if (!t.fixup) return 0;
@@ -824,7 +823,11 @@ extern "C" int udt_gemm(const udt_gemm_desc* d, void* workspace, size_t workspac
   p.ksz = d->ksize; p.stride = d->stride; p.pad_t = d->pad_t; p.pad_l = d->pad_l; p.ups = d->upsample ? 1 : 0;
   p.rows_per_batch = d->rows_per_batch > 0 ? d->rows_per_batch : d->M;
   p.ldrv = d->ld_rowvec > 0 ? d->ld_rowvec : d->N;
-  p.flags = d->flags | (g_rows_epi ? 0 : INTERNAL_DIRECT_EPI) | g_dbg_bits;
+  if (d->flags & ~PUBLIC_FLAGS) return UDT_ERR_BAD_ARG;
+  p.flags = d->flags | (g_rows_epi.load(std::memory_order_relaxed) ? 0 : INTERNAL_DIRECT_EPI);
+#ifdef UDT_MEASURE
+  p.flags |= g_dbg_bits.load(std::memory_order_relaxed);
+#endif
   p.n_block = 1;
   p.alpha = d->alpha;
   const int cls = (conv && d->ksize == 3) ? 0 : 1;
@@ -861,13 +864,13 @@ extern "C" int udt_gemm(const udt_gemm_desc* d, void* workspace, size_t workspac
     }
   }
   if (use_gemm8(d)) {
-    const bool nine = use_gemm9(d);
-    const TilePlan t8 = nine ? plan_tiles9(d) : plan_tiles8(d);
+    const TilePlan t8 = plan_tiles8(d);
     p.tiles_m = t8.tiles_m; p.tiles_n = t8.tiles_n; p.tiles_per_batch = t8.tiles_m * t8.tiles_n;
-    if (g_n_block != 0 && !conv && (g_n_block > 0 || t8.tiles_n >= 8)) {    // wide outputs only (measured: N = 640 loses)
+    const int n_block_knob = g_n_block.load(std::memory_order_relaxed);
+    if (n_block_knob != 0 && !conv && (n_block_knob > 0 || t8.tiles_n >= 8)) {    // wide outputs only (measured: N = 640 loses)
       // weight block of ~2 MiB: bn * K * 2 bytes per N-tile
       const long long wt = (long long)t8.bn * d->K * 2;
-      long long nb = g_n_block > 0 ? g_n_block : (2LL << 20) / (wt > 0 ? wt : 1);
+      long long nb = n_block_knob > 0 ? n_block_knob : (2LL << 20) / (wt > 0 ? wt : 1);
       if (nb < 1) nb = 1;
       if (nb > t8.tiles_n) nb = t8.tiles_n;
       p.n_block = (int)nb;
@@ -882,7 +885,7 @@ extern "C" int udt_gemm(const udt_gemm_desc* d, void* workspace, size_t workspac
     pp.a_bytes = conv ? 0u : (unsigned)((long long)d->M * d->lda * 2);
     pp.w_bytes = (unsigned)((long long)d->N * p.ldw * 2);
     if (t8.fixup) {
-      const size_t need = G8_HEADER_BYTES + (size_t)(nine ? 2 : 1) * t8.G * t8.bm * t8.bn * sizeof(float);
+      const size_t need = G8_HEADER_BYTES + (size_t)t8.G * t8.bm * t8.bn * sizeof(float);
       if (!workspace || workspace_bytes < need) return UDT_ERR_WORKSPACE;
       pp.flags = reinterpret_cast<int*>(workspace);
       pp.err = pp.flags + 1023;
@@ -891,15 +894,12 @@ extern "C" int udt_gemm(const udt_gemm_desc* d, void* workspace, size_t workspac
     UdtProfScope prof8(cls, s);
     if (prof8.rec) {
       char tag[96];
-      snprintf(tag, sizeof(tag), "gemm%d M=%d N=%d K=%d conv=%d ks=%d fl=0x%x tile=%dx%d G=%d ipw=%d b=%d", nine ? 9 : 8,
+      snprintf(tag, sizeof(tag), "gemm8 M=%d N=%d K=%d conv=%d ks=%d fl=0x%x tile=%dx%d G=%d ipw=%d b=%d",
                d->M, d->N, d->K, conv ? 1 : 0, d->ksize, d->flags, t8.bm, t8.bn, t8.G, t8.ipw, batch);
       udt_prof_tag(prof8.rec, tag);
     }
     hipError_t e8;
-    if (nine) {
-      if (trans) e8 = launch9<false, true>(pp, t8, s);
-      else e8 = conv ? launch9<true, false>(pp, t8, s) : launch9<false, false>(pp, t8, s);
-    } else if (t8.bn == 160) {
+    if (t8.bn == 160) {
       e8 = conv ? launch8<8, 1, 1, 5, true, false>(pp, t8, s) : launch8<8, 1, 1, 5, false, false>(pp, t8, s);
     } else if (trans) {
       e8 = launch8<4, 2, 2, 2, false, true>(pp, t8, s);

@@ -174,7 +174,7 @@ UDT_DEVINL void epilogue8_rows(const GemmParams& p, f32x16 (&acc)[TM][2], MOF mo
       for (int q = 0; q < 4; ++q) {
         const int nx = nx0 + q * 8 + hi * 4;
         f32x4 bx = {0.f, 0.f, 0.f, 0.f}, bg = {0.f, 0.f, 0.f, 0.f};
-        if (p.bias && nx < p.N && !(p.flags & (1 << 24))) {
+        if (p.bias && nx < p.N && !UDT_DBG(p.flags, 24)) {
           bx = *reinterpret_cast<const f32x4*>(p.bias + nx);
           bg = *reinterpret_cast<const f32x4*>(p.bias + nx + 32);
         }
@@ -193,11 +193,11 @@ UDT_DEVINL void epilogue8_rows(const GemmParams& p, f32x16 (&acc)[TM][2], MOF mo
       const u32x4 v = *reinterpret_cast<const u32x4*>(wlds + row * 64 + ((ch ^ (row & 3)) << 4));
       const long long m = mof(row);
       const int no = no0 + ch * 8;
-      if (m >= 0 && (nx0 + ch * 8) < p.N && !(flags & (1 << 26))) *reinterpret_cast<u32x4*>(out + m * p.ldo + no) = v;
+      if (m >= 0 && (nx0 + ch * 8) < p.N && !UDT_DBG(p.flags, 26)) *reinterpret_cast<u32x4*>(out + m * p.ldo + no) = v;
     }
     return;
   }
-  const uint16_t* __restrict__ R = (p.res && !(p.flags & (1 << 25))) ? (p.res + (long long)batch * p.sR) : nullptr;
+  const uint16_t* __restrict__ R = (p.res && !UDT_DBG(p.flags, 25)) ? (p.res + (long long)batch * p.sR) : nullptr;
   if (R) {
     // residual block -> LDS in whole rows (8 lanes x 16 B = one 128-byte line), read back in accumulator order below
 #pragma unroll
@@ -232,12 +232,12 @@ UDT_DEVINL void epilogue8_rows(const GemmParams& p, f32x16 (&acc)[TM][2], MOF mo
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = acc[tm][tn][q * 4 + r] * p.alpha;
         if (n < p.N) {
-          if (p.bias && !(p.flags & (1 << 24))) {
+          if (p.bias && !UDT_DBG(p.flags, 24)) {
             const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + n);
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] += bv[r];
           }
-          if (p.rowvec && !(p.flags & (1 << 24))) {
+          if (p.rowvec && !UDT_DBG(p.flags, 24)) {
             const f32x4 rv = *reinterpret_cast<const f32x4*>(p.rowvec + (long long)b * p.ldrv + n);
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] += rv[r];
@@ -269,7 +269,7 @@ UDT_DEVINL void epilogue8_rows(const GemmParams& p, f32x16 (&acc)[TM][2], MOF mo
     const u32x4 v = *reinterpret_cast<const u32x4*>(wlds + row * 128 + ((ch ^ (row & 7)) << 4));
     const long long m = mof(row);
     const int n = nw + ch * 8;
-    if (m >= 0 && n + 8 <= p.N && !(flags & (1 << 26))) {
+    if (m >= 0 && n + 8 <= p.N && !UDT_DBG(p.flags, 26)) {
       *reinterpret_cast<u32x4*>(out + m * p.ldo + n) = v;
     } else if (m >= 0 && n < p.N) {
       u32x2 h = {v[0], v[1]};
@@ -291,7 +291,7 @@ UDT_DEVINL void epilogue8_rows16(const GemmParams& p, f32x16 (&acc)[1][TN], MOF 
   const int hi = lane >> 5;
   const int flags = p.flags;
   uint16_t* out = reinterpret_cast<uint16_t*>(p.out) + (long long)batch * p.sO;
-  const uint16_t* __restrict__ R = (p.res && !(p.flags & (1 << 25))) ? (p.res + (long long)batch * p.sR) : nullptr;
+  const uint16_t* __restrict__ R = (p.res && !UDT_DBG(p.flags, 25)) ? (p.res + (long long)batch * p.sR) : nullptr;
   const int rl = lane / NC;                    // 0..2 (lane 60..63: idle)
   const int ch = lane - rl * NC;
 #pragma unroll
@@ -330,12 +330,12 @@ UDT_DEVINL void epilogue8_rows16(const GemmParams& p, f32x16 (&acc)[1][TN], MOF 
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[r] = acc[0][tn][q * 4 + r] * p.alpha;
           if (n < p.N) {
-            if (p.bias && !(p.flags & (1 << 24))) {
+            if (p.bias && !UDT_DBG(p.flags, 24)) {
               const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + n);
 #pragma unroll
               for (int r = 0; r < 4; ++r) v[r] += bv[r];
             }
-            if (p.rowvec && !(p.flags & (1 << 24))) {
+            if (p.rowvec && !UDT_DBG(p.flags, 24)) {
               const f32x4 rv = *reinterpret_cast<const f32x4*>(p.rowvec + (long long)b * p.ldrv + n);
 #pragma unroll
               for (int r = 0; r < 4; ++r) v[r] += rv[r];
@@ -367,7 +367,7 @@ UDT_DEVINL void epilogue8_rows16(const GemmParams& p, f32x16 (&acc)[1][TN], MOF 
       if (rl < 3 && row < 16) {
         const u32x4 v = *reinterpret_cast<const u32x4*>(wlds + row * RS + ch * 16);
         const int n = nw + ch * 8;
-        if (m >= 0 && n + 8 <= p.N && !(flags & (1 << 26))) {
+        if (m >= 0 && n + 8 <= p.N && !UDT_DBG(p.flags, 26)) {
           *reinterpret_cast<u32x4*>(out + m * p.ldo + n) = v;
         } else if (m >= 0 && n < p.N) {
           u32x2 h = {v[0], v[1]};
@@ -591,7 +591,7 @@ UDT_DEVINL bool epilogue8_fast_dispatch(const GemmParams& p, f32x16 (&acc)[TM][T
                                         char* wlds, bool interior) {
   constexpr int PUB = UDT_GEMM_OUT_F32 | UDT_GEMM_GEGLU | UDT_GEMM_RELU | UDT_GEMM_SILU_OUT | (1 << 30) | (1 << 24) |
                       (1 << 25) | (1 << 26);
-  if (!interior || (p.flags & (1 << 22))) return false;
+  if (!interior || UDT_DBG(p.flags, 22)) return false;
   const int f = p.flags & PUB;
   if constexpr (TN == 2) {
     if (f == UDT_GEMM_GEGLU && p.bias && !p.res && !p.rowvec) {
@@ -845,7 +845,7 @@ __global__ void __launch_bounds__(NTHREADS) gemm8_kernel(const Params pp) {
     }
 
     // (bits 28 / 27 of flags: measurement modes of udt_debug_set — no slab exchange / no epilogue; wrong results)
-    const bool noxchg = (p.flags & (1 << 28)) != 0;
+    const bool noxchg = UDT_DBG(p.flags, 28);
     const bool full = noxchg || ((kt0 == 0) && (kt1 == p.n_ktiles));
     const bool publish = !noxchg && (kt0 > 0);            // head segment of a tile another workgroup started
     const int cur_tile = tile, cur_batch = batch, cur_m0 = m0, cur_n0 = n0;
@@ -887,40 +887,57 @@ __global__ void __launch_bounds__(NTHREADS) gemm8_kernel(const Params pp) {
       if (more) {
         // the drain above also retired the prefetch; nothing else to do (its data is simply already there)
       }
-    } else if (!(p.flags & (1 << 27))) {
+    } else if (!UDT_DBG(p.flags, 27)) {
       if (!full) {
         // this workgroup owns the start of the tile: collect the partners' slabs
         const long long tile_end = ((long long)cur_tile + 1) * p.n_ktiles;
         const int g_last = (int)((tile_end - 1) / p.iters_per_wg);
+        // (a partner that never shows up — a launch that was not fully resident — must not be summed: the finisher
+        //  sets the workspace's err word, leaves the flags alone and poisons its tile; udt_check_async_error reports it)
+        int* const bcast = reinterpret_cast<int*>(smem + 2 * STAGE_BYTES);   // ring stage 2 is idle here
+        if (!more) __syncthreads();        // (with `more` the barrier ahead of the prefetch already closed the ring)
         if (tid == 0) {
-          for (int pg = g + 1; pg <= g_last; ++pg) {
+          int ok = 1;
+          for (int pg = g + 1; pg <= g_last && ok; ++pg) {
             int spins = 0;
             while (__hip_atomic_load(pp.flags + pg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
               __builtin_amdgcn_s_sleep(8);
               if (++spins > SPIN_LIMIT) {
                 __hip_atomic_store(pp.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ok = 0;
                 break;
               }
             }
           }
           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+          *bcast = ok;
         }
         __syncthreads();
-        for (int pg = g + 1; pg <= g_last; ++pg) {
-          const f32x4* slab = reinterpret_cast<const f32x4*>(pp.slab_base + (long long)pg * (BM * BN));
+        const bool partners_ok = *bcast != 0;
+        if (partners_ok) {
+          for (int pg = g + 1; pg <= g_last; ++pg) {
+            const f32x4* slab = reinterpret_cast<const f32x4*>(pp.slab_base + (long long)pg * (BM * BN));
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+              for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                  const f32x4 v = slab[((tm * TN + tn) * 4 + q) * NTHREADS + tid];
+#pragma unroll
+                  for (int r = 0; r < 4; ++r) acc[tm][tn][q * 4 + r] += v[r];
+                }
+          }
+        } else {
 #pragma unroll
           for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
             for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
-              for (int q = 0; q < 4; ++q) {
-                const f32x4 v = slab[((tm * TN + tn) * 4 + q) * NTHREADS + tid];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) acc[tm][tn][q * 4 + r] += v[r];
-              }
+              for (int r = 0; r < 16; ++r) acc[tm][tn][r] = __builtin_nanf("");
         }
         __syncthreads();
-        if (tid == 0)
+        if (tid == 0 && partners_ok)
           for (int pg = g + 1; pg <= g_last; ++pg)
             __hip_atomic_store(pp.flags + pg, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }

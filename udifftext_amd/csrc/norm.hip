@@ -252,228 +252,7 @@ __global__ void __launch_bounds__(256) layernorm_kernel(const uint16_t* __restri
 }
 
 
-// ---- single-pass GroupNorm -------------------------------------------------------------------------------------
-// grid (nchunks, B) with nchunks * B <= #CUs, so every workgroup is resident.  A workgroup copies its rows x C slab
-// of sample b into LDS ONCE, publishes per-group partial sums, waits at a per-sample arrival counter (agent scope)
-// until the sample's other slabs have published theirs, then normalises straight out of LDS.  One HBM read and
-// one HBM write per element instead of the two reads + one write of the stats/apply pair.
-constexpr int GNF_THREADS = 1024;
-constexpr int GNF_MAX_DATA = 112 * 1024;     // + scale/shift (<= 32 KiB) + 16.25 KiB of reduction space <= 160 KiB
-constexpr int GNF_SPIN_LIMIT = 1 << 22;
-
-__global__ void __launch_bounds__(GNF_THREADS) gn_fused_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ x2,
-                                                               uint16_t* __restrict__ y, float* __restrict__ partials,
-                                                               const float* __restrict__ gamma,
-                                                               const float* __restrict__ beta, int* __restrict__ sync,
-                                                               const uint16_t* __restrict__ zero, int rows, long long HW, int C1, int C2, int G, int nchunks,
-                                                               float eps, int act) {
-  extern __shared__ __attribute__((aligned(16))) char fsm[];
-  const int C = C1 + C2;
-  const int c8 = C >> 3;
-  const int cpg = C / G;
-  const int t = threadIdx.x;
-  const int chunk = blockIdx.x;
-  const int b = blockIdx.y;
-  const long long p0 = (long long)chunk * rows;
-  const int n16 = rows * c8;                               // 16-byte pieces in this slab
-  char* data = fsm;
-  float* sc = reinterpret_cast<float*>(fsm + (size_t)((n16 + 63) & ~63) * 16);
-  float* sh = sc + C;
-  double* dred = reinterpret_cast<double*>(sh + C);        // [2][GNF_THREADS] doubles (8-byte aligned: C % 8 == 0)
-  float* red = reinterpret_cast<float*>(dred);             // phase 1b uses the same area as [2][GNF_THREADS] floats
-  float* gm = reinterpret_cast<float*>(dred + 2 * GNF_THREADS);   // [G] mean, [G] rstd
-  float* gr = gm + G;
-  const uint16_t* xb1 = x + ((long long)b * HW + p0) * C1;
-  const uint16_t* xb2 = x2 ? (x2 + ((long long)b * HW + p0) * C2) : nullptr;
-
-  // ---- phase 1a: slab -> LDS (row-major [rows][C] bf16) by LDS-DMA: every request of the slab is in flight at
-  // once, no registers in between.  Piece j = 16-byte chunks [64j, 64j+64); lanes past the slab read the zero page.
-  {
-    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int lane = t & 63;
-    const int npieces = (n16 + 63) >> 6;
-    for (int j = wave; j < npieces; j += GNF_THREADS / 64) {
-      const int i = j * 64 + lane;
-      const uint16_t* src = zero;
-      if (i < n16) {
-        const int pix = i / c8;
-        const int cc = i - pix * c8;
-        src = (cc * 8 < C1) ? (xb1 + (long long)pix * C1 + cc * 8) : (xb2 + (long long)pix * C2 + (cc * 8 - C1));
-      }
-      glds16(src, data + (size_t)j * 1024);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  }
-  __syncthreads();
-
-  // ---- phase 1b: per-group sums of the slab.  thread = (pixel lane pl, group g); cpg is even (C % 8 == 0, G = 32)
-  {
-    const int PL = GNF_THREADS / G;
-    const int g = t % G, pl = t / G;
-    float a = 0.f, q = 0.f;
-    if (pl < PL) {
-      const int w = cpg >> 1;                              // dwords per (pixel, group)
-      for (int pix = pl; pix < rows; pix += PL) {
-        const uint32_t* src = reinterpret_cast<const uint32_t*>(data + ((size_t)pix * C + (size_t)g * cpg) * 2);
-        for (int k = 0; k < w; ++k) {
-          const uint32_t v = src[k];
-          const float lo = bf16_lo(v), hi2 = bf16_hi(v);
-          a += lo + hi2;
-          q += lo * lo + hi2 * hi2;
-        }
-      }
-    }
-    red[t] = a;
-    red[GNF_THREADS + t] = q;
-    __syncthreads();
-    if (t < G) {
-      a = 0.f; q = 0.f;
-      for (int l = 0; l < PL; ++l) { a += red[l * G + t]; q += red[GNF_THREADS + l * G + t]; }
-      float* dst = partials + (((long long)b * nchunks + chunk) * G + t) * 2;
-      // write-through (sc1) stores: visible at agent scope once vmcnt drains, so no L2 write-back fence is needed
-      // before the arrival increment (measured: the buffer_wbl2 of a release fence costs 4-5 us here)
-      __hip_atomic_store(dst, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(dst + 1, q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-  }
-
-  // ---- per-sample arrival: publish, then wait for the sample's other slabs
-  int* arrive = sync + 2 * b;
-  int* leave = arrive + 1;
-  if (t == 0) {
-    __hip_atomic_fetch_add(arrive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    int spins = 0;
-    while (__hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < nchunks) {
-      __builtin_amdgcn_s_sleep(4);
-      if (++spins > GNF_SPIN_LIMIT) break;               // not co-resident (never with <= #CUs workgroups): give up
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    // the last workgroup to leave re-arms the counters for the next launch
-    if (__hip_atomic_fetch_add(leave, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nchunks - 1) {
-      __hip_atomic_store(arrive, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(leave, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-  }
-  __syncthreads();
-
-  // ---- phase 2: statistics of the whole sample: (pixel-lane, group) threads add a strided subset of the slabs'
-  // partials in double, G threads finish; then per-channel scale / shift
-  {
-    const int PL = GNF_THREADS / G;
-    const int g = t % G, pl = t / G;
-    double da = 0.0, dq = 0.0;
-    for (int k = pl; k < nchunks; k += PL) {
-      const float* src = partials + (((long long)b * nchunks + k) * G + g) * 2;
-      da += (double)src[0];
-      dq += (double)src[1];
-    }
-    dred[t] = da;
-    dred[GNF_THREADS + t] = dq;
-    __syncthreads();
-    if (t < G) {
-      da = 0.0; dq = 0.0;
-      for (int l = 0; l < PL; ++l) { da += dred[l * G + t]; dq += dred[GNF_THREADS + l * G + t]; }
-      const double n = (double)HW * (double)cpg;
-      const double mean = da / n;
-      double var = dq / n - mean * mean;
-      if (var < 0.0) var = 0.0;
-      gm[t] = (float)mean;
-      gr[t] = (float)(1.0 / sqrt(var + (double)eps));
-    }
-  }
-  __syncthreads();
-  for (int c = t; c < C; c += GNF_THREADS) {
-    const int g = c / cpg;
-    const float a = gr[g] * gamma[c];
-    sc[c] = a;
-    sh[c] = beta[c] - gm[g] * a;
-  }
-  __syncthreads();
-
-  // ---- phase 3: normalise out of LDS, coalesced 16-byte stores
-  uint16_t* yb = y + ((long long)b * HW + p0) * C;
-  for (int i = t; i < n16; i += GNF_THREADS) {
-    const int pix = i / c8;
-    const int cc = i - pix * c8;
-    const u32x4 v = *reinterpret_cast<const u32x4*>(data + (size_t)i * 16);
-    const f32x4 s0 = *reinterpret_cast<const f32x4*>(sc + cc * 8);
-    const f32x4 s1 = *reinterpret_cast<const f32x4*>(sc + cc * 8 + 4);
-    const f32x4 h0 = *reinterpret_cast<const f32x4*>(sh + cc * 8);
-    const f32x4 h1 = *reinterpret_cast<const f32x4*>(sh + cc * 8 + 4);
-    float o[8];
-    o[0] = bf16_lo(v[0]) * s0[0] + h0[0];
-    o[1] = bf16_hi(v[0]) * s0[1] + h0[1];
-    o[2] = bf16_lo(v[1]) * s0[2] + h0[2];
-    o[3] = bf16_hi(v[1]) * s0[3] + h0[3];
-    o[4] = bf16_lo(v[2]) * s1[0] + h1[0];
-    o[5] = bf16_hi(v[2]) * s1[1] + h1[1];
-    o[6] = bf16_lo(v[3]) * s1[2] + h1[2];
-    o[7] = bf16_hi(v[3]) * s1[3] + h1[3];
-    if (act == 1) {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) o[j] = silu_f(o[j]);
-    }
-    u32x4 ov = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7])};
-    *reinterpret_cast<u32x4*>(yb + (size_t)i * 8) = ov;
-  }
-}
-
-// slabs per sample for the single-pass kernel, 0 when the shape does not fit it
-int gn_fused_chunks(int B, long long HW, int C, int G) {
-  if (B <= 0 || B > 256 || G <= 0 || GNF_THREADS % G != 0 || C % G != 0 || ((C / G) & 1)) return 0;
-  long long n = 256 / B;
-  if (n > HW) n = HW;
-  while (n > 1 && HW % n != 0) --n;
-  const long long rows = HW / n;
-  const long long smem = ((rows * C * 2 + 1023) & ~1023LL) + 2LL * C * 4 + 2LL * GNF_THREADS * 8 + 2LL * G * 4;
-  if (rows * C * 2 > GNF_MAX_DATA || smem > 160 * 1024) return 0;
-  return (int)n;
-}
-
 }  // namespace
-
-extern "C" int32_t udt_gn_fused_nchunks(int32_t B, int64_t HW, int32_t C, int32_t G) {
-  return gn_fused_chunks(B, HW, C, G);
-}
-
-extern "C" int udt_gn_fused(const void* x, const void* x2, void* y, float* partials, const float* gamma,
-                            const float* beta, int32_t B, int64_t HW, int32_t C1, int32_t C2, int32_t G, float eps,
-                            int32_t act, void* stream) {
-  if (!x || !y || !partials || !gamma || !beta || (C2 > 0 && !x2)) return UDT_ERR_BAD_ARG;
-  if (C2 < 0 || C1 <= 0 || C1 % 8 != 0 || C2 % 8 != 0) return UDT_ERR_BAD_SHAPE;
-  const int C = C1 + C2;
-  if (HW <= 0 || C > GN_MAX_C) return UDT_ERR_BAD_SHAPE;
-  const int nchunks = gn_fused_chunks(B, HW, C, G);
-  if (nchunks <= 0) return UDT_ERR_BAD_SHAPE;
-  int* sync = udt_sync_page();
-  if (!sync) return UDT_ERR_HIP;
-  const int rows = (int)(HW / nchunks);
-  const size_t smem = (((size_t)rows * C * 2 + 1023) & ~(size_t)1023) + (size_t)2 * C * sizeof(float) +
-                      (size_t)2 * GNF_THREADS * sizeof(double) + (size_t)2 * G * sizeof(float);
-  const uint16_t* zero = udt_zero_page();
-  if (!zero) return UDT_ERR_HIP;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gn_fused_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return udt_set_hip_error(e);
-    attr_set = true;
-  }
-  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  UdtProfScope prof(4, s);
-  if (prof.rec) {
-    char tag[96];
-    snprintf(tag, sizeof(tag), "gn_fused B=%d HW=%lld C=%d chunks=%d", B, (long long)HW, C, nchunks);
-    udt_prof_tag(prof.rec, tag);
-  }
-  hipLaunchKernelGGL(gn_fused_kernel, dim3(nchunks, B), dim3(GNF_THREADS), smem, s, reinterpret_cast<const uint16_t*>(x),
-                     reinterpret_cast<const uint16_t*>(x2), reinterpret_cast<uint16_t*>(y), partials, gamma, beta, sync,
-                     zero, rows, (long long)HW, C1, C2, G, nchunks, eps, act);
-  UDT_CHECK_LAUNCH();
-  return UDT_OK;
-}
 
 extern "C" int32_t udt_gn_nchunks(int64_t HW, int32_t C) {
   (void)C;

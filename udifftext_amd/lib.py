@@ -34,7 +34,7 @@ class GemmDesc(C.Structure):
         ("Hout", C.c_int32), ("Wout", C.c_int32),
         ("ksize", C.c_int32), ("stride", C.c_int32), ("pad_t", C.c_int32), ("pad_l", C.c_int32),
         ("upsample", C.c_int32), ("rows_per_batch", C.c_int32), ("ld_rowvec", C.c_int32), ("flags", C.c_int32),
-        ("alpha", C.c_float),
+        ("alpha", C.c_float), ("cu_share", C.c_int32),
     ]
 
 
@@ -43,6 +43,7 @@ _vp, _i32, _i64, _f32, _fp = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_vo
 SYMBOLS = {
     "udt_gemm_workspace_bytes": (C.c_size_t, [C.POINTER(GemmDesc)]),
     "udt_gemm": (C.c_int, [C.POINTER(GemmDesc), _vp, C.c_size_t, _vp]),
+    "udt_check_async_error": (C.c_int, [_vp, C.c_size_t, _vp]),
     "udt_attn_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32,
                                _i64, _i64, _i64, _i64, _f32, _vp]),
     "udt_xattn_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _fp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp]),
@@ -50,8 +51,6 @@ SYMBOLS = {
     "udt_gn_nchunks": (_i32, [_i64, _i32]),
     "udt_gn_stats": (C.c_int, [_vp, _vp, _fp, _i32, _i64, _i32, _i32, _i32, _vp]),
     "udt_gn_apply": (C.c_int, [_vp, _vp, _vp, _fp, _fp, _fp, _i32, _i64, _i32, _i32, _i32, _f32, _i32, _vp]),
-    "udt_gn_fused_nchunks": (C.c_int32, [_i32, _i64, _i32, _i32]),
-    "udt_gn_fused": (C.c_int, [_vp, _vp, _vp, _fp, _fp, _fp, _i32, _i64, _i32, _i32, _i32, _f32, _i32, _vp]),
     "udt_layernorm": (C.c_int, [_vp, _vp, _fp, _fp, _i64, _i32, _f32, _vp]),
     "udt_unet_input": (C.c_int, [_fp, _vp, _i32, _i32, _i32, _f32, _vp]),
     "udt_cfg_euler_step": (C.c_int, [_fp, _fp, _fp, _i32, _i32, _i32, _f32, _f32, _f32, _f32, _vp]),

@@ -5,17 +5,61 @@ libudt_kernels.so.  All functions raise if a tensor is not on a GPU — there is
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
+import threading
 from typing import Optional
 
 import torch
 
 from . import lib as L
 
-_workspace: dict = {}
-GN_FUSED = False         # single-pass cooperative GroupNorm (udt_gn_fused): measured neutral on the UNet step
-#                          (15.16 vs 15.19 ms, MI355X) — the slab's load -> exchange -> store phases do not overlap
-#                          inside one workgroup per CU — so the two-kernel path stays the default
+# ---------------------------------------------------------------------------------------- launch context
+# The stream-K kernels need (a) a workspace whose first 4 KiB (slab flags + error word) are zero between launches
+# and that no concurrent stream shares, and (b) the number of launch streams sharing the device (``cu_share``: all
+# their workgroups must be resident).  Both are properties of the CALLER's launch stream, so they travel in a
+# thread-local context that ``gemm_desc`` / ``run_gemm`` read — the C ABI itself keeps no such state
+# (udt_gemm_desc.cu_share, caller-owned workspace).
+WORKSPACE_BYTES = 96 << 20      # >= 256 workgroups x (256 x 160) fp32 slab + header: covers every plan of the library
+
+
+class Workspace:
+    """A stream-K workspace owned by whoever launches on one stream (a sampling runner, a captured graph): allocated
+    with it, passed explicitly, freed with it, never regrown while launches or captured graphs may reference it."""
+
+    def __init__(self, device, nbytes: int = WORKSPACE_BYTES):
+        if torch.device(device).type != "cuda":
+            raise L.UdtError("udifftext_amd workspaces live on the GPU (no CPU fallback)")
+        # zero-initialised: the kernels keep 'slab ready' flags in the first 4 KiB and restore them to 0
+        self.buf = torch.zeros(nbytes, dtype=torch.uint8, device=device)
+
+    def check(self, stream: Optional[int] = None) -> None:
+        """synchronise ``stream`` (default: current) and raise UdtError if a launch on this workspace timed out"""
+        L.check(L.load().udt_check_async_error(self.buf.data_ptr(), self.buf.numel(), _stream() if stream is None else stream),
+                "udt_check_async_error")
+
+
+class _Ctx(threading.local):
+    cu_share = 1
+    workspace: Optional[Workspace] = None
+
+
+_ctx = _Ctx()
+_default_ws: dict = {}
+
+
+@contextlib.contextmanager
+def launch_context(cu_share: Optional[int] = None, workspace: Optional[Workspace] = None):
+    """launches issued inside run with this CU share / on this workspace (thread-local, re-entrant)"""
+    prev = (_ctx.cu_share, _ctx.workspace)
+    if cu_share is not None:
+        _ctx.cu_share = max(1, int(cu_share))
+    if workspace is not None:
+        _ctx.workspace = workspace
+    try:
+        yield
+    finally:
+        _ctx.cu_share, _ctx.workspace = prev
 
 
 def _stream() -> int:
@@ -31,14 +75,23 @@ def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
 
 
 def _ws(nbytes: int, device) -> torch.Tensor:
-    # one workspace per (device, stream): concurrent streams must not share the stream-K flags and slabs
-    key = (device.type, device.index, _stream())
-    buf = _workspace.get(key)
-    if buf is None or buf.numel() < nbytes:
-        # zero-initialised: the stream-K kernels keep 'slab ready' flags in the first 4 KiB and restore them to 0
-        buf = torch.zeros(max(nbytes, 96 << 20), dtype=torch.uint8, device=device)
-        _workspace[key] = buf
-    return buf
+    ws = _ctx.workspace
+    if ws is None:
+        # eager callers without a context: one default workspace per (device, stream) — concurrent streams must not
+        # share the flags and slabs.  Fixed size, so a buffer a captured graph references is never replaced.
+        key = (device.type, device.index, _stream())
+        ws = _default_ws.get(key)
+        if ws is None:
+            ws = _default_ws[key] = Workspace(device)
+    if ws.buf.numel() < nbytes:
+        raise L.UdtError(f"stream-K workspace of {ws.buf.numel()} bytes is too small for this launch ({nbytes})")
+    return ws.buf
+
+
+def check_async_errors() -> None:
+    """check every default (per-stream) workspace — tests and eager callers; runners check their own"""
+    for (_, _, stream), ws in list(_default_ws.items()):
+        ws.check(stream)
 
 
 def _bf16(t: torch.Tensor) -> None:
@@ -51,6 +104,7 @@ def gemm_desc(**kw) -> L.GemmDesc:
     d = L.GemmDesc()
     d.batch = 1
     d.alpha = 1.0
+    d.cu_share = _ctx.cu_share
     for k, v in kw.items():
         setattr(d, k, v)
     return d
@@ -208,12 +262,6 @@ def group_norm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, groups:
     lib = L.load()
     if out is None:
         out = torch.empty(x.shape[:-1] + (C1 + C2,), dtype=torch.bfloat16, device=x.device)
-    nfused = lib.udt_gn_fused_nchunks(B, HW, C1 + C2, groups) if GN_FUSED else 0
-    if nfused > 0:                      # single pass: the sample's slabs stay in LDS across the statistics exchange
-        part = torch.empty((B, nfused, groups, 2), dtype=torch.float32, device=x.device)
-        L.check(lib.udt_gn_fused(_ptr(x), _ptr(x2), _ptr(out), _ptr(part), _ptr(gamma), _ptr(beta), B, HW, C1, C2, groups,
-                                 eps, 1 if silu else 0, _stream()), "udt_gn_fused")
-        return out
     nch = lib.udt_gn_nchunks(HW, C1 + C2)
     part = torch.empty((B, nch, groups, 2), dtype=torch.float32, device=x.device)
     L.check(lib.udt_gn_stats(_ptr(x), _ptr(x2), _ptr(part), B, HW, C1, C2, groups, _stream()), "udt_gn_stats")
@@ -333,11 +381,6 @@ def bias_add(x: torch.Tensor, bias: torch.Tensor, out: Optional[torch.Tensor] = 
     assert x.is_contiguous() and out.is_contiguous() and bias.dtype == torch.float32 and bias.numel() >= Cc
     L.check(L.load().udt_bias_add_bf16(_ptr(x), _ptr(bias), _ptr(out), x.numel() // Cc, Cc, _stream()), "udt_bias_add_bf16")
     return out
-
-
-def set_cu_share(n: int) -> None:
-    """number of concurrent launch streams the cooperative (stream-K) kernels have to share the CUs with"""
-    L.check(L.load().udt_debug_set(b"cu_share", int(n)), "udt_debug_set")
 
 
 # ------------------------------------------------------------------------------------------ profiling

@@ -80,6 +80,25 @@ class EDMSampler(SingleStepDiffusionSampler):
 DUAL_STREAM = os.environ.get("UDT_DUAL_STREAM", "1") != "0"
 
 
+def weights_fingerprint(model) -> int:
+    """changes whenever a parameter of ``model`` is re-assigned, moved or written in place (load_state_dict,
+    init_from_ckpt, .to()): captured hipGraphs bake in the device pointers of the packed weights, so the graph caches
+    are keyed by it (~1 ms for the engine's 1330 tensors, once per sampling call)"""
+    h = 0
+    for p in model.parameters():
+        h = (h * 1000003 + p._version * 8191 + p.data_ptr()) & 0xFFFFFFFFFFFFFFFF
+    return h
+
+
+def _is_capture_failure(e: BaseException) -> bool:
+    """only 'this stream / runtime cannot capture' errors may downgrade the sampler to eager launches"""
+    from udifftext_amd import lib as L
+    if isinstance(e, (L.UdtError, torch.OutOfMemoryError)):
+        return False
+    msg = str(e).lower()
+    return "captur" in msg or "graph" in msg
+
+
 class _Stepper:
     """Step-invariant device state of one sampling run + the fused per-step launch sequence."""
 
@@ -111,6 +130,11 @@ class _Stepper:
         ops.nhwc_set_channels(concat, self.xin, 4)                         # channels 4..8: mask, masked latent
         self._emb_cache: Dict[int, torch.Tensor] = {}
         self.dev = dev
+        # stream-K workspaces owned by this stepper (one per launch stream): allocated with it, referenced by the
+        # graphs captured from it, freed with it
+        self.ws = ops.Workspace(dev)
+        self.ws_side = ops.Workspace(dev) if self.dual else None
+        self.cu_share = 1               # launch streams of OTHER runners sharing the device (set by _GraphedSteps)
 
     def quantise(self, sigma: float):
         idx = int((self.table - sigma).abs().argmin())
@@ -131,28 +155,35 @@ class _Stepper:
         ops.unet_input(x, self.xin, c_in)
         if emit_maps:
             self.unet.clear_attn_map()
+        emb = self.emb_rows(idx)
         if self.dual and not emit_maps:
-            eps = self._forward_two_streams(self.emb_rows(idx))
+            eps = self._forward_two_streams(emb)
         else:
-            eps = self.unet.forward_nhwc(self.xin, self.emb_rows(idx), self.t_kv, emit_maps=emit_maps,
-                                         zero_ctx_rows=self.zero_ctx_rows)
+            with ops.launch_context(cu_share=self.cu_share, workspace=self.ws):
+                eps = self.unet.forward_nhwc(self.xin, emb, self.t_kv, emit_maps=emit_maps,
+                                             zero_ctx_rows=self.zero_ctx_rows)
         ops.cfg_euler_step(x, eps, sigma, sigma_next, self.scale, c_out=-sq)
 
+    def check(self) -> None:
+        """synchronise and raise if a stream-K launch of this stepper timed out (library err word)"""
+        self.ws.check()
+        if self.ws_side is not None:
+            self.ws_side.check(self.side.cuda_stream)
+
     def _forward_two_streams(self, emb: torch.Tensor) -> torch.Tensor:
-        """uc half on the current stream, c half on the side stream (fork / join; captured as two graph branches)"""
+        """uc half on the current stream, c half on the side stream (fork / join; captured as two graph branches);
+        the stream-K kernels of both streams must be co-resident: each is planned for half of this stepper's CUs"""
         B = self.B
         main = torch.cuda.current_stream()
-        ops.set_cu_share(2)              # stream-K kernels of both streams must be co-resident: half the CUs each
-        try:
-            self.side.wait_stream(main)
-            with torch.cuda.stream(self.side):
-                eps_c = self.unet.forward_nhwc(self.xin[B:], emb[B:], self.t_kv_c, zero_ctx_rows=0)
-                self.eps[B:].copy_(eps_c)
+        share = 2 * self.cu_share
+        self.side.wait_stream(main)
+        with torch.cuda.stream(self.side), ops.launch_context(cu_share=share, workspace=self.ws_side):
+            eps_c = self.unet.forward_nhwc(self.xin[B:], emb[B:], self.t_kv_c, zero_ctx_rows=0)
+            self.eps[B:].copy_(eps_c)
+        with ops.launch_context(cu_share=share, workspace=self.ws):
             eps_u = self.unet.forward_nhwc(self.xin[:B], emb[:B], self.t_kv_u, zero_ctx_rows=self.zero_ctx_rows)
             self.eps[:B].copy_(eps_u)
-            main.wait_stream(self.side)
-        finally:
-            ops.set_cu_share(1)
+        main.wait_stream(self.side)
         return self.eps
 
 
@@ -169,12 +200,14 @@ class _GraphedSteps:
         # the CUs and its UNet stays on one stream (the concurrency comes from the other batches)
         self.cu_share = int(cu_share)
         self.st = _Stepper(model, cond, uc, batch_size, latent_hw, scale, two_streams=None if cu_share == 1 else False)
+        self.st.cu_share = self.cu_share
+        self.fingerprint = weights_fingerprint(model)
         h, w = latent_hw
         self.x = torch.zeros((batch_size, 4, h, w), dtype=torch.float32, device=self.st.dev)
         self.sig = list(sig)
         self.graphs: Dict[int, torch.cuda.CUDAGraph] = {}
         self.pool = torch.cuda.graph_pool_handle()
-        self.capture_stream = torch.cuda.Stream(device=self.st.dev)   # also keys this runner's stream-K workspace
+        self.capture_stream = torch.cuda.Stream(device=self.st.dev)
         self.warm = False
 
     def rebind(self, cond, uc) -> bool:
@@ -195,32 +228,19 @@ class _GraphedSteps:
         st = self.st
         st.emb_rows(st.quantise(self.sig[i])[0])                 # time-embedding rows are cached outside the graph
         if not self.warm:
-            # one eager pass on the capture stream: sets kernel attributes, sizes that stream's stream-K workspace,
-            # allocates the library's pages
+            # one eager pass on the capture stream: sets kernel attributes, allocates the library's pages
             torch.cuda.synchronize()
-            if self.cu_share > 1:
-                ops.set_cu_share(self.cu_share)
-            try:
-                with torch.cuda.stream(self.capture_stream):
-                    keep = self.x.clone()
-                    st.step(self.x, self.sig[i], self.sig[i + 1])
-                    self.x.copy_(keep)
-            finally:
-                if self.cu_share > 1:
-                    ops.set_cu_share(1)
+            with torch.cuda.stream(self.capture_stream):
+                keep = self.x.clone()
+                st.step(self.x, self.sig[i], self.sig[i + 1])
+                self.x.copy_(keep)
             torch.cuda.synchronize()
             self.warm = True
         g = torch.cuda.CUDAGraph()
-        if self.cu_share > 1:
-            ops.set_cu_share(self.cu_share)
-        try:
-            # thread_local: other threads of the process (the RCCL watchdog under torch.distributed) may touch the
-            # HIP runtime while this thread captures
-            with torch.cuda.graph(g, pool=self.pool, stream=self.capture_stream, capture_error_mode="thread_local"):
-                st.step(self.x, self.sig[i], self.sig[i + 1])
-        finally:
-            if self.cu_share > 1:
-                ops.set_cu_share(1)
+        # thread_local: other threads of the process (the RCCL watchdog under torch.distributed) may touch the
+        # HIP runtime while this thread captures
+        with torch.cuda.graph(g, pool=self.pool, stream=self.capture_stream, capture_error_mode="thread_local"):
+            st.step(self.x, self.sig[i], self.sig[i + 1])
         self.graphs[i] = g
         return g
 
@@ -231,7 +251,9 @@ class _GraphedSteps:
             if g is None:
                 g = self._capture(i)
             g.replay()
-        return self.x.clone()
+        out = self.x.clone()
+        self.st.check()                       # one sync per sampling loop: surfaces a stream-K time-out as UdtError
+        return out
 
 
 class EulerEDMSampler(EDMSampler):
@@ -278,6 +300,7 @@ class EulerEDMSampler(EDMSampler):
             scores.append(ll[ll.shape[0] // 2:])
             randn = torch.randn(shape).to(dev)
         stepper.unet.clear_attn_map()
+        stepper.check()
         score = torch.stack(scores, 0)                                   # [iters, B]
         best = score.argmin(dim=0)                                        # first minimum, like the stable sort
         print(f"Init local loss: Best {score.min().item()} Worst {score.max().item()}")
@@ -325,6 +348,7 @@ class EulerEDMSampler(EDMSampler):
         for i in self.get_sigma_gen(len(sig), init_step=init_step):
             stepper.step(x, sig[i], sig[i + 1], emit_maps=False)
         stepper.unet.cache_attn_maps = prev
+        stepper.check()
         return x
 
     # ------------------------------------------------------------------------------- batches in flight
@@ -343,12 +367,16 @@ class EulerEDMSampler(EDMSampler):
         sig = self._host_sigmas(None)
         steps = list(self.get_sigma_gen(len(sig), init_step=init_step))
         cache = self.__dict__.setdefault("_in_flight", {})
+        fp = weights_fingerprint(model)
         runners = []
         for slot, (x, c, u) in enumerate(zip(xs, conds, ucs)):
             require_gpu(x, "EulerEDMSampler")
             u = default(u, c)
             key = (slot, n, id(model), tuple(x.shape), len(sig), float(self.guider.scale), tuple(sig[:2]), x.device.index)
             gs = cache.get(key)
+            if gs is not None and gs.fingerprint != fp:        # weights changed: the captured pointers are stale
+                cache.pop(key)
+                gs = None
             if gs is None or not gs.rebind(c, u):
                 gs = _GraphedSteps(model, c, u, x.shape[0], x.shape[2:], self.guider.scale, sig, cu_share=n)
                 cache.pop(key, None)
@@ -370,7 +398,10 @@ class EulerEDMSampler(EDMSampler):
                     gs.graphs[i].replay()
         for gs in runners:
             main.wait_stream(gs.capture_stream)
-        return [gs.x.clone() for gs in runners]
+        outs = [gs.x.clone() for gs in runners]
+        for gs in runners:
+            gs.st.check()
+        return outs
 
     def _run_graphed(self, model, x, cond, uc, sig, init_step):
         """replay (capturing on first use) the hipGraphs of this sampling configuration; None -> eager launches"""
@@ -378,15 +409,24 @@ class EulerEDMSampler(EDMSampler):
         cache = self.__dict__.setdefault("_graphed", {})
         try:
             gs = cache.get(key)
+            if gs is not None and gs.fingerprint != weights_fingerprint(model):
+                gs = None                                       # weights changed under the captured graphs
             if gs is None or not gs.rebind(cond, uc):
-                gs = _GraphedSteps(model, cond, uc, x.shape[0], x.shape[2:], self.guider.scale, sig)
                 cache.clear()                                   # one configuration at a time (each holds a memory pool)
+                gs = _GraphedSteps(model, cond, uc, x.shape[0], x.shape[2:], self.guider.scale, sig)
                 cache[key] = gs
             return gs.run(x, self.get_sigma_gen(len(sig), init_step=init_step))
-        except RuntimeError as e:                               # capture not possible here: keep launching eagerly
+        except RuntimeError as e:
+            if not _is_capture_failure(e):                      # kernel status errors, OOM, ...: never hidden
+                raise
             if not self.__dict__.get("_graph_warned"):
                 print(f"[udifftext_amd] hipGraph capture unavailable ({e}); using eager launches", file=sys.stderr)
                 self._graph_warned = True
             self.use_graphs = False
             cache.clear()
             return None
+
+    def invalidate_graphs(self) -> None:
+        """drop every captured hipGraph (explicit hook; the caches also notice changed weights by fingerprint)"""
+        self.__dict__.pop("_graphed", None)
+        self.__dict__.pop("_in_flight", None)
