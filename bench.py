@@ -1,25 +1,36 @@
 #!/usr/bin/env python
 """Benchmark of the UDiffText denoising hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W                        # BASELINE config #2 per GPU (weak scaling)
+    python bench.py --size 768 --batch 8 --chars 12                      # BASELINE config #4
+    torchrun ... bench.py --gpus 8 --global-batch 64                     # BASELINE config #3 (one sharded global batch)
 
-One "step" = one pass of the hot path over one batch of synthetic input: BASELINE config #2 —
+One "step" = one pass of the hot path over one GLOBAL batch of synthetic input.  Default (BASELINE config #2):
 512x512, 50 deterministic Euler (== DDIM eta 0) steps with CFG 5.0, batch 4 per GPU, 9-character labels,
 noise_iters 0 — i.e. conditioner (LabelEncoder + mask rescale + VAE encode of the masked image + 2 posterior
-samples), 50 UNet calls on the CFG pair (8 samples), VAE decode, clamp.  Weights are the deterministic synthetic
-recipe (no checkpoints exist here), inputs are seeded synthetic batches already resident in HBM when the
-timed region starts.  For N > 1 (launched by torch.distributed.run, one rank per GPU over RCCL) every rank
-samples its own 4 images (weak scaling) and the decoded frames are all-gathered once per step.
+samples), 50 UNet calls on the CFG pair (8 samples per call), VAE decode, clamp.  Weights are the deterministic
+synthetic recipe (no checkpoints exist here), inputs are seeded synthetic batches already resident in HBM when the
+timed region starts.  The global batch (--global-batch, default batch x N) is sharded over the N ranks by
+``parallel.predict_sharded`` (per-image seeds: results do not depend on N) and the decoded frames are all-gathered
+once per global batch over RCCL.
 
-Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel class (3x3 implicit-GEMM convolution):
-algorithmic FLOPs of its launches / their summed duration, measured live with HIP events on the launch stream
-(udt_prof_*) — on one extra eager pass of the same batch right after the timed region, because the timed region
-replays hipGraphs (no per-launch host calls to bracket).  `cpu_baseline` times the CPU oracle (oracle/, a port pinned against the real
-reference) on the host cores for a bounded sample and extrapolates (rank 0, N = 1 only).
+`value` is the on-config number: every UNet call runs on ONE batch of --batch images (its CFG pair); two such
+batches are in flight per GPU on two launch streams (--in-flight 2, stated in config.workload).  The other launch
+modes (one batch at a time; throughput mode with batches concatenated into larger UNet calls) are reported under
+`images_per_s_by_launch_mode` and are never `value`.
+
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel class (3x3 convolution); `roofline_classes`
+adds the GEMM (linears + 1x1 convolutions) and flash-attention classes: algorithmic FLOPs of the launches / their
+summed duration, measured live with HIP events on the launch stream (udt_prof_*) on one extra eager pass of the same
+batch right after the timed region (the timed region replays hipGraphs: no per-launch host calls to bracket).
+`cpu_baseline` times the CPU oracle (oracle/, a port pinned against the real reference) on the host cores for a
+bounded sample and extrapolates (rank 0, N = 1 only).
 """
 from __future__ import annotations
 
 import argparse
+import contextlib
+import glob
 import json
 import os
 import sys
@@ -30,44 +41,53 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-FLOP_PER_IMAGE = 83505e9       # 50 x 1597.326 + 1116.7 + 2514.6 + 7.2 GFLOP
+# UNet GFLOP per image-step / VAE encode / VAE decode / LabelEncoder, by image size
+WORK = {256: (355.320, 272.7, 622.2), 512: (1597.326, 1116.7, 2514.6), 768: (4279.809, 2609.1, 5754.4)}
 PEAK_BF16 = 2500e12            # dense MFMA peak, MI355X_MICROARCH.md
+PEAK_HBM = 8.0e12
+
+
+def flop_per_image(size: int, sampler_steps: int) -> float:
+    unet, enc, dec = WORK.get(size, WORK[512])
+    return (sampler_steps * unet + enc + dec + 7.2) * 1e9
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=4)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=4, help="images per GPU (BASELINE config #2: 4)")
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=4, help="images per UNet call and GPU (BASELINE config #2: 4)")
+    ap.add_argument("--global-batch", type=int, default=0, help="images per step over ALL GPUs (0 = batch x GPUs); "
+                    "config #3: 64 on 8 GPUs")
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--sampler-steps", type=int, default=50)
     ap.add_argument("--chars", type=int, default=9)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-mode-table", action="store_true", help="skip the extra passes in the stricter launch modes")
-    ap.add_argument("--in-flight", type=int, default=2, help="launch streams sampling concurrently per GPU (1 = one at a time)")
-    ap.add_argument("--fuse", type=int, default=0, help="batches concatenated into one sampling batch per stream "
-                    "(0 = automatic: the timed steps are spread over the streams, at most 4 per sampling batch)")
+    ap.add_argument("--no-mode-table", action="store_true", help="skip the extra passes in the other launch modes")
+    ap.add_argument("--in-flight", type=int, default=2, help="batches sampled concurrently per GPU, one launch stream each")
+    ap.add_argument("--fuse", type=int, default=1, help="batches concatenated into one UNet call (1 = the on-config "
+                    "batch per call; > 1 or 0 = throughput mode, never the headline value)")
     return ap.parse_args()
 
 
 def measured_traffic():
     """HBM bytes per launch of c3p::conv3p_kernel (the dominant kernel) over one batch of this workload, from the
-    committed rocprofv3 PMC passes (profiles/r01_traffic.json, tools/collect_profiles.sh + tools/pmc_extrapolate.py:
-    FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, separate passes).  Counter collection cannot run inside the
-    timed region, hence the file; None if absent."""
-    path = os.path.join(ROOT, "profiles", "r01_traffic.json")
-    if not os.path.exists(path):
-        return None
-    try:
-        return float(json.load(open(path))["conv3p"]["hbm_bytes_per_launch"])
-    except Exception:
-        return None
+    committed rocprofv3 PMC passes (profiles/rNN_traffic.json, newest round; tools/collect_profiles.sh +
+    tools/pmc_extrapolate.py: FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, separate passes).  Counter collection
+    cannot run inside the timed region, hence the file; None if absent."""
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")), reverse=True):
+        try:
+            return float(json.load(open(path))["conv3p"]["hbm_bytes_per_launch"]), os.path.basename(path)
+        except Exception:
+            continue
+    return None, None
 
 
 def cpu_baseline(model, size: int, chars: int, sampler_steps: int) -> dict:
-    """time the CPU oracle on a bounded sample of the same workload: 2 UNet calls on one CFG pair at the bench
-    resolution + LabelEncoder + 1 VAE encode + 1 VAE decode; extrapolate to sampler_steps UNet calls per image"""
+    """time the CPU oracle on a bounded sample: BASELINE config #1 in full (256x256, 10 steps, 4 characters, batch 1)
+    + for the bench resolution 2 UNet calls on one CFG pair, LabelEncoder, 1 VAE encode, 1 VAE decode, extrapolated to
+    sampler_steps UNet calls per image (every step costs the same)"""
     from oracle import nets, sampling, spec
     from udifftext_amd import synth
     cfg = spec.EngineConfig()
@@ -76,8 +96,10 @@ def cpu_baseline(model, size: int, chars: int, sampler_steps: int) -> dict:
     batch = synth.synthetic_batch(1, size, size, chars, seed=0)
     h = size // 8
     with torch.no_grad():
+        torch.manual_seed(0)
+        t0 = time.time(); sampling.predict(sd, cfg, synth.synthetic_batch(1, 256, 256, 4, seed=0), steps=10, scale=5.0); t_c1 = time.time() - t0
         t0 = time.time(); ctx = nets.label_encoder(sd, batch["label"], cfg.label); t_label = time.time() - t0
-        t0 = time.time(); mom = nets.vae_encode_moments(sd, batch["masked"], cfg.vae, "conditioner.embedders.2.model."); t_enc = time.time() - t0
+        t0 = time.time(); nets.vae_encode_moments(sd, batch["masked"], cfg.vae, "conditioner.embedders.2.model."); t_enc = time.time() - t0
         xin = torch.randn(2, 9, h, h)
         tctx = torch.cat([torch.zeros_like(ctx), ctx])
         ts = torch.tensor([999, 999])
@@ -89,9 +111,11 @@ def cpu_baseline(model, size: int, chars: int, sampler_steps: int) -> dict:
         t0 = time.time(); nets.vae_decode(sd, torch.randn(1, 4, h, h), cfg.vae); t_dec = time.time() - t0
     per_image = sampler_steps * t_unet + t_enc + t_dec + t_label
     return {"value": 1.0 / per_image, "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": f"oracle (fp32 torch CPU): 2 warm UNet calls on one CFG pair @{size}x{size} ({t_unet:.2f} s each), "
-                      f"1 VAE encode ({t_enc:.2f} s), 1 VAE decode ({t_dec:.2f} s), LabelEncoder ({t_label:.2f} s); "
-                      f"extrapolated to {sampler_steps} UNet calls per image"}
+            "config1_full_run_s": t_c1, "config1_images_per_s": 1.0 / t_c1,
+            "sample": f"oracle (fp32 torch CPU): BASELINE config #1 in full (256x256, 10 steps, batch 1: {t_c1:.2f} s); at "
+                      f"{size}x{size}: 2 warm UNet calls on one CFG pair ({t_unet:.2f} s each), 1 VAE encode ({t_enc:.2f} s), "
+                      f"1 VAE decode ({t_dec:.2f} s), LabelEncoder ({t_label:.2f} s); extrapolated to {sampler_steps} UNet "
+                      "calls per image"}
 
 
 def main():
@@ -112,19 +136,19 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     import udifftext_amd  # noqa: F401
-    from udifftext_amd import config as C, lib as L, ops, pipeline, synth
-    from udifftext_amd.parallel import gather_frames
-    import sgm.modules.hipnn as H
+    from udifftext_amd import config as C, lib as L, ops, parallel, pipeline, synth
 
     torch.set_grad_enabled(False)
-    import contextlib
     with contextlib.redirect_stdout(sys.stderr):          # the conditioner announces its embedders like the reference does;
         model = pipeline.build_engine(dev)                # stdout carries the ONE JSON line only
     sampler = pipeline.init_sampling(args.sampler_steps, 5.0, dev)
     cfgs = C.default_runtime_config(steps=args.sampler_steps, batch_size=args.batch, noise_iters=0, gpu=local_rank)
+    G = args.global_batch if args.global_batch > 0 else args.batch * world
+    weak = args.global_batch <= 0
 
-    def make_batch(i):
-        b = synth.synthetic_batch(args.batch, args.size, args.size, args.chars, seed=1000 * rank + i)
+    def make_global_batch(i):
+        # identical on every rank (same seed): each rank slices its shard out of it
+        b = synth.synthetic_batch(G, args.size, args.size, args.chars, seed=1000 + i)
         return {k: (v.to(dev) if isinstance(v, torch.Tensor) else v) for k, v in b.items()}
 
     def barrier():
@@ -133,86 +157,90 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def one_step(batch):
-        samples, _ = pipeline.predict(cfgs, model, sampler, batch, dev)
-        return gather_frames(samples, dist)
+    def run_steps(gbs, seeds, in_flight=None, fuse=None):
+        """K steps = K global batches; every rank samples its shard (micro-batches of --batch images, --in-flight of
+        them concurrently) and joins ONE all-gather of frames per global batch"""
+        return parallel.predict_sharded(cfgs, model, sampler, gbs, seeds, dist=dist, micro_batch=args.batch,
+                                        in_flight=args.in_flight if in_flight is None else in_flight,
+                                        fuse=args.fuse if fuse is None else fuse, device=dev)
 
-    def run_steps(blist, in_flight=None, fuse=None):
-        """K steps = K batches; up to --in-flight of them are sampled concurrently on separate launch streams"""
-        outs = pipeline.predict_many(cfgs, model, sampler, blist, dev, in_flight=args.in_flight if in_flight is None else in_flight,
-                                     fuse=args.fuse if fuse is None else fuse)
-        return [gather_frames(smp, dist) for smp, _ in outs]
-
-    torch.manual_seed(1234 + rank)
-    batches = [make_batch(i) for i in range(args.warmup + args.steps)]
+    n_b = args.warmup + args.steps
+    batches = [make_global_batch(i) for i in range(n_b)]
+    seeds = [77 + i for i in range(n_b)]
+    timed_b, timed_s = batches[args.warmup:], seeds[args.warmup:]
     if args.warmup > 0:
         # untimed: W batches, topped up to the number of timed steps so that the same grouping (full groups in flight
         # plus whatever is left over) has captured its hipGraphs before the clock starts
-        warm = [batches[i % args.warmup] for i in range(max(args.warmup, args.steps))]
-        run_steps(warm)
+        idx = [i % args.warmup for i in range(max(args.warmup, args.steps))]
+        run_steps([batches[i] for i in idx], [seeds[i] for i in idx])
 
     # ---- timed region ------------------------------------------------------------------------------------
     # (the sampling loop replays hipGraphs captured during warm-up, or on the first timed step when --warmup 0)
     barrier()
     t0 = time.perf_counter()
-    frames = None
-    frames = run_steps(batches[args.warmup:args.warmup + args.steps])[-1]
+    frames = run_steps(timed_b, timed_s)[-1]
     barrier()
     elapsed = time.perf_counter() - t0
-
-    # ---- roofline pass: graph replay issues no per-launch host calls, so the per-kernel HIP events (udt_prof_*,
-    # recorded on the launch stream around every 3x3-convolution launch) are taken on ONE extra pass of the same
-    # workload with eager launches, right after the timed region
-    import sgm.modules.diffusionmodules.sampling as S
-    graphs_on = bool(getattr(sampler, "use_graphs", False))
-    sampler.use_graphs = False
-    dual_prev, S.DUAL_STREAM = S.DUAL_STREAM, False     # one launch stream: every kernel is timed alone on the chip
-    H.FLOP_COUNTER = {}
-    ops.prof_reset()
-    ops.prof_enable(1 << L.PROF_CONV3X3)
-    one_step(batches[-1])
-    torch.cuda.synchronize()
-    ops.prof_enable(0)
-    conv_ms, conv_launches = ops.prof_get(L.PROF_CONV3X3)
-    conv_flops = H.FLOP_COUNTER.get("conv3x3", 0.0)
-    conv_bytes = H.FLOP_COUNTER.get("conv3x3_bytes", 0.0)
-    c3p_bytes, c3p_launches = H.FLOP_COUNTER.get("conv3p_bytes", 0.0), H.FLOP_COUNTER.get("conv3p_launches", 0.0)
-    H.FLOP_COUNTER = None
-    sampler.use_graphs = graphs_on
-    S.DUAL_STREAM = dual_prev
-
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if dist is not None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
+    assert frames.shape[0] == G and bool(torch.isfinite(frames).all())
 
-    # ---- the same K steps in the stricter launch modes, for reference next to `value` (same barriers / max over ranks)
+    # ---- roofline pass: graph replay issues no per-launch host calls, so the per-kernel HIP events (udt_prof_*,
+    # recorded on the launch stream around every launch of the three MFMA classes) are taken on ONE extra pass of one
+    # local batch with eager launches on a single stream, right after the timed region
+    import sgm.modules.diffusionmodules.sampling as S
+    graphs_on = bool(getattr(sampler, "use_graphs", False))
+    sampler.use_graphs = False
+    dual_prev, S.DUAL_STREAM = S.DUAL_STREAM, False     # one launch stream: every kernel is timed alone on the chip
+    lo, hi = parallel.shard_range(G, rank, world)
+    local = parallel.slice_batch(batches[-1], lo, min(hi, lo + args.batch))
+    cfg1 = C.default_runtime_config(steps=args.sampler_steps, batch_size=len(local["label"]), noise_iters=0, gpu=local_rank)
+    ops.WORK_COUNTER = {}
+    ops.prof_reset()
+    ops.prof_enable((1 << L.PROF_CONV3X3) | (1 << L.PROF_GEMM) | (1 << L.PROF_ATTN))
+    pipeline.predict(cfg1, model, sampler, local, dev)
+    torch.cuda.synchronize()
+    ops.prof_enable(0)
+    conv_ms, conv_launches = ops.prof_get(L.PROF_CONV3X3)
+    gemm_ms, gemm_launches = ops.prof_get(L.PROF_GEMM)
+    attn_ms, attn_launches = ops.prof_get(L.PROF_ATTN)
+    W = ops.WORK_COUNTER
+    ops.WORK_COUNTER = None
+    sampler.use_graphs = graphs_on
+    S.DUAL_STREAM = dual_prev
+    conv_flops, conv_bytes = W.get("conv3x3", 0.0), W.get("conv3x3_bytes", 0.0)
+    c3p_bytes, c3p_launches = W.get("conv3p_bytes", 0.0), W.get("conv3p_launches", 0.0)
+    gemm_flops = W.get("gemm", 0.0) + W.get("conv1x1", 0.0)
+    gemm_bytes = W.get("gemm_bytes", 0.0) + W.get("conv1x1_bytes", 0.0)
+    attn_flops, attn_bytes = W.get("attn", 0.0), W.get("attn_bytes", 0.0)
+
+    # ---- the same K steps in the other launch modes, for reference next to `value` (same barriers / max over ranks)
     def timed_mode(in_flight, fuse):
-        blist = batches[args.warmup:args.warmup + args.steps]
         if args.warmup > 0:
-            run_steps(blist, in_flight, fuse)                    # captures this mode's hipGraphs
+            run_steps(timed_b, timed_s, in_flight, fuse)         # captures this mode's hipGraphs
         barrier()
         t1 = time.perf_counter()
-        run_steps(blist, in_flight, fuse)
+        run_steps(timed_b, timed_s, in_flight, fuse)
         barrier()
         tt = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev)
         if dist is not None:
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        return args.steps * args.batch * world / float(tt.item())
+        return args.steps * G / float(tt.item())
 
     other_modes = {}
     if not args.no_mode_table:
-        if args.in_flight > 1 or args.fuse != 1:
+        if not (args.in_flight == 1 and args.fuse == 1):
             other_modes["one_batch_at_a_time"] = timed_mode(1, 1)
-        if args.in_flight > 1 and args.fuse != 1:
-            other_modes[f"{args.in_flight}_batches_in_flight_unfused"] = timed_mode(args.in_flight, 1)
-    assert frames.shape[0] == args.batch * world and bool(torch.isfinite(frames).all())
+        if args.fuse == 1 and args.steps * (G // world) // args.batch >= 4:
+            other_modes["throughput_mode_batches_concatenated_per_unet_call (off-config)"] = timed_mode(2, 0)
 
     # per-step UNet time (second half of BASELINE's metric): ONE batch alone on the GPU, one sampler step on its CFG
     # pair, hipGraph replay (eager launches if graphs are off), averaged over 10 steps
     if rank == 0:
         n_meas = 10
-        batch, buc = pipeline.prepare_batch(batches[0], dev)
+        batch, buc = pipeline.prepare_batch(parallel.slice_batch(batches[0], 0, args.batch), dev)
         c, uc = model.conditioner.get_unconditional_conditioning(batch, batch_uc=buc, force_uc_zero_embeddings=["label"])
         sig = sampler._host_sigmas()
         hw = (args.size // 8, args.size // 8)
@@ -241,45 +269,63 @@ def main():
         torch.cuda.synchronize()
         unet_ms = e0.elapsed_time(e1) / n_meas
 
-    fuse_eff = args.fuse if args.fuse > 0 else min(4, max(1, -(-args.steps // max(args.in_flight, 1))))
     if rank == 0:
-        images = args.steps * args.batch * world
+        images = args.steps * G
         value = images / elapsed
-        achieved = conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+        fpi = flop_per_image(args.size, args.sampler_steps)
+        traffic, traffic_file = measured_traffic()
+
+        def cls(name, flops, nbytes, ms, launches):
+            tf = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+            return {"kernel": name, "bound": "mfma", "achieved": tf, "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
+                    "frac": tf / (PEAK_BF16 / 1e12), "launches": launches, "avg_launch_us": ms * 1e3 / max(launches, 1),
+                    "algorithmic_gflop_per_launch": flops / max(launches, 1) / 1e9,
+                    "algorithmic_bytes_per_launch": nbytes / max(launches, 1),
+                    "algorithmic_hbm_gbps": nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0,
+                    "share_of_mfma_class_time": ms / max(conv_ms + gemm_ms + attn_ms, 1e-9)}
+
+        conv = cls("3x3 convolution: c3p::conv3p_kernel (LDS-staged patches, GroupNorm+SiLU applied on the staged patch) + "
+                   "g8::gemm8_kernel<CONV> (stride-2 / upsampling gathers), UNet + VAE", conv_flops, conv_bytes, conv_ms,
+                   conv_launches)
+        conv.update({"traffic": traffic, "traffic_source": traffic_file,
+                     "traffic_hbm_gbps": (traffic / (conv["avg_launch_us"] * 1e-6) / 1e9) if traffic else None,
+                     "traffic_frac_of_hbm_peak": (traffic / (conv["avg_launch_us"] * 1e-6) / PEAK_HBM) if traffic else None,
+                     "traffic_scope": "c3p::conv3p_kernel launches only (%d of the %d launches of the class): algorithmic "
+                                      "%.1f MB per launch" % (int(c3p_launches), conv_launches, c3p_bytes / max(c3p_launches, 1) / 1e6),
+                     "measured_on": "one eager single-stream pass of one local batch right after the timed region: HIP "
+                                    "events around every launch, each kernel alone on the chip (the timed region replays "
+                                    "hipGraphs with batches in flight, where launches of two streams overlap)",
+                     "whole_path_frac_of_peak": value * fpi / (world * PEAK_BF16)})
+        cfg_id = ("BASELINE.json configs[1]" if (args.size, args.batch, args.chars, args.sampler_steps, G) == (512, 4, 9, 50, 4 * world)
+                  else "BASELINE.json configs[2]" if (args.size, args.sampler_steps, G, world) == (512, 50, 64, 8)
+                  else "BASELINE.json configs[3]" if (args.size, args.batch, args.chars, args.sampler_steps) == (768, 8, 12, 50)
+                  else "non-baseline shape")
+        per_rank = G // world
         line = {
             "metric": f"{args.size}x{args.size} {args.sampler_steps}-step denoised images/sec (UDiffText hot path: conditioner + "
                       f"{args.sampler_steps} CFG Euler steps + VAE decode)",
             "value": value, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak" if weak else "strong",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "images_per_s_by_launch_mode": dict(other_modes, **{"throughput_mode (value)": value}),
+            "images_per_s_by_launch_mode": dict(other_modes, **{"value": value}),
             "unet_ms_per_sampler_step": unet_ms,
-            "unet_ms_note": "one batch alone on the whole GPU (latency); with batches in flight the per-batch cost is lower",
-            "config": {"workload": f"{args.size}x{args.size}, {args.sampler_steps} Euler/DDIM(eta 0) steps, CFG 5.0, "
-                                   f"batch {args.batch} per step ({2 * args.batch * fuse_eff} samples per UNet call), {args.chars}-char "
-                                   "labels, noise_iters 0; " + ("BASELINE.json configs[1]" if (args.size, args.batch, args.chars,
-                                   args.sampler_steps) == (512, 4, 9, 50) else "BASELINE.json configs[3]" if (args.size, args.batch,
-                                   args.chars) == (768, 8, 12) else "non-baseline shape"),
-                       "global_batch": args.batch * world, "parallelism": f"dp{world} (images sharded, one all-gather of frames)",
+            "unet_ms_note": f"one batch of {args.batch} alone on the whole GPU (latency of one UNet call on its CFG pair + "
+                            "the fused CFG/Euler update); with batches in flight the per-batch cost is lower",
+            "config": {"workload": f"{args.size}x{args.size}, {args.sampler_steps} Euler/DDIM(eta 0) steps, CFG 5.0, {args.chars}-char "
+                                   f"labels, noise_iters 0; global batch {G} per step sharded over {world} GPU(s) = {per_rank} "
+                                   f"images per GPU in micro-batches of {args.batch}: every UNet call runs ONE batch of "
+                                   f"{args.batch} ({2 * args.batch * max(args.fuse, 1)} samples with CFG); {args.in_flight} such "
+                                   f"batch(es) in flight per GPU on separate launch streams; " + cfg_id,
+                       "global_batch": G, "parallelism": f"dp{world} (images sharded contiguously, per-image seeds, one "
+                                                         "all-gather of frames per global batch)",
                        "weights": "synthetic (name-keyed recipe), 1361.2 M parameters",
-                       "launch": "hipGraph replay of the 50 sampler steps" if graphs_on else "eager kernel launches",
-                       "in_flight": (f"throughput mode of pipeline.predict_many: {fuse_eff} consecutive batches concatenated per "
-                                     f"sampling batch, {args.in_flight} sampling batches concurrently per GPU (one launch stream "
-                                     f"each, planned for 1/{args.in_flight} of the CUs); left-overs run in smaller groups")
-                                    if (args.in_flight > 1 or fuse_eff > 1) else "one batch at a time"},
-            "roofline": {"kernel": "3x3 convolution: c3p::conv3p_kernel (LDS-staged patches) + g8::gemm8_kernel<CONV> "
-                                   "(stride-2 / upsampling gathers), UNet + VAE", "bound": "mfma",
-                         "achieved": achieved, "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s", "frac": achieved / (PEAK_BF16 / 1e12),
-                         "traffic": measured_traffic(), "launches": conv_launches,
-                         "measured_on": "one eager single-stream pass of the same batch right after the timed region: HIP "
-                                        "events around every launch, each kernel alone on the chip (the timed region "
-                                        "replays hipGraphs with batches in flight, where launches of two streams overlap)",
-                         "avg_launch_us": conv_ms * 1e3 / max(conv_launches, 1),
-                         "algorithmic_gflop_per_launch": conv_flops / max(conv_launches, 1) / 1e9,
-                         "algorithmic_bytes_per_launch": conv_bytes / max(conv_launches, 1),
-                         "traffic_scope": "c3p::conv3p_kernel launches only (%d of the %d launches of the class): algorithmic "
-                                          "%.1f MB per launch" % (int(c3p_launches), conv_launches, c3p_bytes / max(c3p_launches, 1) / 1e6),
-                         "whole_path_frac_of_peak": value * FLOP_PER_IMAGE / (world * PEAK_BF16)},
+                       "launch": "hipGraph replay of the sampler steps" if graphs_on else "eager kernel launches",
+                       "in_flight": args.in_flight, "batches_per_unet_call": max(args.fuse, 1) if args.fuse else "auto"},
+            "roofline": conv,
+            "roofline_classes": {
+                "gemm": cls("linears + 1x1 convolutions: g8::gemm8_kernel (plain / GEGLU / transposed epilogues)", gemm_flops,
+                            gemm_bytes, gemm_ms, gemm_launches),
+                "attention": cls("flash self-attention: attn_d64_kernel", attn_flops, attn_bytes, attn_ms, attn_launches)},
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(model, args.size, args.chars, args.sampler_steps)

@@ -5,7 +5,8 @@
 Arithmetic: bf16 storage + MFMA products, fp32 accumulation / statistics / sampler state.  Stated tolerances
 (relative to the tensor's RMS, "rel_rms"; and worst element relative to the max magnitude, "rel_max"):
     single network call (UNet eps, VAE, LabelEncoder) : rel_rms <= 2e-2, rel_max <= 8e-2
-    10 chaotic Euler steps with random weights (latent): rel_rms <= 6e-2
+    10 chaotic Euler steps with random weights (latent): rel_rms <= 6e-2, decoded image <= 4e-2
+    the 50-step schedule (benchmarked step count)       : rel_rms <= 6e-2 / 1e-1 / 1.5e-1 after 10 / 25 / 50 steps
 Measured values are written to gpurun_out/parity_report.txt.
 """
 import json
@@ -175,7 +176,116 @@ def test_ten_step_sampling_vs_reference_golden(engine, cond256, eg, cuda):
     z = sampler(engine, x0.clone(), cond=c, batch=batch, uc=uc)
     _check("10-step latent (config #1) vs reference", z.cpu(), eg["g9_latent"], 6e-2)
     dec = engine.decode_first_stage(z)
-    _check("decoded image of the 10-step latent vs reference", dec[:, :, ::8, ::8].cpu(), eg["g9_decoded_sub"], 1e-1)
+    _check("decoded image of the 10-step latent vs reference", dec[:, :, ::8, ::8].cpu(), eg["g9_decoded_sub"], 4e-2)
+
+
+def test_fifty_step_sampling_vs_reference_golden(engine, cond256, cuda):
+    """the benchmarked step count (configs/test.yaml:20): 50 Euler steps, 256x256, "TEXT", batch 1, CFG 5 against the
+    trajectory of the REAL reference (tests/golden/engine_golden_50.npz, make_golden.py --g11).  With random weights the
+    denoiser is chaotic, so the stated tolerance grows with the horizon: rel_rms <= 6e-2 after 10 steps (as G9),
+    1e-1 after 25, 1.5e-1 after 50 (the sigma schedule contracts errors late in the trajectory)."""
+    from udifftext_amd import config as C, pipeline
+    g11 = np.load(os.path.join(GOLD, "engine_golden_50.npz"))
+    batch, c, uc = cond256
+    cfgs = C.default_runtime_config(steps=50, batch_size=1, noise_iters=0)
+    for horizon, tol in ((10, 6e-2), (25, 1e-1), (50, 1.5e-1)):
+        sampler = pipeline.init_sampling(50, 5.0, cuda)
+        torch.manual_seed(4242)
+        x0 = sampler.get_init_noise(cfgs, engine, cond=c, batch=batch, uc=uc)
+        np.testing.assert_array_equal(x0.cpu().numpy(), g11["g11_x0"])
+        if horizon == 50:
+            z = sampler(engine, x0.clone(), cond=c, batch=batch, uc=uc)
+        else:                                   # the first `horizon` steps of the 50-step schedule, eager launches
+            from sgm.modules.diffusionmodules.sampling import _Stepper
+            sig = sampler._host_sigmas()
+            z = x0.clone().float() * (1.0 + sig[0] ** 2.0) ** 0.5
+            st = _Stepper(engine, c, uc, 1, z.shape[2:], 5.0)
+            for i in range(horizon):
+                st.step(z, sig[i], sig[i + 1])
+            st.check()
+        _check(f"50-step schedule, latent after {horizon} steps vs reference", z.cpu(), g11[f"g11_latent_{horizon}"], tol)
+    dec = engine.decode_first_stage(z)
+    _check("decoded image of the 50-step latent vs reference", dec[:, :, ::8, ::8].cpu(), g11["g11_decoded_sub"], 1.5e-1)
+
+
+def test_unet_call_at_benchmarked_shape_vs_oracle(engine, cuda):
+    """BASELINE config #2's UNet call: 64x64 latents, batch 4 -> 8 samples (uc half first, zero text context), the
+    tile / stream-K plans of the benchmarked shape — against the fp32 CPU oracle on the same weights.  The oracle
+    evaluates 2 + 2 of the 8 samples (samples are independent: per-sample GroupNorm / LayerNorm / attention)."""
+    from oracle import nets, spec
+    from udifftext_amd import synth
+    torch.manual_seed(31)
+    B = 4
+    le = engine.conditioner.embedders[0]
+    ctx = le(synth.synthetic_batch(B, 512, 512, 9, seed=6)["label"])
+    tctx = torch.cat([torch.zeros_like(ctx), ctx])
+    x = torch.randn((2 * B, 9, 64, 64), device=cuda)
+    ts = torch.full((2 * B,), 441, device=cuda)
+    eps = engine.model.diffusion_model(x, timesteps=ts, t_context=tctx)
+    assert eps.shape == (2 * B, 4, 64, 64)
+    pick = [0, 3, 4, 7]
+    sd = {k: v.detach().float().cpu() for k, v in engine.state_dict().items() if k.startswith("model.")}
+    with torch.no_grad():
+        ref = nets.unet_forward(sd, x[pick].cpu(), ts[pick].cpu(), tctx[pick].float().cpu(), spec.EngineConfig().unet)
+    _check("UNet eps at 64x64 latents, 8 samples (config #2 call) vs oracle", eps[pick].cpu(), ref, 2e-2, 8e-2)
+
+
+def test_unet_call_in_flight_shape_vs_oracle(engine, cuda):
+    """the throughput-mode call: 32 samples per UNet call (4 batches of 4 concatenated), planned for half of the CUs
+    (cu_share 2) on a side stream with its own workspace WHILE a second stream runs another call — exactly how
+    EulerEDMSampler.sample_in_flight launches it — against the oracle on 4 of the 32 samples"""
+    from oracle import nets, spec
+    from udifftext_amd import ops, packing, synth
+    torch.manual_seed(32)
+    unet = engine.model.diffusion_model
+    n = 16
+    le = engine.conditioner.embedders[0]
+    labels = [synth.synthetic_label(9, i) for i in range(n)]
+    ctx = le(labels)
+    tctx = torch.cat([torch.zeros_like(ctx), ctx])
+    x = torch.randn((2 * n, 9, 64, 64), device=cuda)
+    ts = torch.full((2 * n,), 701.0, device=cuda)
+    xin = ops.nchw_to_nhwc(x.float().contiguous(), packing.KPAD)
+    emb = unet.time_embedding_rows(ts)
+    t_kv = unet.project_context(tctx)
+    s1, s2 = torch.cuda.Stream(device=cuda), torch.cuda.Stream(device=cuda)
+    w1, w2 = ops.Workspace(cuda), ops.Workspace(cuda)
+    torch.cuda.synchronize()
+    with torch.cuda.stream(s2), ops.launch_context(cu_share=2, workspace=w2):
+        other = unet.forward_nhwc(xin.flip(0).contiguous(), emb, t_kv, zero_ctx_rows=0)
+    with torch.cuda.stream(s1), ops.launch_context(cu_share=2, workspace=w1):
+        eps = unet.forward_nhwc(xin, emb, t_kv, zero_ctx_rows=n)
+    torch.cuda.synchronize()
+    w1.check(); w2.check()
+    assert torch.isfinite(other).all()
+    got = ops.nhwc_to_nchw(eps, 4)
+    pick = [0, 15, 16, 31]
+    sd = {k: v.detach().float().cpu() for k, v in engine.state_dict().items() if k.startswith("model.")}
+    with torch.no_grad():
+        ref = nets.unet_forward(sd, x[pick].cpu(), ts[pick].long().cpu(), tctx[pick].float().cpu(), spec.EngineConfig().unet)
+    _check("UNet eps, 32 samples per call under cu_share 2 on two streams vs oracle", got[pick].cpu(), ref, 2e-2, 8e-2)
+
+
+def test_vae_at_512_vs_oracle(engine, cuda):
+    """the benchmarked VAE shapes: encode of one 512x512 image (moments) and decode of one 64x64 latent (N = 4096
+    single-head attention, 512x512x128 convolutions) against the oracle"""
+    from oracle import nets, spec
+    from udifftext_amd import ops, synth
+    cfg = spec.EngineConfig()
+    batch = synth.synthetic_batch(1, 512, 512, 9, seed=8)
+    fs = engine.first_stage_model
+    mom = ops.nhwc_to_nchw(fs.encode_moments(batch["masked"].to(cuda)), 8)
+    sd = {k: v.detach().float().cpu() for k, v in engine.state_dict().items() if k.startswith("first_stage_model.")}
+    with torch.no_grad():
+        ref_m = nets.vae_encode_moments(sd, batch["masked"], cfg.vae)
+    _check("VAE encoder moments at 512x512 vs oracle", mom.cpu(), ref_m, 2e-2, 8e-2)
+    g = torch.Generator().manual_seed(9)
+    z = torch.randn((1, 4, 64, 64), generator=g) * 3.0
+    dec = fs.decode(z.to(cuda))
+    with torch.no_grad():
+        ref_d = nets.vae_decode(sd, z, cfg.vae)
+    assert dec.shape == (1, 3, 512, 512)
+    _check("VAE decoder 64x64 -> 512x512 vs oracle", dec.cpu(), ref_d, 2e-2, 8e-2)
 
 
 def test_graph_replay_matches_eager_launches(engine, cond256, cuda):

@@ -94,6 +94,16 @@ def check_async_errors() -> None:
         ws.check(stream)
 
 
+# optional algorithmic work accounting for bench.py's roofline objects: {"gemm": flops, "gemm_bytes": bytes, "attn": ...}
+# (2*M*N*K per GEMM launch, 4*B*H*Nq*Nk*D per flash-attention launch; operands + result once for the bytes)
+WORK_COUNTER: Optional[dict] = None
+
+
+def count_work(kind: str, amount: float) -> None:
+    if WORK_COUNTER is not None:
+        WORK_COUNTER[kind] = WORK_COUNTER.get(kind, 0.0) + amount
+
+
 def _bf16(t: torch.Tensor) -> None:
     if t.dtype != torch.bfloat16:
         raise ValueError(f"expected bf16 tensor, got {t.dtype}")
@@ -145,6 +155,11 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
                   rows_per_batch=rows_per_batch, ld_rowvec=(rowvec.stride(0) if rowvec is not None else 0), flags=flags,
                   alpha=alpha)
     run_gemm(d, x.device)
+    if WORK_COUNTER is not None:
+        count_work("gemm", 2.0 * M * N * K)
+        count_work("gemm_bytes", 2.0 * (M * K + N * K) + out.numel() * out.element_size()
+                   + (2.0 * M * n_cols if residual is not None else 0.0))
+        count_work("gemm_launches", 1.0)
     return out
 
 
@@ -160,6 +175,10 @@ def bmm_nt(a: torch.Tensor, w: torch.Tensor, *, out: Optional[torch.Tensor] = No
                   ldo=out.stride(1), batch=B, stride_a=a.stride(0), stride_w=w.stride(0), stride_out=out.stride(0),
                   alpha=alpha)
     run_gemm(d, a.device)
+    if WORK_COUNTER is not None:
+        count_work("gemm", 2.0 * B * M * N * K)
+        count_work("gemm_bytes", 2.0 * B * (M * K + N * K + M * N))
+        count_work("gemm_launches", 1.0)
     return out
 
 
@@ -216,6 +235,10 @@ def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, heads: int, sc
                                   q.stride(1), k.stride(1), vt.stride(1), out.stride(1),
                                   q.stride(0), k.stride(0), vt.stride(0), out.stride(0), scale, _stream()),
             "udt_attn_fwd")
+    if WORK_COUNTER is not None:
+        count_work("attn", 4.0 * B * heads * Nq * Nk * 64)
+        count_work("attn_bytes", 2.0 * B * heads * 64 * (2 * Nq + 2 * Nk))
+        count_work("attn_launches", 1.0)
     return out
 
 

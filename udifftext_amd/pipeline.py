@@ -6,6 +6,7 @@ The reference's own ``test.py`` needs datasets, checkpoints and packages that do
 """
 from __future__ import annotations
 
+import contextlib
 import time
 from typing import Optional, Tuple
 
@@ -13,7 +14,7 @@ import torch
 
 import udifftext_amd  # noqa: F401  (puts the sgm mirror on sys.path)
 from udifftext_amd import config as C
-from udifftext_amd import synth
+from udifftext_amd import rng, synth
 
 
 def build_engine(device: torch.device, synthetic_weights: bool = True, verbose: bool = False):
@@ -101,12 +102,13 @@ def _cat_cond(conds):
 
 
 def predict_many(cfgs, model, sampler, batches, device: Optional[torch.device] = None, in_flight: Optional[int] = None,
-                 fuse: Optional[int] = None):
+                 fuse: Optional[int] = None, image_seeds: Optional[list] = None):
     """``predict`` over a list of batches in throughput mode: ``fuse`` consecutive batches are concatenated into one
     sampling batch, and up to ``in_flight`` such batches are sampled concurrently on separate launch streams
     (EulerEDMSampler.sample_in_flight).  Conditioning and noise draws stay per input batch, in the order and from the
-    CPU generator that calling ``predict`` batch by batch would use; decoding runs on the fused batch.  Returns
-    [(samples, z), ...] in input order."""
+    CPU generator that calling ``predict`` batch by batch would use; decoding runs on the fused batch.
+    ``image_seeds[k]`` (optional): one seed per image of batch k — its draws then come from per-image generators
+    (``rng.per_image``), independent of batching and sharding.  Returns [(samples, z), ...] in input order."""
     device = device or next(model.parameters()).device
     n = max(1, int(in_flight if in_flight is not None else IN_FLIGHT))
     f = int(fuse if fuse is not None else FUSE)
@@ -118,11 +120,13 @@ def predict_many(cfgs, model, sampler, batches, device: Optional[torch.device] =
     for k in range(0, len(batches), n * f):
         group = batches[k:k + n * f]
         xs, cs, ucs, sizes = [], [], [], []
-        for b in group:
+        for gi, b in enumerate(group):
             b, buc = prepare_batch(b, device)
-            c, uc = model.conditioner.get_unconditional_conditioning(
-                b, batch_uc=buc, force_uc_zero_embeddings=cfgs.force_uc_zero_embeddings)
-            xs.append(sampler.get_init_noise(cfgs, model, cond=c, batch=b, uc=uc))
+            seeds = image_seeds[k + gi] if image_seeds is not None else None
+            with (rng.per_image(seeds) if seeds is not None else contextlib.nullcontext()):
+                c, uc = model.conditioner.get_unconditional_conditioning(
+                    b, batch_uc=buc, force_uc_zero_embeddings=cfgs.force_uc_zero_embeddings)
+                xs.append(sampler.get_init_noise(cfgs, model, cond=c, batch=b, uc=uc))
             cs.append(c)
             ucs.append(uc)
             sizes.append(xs[-1].shape[0])

@@ -21,7 +21,7 @@ from typing import Dict, Union
 import numpy as np
 import torch
 
-from udifftext_amd import ops, packing
+from udifftext_amd import ops, packing, rng
 
 from ...util import default, instantiate_from_config, require_gpu
 from .guiders import VanillaCFG
@@ -282,7 +282,7 @@ class EulerEDMSampler(EDMSampler):
         H, W = batch["target_size_as_tuple"][0]
         shape = (cfgs.batch_size, cfgs.channel, int(H) // cfgs.factor, int(W) // cfgs.factor)
         dev = cond["concat"].device
-        randn = torch.randn(shape).to(dev)
+        randn = rng.randn(shape).to(dev)
         if cfgs.noise_iters <= 0:
             return randn
         stepper = _Stepper(model, cond, default(uc, cond), shape[0], shape[2:], self.guider.scale)
@@ -298,7 +298,7 @@ class EulerEDMSampler(EDMSampler):
                 ll = model.loss_fn.get_min_local_loss(stepper.unet.attn_map_cache, mask, seg)
             cands.append(randn)
             scores.append(ll[ll.shape[0] // 2:])
-            randn = torch.randn(shape).to(dev)
+            randn = rng.randn(shape).to(dev)
         stepper.unet.clear_attn_map()
         stepper.check()
         score = torch.stack(scores, 0)                                   # [iters, B]

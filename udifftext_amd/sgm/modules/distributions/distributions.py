@@ -1,11 +1,11 @@
 """Diagonal Gaussian posterior of the KL autoencoder (reference sgm/modules/distributions/distributions.py:24-41).
 
 ``sample()`` keeps the reference's RNG contract: the noise is drawn with ``torch.randn`` on the CPU default
-generator and moved to the device; the arithmetic runs in the HIP kernel ``udt_posterior_sample``.
+generator (``udifftext_amd.rng.randn``; per-image generators under sharded sampling) and moved to the device; the arithmetic runs in the HIP kernel ``udt_posterior_sample``.
 """
 import torch
 
-from udifftext_amd import ops
+from udifftext_amd import ops, rng
 
 
 class DiagonalGaussianDistribution(object):
@@ -20,7 +20,7 @@ class DiagonalGaussianDistribution(object):
 
     def sample(self, scale: float = 1.0) -> torch.Tensor:
         B, h, w, _ = self.parameters.shape
-        noise = torch.randn((B, 4, h, w)).to(device=self.parameters.device)
+        noise = rng.randn((B, 4, h, w)).to(device=self.parameters.device)
         if self.deterministic:
             noise = torch.zeros_like(noise)
         return ops.posterior_sample(self.parameters, noise, scale)

@@ -19,13 +19,9 @@ from udifftext_amd import ops, packing
 from ..util import init_skipped
 
 
-# optional algorithmic-FLOP accounting (bench.py's roofline object): {"conv3x3": flops, "conv1x1": ..., "linear": ...}
-FLOP_COUNTER = None
-
-
 def count_flops(kind: str, flops: float) -> None:
-    if FLOP_COUNTER is not None:
-        FLOP_COUNTER[kind] = FLOP_COUNTER.get(kind, 0.0) + flops
+    """algorithmic-work accounting for bench.py's roofline objects (ops.WORK_COUNTER)"""
+    ops.count_work(kind, flops)
 
 
 def _init_uniform_(p: torch.Tensor, fan_in: int) -> None:
@@ -104,7 +100,7 @@ class Conv2d(_Packed):
             pad = (self.padding, self.padding)
         out = ops.conv2d(x, w, b, ksize=self.kernel_size, stride=self.stride, pad=pad, upsample=upsample, x2=x2,
                          out_hw=out_hw, residual=residual, rowvec=rowvec, flags=flags, n_out=w.shape[0])
-        if FLOP_COUNTER is not None:   # algorithmic (un-padded) multiply-adds x 2
+        if ops.WORK_COUNTER is not None:   # algorithmic (un-padded) multiply-adds x 2
             k = self.kernel_size
             kind = "conv3x3" if k == 3 else "conv1x1"
             npix_out = out.shape[0] * out.shape[1] * out.shape[2]
