@@ -102,6 +102,15 @@ typedef struct {
   int32_t ld_rowvec;    /* elements between rows of rowvec (0 = N)                                 */
   int32_t flags;
   float alpha;          /* acc * alpha before bias (softmax scale for QK^T GEMMs); 1.0 default    */
+  /* fused GroupNorm (north star: "3x3 conv + GroupNorm + SiLU fused blocks"; reference chain
+     openaimodel.py:183-187,218-231, util.py:258-275, model.py:128-148)                                             */
+  const float* in_scsh; /* 3x3 / stride 1 / pad 1 convolutions only (see udt_gn_silu_conv3x3_fwd): per-(sample,
+                           channel) scale / shift from udt_gn_finalize, applied — with in_act — to the input patch
+                           as it is staged in LDS: y = act(x * scale + shift); zero padding stays zero.  NULL = off */
+  int32_t in_act;       /* 0 none, 1 SiLU                                                                          */
+  float* colstats;      /* optional output: per-(row slot, output column) partial (sum, sum of squares) of the
+                           result, fp32 [udt_gemm_colstats_slots][N][2]: the GroupNorm statistics of the NEXT
+                           layer come out of this layer's epilogue.  NULL = off                                   */
   int32_t cu_share;     /* number of launch streams that share the device with this call (0 / 1: none).
                            The persistent stream-K kernels wait on partner workgroups, so all their
                            workgroups must be resident: the launch is planned for 1/cu_share of the CUs.
@@ -113,6 +122,19 @@ typedef struct {
  * every successful launch) and give concurrent streams separate workspaces. */
 size_t udt_gemm_workspace_bytes(const udt_gemm_desc* d);
 int udt_gemm(const udt_gemm_desc* d, void* workspace, size_t workspace_bytes, void* stream);
+/* Column-statistics geometry of udt_gemm for this problem: rows of the output covered by one slot of `colstats`
+ * (32 or 64; slot s covers rows [s*rows, (s+1)*rows) of M for plain GEMMs / gathered convolutions and the same number of
+ * pixels of ONE image in tile order for the patch-staged convolution — either way the slots of a sample are contiguous:
+ * slots_per_sample = rows_per_batch / rows) and the number of slots.  0 = this problem cannot emit them (transposed /
+ * GEGLU / fp32 outputs, first-generation kernel, rows_per_batch not a multiple of the slot). */
+int32_t udt_gemm_colstats_rows(const udt_gemm_desc* d);
+int32_t udt_gemm_colstats_slots(const udt_gemm_desc* d);
+/* 1 if udt_gemm accepts `in_scsh` for this problem (patch-staged 3x3 convolution geometry; one or two NHWC sources). */
+int32_t udt_gemm_in_scsh_ok(const udt_gemm_desc* d);
+/* The north star's fused block under its own name: GroupNorm(+SiLU) applied on the staged input patch -> 3x3 conv ->
+ * epilogue (bias, time-embedding row vector, residual) -> optional statistics of the output.  Same as udt_gemm with a
+ * descriptor that has UDT_GEMM_CONV, ksize 3, stride 1, pad 1 and in_scsh set; anything else is UDT_ERR_BAD_ARG. */
+int udt_gn_silu_conv3x3_fwd(const udt_gemm_desc* d, void* workspace, size_t workspace_bytes, void* stream);
 /* Synchronises `stream` and reports (UDT_ERR_ASYNC) whether any udt_gemm launch that used `workspace` gave up waiting
  * for a partner workgroup since the last check; in that case the header is re-zeroed so the workspace stays usable.
  * Callers check at their natural sync points (the sampler: once per sampling loop). */
@@ -157,6 +179,16 @@ int udt_gn_stats(const void* x, const void* x2, float* partials, int32_t B, int6
 int udt_gn_apply(const void* x, const void* x2, void* y, const float* partials, const float* gamma,
                  const float* beta, int32_t B, int64_t HW, int32_t C, int32_t C2, int32_t G, float eps, int32_t act,
                  void* stream);
+/* GroupNorm statistics from producer epilogues -> per-(sample, channel) scale / shift for udt_gemm's in_scsh.
+ *   stats1 fp32 [B * slots1][C1][2] (+ optional stats2 [B * slots2][C2][2] for a channel concat x ‖ x2): the colstats of
+ *   the layer(s) that produced the input; slotsN = slots per sample.  Groups run over the C1 + C2 concatenated channels.
+ *   scsh out fp32 [B][(C1+C2)/64][2][64]: chunk-blocked (scale of 64 channels, then their shift) — the layout the
+ *   convolution's LDS-DMA reads.  scale = rstd * gamma, shift = beta - mean * scale; fp32 partials, fp64 combine.
+ *   (C1 + C2) % 64 == 0, (C1 + C2) % G == 0. */
+int udt_gn_finalize(const float* stats1, int32_t slots1, int32_t C1, const float* stats2, int32_t slots2, int32_t C2,
+                    const float* gamma, const float* beta, float* scsh, int32_t B, int64_t HW, int32_t G, float eps,
+                    void* stream);
+
 /* LayerNorm over the last dim of bf16 [rows, C] (C % 8 == 0, C <= 4096). */
 int udt_layernorm(const void* x, void* y, const float* gamma, const float* beta,
                   int64_t rows, int32_t C, float eps, void* stream);

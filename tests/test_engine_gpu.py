@@ -6,7 +6,7 @@ Arithmetic: bf16 storage + MFMA products, fp32 accumulation / statistics / sampl
 (relative to the tensor's RMS, "rel_rms"; and worst element relative to the max magnitude, "rel_max"):
     single network call (UNet eps, VAE, LabelEncoder) : rel_rms <= 2e-2, rel_max <= 8e-2
     10 chaotic Euler steps with random weights (latent): rel_rms <= 6e-2, decoded image <= 4e-2
-    the 50-step schedule (benchmarked step count)       : rel_rms <= 6e-2 / 1e-1 / 1.5e-1 after 10 / 25 / 50 steps
+    the 50-step schedule (benchmarked step count)       : rel_rms <= 3e-2 after 10 / 25 / 50 steps, decoded image <= 4e-2
 Measured values are written to gpurun_out/parity_report.txt.
 """
 import json
@@ -182,13 +182,13 @@ def test_ten_step_sampling_vs_reference_golden(engine, cond256, eg, cuda):
 def test_fifty_step_sampling_vs_reference_golden(engine, cond256, cuda):
     """the benchmarked step count (configs/test.yaml:20): 50 Euler steps, 256x256, "TEXT", batch 1, CFG 5 against the
     trajectory of the REAL reference (tests/golden/engine_golden_50.npz, make_golden.py --g11).  With random weights the
-    denoiser is chaotic, so the stated tolerance grows with the horizon: rel_rms <= 6e-2 after 10 steps (as G9),
-    1e-1 after 25, 1.5e-1 after 50 (the sigma schedule contracts errors late in the trajectory)."""
+    stated tolerance is rel_rms <= 3e-2 at every horizon (10 / 25 / 50 steps; measured on MI355X: 1.0e-2 at all three —
+    the error does not grow along the trajectory) and <= 4e-2 for the decoded image (measured 1.8e-2)."""
     from udifftext_amd import config as C, pipeline
     g11 = np.load(os.path.join(GOLD, "engine_golden_50.npz"))
     batch, c, uc = cond256
     cfgs = C.default_runtime_config(steps=50, batch_size=1, noise_iters=0)
-    for horizon, tol in ((10, 6e-2), (25, 1e-1), (50, 1.5e-1)):
+    for horizon, tol in ((10, 3e-2), (25, 3e-2), (50, 3e-2)):
         sampler = pipeline.init_sampling(50, 5.0, cuda)
         torch.manual_seed(4242)
         x0 = sampler.get_init_noise(cfgs, engine, cond=c, batch=batch, uc=uc)
@@ -205,7 +205,7 @@ def test_fifty_step_sampling_vs_reference_golden(engine, cond256, cuda):
             st.check()
         _check(f"50-step schedule, latent after {horizon} steps vs reference", z.cpu(), g11[f"g11_latent_{horizon}"], tol)
     dec = engine.decode_first_stage(z)
-    _check("decoded image of the 50-step latent vs reference", dec[:, :, ::8, ::8].cpu(), g11["g11_decoded_sub"], 1.5e-1)
+    _check("decoded image of the 50-step latent vs reference", dec[:, :, ::8, ::8].cpu(), g11["g11_decoded_sub"], 4e-2)
 
 
 def test_unet_call_at_benchmarked_shape_vs_oracle(engine, cuda):

@@ -76,6 +76,38 @@ UDT_DEVINL f32x16 mfma32(bf16x8_t a, bf16x8_t b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
 
+// ---- per-column partial sums of a wave's output block -----------------------------------------------------------
+// Reduce-scatter over lane bits: every lane of a wave holds N values v[0..N) (the same N logical columns in every
+// lane, different rows); after the call lane L holds, in v[0..N >> popcount(halved bits)), the sums over the lanes that
+// differ from L in the bits of MASK.  Each step exchanges HALF of the live values with the partner lane (lane ^ bit)
+// and keeps the other half: N-1 shuffles instead of N * log2(lanes).  Step order: highest bit first; a lane whose bit
+// is set keeps the UPPER half.  So after halving over bits b1 > b2 > ... the value k of lane L is the column
+//   (L&b1 ? N/2 : 0) + (L&b2 ? N/4 : 0) + ... + k.
+// When the live count becomes odd the remaining bits are plain butterfly adds (all partner lanes hold the sum).
+template <int N, int BIT, int LOWEST>
+UDT_DEVINL void lane_reduce_scatter(float (&v)[N], int lane) {
+  if constexpr (BIT >= LOWEST) {
+    if constexpr (N % 2 == 0) {
+      constexpr int H = N / 2;
+      const bool up = (lane & BIT) != 0;
+      float keep[H];
+#pragma unroll
+      for (int j = 0; j < H; ++j) {
+        const float mine = up ? v[j + H] : v[j];
+        const float send = up ? v[j] : v[j + H];
+        keep[j] = mine + __shfl_xor(send, BIT);
+      }
+      lane_reduce_scatter<H, BIT / 2, LOWEST>(keep, lane);
+#pragma unroll
+      for (int j = 0; j < H; ++j) v[j] = keep[j];
+    } else {
+#pragma unroll
+      for (int j = 0; j < N; ++j) v[j] += __shfl_xor(v[j], BIT);
+      lane_reduce_scatter<N, BIT / 2, LOWEST>(v, lane);
+    }
+  }
+}
+
 // ---- host-side helpers -------------------------------------------------------------------------
 int udt_set_hip_error(hipError_t e);   // records e, returns UDT_ERR_HIP (or UDT_OK when e == success)
 const uint16_t* udt_zero_page();       // >= 4 KiB of zeroed memory on the current device (lazily allocated once per device)

@@ -20,15 +20,18 @@ using g8::NTHREADS;
 using g8::Params;
 using g8::raw_barrier;
 
-constexpr int PATCH_ROWS = 400;                    // max pixel rows of a staged patch (4 x 10 x 10)
-constexpr int PATCH_BYTES = PATCH_ROWS * ROW_BYTES;
-constexpr int MAX_PATCH_PIECES = PATCH_ROWS / 8;   // 50 pieces of 8 rows -> at most 7 per wave
+// max pixel rows of a staged patch: 400 (4 x 10 x 10, the four-image 8x8 tile) with 128-channel weight tiles; the
+// 160-channel configuration (N = 320) has 20 KiB weight stages, so its patches are capped at 344 rows (34 x 10 and
+// 18 x 18 tiles) to leave room for the GroupNorm scale/shift stage
+constexpr int patch_rows(int TN) { return TN == 5 ? 344 : 400; }
+constexpr int SCSH_BYTES = 2 * 4 * 512;            // [2 chunks in flight][<= 4 images][64 scale | 64 shift] fp32
 
 struct Geo {            // spatial tiling of the output (= input) map
   int TW, TH, NI;       // tile width / height in pixels, images per tile (TW*TH*NI == 256)
   int tiles_x, tiles_y; // tiles per image row / column
   int img_groups;       // ceil(B / NI)
-  int B, H, W, C;
+  int B, H, W, C;       // C = C1 + C2: channels of the (virtually concatenated) input
+  int C1, C2;           // channels of source 1 / source 2 (0: one source); both multiples of 64
   int prow_w;           // TW + 2
   int prows_img;        // (TH + 2) * (TW + 2)
   int n_pieces;         // ceil(NI * prows_img / 8)
@@ -36,8 +39,10 @@ struct Geo {            // spatial tiling of the output (= input) map
 };
 
 struct CParams {
-  Params base;              // base.a_bytes / base.w_bytes: buffer-descriptor extents
+  Params base;              // base.a_bytes / base.w_bytes: buffer-descriptor extents (source 1, weights)
   Geo geo;
+  unsigned a2_bytes;        // extent of source 2
+  unsigned scsh_bytes;      // extent of the GroupNorm scale/shift table [B][chunks][2][64] fp32
 };
 
 UDT_DEVINL void wait_vmcnt_dyn(int n) {          // n is wave-uniform
@@ -57,19 +62,25 @@ UDT_DEVINL void wait_vmcnt_dyn(int n) {          // n is wave-uniform
   }
 }
 
-// epilogue with an explicit output-row table: mrow[tm] = global NHWC pixel index of this lane's row, or -1
+// epilogue with an explicit output-row table: mrow[tm] = global NHWC pixel index of this lane's row, or -1.
+// `stats` (optional): this wave block's row of the column statistics, fp32 [N][2], offset to the wave's first column
 template <int TM, int TN>
 UDT_DEVINL void epilogue_rows(const GemmParams& p, f32x16 (&acc)[TM][TN], const long long (&mrow)[TM], int n0, int col0,
-                              int lane) {
+                              int lane, float* stats) {
   const int hi = lane >> 5;
   const int flags = p.flags;
+  int bidx[TM];
 #pragma unroll
-  for (int tm = 0; tm < TM; ++tm) {
-    const long long m = mrow[tm];
-    if (m < 0) continue;
-    const int b = (p.rowvec != nullptr) ? (int)(m / p.rows_per_batch) : 0;
+  for (int tm = 0; tm < TM; ++tm) bidx[tm] = (p.rowvec != nullptr && mrow[tm] >= 0) ? (int)(mrow[tm] / p.rows_per_batch) : 0;
 #pragma unroll
-    for (int tn = 0; tn < TN; ++tn)
+  for (int tn = 0; tn < TN; ++tn) {
+    float cs[16], cq[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) cs[j] = cq[j] = 0.f;
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+      const long long m = mrow[tm];
+      if (m < 0) continue;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int n = n0 + col0 + tn * 32 + q * 8 + hi * 4;
@@ -83,7 +94,7 @@ UDT_DEVINL void epilogue_rows(const GemmParams& p, f32x16 (&acc)[TM][TN], const 
             for (int r = 0; r < 4; ++r) v[r] += bv[r];
           }
           if (p.rowvec) {
-            const f32x4 rv = *reinterpret_cast<const f32x4*>(p.rowvec + (long long)b * p.ldrv + n);
+            const f32x4 rv = *reinterpret_cast<const f32x4*>(p.rowvec + (long long)bidx[tm] * p.ldrv + n);
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] += rv[r];
           }
@@ -108,32 +119,54 @@ UDT_DEVINL void epilogue_rows(const GemmParams& p, f32x16 (&acc)[TM][TN], const 
           } else {
             u32x2 pk = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
             *reinterpret_cast<u32x2*>(reinterpret_cast<uint16_t*>(p.out) + m * p.ldo + n) = pk;
+            if (stats) {                 // statistics of the values as stored (bf16-rounded), like the row epilogues
+#pragma unroll
+              for (int r = 0; r < 2; ++r) {
+                const float lo = bf16_lo(pk[r]), hh = bf16_hi(pk[r]);
+                cs[q * 4 + 2 * r] += lo; cq[q * 4 + 2 * r] += lo * lo;
+                cs[q * 4 + 2 * r + 1] += hh; cq[q * 4 + 2 * r + 1] += hh * hh;
+              }
+            }
           }
         }
       }
+    }
+    if (stats) g8::colstat_emit_acc(cs, cq, lane, stats + tn * 64, p.N - (n0 + col0 + tn * 32));
   }
 }
 
 using g8::wait_vm;
 using g8::buf_lds16;
 using g8::OOB;
-constexpr int PP = 7;                      // patch pieces per wave and chunk (padded with duplicate pieces)
-
 // WGM x WGN waves, each TM x TN MFMA tiles of 32x32; BM = 256 output pixels.
 // The stream-K iteration unit is one 64-channel CHUNK (= 9 K-tiles, one per tap): ranges never cut a chunk, so the tap
 // loop is fully unrolled — stage indices, tap offsets and every s_waitcnt immediate are compile-time constants, and the
 // per-K-tile address work is one scalar offset per load (buffer descriptors: uniform base + per-lane voffset fixed for
 // the whole tile + scalar soffset per K-tile; out-of-image halo pixels use an out-of-range voffset and read zeros).
-template <int WGM, int WGN, int TM, int TN>
+//
+// The input may be the channel concatenation of TWO NHWC sources (the UNet's skip concat, openaimodel.py:620): a chunk
+// lies in exactly one of them (C1 % 64 == 0), so only the descriptor and the pixel stride change per chunk.
+//
+// GN = true: GroupNorm (+ SiLU) of the input is applied ON THE STAGED PATCH (reference chain GroupNorm32 -> SiLU ->
+// conv, openaimodel.py:183-187,218-231): the per-(sample, channel) scale / shift of the chunk (udt_gn_finalize, from the
+// producers' epilogue statistics) arrives by one more LDS-DMA next to the patch, and every wave rewrites the pieces IT
+// staged — in-image rows only, the zero padding stays zero — as y = act(x * scale + shift) in fp32, rounded to bf16
+// once.  The patch of chunk c+1 lands during taps 0..2 of chunk c; its pieces are transformed one per tap behind the
+// MFMAs of taps 3..8 (VALU beside the other wave's matrix work), so only the first chunk of a segment pays for it.
+template <int WGM, int WGN, int TM, int TN, bool GN>
 __global__ void __launch_bounds__(NTHREADS) conv3p_kernel(const CParams cp) {
   static_assert(WGM * WGN == 8 && WGM * TM * 32 == 256, "8 waves, 256 output pixels");
   constexpr int BN = WGN * TN * 32;
   constexpr int W_BYTES = BN * ROW_BYTES;
   constexpr int W_PIECES = BN / 8;                  // 16 or 20
   constexpr int NWP = (W_PIECES + 7) / 8;           // weight pieces per wave and K-tile (2 or 3, padded with duplicates)
+  constexpr int PATCH_BYTES = patch_rows(TN) * ROW_BYTES;
+  constexpr int PP = (patch_rows(TN) / 8 + 7) / 8;  // patch pieces per wave and chunk (6 or 7, padded with duplicates)
+  constexpr int PPL = PP + (GN ? 1 : 0);            // + the scale/shift piece
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const wring = smem;                              // NSTAGE weight stages
   char* const patches = smem + NSTAGE * W_BYTES;         // 2 patch stages
+  char* const scsh_lds = patches + 2 * PATCH_BYTES;      // GN: [2][4 images][64 scale | 64 shift] fp32
 
   const GemmParams& p = cp.base.g;
   const Geo& ge = cp.geo;
@@ -151,6 +184,7 @@ __global__ void __launch_bounds__(NTHREADS) conv3p_kernel(const CParams cp) {
   const int swz_w = (l31 >> 1) & 7;
   const int w_frag_row = (col0 + l31) * ROW_BYTES;
   const int chunks = p.n_ktiles;                         // iteration unit: chunk
+  const int nch1 = ge.C1 >> 6;                           // chunks of source 1
 
   const int g = range_index(blockIdx.x, p.G);
   long long it = (long long)g * p.iters_per_wg;
@@ -162,6 +196,10 @@ __global__ void __launch_bounds__(NTHREADS) conv3p_kernel(const CParams cp) {
       __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.w), 0, cp.base.w_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsrc_a =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.a), 0, cp.base.a_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_a2 =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.a2 ? p.a2 : p.a), 0, p.a2 ? cp.a2_bytes : 0u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_s =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(GN ? p.in_scsh : nullptr), 0, GN ? cp.scsh_bytes : 0u, 0x00020000);
 
   // ---- per-lane state of the current tile ------------------------------------------------------------------
   // piece index of load i of this wave: wave + 8*i, wrapped back by multiples of 8 when past the last piece (the
@@ -175,13 +213,17 @@ __global__ void __launch_bounds__(NTHREADS) conv3p_kernel(const CParams cp) {
     w_piece[i] = idx;
   }
   int p_piece[PP];
-  unsigned p_voff[PP];
+  int p_info[PP];                      // input pixel index of this lane's patch row | image-in-tile << 28, or -1 (padding)
 #pragma unroll
   for (int i = 0; i < PP; ++i) {
     int idx = wave + 8 * i;
     while (idx >= ge.n_pieces) idx -= 8;
     p_piece[i] = idx;
   }
+  // 16-byte slot of this lane inside every patch row it stages: row = piece * 8 + l3 and piece = wave (mod 8), so the
+  // XOR swizzle ((row >> 1) & 7) depends on the lane and the wave's parity only
+  const int koff = (pslot ^ ((((wave & 1) << 2) + (l3 >> 1)) & 7)) * 8;       // first of the lane's 8 channels in a chunk
+  unsigned s_voff = OOB;               // GN: this lane's 16 bytes of the tile's scale/shift rows
   int a_prow[TM];                      // patch row of this lane's output pixel at tap (0,0)
   long long mrow[TM];                  // global output pixel index of this lane's rows (epilogue)
 
@@ -195,21 +237,26 @@ __global__ void __launch_bounds__(NTHREADS) conv3p_kernel(const CParams cp) {
 #pragma unroll
     for (int i = 0; i < NWP; ++i) {
       const int row = w_piece[i] * 8 + l3;
-      const int koff = (pslot ^ ((row >> 1) & 7)) * 8;
+      const int kw = (pslot ^ ((row >> 1) & 7)) * 8;
       const int n = n0 + row;
-      w_voff[i] = (n < p.N) ? (unsigned)(((long long)n * p.ldw + koff) * 2) : OOB;
+      w_voff[i] = (n < p.N) ? (unsigned)(((long long)n * p.ldw + kw) * 2) : OOB;
     }
 #pragma unroll
     for (int i = 0; i < PP; ++i) {
       const int prow = p_piece[i] * 8 + l3;
-      const int koff = (pslot ^ ((prow >> 1) & 7)) * 8;
       const int img = prow / ge.prows_img;
       const int rem = prow - img * ge.prows_img;
       const int yy = rem / ge.prow_w;
       const int xx = rem - yy * ge.prow_w;
       const int gy = y0 + yy - 1, gx = x0 + xx - 1, b = b0 + img;
       const bool ok = (img < ge.NI) && (b < ge.B) && ((unsigned)gy < (unsigned)ge.H) && ((unsigned)gx < (unsigned)ge.W);
-      p_voff[i] = ok ? (unsigned)(((((long long)b * ge.H + gy) * ge.W + gx) * ge.C + koff) * 2) : OOB;
+      p_info[i] = ok ? ((((b * ge.H + gy) * ge.W + gx)) | (img << 28)) : -1;
+    }
+    if constexpr (GN) {
+      // scale/shift stage of a chunk: [image][64 scale | 64 shift] = 512 B per image; piece (wave & 1) of 1 KiB
+      const int img = ((wave & 1) << 1) + (lane >> 5);
+      const int b = b0 + img;
+      s_voff = (img < ge.NI && b < ge.B) ? (unsigned)(((long long)b * chunks * 512) + (lane & 31) * 16) : OOB;
     }
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm) {
@@ -233,10 +280,55 @@ __global__ void __launch_bounds__(NTHREADS) conv3p_kernel(const CParams cp) {
   };
   auto issue_patch = [&](int c) {
     char* pbuf = patches + (c & 1) * PATCH_BYTES;
-    const int soff = c * 128;
+    const bool second = c >= nch1;                   // wave-uniform: the chunk lies in source 2
+    const int cs = second ? ge.C2 : ge.C1;
+    const int soff = (second ? c - nch1 : c) * 128;
 #pragma unroll
-    for (int i = 0; i < PP; ++i) buf_lds16(rsrc_a, pbuf + p_piece[i] * 1024, p_voff[i], soff);
+    for (int i = 0; i < PP; ++i) {
+      const unsigned voff = (p_info[i] >= 0) ? (unsigned)(((long long)(p_info[i] & 0x0fffffff) * cs + koff) * 2) : OOB;
+      buf_lds16(second ? rsrc_a2 : rsrc_a, pbuf + p_piece[i] * 1024, voff, soff);
+    }
+    if constexpr (GN) buf_lds16(rsrc_s, scsh_lds + (c & 1) * 2048 + (wave & 1) * 1024, s_voff, c * 512);
   };
+  // GN: rewrite piece i of chunk c's patch (staged by THIS wave, already landed) as act(x * scale + shift)
+  auto transform_piece = [&](auto i_c, int c) {
+    constexpr int I = decltype(i_c)::value;
+    if constexpr (GN && I < PP) {
+      if (wave + 8 * I < ge.n_pieces) {              // not a duplicate (wave-uniform)
+        const int info = p_info[I];
+        char* cell = patches + (c & 1) * PATCH_BYTES + p_piece[I] * 1024 + lane * 16;
+        if (info >= 0) {
+          const u32x4 v = *reinterpret_cast<const u32x4*>(cell);
+          const float* sc = reinterpret_cast<const float*>(scsh_lds + (c & 1) * 2048 + ((info >> 28) & 3) * 512) + koff;
+          const f32x4 s0 = *reinterpret_cast<const f32x4*>(sc), s1 = *reinterpret_cast<const f32x4*>(sc + 4);
+          const f32x4 h0 = *reinterpret_cast<const f32x4*>(sc + 64), h1 = *reinterpret_cast<const f32x4*>(sc + 68);
+          float o[8];
+          o[0] = bf16_lo(v[0]) * s0[0] + h0[0];
+          o[1] = bf16_hi(v[0]) * s0[1] + h0[1];
+          o[2] = bf16_lo(v[1]) * s0[2] + h0[2];
+          o[3] = bf16_hi(v[1]) * s0[3] + h0[3];
+          o[4] = bf16_lo(v[2]) * s1[0] + h1[0];
+          o[5] = bf16_hi(v[2]) * s1[1] + h1[1];
+          o[6] = bf16_lo(v[3]) * s1[2] + h1[2];
+          o[7] = bf16_hi(v[3]) * s1[3] + h1[3];
+          if (p.in_act == 1) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = silu_f(o[j]);
+          }
+          u32x4 ov = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7])};
+          *reinterpret_cast<u32x4*>(cell) = ov;
+        }
+      }
+    }
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  using I2 = std::integral_constant<int, 2>;
+  using I3 = std::integral_constant<int, 3>;
+  using I4 = std::integral_constant<int, 4>;
+  using I5 = std::integral_constant<int, 5>;
+  using I6 = std::integral_constant<int, 6>;
+  auto lds_writes_done = [&]() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); };
 
   int tile = (int)(it / chunks);
   int c0 = (int)(it - (long long)tile * chunks);
@@ -251,6 +343,14 @@ __global__ void __launch_bounds__(NTHREADS) conv3p_kernel(const CParams cp) {
   while (true) {
     int c1 = chunks;
     if ((long long)(c1 - c0) > it_end - it) c1 = c0 + (int)(it_end - it);
+
+    if constexpr (GN) {
+      // first chunk of the segment: its patch (+ scale/shift) was requested ahead of the two weight tiles in flight
+      wait_vm<2 * NWP>();
+      transform_piece(I0{}, c0); transform_piece(I1{}, c0); transform_piece(I2{}, c0); transform_piece(I3{}, c0);
+      transform_piece(I4{}, c0); transform_piece(I5{}, c0); transform_piece(I6{}, c0);
+      lds_writes_done();
+    }
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -279,7 +379,7 @@ __global__ void __launch_bounds__(NTHREADS) conv3p_kernel(const CParams cp) {
       if (DX == 2 && dy == 2) {                                   // tap 8: next weights belong to the next chunk
         if (nxt) wait_vm<NWP>(); else wait_vm<0>();
       } else if (DX != 0 && dy == 0 && nxt) {                     // taps 1, 2: the patch requested at tap 0 may be in flight
-        wait_vm<NWP + PP>();
+        wait_vm<NWP + PPL>();
       } else {
         wait_vm<NWP>();
       }
@@ -308,17 +408,30 @@ __global__ void __launch_bounds__(NTHREADS) conv3p_kernel(const CParams cp) {
         for (int t = 0; t < TN; ++t) fw[ks][t] = lds_read_frag(wbuf + w_frag_row + t * 32 * ROW_BYTES + slot);
       }
     };
-    using I0 = std::integral_constant<int, 0>;
-    using I1 = std::integral_constant<int, 1>;
-    using I2 = std::integral_constant<int, 2>;
+    // GN: the next chunk's patch has landed once the tap-3 wait has passed (it was requested before W(c, 3)); this
+    // wave's pieces are rewritten one per tap behind the MFMAs of taps 3..8
+    auto transform_next = [&](auto dx_c, int c, int dy, bool nxt) {
+      constexpr int DX = decltype(dx_c)::value;
+      if constexpr (GN) {
+        if (nxt && dy >= 1) {
+          if (dy == 1) {
+            transform_piece(std::integral_constant<int, DX>{}, c + 1);
+          } else {
+            transform_piece(std::integral_constant<int, 3 + DX>{}, c + 1);
+            if (DX == 2) transform_piece(I6{}, c + 1);
+          }
+          lds_writes_done();
+        }
+      }
+    };
     // (the lead/lag wave-role split of gemm8.h measured no gain once the per-K-tile instruction overhead was gone, and
     //  holding a K-tile of operands across the barrier cost spills here — all waves run the same straight loop)
     for (int c = c0; c < c1; ++c) {
       const bool nxt = (c + 1 < c1);
       for (int dy = 0; dy < 3; ++dy) {
-        head(I0{}, c, dy, nxt); read_all(I0{}, c, dy); mfma_all();
-        head(I1{}, c, dy, nxt); read_all(I1{}, c, dy); mfma_all();
-        head(I2{}, c, dy, nxt); read_all(I2{}, c, dy); mfma_all();
+        head(I0{}, c, dy, nxt); read_all(I0{}, c, dy); mfma_all(); transform_next(I0{}, c, dy, nxt);
+        head(I1{}, c, dy, nxt); read_all(I1{}, c, dy); mfma_all(); transform_next(I1{}, c, dy, nxt);
+        head(I2{}, c, dy, nxt); read_all(I2{}, c, dy); mfma_all(); transform_next(I2{}, c, dy, nxt);
       }
     }
 
@@ -326,7 +439,7 @@ __global__ void __launch_bounds__(NTHREADS) conv3p_kernel(const CParams cp) {
     const bool noxchg = UDT_DBG(p.flags, 28);       // measurement modes (udt_debug_set): wrong results
     const bool full = noxchg || ((j0 == 0) && (j1 == p.n_ktiles));
     const bool publish = !noxchg && (j0 > 0);
-    const int cur_tile = tile, cur_n0 = n0;
+    const int cur_tile = tile, cur_n0 = n0, cur_tile_m = tile_m;
     long long cur_mrow[TM];
 #pragma unroll
     for (int t = 0; t < TM; ++t) cur_mrow[t] = mrow[t];
@@ -416,7 +529,9 @@ __global__ void __launch_bounds__(NTHREADS) conv3p_kernel(const CParams cp) {
       }
       // (the row-coalesced LDS epilogue of gemm8.h was measured here too: 109 vs 95 us per launch — the cross-lane
       //  row table and the extra live state cost more than the whole-line stores return; direct stores stay)
-      epilogue_rows<TM, TN>(p, acc, cur_mrow, cur_n0, col0, lane);
+      // column statistics: one slot per wave row block (TM * 32 pixels of one image), slots in tile order
+      float* stats = p.colstats ? p.colstats + (((long long)cur_tile_m * WGM + wm) * p.N + cur_n0 + col0) * 2 : nullptr;
+      epilogue_rows<TM, TN>(p, acc, cur_mrow, cur_n0, col0, lane, stats);
     }
     if (!more) break;
   }

@@ -42,6 +42,9 @@ struct GemmParams {
   const uint16_t* res;
   const float* rowvec;
   void* out;
+  const float* in_scsh;  // patch-staged convolution: GroupNorm scale/shift table of the input (conv3p.h), or nullptr
+  float* colstats;       // per-(row slot, column) partial sums of the output, or nullptr
+  int in_act;
   float* slabs;          // [G][2][16][256] float4 accumulator parking space
   int M, N, K;
   int lda, ldo, ldr, ldw;
@@ -653,26 +656,30 @@ bool conv3p_geometry(const udt_gemm_desc* d, c3p::Geo& ge) {
     g_conv3p.store(on, std::memory_order_relaxed);
   }
   if (!on || gemm_impl() == 4) return false;
-  if (!(d->flags & UDT_GEMM_CONV) || d->ksize != 3 || d->stride != 1 || d->upsample || d->C2 != 0) return false;
+  if (!(d->flags & UDT_GEMM_CONV) || d->ksize != 3 || d->stride != 1 || d->upsample) return false;
   if (d->pad_t != 1 || d->pad_l != 1 || d->Hout != d->Hin || d->Wout != d->Win || d->N <= 64) return false;
   if (d->flags & (UDT_GEMM_GEGLU | UDT_GEMM_TRANSPOSED)) return false;
+  if (d->C1 <= 0 || d->C1 % 64 != 0 || d->C2 < 0 || d->C2 % 64 != 0) return false;
   const int H = d->Hin, W = d->Win;
   if (W % 32 == 0 && H % 8 == 0) { ge.TW = 32; ge.TH = 8; ge.NI = 1; }
   else if (W == 16 && H % 16 == 0) { ge.TW = 16; ge.TH = 16; ge.NI = 1; }
   else if (W == 8 && H == 8) { ge.TW = 8; ge.TH = 8; ge.NI = 4; }
   else return false;
   ge.B = d->M / (H * W);
-  ge.H = H; ge.W = W; ge.C = d->C1;
+  ge.H = H; ge.W = W; ge.C1 = d->C1; ge.C2 = d->C2; ge.C = d->C1 + d->C2;
   ge.tiles_x = W / ge.TW;
   ge.tiles_y = H / ge.TH;
   ge.img_groups = (ge.B + ge.NI - 1) / ge.NI;
   ge.prow_w = ge.TW + 2;
   ge.prows_img = (ge.TH + 2) * (ge.TW + 2);
   ge.n_pieces = (ge.NI * ge.prows_img + 7) / 8;
-  ge.chunks = d->C1 / 64;
-  // buffer-descriptor addressing: 31-bit byte offsets (bit 31 marks zero padding)
-  if ((long long)d->M * d->C1 * 2 >= (1LL << 31) || (long long)d->N * (d->ldw > 0 ? d->ldw : d->K) * 2 >= (1LL << 31)) return false;
-  return ge.n_pieces * 8 <= c3p::PATCH_ROWS && ge.n_pieces >= 8;
+  ge.chunks = ge.C / 64;
+  // buffer-descriptor addressing: 31-bit byte offsets (bit 31 marks zero padding); pixel indices are kept in 28 bits
+  if ((long long)d->M * d->C1 * 2 >= (1LL << 31) || (long long)d->M * d->C2 * 2 >= (1LL << 31) || d->M >= (1 << 28)) return false;
+  if ((long long)d->N * (d->ldw > 0 ? d->ldw : d->K) * 2 >= (1LL << 31)) return false;
+  if ((long long)ge.B * ge.chunks * 512 >= (1LL << 31)) return false;
+  const int bn = (d->N % 160 == 0 && d->N % 128 != 0) ? 160 : 128;
+  return ge.n_pieces * 8 <= c3p::patch_rows(bn == 160 ? 5 : 2) && ge.n_pieces >= 8;
 }
 
 TilePlan plan_tiles3p(const udt_gemm_desc* d, const c3p::Geo& ge) {
@@ -695,16 +702,43 @@ TilePlan plan_tiles3p(const udt_gemm_desc* d, const c3p::Geo& ge) {
   return t;
 }
 
-template <int WGM, int WGN, int TM, int TN>
+template <int WGM, int WGN, int TM, int TN, bool GN>
 hipError_t launch3p(const c3p::CParams& cp, const TilePlan& t, hipStream_t s) {
   constexpr int BN = WGN * TN * 32;
-  constexpr int smem = g8::NSTAGE * BN * ROW_BYTES + 2 * c3p::PATCH_BYTES;
+  constexpr int smem = g8::NSTAGE * BN * ROW_BYTES + 2 * c3p::patch_rows(TN) * ROW_BYTES + (GN ? c3p::SCSH_BYTES : 0);
+  static_assert(smem <= 160 * 1024, "one workgroup per CU: at most the CU's 160 KiB of LDS");
   static AttrOnce once;
-  auto kern = c3p::conv3p_kernel<WGM, WGN, TM, TN>;
+  auto kern = c3p::conv3p_kernel<WGM, WGN, TM, TN, GN>;
   hipError_t e = once.ensure(reinterpret_cast<const void*>(kern), smem);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(kern, dim3(t.G), dim3(g8::NTHREADS), smem, s, cp);
   return hipGetLastError();
+}
+
+// rows of the output one colstats slot covers for this problem, 0 = statistics not available
+int colstats_rows(const udt_gemm_desc* d) {
+  if (d->flags & (UDT_GEMM_OUT_F32 | UDT_GEMM_GEGLU | UDT_GEMM_TRANSPOSED)) return 0;
+  if ((d->batch > 1) || d->M <= 0 || d->N <= 0 || d->K <= 0 || d->K % BK != 0) return 0;
+  int rows = 0;
+  c3p::Geo ge;
+  if (conv3p_geometry(d, ge)) {
+    rows = (d->N % 160 == 0 && d->N % 128 != 0) ? 32 : 64;
+    if ((ge.TW * ge.TH) % rows != 0) return 0;                    // a wave row block lies in one image
+  } else if (use_gemm8(d) && g_rows_epi.load(std::memory_order_relaxed)) {
+    rows = (plan_tiles8(d).bn == 160) ? 32 : 64;
+  } else {
+    return 0;
+  }
+  const int rpb = d->rows_per_batch > 0 ? d->rows_per_batch : d->M;
+  return (rpb % rows == 0) ? rows : 0;
+}
+
+int colstats_slots(const udt_gemm_desc* d) {
+  const int rows = colstats_rows(d);
+  if (rows == 0) return 0;
+  c3p::Geo ge;
+  if (conv3p_geometry(d, ge)) return ge.img_groups * ge.tiles_y * ge.tiles_x * (256 / rows);
+  return ((d->M + 255) / 256) * (256 / rows);
 }
 
 }  // namespace
@@ -744,6 +778,20 @@ extern "C" int udt_check_async_error(void* workspace, size_t workspace_bytes, vo
   if (e == hipSuccess) e = hipStreamSynchronize(s);
   if (e != hipSuccess) return udt_set_hip_error(e);
   return UDT_ERR_ASYNC;
+}
+
+extern "C" int32_t udt_gemm_colstats_rows(const udt_gemm_desc* d) { return d ? colstats_rows(d) : 0; }
+extern "C" int32_t udt_gemm_colstats_slots(const udt_gemm_desc* d) { return d ? colstats_slots(d) : 0; }
+extern "C" int32_t udt_gemm_in_scsh_ok(const udt_gemm_desc* d) {
+  if (!d || d->K <= 0 || d->K % BK != 0) return 0;
+  c3p::Geo ge;
+  return conv3p_geometry(d, ge) ? 1 : 0;
+}
+
+extern "C" int udt_gn_silu_conv3x3_fwd(const udt_gemm_desc* d, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!d || !(d->flags & UDT_GEMM_CONV) || d->ksize != 3 || d->stride != 1 || d->pad_t != 1 || d->pad_l != 1 || !d->in_scsh)
+    return UDT_ERR_BAD_ARG;
+  return udt_gemm(d, workspace, workspace_bytes, stream);
 }
 
 extern "C" size_t udt_gemm_workspace_bytes(const udt_gemm_desc* d) {
@@ -813,7 +861,13 @@ extern "C" int udt_gemm(const udt_gemm_desc* d, void* workspace, size_t workspac
   p.res = reinterpret_cast<const uint16_t*>(d->residual);
   p.rowvec = d->rowvec;
   p.out = d->out;
+  p.in_scsh = d->in_scsh;
+  p.in_act = d->in_act;
+  p.colstats = d->colstats;
   p.slabs = nullptr;
+  if (d->colstats && colstats_rows(d) == 0) return UDT_ERR_BAD_ARG;     // ask udt_gemm_colstats_rows first
+  if (d->in_scsh && !udt_gemm_in_scsh_ok(d)) return UDT_ERR_BAD_ARG;
+  if (d->in_act != 0 && d->in_act != 1) return UDT_ERR_BAD_ARG;
   p.M = d->M; p.N = d->N; p.K = d->K;
   p.lda = d->lda; p.ldo = d->ldo; p.ldr = d->ldr;
   p.ldw = d->ldw > 0 ? d->ldw : d->K;
@@ -841,6 +895,8 @@ extern "C" int udt_gemm(const udt_gemm_desc* d, void* workspace, size_t workspac
       p.iters_per_wg = t3.ipw;
       p.G = t3.G;
       cp.base.a_bytes = (unsigned)((long long)d->M * d->C1 * 2);
+      cp.a2_bytes = (unsigned)((long long)d->M * d->C2 * 2);
+      cp.scsh_bytes = (unsigned)((long long)cp.geo.B * cp.geo.chunks * 512);
       cp.base.w_bytes = (unsigned)((long long)d->N * p.ldw * 2);
       cp.base.g = p;
       cp.base.flags = nullptr; cp.base.err = nullptr; cp.base.slab_base = nullptr;
@@ -854,11 +910,13 @@ extern "C" int udt_gemm(const udt_gemm_desc* d, void* workspace, size_t workspac
       UdtProfScope prof3(cls, s);
       if (prof3.rec) {
         char tag[96];
-        snprintf(tag, sizeof(tag), "conv3p M=%d N=%d K=%d %dx%d tile=%dx%dx%d bn=%d G=%d ipw=%d", d->M, d->N, d->K, d->Hin,
-                 d->Win, cp.geo.TW, cp.geo.TH, cp.geo.NI, t3.bn, t3.G, t3.ipw);
+        snprintf(tag, sizeof(tag), "conv3p%s M=%d N=%d K=%d %dx%d tile=%dx%dx%d bn=%d G=%d ipw=%d", d->in_scsh ? "+gn" : "", d->M,
+                 d->N, d->K, d->Hin, d->Win, cp.geo.TW, cp.geo.TH, cp.geo.NI, t3.bn, t3.G, t3.ipw);
         udt_prof_tag(prof3.rec, tag);
       }
-      hipError_t e3 = (t3.bn == 160) ? launch3p<8, 1, 1, 5>(cp, t3, s) : launch3p<4, 2, 2, 2>(cp, t3, s);
+      hipError_t e3;
+      if (d->in_scsh) e3 = (t3.bn == 160) ? launch3p<8, 1, 1, 5, true>(cp, t3, s) : launch3p<4, 2, 2, 2, true>(cp, t3, s);
+      else e3 = (t3.bn == 160) ? launch3p<8, 1, 1, 5, false>(cp, t3, s) : launch3p<4, 2, 2, 2, false>(cp, t3, s);
       if (e3 != hipSuccess) return udt_set_hip_error(e3);
       return UDT_OK;
     }

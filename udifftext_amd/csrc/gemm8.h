@@ -147,6 +147,40 @@ UDT_DEVINL void epilogue8(const GemmParams& p, f32x16 (&acc)[TM][TN], int m0, in
   }
 }
 
+// ---- column statistics of the output (GroupNorm partial sums for the NEXT layer) -------------------------------------
+// udt_gemm_desc.colstats: fp32 [slots][N][2] = per-(row slot, column) (sum, sum of squares) of the stored values.  A slot
+// is one wave's row block (64 rows of the 256x128 tile, 32 rows of the 256x160 tile), written exactly once by the
+// workgroup that finishes the tile: plain stores, no atomics, so the statistics are deterministic.
+UDT_DEVINL void colstat_acc8(const u32x4 v, float (&s)[8], float (&q)[8]) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float a = bf16_lo(v[j]), b = bf16_hi(v[j]);
+    s[2 * j] += a; q[2 * j] += a * a;
+    s[2 * j + 1] += b; q[2 * j + 1] += b * b;
+  }
+}
+// rows layout (8 lanes x 16 B cover one 128-byte row; lane>>3 = row within a group of 8): reduce over the row lanes
+UDT_DEVINL void colstat_emit_rows(float (&s)[8], float (&q)[8], int lane, float* dst, int ncols) {
+  lane_reduce_scatter<8, 32, 8>(s, lane);
+  lane_reduce_scatter<8, 32, 8>(q, lane);
+  const int col = (lane & 7) * 8 + ((lane >> 5) & 1) * 4 + ((lane >> 4) & 1) * 2 + ((lane >> 3) & 1);
+  if (col < ncols) {
+    f32x2 o = {s[0], q[0]};
+    *reinterpret_cast<f32x2*>(dst + col * 2) = o;
+  }
+}
+// accumulator layout (lane = one row, 16 (q, r) columns of a 32-column MFMA tile): reduce over the 32 row lanes
+UDT_DEVINL void colstat_emit_acc(float (&s16)[16], float (&q16)[16], int lane, float* dst_tile, int ncols) {
+  lane_reduce_scatter<16, 16, 1>(s16, lane);
+  lane_reduce_scatter<16, 16, 1>(q16, lane);
+  const int idx = ((lane & 16) ? 8 : 0) + ((lane & 8) ? 4 : 0) + ((lane & 4) ? 2 : 0) + ((lane & 2) ? 1 : 0);
+  const int col = (idx >> 2) * 8 + (lane >> 5) * 4 + (idx & 3);
+  if (!(lane & 1) && col < ncols) {
+    f32x2 o = {s16[0], q16[0]};
+    *reinterpret_cast<f32x2*>(dst_tile + col * 2) = o;
+  }
+}
+
 // ---- row-coalesced epilogue (bf16 output, TN == 2, not transposed) ----------------------------------------------
 // The MFMA accumulator layout gives a lane 4 consecutive columns of ONE row, so a direct store instruction touches 32
 // rows with 16 bytes each: 512 partial-line write requests per wave and tile, and the launch becomes L2-request
@@ -156,9 +190,10 @@ UDT_DEVINL void epilogue8(const GemmParams& p, f32x16 (&acc)[TM][TN], int m0, in
 // added in fp32 BEFORE the single bf16 rounding.  `wlds` = this wave's 8 KiB scratch (free ring stage).
 // `mof(row)` maps a wave-local row (0 .. TM*32-1) to the global output row, or -1 (GEMM: m0 + row0 + row; the
 // patch-staged convolution: the NHWC pixel of that tile position); `nw` = first output column of the wave.
+// `stats`: this wave block's row of p.colstats (+ 2 * nw), or nullptr
 template <int TM, class MOF>
 UDT_DEVINL void epilogue8_rows(const GemmParams& p, f32x16 (&acc)[TM][2], MOF mof, int nw, int batch, int lane,
-                               char* wlds) {
+                               char* wlds, float* stats) {
   const int l31 = lane & 31;
   const int hi = lane >> 5;
   const int flags = p.flags;
@@ -262,6 +297,9 @@ UDT_DEVINL void epilogue8_rows(const GemmParams& p, f32x16 (&acc)[TM][2], MOF mo
         *reinterpret_cast<u32x2*>(cell) = pk;
       }
   }
+  float cs[8], cq[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) cs[j] = cq[j] = 0.f;
 #pragma unroll
   for (int i = 0; i < TM * 4; ++i) {
     const int row = i * 8 + (lane >> 3);
@@ -275,16 +313,35 @@ UDT_DEVINL void epilogue8_rows(const GemmParams& p, f32x16 (&acc)[TM][2], MOF mo
       u32x2 h = {v[0], v[1]};
       *reinterpret_cast<u32x2*>(out + m * p.ldo + n) = h;
     }
+    if (stats && m >= 0) colstat_acc8(v, cs, cq);
   }
+  if (stats) colstat_emit_rows(cs, cq, lane, stats, p.N - nw);
 }
 
 // the same for the 256x160 configuration (TM = 1, TN = 5: a wave owns 32 rows x 160 columns = 320-byte rows).  The
 // free ring stage holds 52 KiB, so the block goes through LDS in two passes of 16 rows (rows padded to 336 bytes:
 // 84-dword stride spreads the 16 rows over the banks without a swizzle); 20 lanes cover one row, 3 rows per
 // instruction.
+// 20 lanes x 16 B cover one 320-byte row, 3 rows per instruction: column sums = own rows + the two partner lanes
+template <int NC>
+UDT_DEVINL void colstat_emit_rows16(float (&s)[8], float (&q)[8], int lane, float* dst, int ncols) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    s[j] += __shfl(s[j], lane + NC) + __shfl(s[j], lane + 2 * NC);
+    q[j] += __shfl(q[j], lane + NC) + __shfl(q[j], lane + 2 * NC);
+  }
+  if (lane < NC && lane * 8 < ncols) {
+#pragma unroll
+    for (int j = 0; j < 8; j += 2) {
+      f32x4 o = {s[j], q[j], s[j + 1], q[j + 1]};
+      *reinterpret_cast<f32x4*>(dst + (lane * 8 + j) * 2) = o;
+    }
+  }
+}
+
 template <int TN, class MOF>
 UDT_DEVINL void epilogue8_rows16(const GemmParams& p, f32x16 (&acc)[1][TN], MOF mof, int nw, int batch, int lane,
-                                 char* wlds) {
+                                 char* wlds, float* stats) {
   constexpr int NC = TN * 4;                   // 16-byte chunks per row
   constexpr int RS = TN * 64 + 16;             // padded row stride
   const int l31 = lane & 31;
@@ -294,6 +351,9 @@ UDT_DEVINL void epilogue8_rows16(const GemmParams& p, f32x16 (&acc)[1][TN], MOF 
   const uint16_t* __restrict__ R = (p.res && !UDT_DBG(p.flags, 25)) ? (p.res + (long long)batch * p.sR) : nullptr;
   const int rl = lane / NC;                    // 0..2 (lane 60..63: idle)
   const int ch = lane - rl * NC;
+  float cs[8], cq[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) cs[j] = cq[j] = 0.f;
 #pragma unroll
   for (int pass = 0; pass < 2; ++pass) {
     const bool mine = (l31 >> 4) == pass;
@@ -373,9 +433,11 @@ UDT_DEVINL void epilogue8_rows16(const GemmParams& p, f32x16 (&acc)[1][TN], MOF 
           u32x2 h = {v[0], v[1]};
           *reinterpret_cast<u32x2*>(out + m * p.ldo + n) = h;
         }
+        if (stats && m >= 0) colstat_acc8(v, cs, cq);
       }
     }
   }
+  if (stats) colstat_emit_rows16<NC>(cs, cq, lane, stats, p.N - nw);
 }
 
 // ---- fast variants of the row-coalesced epilogues ----------------------------------------------------------------
@@ -386,7 +448,7 @@ UDT_DEVINL void epilogue8_rows16(const GemmParams& p, f32x16 (&acc)[1][TN], MOF 
 // sample per wave block) and issue all their loads up front; anything else takes the generic path.
 template <int TM, bool BIAS, bool ROWVEC, bool RES, class MOF>
 UDT_DEVINL void epilogue8_rows_fast(const GemmParams& p, f32x16 (&acc)[TM][2], MOF mof, int nw, int batch, int lane,
-                                    char* wlds) {
+                                    char* wlds, float* stats) {
   const int l31 = lane & 31;
   const int hi = lane >> 5;
   uint16_t* out = reinterpret_cast<uint16_t*>(p.out) + (long long)batch * p.sO;
@@ -444,12 +506,17 @@ UDT_DEVINL void epilogue8_rows_fast(const GemmParams& p, f32x16 (&acc)[TM][2], M
         *reinterpret_cast<u32x2*>(cell) = pk;
       }
   }
+  float cs[8], cq[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) cs[j] = cq[j] = 0.f;
 #pragma unroll
   for (int i = 0; i < TM * 4; ++i) {
     const int row = i * 8 + (lane >> 3);
     const u32x4 v = *reinterpret_cast<const u32x4*>(wlds + row * 128 + ((ch ^ (row & 7)) << 4));
     *reinterpret_cast<u32x4*>(out + mrow[i] * p.ldo + nw + ch * 8) = v;
+    if (stats) colstat_acc8(v, cs, cq);
   }
+  if (stats) colstat_emit_rows(cs, cq, lane, stats, 64);
 }
 
 // GEGLU, interior tile, bias present
@@ -494,7 +561,7 @@ UDT_DEVINL void epilogue8_geglu_fast(const GemmParams& p, f32x16 (&acc)[TM][2], 
 // 256x160 configuration (TM = 1): per-column constants (bias + row vector) staged once in LDS behind the 16-row block
 template <int TN, bool BIAS, bool ROWVEC, bool RES, class MOF>
 UDT_DEVINL void epilogue8_rows16_fast(const GemmParams& p, f32x16 (&acc)[1][TN], MOF mof, int nw, int batch, int lane,
-                                      char* wlds) {
+                                      char* wlds, float* stats) {
   constexpr int NC = TN * 4;
   constexpr int RS = TN * 64 + 16;
   const int l31 = lane & 31;
@@ -525,6 +592,9 @@ UDT_DEVINL void epilogue8_rows16_fast(const GemmParams& p, f32x16 (&acc)[1][TN],
       const int row = i * 3 + rl;
       mrow[pass][i] = mof(pass * 16 + (row < 16 ? row : 15));
     }
+  float cs[8], cq[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) cs[j] = cq[j] = 0.f;
   u32x4 rv[2][6];
   if constexpr (RES) {
     const uint16_t* __restrict__ R = p.res + (long long)batch * p.sR;
@@ -578,9 +648,11 @@ UDT_DEVINL void epilogue8_rows16_fast(const GemmParams& p, f32x16 (&acc)[1][TN],
       if (rl < 3 && row < 16) {
         const u32x4 v = *reinterpret_cast<const u32x4*>(wlds + row * RS + ch * 16);
         *reinterpret_cast<u32x4*>(out + mrow[pass][i] * p.ldo + nw + ch * 8) = v;
+        if (stats) colstat_acc8(v, cs, cq);
       }
     }
   }
+  if (stats) colstat_emit_rows16<NC>(cs, cq, lane, stats, TN * 32);
 }
 
 // feature-set dispatch shared by the GEMM and the patch-staged convolution.  `interior`: every row of the wave block
@@ -588,7 +660,7 @@ UDT_DEVINL void epilogue8_rows16_fast(const GemmParams& p, f32x16 (&acc)[1][TN],
 // row vector).  Returns false when the generic epilogue has to run.
 template <int TM, int TN, class MOF>
 UDT_DEVINL bool epilogue8_fast_dispatch(const GemmParams& p, f32x16 (&acc)[TM][TN], MOF mof, int nw, int batch, int lane,
-                                        char* wlds, bool interior) {
+                                        char* wlds, bool interior, float* stats) {
   constexpr int PUB = UDT_GEMM_OUT_F32 | UDT_GEMM_GEGLU | UDT_GEMM_RELU | UDT_GEMM_SILU_OUT | (1 << 30) | (1 << 24) |
                       (1 << 25) | (1 << 26);
   if (!interior || UDT_DBG(p.flags, 22)) return false;
@@ -604,18 +676,18 @@ UDT_DEVINL bool epilogue8_fast_dispatch(const GemmParams& p, f32x16 (&acc)[TM][T
   const int code = (p.bias ? 1 : 0) | (p.rowvec ? 2 : 0) | (p.res ? 4 : 0);
   if constexpr (TN == 2) {
     switch (code) {
-      case 0: epilogue8_rows_fast<TM, false, false, false>(p, acc, mof, nw, batch, lane, wlds); return true;
-      case 1: epilogue8_rows_fast<TM, true, false, false>(p, acc, mof, nw, batch, lane, wlds); return true;
-      case 3: epilogue8_rows_fast<TM, true, true, false>(p, acc, mof, nw, batch, lane, wlds); return true;
-      case 5: epilogue8_rows_fast<TM, true, false, true>(p, acc, mof, nw, batch, lane, wlds); return true;
+      case 0: epilogue8_rows_fast<TM, false, false, false>(p, acc, mof, nw, batch, lane, wlds, stats); return true;
+      case 1: epilogue8_rows_fast<TM, true, false, false>(p, acc, mof, nw, batch, lane, wlds, stats); return true;
+      case 3: epilogue8_rows_fast<TM, true, true, false>(p, acc, mof, nw, batch, lane, wlds, stats); return true;
+      case 5: epilogue8_rows_fast<TM, true, false, true>(p, acc, mof, nw, batch, lane, wlds, stats); return true;
       default: return false;
     }
   } else {
     switch (code) {
-      case 0: epilogue8_rows16_fast<TN, false, false, false>(p, acc, mof, nw, batch, lane, wlds); return true;
-      case 1: epilogue8_rows16_fast<TN, true, false, false>(p, acc, mof, nw, batch, lane, wlds); return true;
-      case 3: epilogue8_rows16_fast<TN, true, true, false>(p, acc, mof, nw, batch, lane, wlds); return true;
-      case 5: epilogue8_rows16_fast<TN, true, false, true>(p, acc, mof, nw, batch, lane, wlds); return true;
+      case 0: epilogue8_rows16_fast<TN, false, false, false>(p, acc, mof, nw, batch, lane, wlds, stats); return true;
+      case 1: epilogue8_rows16_fast<TN, true, false, false>(p, acc, mof, nw, batch, lane, wlds, stats); return true;
+      case 3: epilogue8_rows16_fast<TN, true, true, false>(p, acc, mof, nw, batch, lane, wlds, stats); return true;
+      case 5: epilogue8_rows16_fast<TN, true, false, true>(p, acc, mof, nw, batch, lane, wlds, stats); return true;
       default: return false;
     }
   }
@@ -948,8 +1020,9 @@ __global__ void __launch_bounds__(NTHREADS) gemm8_kernel(const Params pp) {
           auto mof = [&](int row) -> long long { return (mwv + row < p.M) ? (long long)(mwv + row) : -1LL; };
           char* wl = smem + 2 * STAGE_BYTES + wave * EPI_WAVE_BYTES;
           const bool interior = (cur_m0 + BM <= p.M) && (cur_n0 + BN <= p.N);
-          if (!epilogue8_fast_dispatch<TM, TN>(p, acc, mof, cur_n0 + col0, cur_batch, lane, wl, interior))
-            epilogue8_rows16<TN>(p, acc, mof, cur_n0 + col0, cur_batch, lane, wl);
+          float* stats = p.colstats ? p.colstats + ((long long)(mwv / (TM * 32)) * p.N + cur_n0 + col0) * 2 : nullptr;
+          if (!epilogue8_fast_dispatch<TM, TN>(p, acc, mof, cur_n0 + col0, cur_batch, lane, wl, interior, stats))
+            epilogue8_rows16<TN>(p, acc, mof, cur_n0 + col0, cur_batch, lane, wl, stats);
         } else {
           epilogue8<TM, TN, TRANS>(p, acc, cur_m0, cur_n0, cur_batch, row0, col0, lane);
         }
@@ -961,8 +1034,9 @@ __global__ void __launch_bounds__(NTHREADS) gemm8_kernel(const Params pp) {
           auto mof = [&](int row) -> long long { return (mwv + row < p.M) ? (long long)(mwv + row) : -1LL; };
           char* wl = smem + 2 * STAGE_BYTES + wave * EPI_WAVE_BYTES;
           const bool interior = (cur_m0 + BM <= p.M) && (cur_n0 + BN <= p.N);
-          if (!epilogue8_fast_dispatch<TM, TN>(p, acc, mof, cur_n0 + col0, cur_batch, lane, wl, interior))
-            epilogue8_rows<TM>(p, acc, mof, cur_n0 + col0, cur_batch, lane, wl);
+          float* stats = p.colstats ? p.colstats + ((long long)(mwv / (TM * 32)) * p.N + cur_n0 + col0) * 2 : nullptr;
+          if (!epilogue8_fast_dispatch<TM, TN>(p, acc, mof, cur_n0 + col0, cur_batch, lane, wl, interior, stats))
+            epilogue8_rows<TM>(p, acc, mof, cur_n0 + col0, cur_batch, lane, wl, stats);
         } else {
           epilogue8<TM, TN, TRANS>(p, acc, cur_m0, cur_n0, cur_batch, row0, col0, lane);
         }
