@@ -158,6 +158,9 @@ CONV_CASES = [
     (3, 16, 16, 1280, 0, 1280, 3, 1, (1, 1), False),
     (1, 32, 64, 128, 0, 128, 3, 1, (1, 1), False),       # non-square, VAE-like
     (1, 16, 32, 192, 0, 256, 3, 1, (1, 1), False),       # 3 chunks
+    (2, 32, 32, 640, 320, 640, 3, 1, (1, 1), False),     # patch-staged, two sources (skip concat), 15 chunks
+    (4, 8, 8, 1280, 1280, 1280, 3, 1, (1, 1), False),    # 8x8 maps, two sources
+    (1, 64, 64, 320, 320, 320, 3, 1, (1, 1), False),     # bn 160, two sources
 ]
 
 
@@ -191,6 +194,141 @@ def test_conv(ops, cuda, case):
         ref = F.conv2d(xin, wq, b, stride=stride, padding=pad)
     ref = ref.permute(0, 2, 3, 1)
     _close(out[..., :N], ref, what=f"conv {case}")
+
+
+def _colstats_ref(out_bhwc, rows, tile=None):
+    """reference column statistics of a [B, H, W, N] output: per (slot of `rows` pixels in the kernel's order, column)"""
+    B, H, W, N = out_bhwc.shape
+    o = out_bhwc.float()
+    if tile is not None:                  # patch-staged conv: pixels in (image group, tile y, tile x, in-tile) order
+        TW, TH, NI = tile
+        if NI == 1:
+            o = o.reshape(B, H // TH, TH, W // TW, TW, N).permute(0, 1, 3, 2, 4, 5).reshape(-1, N)
+        else:
+            Bp = (B + NI - 1) // NI * NI
+            o = torch.cat([o, torch.zeros((Bp - B, H, W, N), device=o.device)], 0).reshape(-1, N)
+    else:
+        o = o.reshape(-1, N)
+        pad = (-o.shape[0]) % 256
+        o = torch.cat([o, torch.zeros((pad, N), device=o.device)], 0)
+    o = o.reshape(-1, rows, N)
+    return torch.stack([o.sum(1), (o * o).sum(1)], dim=-1)            # [slots, N, 2]
+
+
+@pytest.mark.parametrize("M,N,K,hw", [(2048, 640, 640, 256), (4096, 320, 320, 1024), (512, 1280, 1280, 64),
+                                      (384, 1280, 2560, 64), (1000, 256, 128, 200)])
+def test_linear_colstats(ops, cuda, M, N, K, hw):
+    """the GEMM epilogue's per-(row slot, column) partial sums == sums of the bf16 output it stored (256x128 and 256x160
+    tiles, interior and ragged tiles, residual epilogue); unsupported splits (rows_per_batch % slot != 0) give None"""
+    from udifftext_amd import packing
+    x = _rand((M, K), cuda, seed=1).bfloat16()
+    wp = packing.pack_linear(_rand((N, K), cuda, 1.0 / math.sqrt(K), seed=2))
+    b = _rand((N,), cuda, seed=3)
+    res = _rand((M, N), cuda, seed=4).bfloat16()
+    out = ops.linear(x, wp, b, residual=res, rows_per_batch=hw, colstats=True)
+    st = ops.gn_stats_of(out)
+    if hw % 32 != 0:
+        assert st is None
+        return
+    assert st is not None
+    rows = hw // st.slots_per_sample
+    assert rows in (32, 64)
+    ref = _colstats_ref(out.reshape(1, 1, M, N), rows)
+    n = ref.shape[0]
+    torch.testing.assert_close(st.data[:n], ref, rtol=2e-4, atol=2e-3)
+    _close(out, x.float() @ wp.float().t() + b + res.float(), what="linear with colstats")
+
+
+@pytest.mark.parametrize("B,H,W,C1,C2,N", [(2, 32, 32, 320, 0, 640), (1, 64, 64, 320, 0, 320), (3, 16, 16, 640, 0, 1280),
+                                          (5, 8, 8, 1280, 0, 1280), (2, 32, 32, 640, 320, 640), (4, 8, 8, 1280, 1280, 1280),
+                                          (2, 64, 64, 320, 320, 320), (2, 16, 16, 1280, 640, 1280)])
+def test_gn_silu_conv3x3_fused(ops, cuda, B, H, W, C1, C2, N):
+    """udt_gn_silu_conv3x3_fwd: statistics from producer epilogues -> udt_gn_finalize -> GroupNorm + SiLU applied on the
+    staged patch -> conv3x3 (+ time-embedding row vector + residual) -> statistics of the output; one and two sources,
+    every spatial tiling (32x8, 16x16, 4 x 8x8 with a ragged image group), both weight-tile widths.  Reference: torch
+    fp32 group_norm + silu + conv2d on the same bf16 inputs."""
+    from udifftext_amd import packing
+    torch.manual_seed(B * 1000 + H + C1 + C2)
+    # the inputs come out of "producers" (1x1 linears with colstats) so that their statistics exist
+    def produce(C, seed):
+        K = 128
+        a = (_rand((B * H * W, K), cuda, 1.5, seed=seed) + 0.4).bfloat16()
+        wq = packing.pack_linear(_rand((C, K), cuda, 1.0 / math.sqrt(K), seed=seed + 1))
+        bias = _rand((C,), cuda, seed=seed + 2) * 0.5
+        y = ops.linear(a, wq, bias, rows_per_batch=H * W, colstats=True)
+        assert ops.gn_stats_of(y) is not None
+        t = y.reshape(B, H, W, C)
+        t.gn_stats = y.gn_stats
+        return t
+    x1 = produce(C1, 10)
+    x2 = produce(C2, 20) if C2 else None
+    Ct = C1 + C2
+    gamma = _rand((Ct,), cuda, seed=5) * 0.2 + 1.0
+    beta = _rand((Ct,), cuda, seed=6) * 0.2
+    w = _rand((N, Ct, 3, 3), cuda, 1 / math.sqrt(Ct * 9), seed=3)
+    w = w * (1.0 + torch.arange(9, device=cuda).reshape(1, 1, 3, 3) / 4.0)
+    bias = _rand((N,), cuda, seed=4)
+    temb = _rand((B, N), cuda, seed=7)
+    res = _rand((B, H, W, N), cuda, seed=8).bfloat16()
+    wp = packing.pack_conv(w, [C1, C2] if C2 else None)
+    assert ops.conv2d(x1, wp, bias, x2=x2, probe_in_scsh=True)
+    scsh = ops.gn_finalize(x1.gn_stats, C1, x2.gn_stats if C2 else None, C2, gamma, beta, B, H * W, 32, 1e-5)
+    cat = x1.float() if x2 is None else torch.cat([x1, x2], dim=-1).float()
+    gn = F.group_norm(cat.permute(0, 3, 1, 2), 32, gamma, beta, 1e-5)
+    # the table itself: scale = rstd * gamma, shift = beta - mean * scale
+    tab = scsh.reshape(B, Ct // 64, 2, 64)
+    sc = tab[:, :, 0].reshape(B, Ct)
+    sh = tab[:, :, 1].reshape(B, Ct)
+    gn_from_table = cat * sc[:, None, None, :] + sh[:, None, None, :]
+    torch.testing.assert_close(gn_from_table.permute(0, 3, 1, 2), gn, rtol=2e-3, atol=2e-3)
+    out = ops.conv2d(x1, wp, bias, x2=x2, in_scsh=scsh, in_act=1, rowvec=temb, residual=res, colstats=True)
+    ref = F.conv2d(F.silu(gn).bfloat16().float(), w.bfloat16().float(), bias, padding=1).permute(0, 2, 3, 1)
+    ref = ref + temb[:, None, None, :] + res.float()
+    _close(out, ref, atol=3e-2, what=f"gn+silu+conv3x3 fused {B,H,W,C1,C2,N}")
+    # statistics of the output in the patch-staged kernel's slot order
+    st = ops.gn_stats_of(out)
+    assert st is not None
+    rows = (H * W) // st.slots_per_sample
+    tile = (32, 8, 1) if W % 32 == 0 else (16, 16, 1) if W == 16 else (8, 8, 4)
+    sref = _colstats_ref(out, rows, tile)
+    n = min(sref.shape[0], st.data.shape[0])
+    live = B * st.slots_per_sample                               # slots of images that exist
+    torch.testing.assert_close(st.data[:live], sref[:live], rtol=2e-4, atol=5e-3)
+    assert n >= live
+    # and the next layer's normalisation from them == group_norm of the stored output
+    g2 = _rand((N,), cuda, seed=9) * 0.2 + 1.0
+    b2 = _rand((N,), cuda, seed=11) * 0.2
+    tab2 = ops.gn_finalize(st, N, None, 0, g2, b2, B, H * W, 32, 1e-5).reshape(B, N // 64, 2, 64)
+    got2 = out.float() * tab2[:, :, 0].reshape(B, 1, 1, N) + tab2[:, :, 1].reshape(B, 1, 1, N)
+    ref2 = F.group_norm(out.float().permute(0, 3, 1, 2), 32, g2, b2, 1e-5).permute(0, 2, 3, 1)
+    torch.testing.assert_close(got2, ref2, rtol=2e-3, atol=3e-3)
+
+
+def test_fused_gn_matches_unfused_resblock(ops, cuda):
+    """hipnn.Conv2d(norm=...) takes the fused path when statistics ride on the input and the unfused GroupNorm kernels
+    otherwise; both must agree to bf16 rounding of the normalised activations"""
+    import sgm.modules.hipnn as H
+    from sgm.util import skip_param_init
+    from udifftext_amd import packing, synth
+    with skip_param_init():
+        norm = H.GroupNorm(32, 640)
+        conv = H.Conv2d(640, 320, 3, padding=1)
+    synth.fill_module_(norm, "t.norm."); synth.fill_module_(conv, "t.conv.")
+    norm.to(cuda); conv.to(cuda)
+    a = (_rand((2 * 32 * 32, 128), cuda, 1.5, seed=1) + 0.3).bfloat16()
+    wq = packing.pack_linear(_rand((640, 128), cuda, 0.1, seed=2))
+    y = ops.linear(a, wq, None, rows_per_batch=1024, colstats=True)
+    x = H.carry_stats(y.reshape(2, 32, 32, 640), y)
+    prev = H.FUSE_GN
+    try:
+        H.FUSE_GN = True
+        fused = conv(x, norm=norm, norm_silu=True)
+        H.FUSE_GN = False
+        plain = conv(x, norm=norm, norm_silu=True)
+    finally:
+        H.FUSE_GN = prev
+    _close(fused, plain, atol=3e-2, what="fused vs unfused GN+SiLU+conv")
+    assert (fused.float() - plain.float()).abs().mean().item() < 4e-3
 
 
 def test_conv_epilogue(ops, cuda):

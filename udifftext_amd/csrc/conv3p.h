@@ -290,27 +290,36 @@ __global__ void __launch_bounds__(NTHREADS) conv3p_kernel(const CParams cp) {
     }
     if constexpr (GN) buf_lds16(rsrc_s, scsh_lds + (c & 1) * 2048 + (wave & 1) * 1024, s_voff, c * 512);
   };
-  // GN: rewrite piece i of chunk c's patch (staged by THIS wave, already landed) as act(x * scale + shift)
+  // GN: rewrite piece i of chunk c's patch (staged by THIS wave, already landed) as act(x * scale + shift).  A lane's 8
+  // channels are the same for every piece (koff), so with one image per tile the chunk's 16 scale / shift values are
+  // read from LDS once (load_scsh) and kept in registers for all pieces; the four-image 8x8 tile reads them per piece.
+  f32x4 gs0 = {0.f, 0.f, 0.f, 0.f}, gs1 = gs0, gh0 = gs0, gh1 = gs0;
+  const bool one_image = (ge.NI == 1);
+  auto load_scsh = [&](int c, int img) {
+    const float* sc = reinterpret_cast<const float*>(scsh_lds + (c & 1) * 2048 + img * 512) + koff;
+    gs0 = *reinterpret_cast<const f32x4*>(sc);
+    gs1 = *reinterpret_cast<const f32x4*>(sc + 4);
+    gh0 = *reinterpret_cast<const f32x4*>(sc + 64);
+    gh1 = *reinterpret_cast<const f32x4*>(sc + 68);
+  };
   auto transform_piece = [&](auto i_c, int c) {
     constexpr int I = decltype(i_c)::value;
     if constexpr (GN && I < PP) {
       if (wave + 8 * I < ge.n_pieces) {              // not a duplicate (wave-uniform)
         const int info = p_info[I];
         char* cell = patches + (c & 1) * PATCH_BYTES + p_piece[I] * 1024 + lane * 16;
+        if (!one_image) load_scsh(c, (info >> 28) & 3);
         if (info >= 0) {
           const u32x4 v = *reinterpret_cast<const u32x4*>(cell);
-          const float* sc = reinterpret_cast<const float*>(scsh_lds + (c & 1) * 2048 + ((info >> 28) & 3) * 512) + koff;
-          const f32x4 s0 = *reinterpret_cast<const f32x4*>(sc), s1 = *reinterpret_cast<const f32x4*>(sc + 4);
-          const f32x4 h0 = *reinterpret_cast<const f32x4*>(sc + 64), h1 = *reinterpret_cast<const f32x4*>(sc + 68);
           float o[8];
-          o[0] = bf16_lo(v[0]) * s0[0] + h0[0];
-          o[1] = bf16_hi(v[0]) * s0[1] + h0[1];
-          o[2] = bf16_lo(v[1]) * s0[2] + h0[2];
-          o[3] = bf16_hi(v[1]) * s0[3] + h0[3];
-          o[4] = bf16_lo(v[2]) * s1[0] + h1[0];
-          o[5] = bf16_hi(v[2]) * s1[1] + h1[1];
-          o[6] = bf16_lo(v[3]) * s1[2] + h1[2];
-          o[7] = bf16_hi(v[3]) * s1[3] + h1[3];
+          o[0] = bf16_lo(v[0]) * gs0[0] + gh0[0];
+          o[1] = bf16_hi(v[0]) * gs0[1] + gh0[1];
+          o[2] = bf16_lo(v[1]) * gs0[2] + gh0[2];
+          o[3] = bf16_hi(v[1]) * gs0[3] + gh0[3];
+          o[4] = bf16_lo(v[2]) * gs1[0] + gh1[0];
+          o[5] = bf16_hi(v[2]) * gs1[1] + gh1[1];
+          o[6] = bf16_lo(v[3]) * gs1[2] + gh1[2];
+          o[7] = bf16_hi(v[3]) * gs1[3] + gh1[3];
           if (p.in_act == 1) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) o[j] = silu_f(o[j]);
@@ -347,6 +356,7 @@ __global__ void __launch_bounds__(NTHREADS) conv3p_kernel(const CParams cp) {
     if constexpr (GN) {
       // first chunk of the segment: its patch (+ scale/shift) was requested ahead of the two weight tiles in flight
       wait_vm<2 * NWP>();
+      if (one_image) load_scsh(c0, 0);
       transform_piece(I0{}, c0); transform_piece(I1{}, c0); transform_piece(I2{}, c0); transform_piece(I3{}, c0);
       transform_piece(I4{}, c0); transform_piece(I5{}, c0); transform_piece(I6{}, c0);
       lds_writes_done();
@@ -415,12 +425,15 @@ __global__ void __launch_bounds__(NTHREADS) conv3p_kernel(const CParams cp) {
       if constexpr (GN) {
         if (nxt && dy >= 1) {
           if (dy == 1) {
+            if (DX == 0 && one_image) load_scsh(c + 1, 0);
             transform_piece(std::integral_constant<int, DX>{}, c + 1);
           } else {
             transform_piece(std::integral_constant<int, 3 + DX>{}, c + 1);
-            if (DX == 2) transform_piece(I6{}, c + 1);
+            if (DX == 2) {
+              transform_piece(I6{}, c + 1);
+              lds_writes_done();          // LDS ops retire in order: one wait ahead of the next chunk's first barrier
+            }
           }
-          lds_writes_done();
         }
       }
     };

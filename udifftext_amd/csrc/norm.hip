@@ -253,60 +253,65 @@ __global__ void __launch_bounds__(256) layernorm_kernel(const uint16_t* __restri
 
 
 // ---- GroupNorm statistics from producer epilogues -------------------------------------------------------------
-// grid (ceil(G / gpb), B): a workgroup owns `gpb` whole groups of one sample; thread t <-> channel c = g0 * cpg + t.
-// Sums the sample's slots per channel (coalesced over channels), combines channels -> group in fp64 (as gn_apply does),
-// writes the chunk-blocked scale / shift table the patch-staged convolution DMAs: scsh[b][c / 64][0][c % 64] = scale,
+// grid (G, B): one workgroup per (sample, group).  Thread t = (slot lane t / cpg, channel t % cpg): the slot lanes share
+// the sample's slots of a channel (all loads of a workgroup in flight at once — the kernel is pure latency), the
+// channel totals and the group totals are combined in fp64 (as gn_apply does), and the group's channels write the
+// chunk-blocked scale / shift table the patch-staged convolution DMAs: scsh[b][c / 64][0][c % 64] = scale,
 // [1][c % 64] = shift.
 __global__ void __launch_bounds__(256) gn_finalize_kernel(const float* __restrict__ st1, int slots1, int C1,
                                                           const float* __restrict__ st2, int slots2, int C2,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                          float* __restrict__ scsh, long long HW, int G, int gpb, float eps) {
+                                                          float* __restrict__ scsh, long long HW, int G, float eps) {
   __shared__ double ssum[256], ssq[256];
-  __shared__ float gmean[32], grstd[32];
+  __shared__ double csum[128], csq[128];
+  __shared__ float gstat[2];
   const int C = C1 + C2;
-  const int cpg = C / G;
+  const int cpg = C / G;                              // <= 128
   const int b = blockIdx.y;
-  const int g0 = blockIdx.x * gpb;
+  const int g = blockIdx.x;
   const int t = threadIdx.x;
-  int ng = G - g0;
-  if (ng > gpb) ng = gpb;
-  const int c = g0 * cpg + t;
-  const bool active = t < ng * cpg;
+  const int nsl = 256 / cpg;                          // slot lanes
+  const int sl = t / cpg;
+  const int j = t - sl * cpg;
+  const int c = g * cpg + j;
   double a = 0.0, q = 0.0;
-  if (active) {
+  if (sl < nsl) {
     const bool second = c >= C1;
     const float* src = second ? st2 + ((long long)b * slots2 * C2 + (c - C1)) * 2 : st1 + ((long long)b * slots1 * C1 + c) * 2;
     const int n = second ? slots2 : slots1;
     const long long stride = (long long)(second ? C2 : C1) * 2;
-    float fa = 0.f, fq = 0.f;                         // fp32 over <= 16 slots at a time, fp64 across
-    for (int k = 0; k < n; ++k) {
+    for (int k = sl; k < n; k += nsl) {
       const f32x2 v = *reinterpret_cast<const f32x2*>(src + k * stride);
-      fa += v[0];
-      fq += v[1];
-      if ((k & 15) == 15) { a += (double)fa; q += (double)fq; fa = fq = 0.f; }
+      a += (double)v[0];
+      q += (double)v[1];
     }
-    a += (double)fa;
-    q += (double)fq;
   }
   ssum[t] = a;
   ssq[t] = q;
   __syncthreads();
-  if (t < ng) {
+  if (t < cpg) {
+    double ca = 0.0, cq = 0.0;
+    for (int k = 0; k < nsl; ++k) { ca += ssum[k * cpg + t]; cq += ssq[k * cpg + t]; }
+    csum[t] = ca;
+    csq[t] = cq;
+  }
+  __syncthreads();
+  if (t == 0) {
     double ga = 0.0, gq = 0.0;
-    for (int k = 0; k < cpg; ++k) { ga += ssum[t * cpg + k]; gq += ssq[t * cpg + k]; }
+    for (int k = 0; k < cpg; ++k) { ga += csum[k]; gq += csq[k]; }
     const double n = (double)HW * (double)cpg;
     const double mean = ga / n;
     double var = gq / n - mean * mean;
     if (var < 0.0) var = 0.0;
-    gmean[t] = (float)mean;
-    grstd[t] = (float)(1.0 / sqrt(var + (double)eps));
+    gstat[0] = (float)mean;
+    gstat[1] = (float)(1.0 / sqrt(var + (double)eps));
   }
   __syncthreads();
-  if (active) {
-    const int gl = t / cpg;
-    const float sc = grstd[gl] * gamma[c];
-    const float sh = beta[c] - gmean[gl] * sc;
-    float* dst = scsh + (((long long)b * (C >> 6) + (c >> 6)) * 2) * 64 + (c & 63);
+  if (t < cpg) {
+    const int cc = g * cpg + t;
+    const float sc = gstat[1] * gamma[cc];
+    const float sh = beta[cc] - gstat[0] * sc;
+    float* dst = scsh + (((long long)b * (C >> 6) + (cc >> 6)) * 2) * 64 + (cc & 63);
     dst[0] = sc;
     dst[64] = sh;
   }
@@ -318,13 +323,10 @@ extern "C" int udt_gn_finalize(const float* stats1, int32_t slots1, int32_t C1, 
                                int32_t C2, const float* gamma, const float* beta, float* scsh, int32_t B, int64_t HW,
                                int32_t G, float eps, void* stream) {
   if (!stats1 || !gamma || !beta || !scsh || (C2 > 0 && !stats2)) return UDT_ERR_BAD_ARG;
-  if (B <= 0 || HW <= 0 || slots1 <= 0 || C1 <= 0 || C2 < 0 || (C2 > 0 && slots2 <= 0) || G <= 0 || G > 32)
+  if (B <= 0 || HW <= 0 || slots1 <= 0 || C1 <= 0 || C2 < 0 || (C2 > 0 && slots2 <= 0) || G <= 0 || G > 256)
     return UDT_ERR_BAD_SHAPE;
   const int C = C1 + C2;
-  if (C % 64 != 0 || C % G != 0 || C / G > 256) return UDT_ERR_BAD_SHAPE;
-  const int cpg = C / G;
-  int gpb = 256 / cpg;
-  if (gpb > 32) gpb = 32;
+  if (C % 64 != 0 || C % G != 0 || C / G > 128) return UDT_ERR_BAD_SHAPE;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   UdtProfScope prof(4, s);
   if (prof.rec) {
@@ -332,8 +334,8 @@ extern "C" int udt_gn_finalize(const float* stats1, int32_t slots1, int32_t C1, 
     snprintf(tag, sizeof(tag), "gn_finalize B=%d HW=%lld C=%d+%d slots=%d", B, (long long)HW, C1, C2, slots1);
     udt_prof_tag(prof.rec, tag);
   }
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3((G + gpb - 1) / gpb, B), dim3(256), 0, s, stats1, slots1, C1, stats2, slots2, C2,
-                     gamma, beta, scsh, (long long)HW, G, gpb, eps);
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(G, B), dim3(256), 0, s, stats1, slots1, C1, stats2, slots2, C2, gamma, beta, scsh,
+                     (long long)HW, G, eps);
   UDT_CHECK_LAUNCH();
   return UDT_OK;
 }

@@ -8,7 +8,7 @@ from __future__ import annotations
 import contextlib
 import ctypes as C
 import threading
-from typing import Optional
+from typing import NamedTuple, Optional
 
 import torch
 
@@ -120,20 +120,50 @@ def gemm_desc(**kw) -> L.GemmDesc:
     return d
 
 
-def run_gemm(d: L.GemmDesc, device) -> None:
+def run_gemm(d: L.GemmDesc, device, fused_gn: bool = False) -> None:
     lib = L.load()
     need = lib.udt_gemm_workspace_bytes(C.byref(d))
     ws_ptr, ws_bytes = None, 0
     if need:
         ws = _ws(need, device)
         ws_ptr, ws_bytes = ws.data_ptr(), ws.numel()
-    L.check(lib.udt_gemm(C.byref(d), ws_ptr, ws_bytes, _stream()), "udt_gemm")
+    if fused_gn:
+        L.check(lib.udt_gn_silu_conv3x3_fwd(C.byref(d), ws_ptr, ws_bytes, _stream()), "udt_gn_silu_conv3x3_fwd")
+    else:
+        L.check(lib.udt_gemm(C.byref(d), ws_ptr, ws_bytes, _stream()), "udt_gemm")
+
+
+class GnStats(NamedTuple):
+    """column statistics a producer's epilogue emitted for its output (udt_gemm_desc.colstats): fp32
+    [slots, C, 2] = per-(row slot, channel) (sum, sum of squares); a sample owns ``slots_per_sample`` consecutive slots"""
+    data: torch.Tensor
+    slots_per_sample: int
+
+
+def gn_stats_of(t: Optional[torch.Tensor]) -> Optional[GnStats]:
+    return getattr(t, "gn_stats", None) if t is not None else None
+
+
+def _attach_colstats(d: L.GemmDesc, out: torch.Tensor, n_cols: int, rows_per_batch: int) -> bool:
+    """ask the library whether this problem can emit column statistics; if so allocate them and point the
+    descriptor at them (the tensor rides on ``out.gn_stats``)"""
+    lib = L.load()
+    rows = lib.udt_gemm_colstats_rows(C.byref(d))
+    if rows <= 0:
+        return False
+    slots = lib.udt_gemm_colstats_slots(C.byref(d))
+    st = torch.empty((slots, n_cols, 2), dtype=torch.float32, device=out.device)
+    d.colstats = st.data_ptr()
+    out.gn_stats = GnStats(st, rows_per_batch // rows)
+    return True
 
 
 def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, *, out: Optional[torch.Tensor] = None,
            residual: Optional[torch.Tensor] = None, rowvec: Optional[torch.Tensor] = None, rows_per_batch: int = 0,
-           flags: int = 0, alpha: float = 1.0, n_out: Optional[int] = None) -> torch.Tensor:
-    """out[M, N] = epilogue(x[M, K] @ w[N, K]^T).  x may be a strided row view (last dim contiguous)."""
+           flags: int = 0, alpha: float = 1.0, n_out: Optional[int] = None, colstats: bool = False) -> torch.Tensor:
+    """out[M, N] = epilogue(x[M, K] @ w[N, K]^T).  x may be a strided row view (last dim contiguous).
+    colstats: also emit the per-column partial sums of the output (``out.gn_stats``, None when the plan cannot) —
+    the GroupNorm statistics of the next layer; needs rows_per_batch (rows of one sample)."""
     _bf16(x); _bf16(w)
     K = x.shape[-1]
     x2 = x.reshape(-1, K) if x.is_contiguous() else x
@@ -154,6 +184,8 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
                   M=M, N=N, K=K, lda=x2.stride(0), ldo=ldo, ldr=(residual.stride(0) if residual is not None else 0),
                   rows_per_batch=rows_per_batch, ld_rowvec=(rowvec.stride(0) if rowvec is not None else 0), flags=flags,
                   alpha=alpha)
+    if colstats and rows_per_batch > 0 and out.is_contiguous():
+        _attach_colstats(d, out, n_cols, rows_per_batch)
     run_gemm(d, x.device)
     if WORK_COUNTER is not None:
         count_work("gemm", 2.0 * M * N * K)
@@ -186,9 +218,13 @@ def conv2d(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
            pad: Optional[tuple] = None, upsample: bool = False, x2: Optional[torch.Tensor] = None,
            out_hw: Optional[tuple] = None, residual: Optional[torch.Tensor] = None,
            rowvec: Optional[torch.Tensor] = None, flags: int = 0, n_out: Optional[int] = None,
-           out: Optional[torch.Tensor] = None) -> torch.Tensor:
+           out: Optional[torch.Tensor] = None, colstats: bool = False, in_scsh: Optional[torch.Tensor] = None,
+           in_act: int = 0, probe_in_scsh: bool = False):
     """NHWC convolution as implicit GEMM.  x [B,H,W,C1] (+ optional x2 [B,H,W,C2], channel concat) bf16;
-    w [N, ksize*ksize*(C1+C2)] packed tap-major.  Returns [B,Hout,Wout,N]."""
+    w [N, ksize*ksize*(C1+C2)] packed tap-major.  Returns [B,Hout,Wout,N].
+    in_scsh / in_act: GroupNorm scale/shift table (gn_finalize) + activation applied to the input on the staged patch
+    (udt_gn_silu_conv3x3_fwd); colstats: emit the output's column statistics (``out.gn_stats``);
+    probe_in_scsh: no launch — returns whether the library would accept in_scsh for this problem."""
     _bf16(x); _bf16(w)
     assert x.is_contiguous() and w.is_contiguous()
     B, H, W_, C1 = x.shape
@@ -207,16 +243,26 @@ def conv2d(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
     K = ksize * ksize * (C1 + C2)
     assert w.shape[1] == K, (w.shape, K)
     M = B * Ho * Wo
-    if out is None:
+    if out is None and not probe_in_scsh:
         dt = torch.float32 if (flags & L.GEMM_OUT_F32) else torch.bfloat16
         out = torch.empty((B, Ho, Wo, N), dtype=dt, device=x.device)
     d = gemm_desc(a=_ptr(x), a2=_ptr(x2), w=_ptr(w), bias=_ptr(bias), residual=_ptr(residual), rowvec=_ptr(rowvec),
-                  out=_ptr(out), M=M, N=N, K=K, lda=0, ldo=out.stride(2),
+                  out=_ptr(out), M=M, N=N, K=K, lda=0, ldo=(out.stride(2) if out is not None else N),
                   ldr=(residual.stride(2) if residual is not None else 0),
                   Hin=H, Win=W_, C1=C1, C2=C2, Hout=Ho, Wout=Wo, ksize=ksize, stride=stride, pad_t=pad[0], pad_l=pad[1],
                   upsample=1 if upsample else 0, rows_per_batch=Ho * Wo,
                   ld_rowvec=(rowvec.stride(0) if rowvec is not None else 0), flags=flags | L.GEMM_CONV)
-    run_gemm(d, x.device)
+    if probe_in_scsh:
+        return bool(L.load().udt_gemm_in_scsh_ok(C.byref(d)))
+    if colstats:
+        _attach_colstats(d, out, N, Ho * Wo)
+    if in_scsh is not None:
+        assert in_scsh.dtype == torch.float32 and in_scsh.is_contiguous() and in_scsh.numel() == B * (C1 + C2) * 2
+        d.in_scsh = in_scsh.data_ptr()
+        d.in_act = int(in_act)
+        run_gemm(d, x.device, fused_gn=True)
+    else:
+        run_gemm(d, x.device)
     return out
 
 
@@ -291,6 +337,18 @@ def group_norm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, groups:
     L.check(lib.udt_gn_apply(_ptr(x), _ptr(x2), _ptr(out), _ptr(part), _ptr(gamma), _ptr(beta), B, HW, C1, C2, groups,
                              eps, 1 if silu else 0, _stream()), "udt_gn_apply")
     return out
+
+
+def gn_finalize(st1: GnStats, C1: int, st2: Optional[GnStats], C2: int, gamma: torch.Tensor, beta: torch.Tensor, B: int,
+                HW: int, groups: int, eps: float) -> torch.Tensor:
+    """producer-epilogue statistics (one or two concatenated sources) -> per-(sample, channel) GroupNorm scale/shift,
+    fp32 [B, (C1+C2)/64, 2, 64] (the table udt_gn_silu_conv3x3_fwd reads)"""
+    Ct = C1 + C2
+    scsh = torch.empty((B, Ct // 64, 2, 64), dtype=torch.float32, device=st1.data.device)
+    L.check(L.load().udt_gn_finalize(_ptr(st1.data), st1.slots_per_sample, C1, _ptr(st2.data) if st2 is not None else None,
+                                     st2.slots_per_sample if st2 is not None else 0, C2, _ptr(gamma), _ptr(beta), _ptr(scsh),
+                                     B, HW, groups, eps, _stream()), "udt_gn_finalize")
+    return scsh
 
 
 def layer_norm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-5,

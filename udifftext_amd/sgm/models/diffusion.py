@@ -43,7 +43,9 @@ class DiffusionEngine(nn.Module):
         if ckpt_path is not None:
             self.init_from_ckpt(ckpt_path)
 
-    def init_from_ckpt(self, path: str) -> None:
+    def init_from_ckpt(self, path: str):
+        """reference diffusion.py:87-105 (.ckpt / .safetensors, strict=False, prints the key report); also returns
+        (missing, unexpected)"""
         sd = _load_checkpoint(path)
         missing, unexpected = self.load_state_dict(sd, strict=False)
         print(f"Restored from {path} with {len(missing)} missing and {len(unexpected)} unexpected keys")
@@ -51,6 +53,13 @@ class DiffusionEngine(nn.Module):
             print(f"Missing Keys: {missing}")
         if unexpected:
             print(f"Unexpected Keys: {unexpected}")
+        return missing, unexpected
+
+    def prepare(self, free_masters: bool = False, dedup_vae: bool = True):
+        """load-time packing of the device weight layouts, VAE dedup, optional release of the fp32 masters
+        (udifftext_amd.prepare)"""
+        from udifftext_amd.prepare import prepare
+        return prepare(self, free_masters=free_masters, dedup_vae=dedup_vae)
 
     def freeze(self):
         for p in self.parameters():

@@ -30,6 +30,9 @@ class GEGLU(H._Packed):
     def _key(self):
         return self.proj._key()
 
+    def fused_children(self):
+        return [self.proj]
+
     def _pack(self):
         return packing.pack_geglu(self.proj.weight, self.proj.bias)
 
@@ -67,6 +70,9 @@ class CrossAttention(H._Packed):
 
     def _key(self):
         return self.to_k._key() + self.to_v._key()
+
+    def fused_children(self):
+        return [self.to_k, self.to_v]
 
     def _pack(self):
         return H.fuse_rows(self.to_k.weight, self.to_v.weight)
@@ -116,6 +122,9 @@ class MemoryEfficientCrossAttention(H._Packed):
 
     def _key(self):
         return self.to_q._key() + self.to_k._key() + self.to_v._key()
+
+    def fused_children(self):
+        return [self.to_q, self.to_k, self.to_v]
 
     def _pack(self):
         return H.fuse_rows(self.to_q.weight, self.to_k.weight), packing.pack_linear(self.to_v.weight)
@@ -195,5 +204,6 @@ class SpatialTransformer(nn.Module):
         for i, blk in enumerate(self.transformer_blocks):
             t = blk(t, t_context=t_context, t_kv=(t_kv[i] if t_kv is not None else None), emit_map=emit_map,
                     zero_ctx_rows=zero_ctx_rows)
-        out = self.proj_out(t.reshape(B * N, -1), residual=x.reshape(B * N, C))
-        return out.reshape(B, Hh, Ww, C)
+        # the output feeds a ResBlock's GroupNorm (and maybe a skip concat): statistics from the GEMM epilogue
+        out = self.proj_out(t.reshape(B * N, -1), residual=x.reshape(B * N, C), rows_per_batch=N, colstats=True)
+        return H.carry_stats(out.reshape(B, Hh, Ww, C), out)

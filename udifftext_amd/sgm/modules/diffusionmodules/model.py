@@ -28,6 +28,7 @@ class Upsample(nn.Module):
         super().__init__()
         assert with_conv
         self.conv = H.Conv2d(in_channels, in_channels, 3, padding=1)
+        self.conv.emit_colstats = True            # feeds the next ResnetBlock's GroupNorm
 
     def forward(self, x):
         return self.conv(x, upsample=True)
@@ -38,6 +39,7 @@ class Downsample(nn.Module):
         super().__init__()
         assert with_conv
         self.conv = H.Conv2d(in_channels, in_channels, 3, stride=2, padding=0)
+        self.conv.emit_colstats = True
 
     def forward(self, x):
         Hh, Ww = x.shape[1], x.shape[2]
@@ -60,10 +62,11 @@ class ResnetBlock(nn.Module):
             self.nin_shortcut = H.Conv2d(in_channels, out_channels, 1)
 
     def forward(self, x, temb=None):
-        h = self.conv1(self.norm1(x, silu=True))
-        hn = self.norm2(h, silu=True)
+        # GroupNorm(eps 1e-6) -> swish -> conv3x3, twice (reference :128-143): the norms run on the convolutions' staged
+        # input patches with statistics from the producers' epilogues (hipnn.Conv2d.forward, norm=)
+        h = self.conv1(x, norm=self.norm1, norm_silu=True, colstats=True)
         skip = self.nin_shortcut(x) if self.in_channels != self.out_channels else x
-        return self.conv2(hn, residual=skip)
+        return self.conv2(h, residual=skip, norm=self.norm2, norm_silu=True, colstats=True)
 
 
 class MemoryEfficientAttnBlock(H._Packed):
@@ -78,6 +81,9 @@ class MemoryEfficientAttnBlock(H._Packed):
 
     def _key(self):
         return self.q._key() + self.k._key() + self.v._key() + self.proj_out._key()
+
+    def fused_children(self):
+        return [self.q, self.k, self.v, self.proj_out]
 
     def _pack(self):
         c = self.in_channels
@@ -96,8 +102,8 @@ class MemoryEfficientAttnBlock(H._Packed):
         s = ops.bmm_nt(qk[..., :C], qk[..., C:], alpha=C ** -0.5)                    # [B, N, N]
         ops.softmax_rows_(s)
         o = ops.bmm_nt(s, vt)                                                        # [B, N, C]
-        out = ops.linear(o.reshape(B * N, C), wo, bo, residual=x.reshape(B * N, C))
-        return out.reshape(B, Hh, Ww, C)
+        out = ops.linear(o.reshape(B * N, C), wo, bo, residual=x.reshape(B * N, C), rows_per_batch=N, colstats=True)
+        return H.carry_stats(out.reshape(B, Hh, Ww, C), out)
 
 
 def make_attn(in_channels, attn_type="vanilla", attn_kwargs=None):
@@ -122,6 +128,7 @@ class Encoder(nn.Module):
         self.ch, self.num_resolutions, self.num_res_blocks = ch, len(ch_mult), num_res_blocks
         self.resolution, self.in_channels = resolution, in_channels
         self.conv_in = H.Conv2d(in_channels, ch, 3, padding=1)
+        self.conv_in.emit_colstats = True
         in_ch_mult = (1,) + tuple(ch_mult)
         self.down = nn.ModuleList()
         block_in = ch
@@ -152,7 +159,7 @@ class Encoder(nn.Module):
             if lv != self.num_resolutions - 1:
                 h = self.down[lv].downsample(h)
         h = self.mid.block_2(self.mid.attn_1(self.mid.block_1(h)))
-        return self.conv_out(self.norm_out(h, silu=True))
+        return self.conv_out(h, norm=self.norm_out, norm_silu=True)
 
 
 class Decoder(nn.Module):
@@ -166,6 +173,7 @@ class Decoder(nn.Module):
         self.resolution, self.in_channels, self.out_ch = resolution, in_channels, out_ch
         block_in = ch * ch_mult[self.num_resolutions - 1]
         self.conv_in = H.Conv2d(z_channels, block_in, 3, padding=1)
+        self.conv_in.emit_colstats = True
         self.mid = _Level()
         self.mid.block_1 = ResnetBlock(in_channels=block_in, out_channels=block_in, temb_channels=0, dropout=dropout)
         self.mid.attn_1 = make_attn(block_in, attn_type=attn_type)
@@ -197,4 +205,4 @@ class Decoder(nn.Module):
                 h = blk(h)
             if lv != 0:
                 h = self.up[lv].upsample(h)
-        return self.conv_out(self.norm_out(h, silu=True), flags=H.GEMM_OUT_F32)
+        return self.conv_out(h, norm=self.norm_out, norm_silu=True, flags=H.GEMM_OUT_F32)

@@ -49,6 +49,7 @@ class Upsample(nn.Module):
         self.channels = channels
         self.out_channels = out_channels or channels
         self.conv = H.Conv2d(channels, self.out_channels, 3, padding=padding)
+        self.conv.emit_colstats = True            # feeds the next ResBlock's GroupNorm
 
     def forward(self, x):
         assert x.shape[-1] == self.channels
@@ -62,6 +63,7 @@ class Downsample(nn.Module):
         self.channels = channels
         self.out_channels = out_channels or channels
         self.op = H.Conv2d(channels, self.out_channels, 3, stride=2, padding=padding)
+        self.op.emit_colstats = True              # feeds the next ResBlock's GroupNorm (and a skip concat later)
 
     def forward(self, x):
         assert x.shape[-1] == self.channels
@@ -91,14 +93,15 @@ class ResBlock(TimestepBlock):
         """x (+ optional skip source x2, concatenated on channels): bf16 NHWC; emb_rows: fp32 [B, *] whose columns
         [emb_offset, emb_offset + out_channels) hold this block's Linear(SiLU(emb)) (UnifiedUNetModel.time_embedding_rows)."""
         emb_out = emb_rows[:, self.emb_offset:self.emb_offset + self.out_channels]
-        h = self.in_layers[2](self.in_layers[0](x, x2=x2, silu=True), rowvec=emb_out)
-        hn = self.out_layers[0](h, silu=True)
+        # GroupNorm32 -> SiLU -> conv3x3 twice (reference :183-187,218-231): the norms run on the convolutions' staged
+        # input patches, their statistics come out of the producers' epilogues (hipnn.Conv2d.forward, norm=)
+        h = self.in_layers[2](x, x2=x2, rowvec=emb_out, norm=self.in_layers[0], norm_silu=True, colstats=True)
         if isinstance(self.skip_connection, nn.Identity):
             assert x2 is None
             skip = x
         else:
             skip = self.skip_connection(x, x2=x2)
-        return self.out_layers[3](hn, residual=skip)
+        return self.out_layers[3](h, residual=skip, norm=self.out_layers[0], norm_silu=True, colstats=True)
 
 
 class TimestepEmbedSequential(nn.Sequential, TimestepBlock):
@@ -151,6 +154,7 @@ class UnifiedUNetModel(nn.Module):
                                       use_linear=use_linear_in_transformer)
 
         self.input_blocks = nn.ModuleList([TimestepEmbedSequential(H.Conv2d(in_channels, model_channels, 3, padding=1))])
+        self.input_blocks[0][0].emit_colstats = True
         chans = [model_channels]
         ch, ds = model_channels, 1
         for level, mult in enumerate(channel_mult):
@@ -212,6 +216,8 @@ class UnifiedUNetModel(nn.Module):
                                   "visualisation side path, out of scope (DESIGN.md)")
 
     def _emb_pack(self):
+        if getattr(self, "_emb_frozen", False):
+            return self._emb_w, self._emb_b
         key = tuple(rb.emb_layers[1]._key() for rb in self._resblocks)
         if getattr(self, "_emb_key", None) != key:
             with torch.no_grad():
@@ -246,8 +252,7 @@ class UnifiedUNetModel(nn.Module):
         h = self.middle_block(h, emb_rows, **kw)
         for block in self.output_blocks:
             h = block(h, emb_rows, x2=hs.pop(), **kw)
-        hn = self.out[0](h, silu=True)
-        return self.out[2](hn, flags=H.GEMM_OUT_F32)
+        return self.out[2](h, norm=self.out[0], norm_silu=True, flags=H.GEMM_OUT_F32, colstats=False)
 
     def forward(self, x, timesteps=None, t_context=None, v_context=None, y=None, **kwargs):
         """reference signature: x [B, in_channels, h, w] fp32, timesteps [B], t_context [B, L, Dc] -> [B, out, h, w]"""

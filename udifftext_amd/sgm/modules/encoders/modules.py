@@ -215,6 +215,10 @@ class _EncoderLayer(H._Packed):
         p = self.self_attn.in_proj_weight
         return ((p.data_ptr(), p._version, str(p.device)),)
 
+    def own_masters(self):
+        """parameters consumed only through this module's pack (not Linear / Conv2d children)"""
+        return [self.self_attn.in_proj_weight, self.self_attn.in_proj_bias]
+
     def _pack(self):
         from udifftext_amd import packing
         return packing.pack_linear(self.self_attn.in_proj_weight), self.self_attn.in_proj_bias.float().contiguous()

@@ -8,6 +8,7 @@ Activations between containers are bf16, channel-last: ``[B, H, W, C]`` (or ``[r
 from __future__ import annotations
 
 import math
+import os
 from typing import Optional
 
 import torch
@@ -24,6 +25,20 @@ def count_flops(kind: str, flops: float) -> None:
     ops.count_work(kind, flops)
 
 
+# GroupNorm(+SiLU) in front of a 3x3 convolution runs ON THE CONVOLUTION'S STAGED INPUT PATCH whenever the producers
+# of the input emitted their column statistics and the library takes the shape (ops.conv2d(in_scsh=...)); 0 = always the
+# separate gn_stats / gn_apply kernels (A/B runs)
+FUSE_GN = os.environ.get("UDT_FUSE_GN", "1") != "0"
+
+
+def carry_stats(dst: torch.Tensor, src: torch.Tensor) -> torch.Tensor:
+    """a reshape / view makes a new tensor object: hand the producer's column statistics over"""
+    st = ops.gn_stats_of(src)
+    if st is not None:
+        dst.gn_stats = st
+    return dst
+
+
 def _init_uniform_(p: torch.Tensor, fan_in: int) -> None:
     if init_skipped():
         return
@@ -33,13 +48,21 @@ def _init_uniform_(p: torch.Tensor, fan_in: int) -> None:
 
 
 class _Packed(nn.Module):
-    """mixin: cache of repacked device weights, invalidated when parameters move or change"""
+    """mixin: cache of repacked device weights, invalidated when parameters move or change.
+    ``fused_children()``: child modules whose weights this module's ``_pack`` consumes (fused q|k|v, ...) — they are never
+    evaluated on their own, so load-time ``prepare`` does not pack them separately.  After ``prepare(free_masters=True)``
+    the cache is frozen (``_pk_frozen``): the fp32 masters are gone and ``packed()`` never looks at them again."""
 
     def _key(self):
         ps = list(self.parameters(recurse=False))
         return tuple((p.data_ptr(), p._version, str(p.device)) for p in ps)
 
+    def fused_children(self):
+        return []
+
     def packed(self):
+        if getattr(self, "_pk_frozen", False):
+            return self._pk
         key = self._key()
         if getattr(self, "_pk_key", None) != key:
             with torch.no_grad():
@@ -66,9 +89,11 @@ class Linear(_Packed):
     def _pack(self):
         return packing.pack_linear(self.weight), packing.pad_bias(self.bias)
 
-    def forward(self, x, residual=None, flags: int = 0, out=None, rowvec=None, rows_per_batch: int = 0):
+    def forward(self, x, residual=None, flags: int = 0, out=None, rowvec=None, rows_per_batch: int = 0,
+                colstats: bool = False):
         w, b = self.packed()
-        return ops.linear(x, w, b, residual=residual, flags=flags, out=out, rowvec=rowvec, rows_per_batch=rows_per_batch)
+        return ops.linear(x, w, b, residual=residual, flags=flags, out=out, rowvec=rowvec, rows_per_batch=rows_per_batch,
+                          colstats=colstats)
 
 
 class Conv2d(_Packed):
@@ -86,20 +111,40 @@ class Conv2d(_Packed):
         _init_uniform_(self.bias, fan_in)
         self.segments = None
         self.n_pad = 4          # output channels are padded to a multiple of this (64 when the consumer is a GEMM)
+        self.emit_colstats = False      # the output feeds a GroupNorm: emit its statistics from the epilogue
 
     def _pack(self):
         return packing.pack_conv(self.weight, self.segments, self.n_pad), packing.pad_bias(self.bias, self.n_pad)
 
     def forward(self, x, x2=None, residual=None, rowvec=None, upsample: bool = False, flags: int = 0,
-                pad: Optional[tuple] = None, out_hw: Optional[tuple] = None):
-        if x2 is not None and self.segments is None:
+                pad: Optional[tuple] = None, out_hw: Optional[tuple] = None, norm: Optional["GroupNorm"] = None,
+                norm_silu: bool = False, colstats: Optional[bool] = None):
+        """norm (+ norm_silu): GroupNorm (+ SiLU) of the (channel-concatenated) input in front of the convolution —
+        the reference's ``GroupNorm32 -> SiLU -> conv`` chains (openaimodel.py:183-187,218-231; model.py:128-148).  Fused
+        into the convolution (statistics from the producers' epilogues, scale/shift applied on the staged patch) when
+        possible, otherwise the separate GroupNorm kernels run first.  colstats: emit the output's statistics."""
+        if x2 is not None and self.segments is None and not getattr(self, "_pk_frozen", False):
+            # (channel counts of concatenated sources; only matters when one is not a multiple of 64 — never on this path)
             self.segments = [x.shape[-1], x2.shape[-1]]
             self._pk_key = None
         w, b = self.packed()
         if pad is None:
             pad = (self.padding, self.padding)
-        out = ops.conv2d(x, w, b, ksize=self.kernel_size, stride=self.stride, pad=pad, upsample=upsample, x2=x2,
-                         out_hw=out_hw, residual=residual, rowvec=rowvec, flags=flags, n_out=w.shape[0])
+        if colstats is None:
+            colstats = self.emit_colstats
+        kw = dict(ksize=self.kernel_size, stride=self.stride, pad=pad, upsample=upsample, out_hw=out_hw, residual=residual,
+                  rowvec=rowvec, flags=flags, n_out=w.shape[0], colstats=colstats)
+        in_scsh = None
+        if norm is not None:
+            st1, st2 = ops.gn_stats_of(x), ops.gn_stats_of(x2)
+            if (FUSE_GN and st1 is not None and (x2 is None or st2 is not None)
+                    and ops.conv2d(x, w, b, x2=x2, probe_in_scsh=True, **kw)):
+                B = x.shape[0]
+                in_scsh = ops.gn_finalize(st1, x.shape[-1], st2, x2.shape[-1] if x2 is not None else 0, norm.weight,
+                                          norm.bias, B, x.shape[1] * x.shape[2], norm.num_groups, norm.eps)
+            else:
+                x, x2 = norm(x, x2=x2, silu=norm_silu), None
+        out = ops.conv2d(x, w, b, x2=x2, in_scsh=in_scsh, in_act=1 if norm_silu else 0, **kw)
         if ops.WORK_COUNTER is not None:   # algorithmic (un-padded) multiply-adds x 2
             k = self.kernel_size
             kind = "conv3x3" if k == 3 else "conv1x1"
@@ -112,7 +157,7 @@ class Conv2d(_Packed):
                 nbytes += 2.0 * npix_out * self.out_channels
             count_flops(kind + "_bytes", nbytes)
             Hh, Ww = x.shape[1], x.shape[2]
-            if (k == 3 and self.stride == 1 and x2 is None and not upsample and tuple(pad) == (1, 1)
+            if (k == 3 and self.stride == 1 and not upsample and tuple(pad) == (1, 1)
                     and self.out_channels > 64 and not (flags & L.GEMM_OUT_F32)
                     and ((Ww % 32 == 0 and Hh % 8 == 0) or (Ww == 16 and Hh % 16 == 0) or (Ww == 8 and Hh == 8))):
                 # the launches udt_gemm routes to c3p::conv3p_kernel (same test as conv3p_geometry in gemm.hip)
