@@ -115,6 +115,38 @@ def test_unet_call_vs_reference_golden(engine, cond256, eg, cuda):
     _check("get_min_local_loss vs reference", ll.cpu(), eg["g8_local_loss"], 3e-2)
 
 
+def test_unet_and_vae_with_fused_groupnorm_vs_reference_golden(engine, cond256, eg, cuda):
+    """the opt-in fused chain (UDT_FUSE_GN=1: statistics from producer epilogues -> udt_gn_finalize -> GroupNorm + SiLU on
+    the convolution's staged patch, udt_gn_silu_conv3x3_fwd) through the whole UNet and the VAE, against the same
+    reference goldens and tolerances as the default path"""
+    import sgm.modules.hipnn as H
+    from udifftext_amd import ops
+    batch, _, _ = cond256
+    prev = H.FUSE_GN
+    H.FUSE_GN = True
+    try:
+        x7 = torch.from_numpy(eg["g7_x"]).to(cuda)
+        ucc, cc = torch.from_numpy(eg["g6_uc_concat"]).to(cuda), torch.from_numpy(eg["g6_c_concat"]).to(cuda)
+        le = engine.conditioner.embedders[0]
+        tctx = torch.cat([torch.zeros((1, 12, 2048), device=cuda), le(batch["label"])])
+        xin = torch.cat([torch.cat([x7, x7]), torch.cat([ucc, cc])], dim=1)
+        ops.WORK_COUNTER = {}
+        eps = engine.model.diffusion_model(xin, timesteps=torch.tensor([999, 999], device=cuda), t_context=tctx)
+        n_fused = ops.WORK_COUNTER.get("fused_gn_convs", 0)
+        ops.WORK_COUNTER = None
+        assert n_fused >= 30, f"only {n_fused} convolutions took the fused GroupNorm path"
+        _check("UNet eps with fused GroupNorm vs reference", eps.cpu(), eg["g7_eps"], 2e-2, 8e-2)
+        g = torch.Generator().manual_seed(5)
+        img = torch.rand((1, 3, 64, 64), generator=g) * 2 - 1
+        fs = engine.first_stage_model
+        _check("VAE encoder moments with fused GroupNorm vs reference", ops.nhwc_to_nchw(fs.encode_moments(img.to(cuda)), 8).cpu(),
+               eg["g5_moments"], 2e-2, 8e-2)
+        z8 = torch.randn((1, 4, 8, 8), generator=g) * 3.0
+        _check("VAE decoder with fused GroupNorm vs reference", fs.decode(z8.to(cuda)).cpu(), eg["g5_decoded"], 2e-2, 8e-2)
+    finally:
+        H.FUSE_GN = prev
+
+
 def test_zero_context_shortcut_is_bit_exact(engine, cond256, cuda):
     """the sampler skips the t_attn GEMMs of the unconditional half (context == 0 -> x + to_out.bias); the eps must
     be bit-identical to running the full cross-attention on the zero context"""

@@ -158,6 +158,7 @@ CONV_CASES = [
     (3, 16, 16, 1280, 0, 1280, 3, 1, (1, 1), False),
     (1, 32, 64, 128, 0, 128, 3, 1, (1, 1), False),       # non-square, VAE-like
     (1, 16, 32, 192, 0, 256, 3, 1, (1, 1), False),       # 3 chunks
+    (2, 48, 48, 640, 0, 640, 3, 1, (1, 1), False),       # 48x48 maps (768x768 inputs): 3 x 3 tiles of 16x16
     (2, 32, 32, 640, 320, 640, 3, 1, (1, 1), False),     # patch-staged, two sources (skip concat), 15 chunks
     (4, 8, 8, 1280, 1280, 1280, 3, 1, (1, 1), False),    # 8x8 maps, two sources
     (1, 64, 64, 320, 320, 320, 3, 1, (1, 1), False),     # bn 160, two sources
@@ -240,7 +241,7 @@ def test_linear_colstats(ops, cuda, M, N, K, hw):
 
 
 @pytest.mark.parametrize("B,H,W,C1,C2,N", [(2, 32, 32, 320, 0, 640), (1, 64, 64, 320, 0, 320), (3, 16, 16, 640, 0, 1280),
-                                          (5, 8, 8, 1280, 0, 1280), (2, 32, 32, 640, 320, 640), (4, 8, 8, 1280, 1280, 1280),
+                                          (5, 8, 8, 1280, 0, 1280), (2, 32, 32, 640, 320, 640), (4, 8, 8, 1280, 1280, 1280), (1, 48, 48, 640, 640, 640),
                                           (2, 64, 64, 320, 320, 320), (2, 16, 16, 1280, 640, 1280)])
 def test_gn_silu_conv3x3_fused(ops, cuda, B, H, W, C1, C2, N):
     """udt_gn_silu_conv3x3_fwd: statistics from producer epilogues -> udt_gn_finalize -> GroupNorm + SiLU applied on the
@@ -289,7 +290,7 @@ def test_gn_silu_conv3x3_fused(ops, cuda, B, H, W, C1, C2, N):
     st = ops.gn_stats_of(out)
     assert st is not None
     rows = (H * W) // st.slots_per_sample
-    tile = (32, 8, 1) if W % 32 == 0 else (16, 16, 1) if W == 16 else (8, 8, 4)
+    tile = (32, 8, 1) if W % 32 == 0 else (16, 16, 1) if W % 16 == 0 else (8, 8, 4)
     sref = _colstats_ref(out, rows, tile)
     n = min(sref.shape[0], st.data.shape[0])
     live = B * st.slots_per_sample                               # slots of images that exist
@@ -322,9 +323,11 @@ def test_fused_gn_matches_unfused_resblock(ops, cuda):
     prev = H.FUSE_GN
     try:
         H.FUSE_GN = True
-        fused = conv(x, norm=norm, norm_silu=True)
+        fused = conv(x, norm=norm, norm_silu=True, colstats=True)
+        assert ops.gn_stats_of(fused) is not None
         H.FUSE_GN = False
-        plain = conv(x, norm=norm, norm_silu=True)
+        plain = conv(x, norm=norm, norm_silu=True, colstats=True)
+        assert ops.gn_stats_of(plain) is None
     finally:
         H.FUSE_GN = prev
     _close(fused, plain, atol=3e-2, what="fused vs unfused GN+SiLU+conv")

@@ -76,36 +76,33 @@ UDT_DEVINL f32x16 mfma32(bf16x8_t a, bf16x8_t b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
 
-// ---- per-column partial sums of a wave's output block -----------------------------------------------------------
-// Reduce-scatter over lane bits: every lane of a wave holds N values v[0..N) (the same N logical columns in every
-// lane, different rows); after the call lane L holds, in v[0..N >> popcount(halved bits)), the sums over the lanes that
-// differ from L in the bits of MASK.  Each step exchanges HALF of the live values with the partner lane (lane ^ bit)
-// and keeps the other half: N-1 shuffles instead of N * log2(lanes).  Step order: highest bit first; a lane whose bit
-// is set keeps the UPPER half.  So after halving over bits b1 > b2 > ... the value k of lane L is the column
-//   (L&b1 ? N/2 : 0) + (L&b2 ? N/4 : 0) + ... + k.
-// When the live count becomes odd the remaining bits are plain butterfly adds (all partner lanes hold the sum).
-template <int N, int BIT, int LOWEST>
-UDT_DEVINL void lane_reduce_scatter(float (&v)[N], int lane) {
-  if constexpr (BIT >= LOWEST) {
-    if constexpr (N % 2 == 0) {
-      constexpr int H = N / 2;
-      const bool up = (lane & BIT) != 0;
-      float keep[H];
-#pragma unroll
-      for (int j = 0; j < H; ++j) {
-        const float mine = up ? v[j + H] : v[j];
-        const float send = up ? v[j] : v[j + H];
-        keep[j] = mine + __shfl_xor(send, BIT);
-      }
-      lane_reduce_scatter<H, BIT / 2, LOWEST>(keep, lane);
-#pragma unroll
-      for (int j = 0; j < H; ++j) v[j] = keep[j];
-    } else {
-#pragma unroll
-      for (int j = 0; j < N; ++j) v[j] += __shfl_xor(v[j], BIT);
-      lane_reduce_scatter<N, BIT / 2, LOWEST>(v, lane);
-    }
-  }
+// ---- cross-lane sums without LDS traffic ---------------------------------------------------------------------------
+// DPP row operations (quad_perm / row_ror inside a row of 16 lanes) and the gfx950 row / half swaps add a value over
+// lane groups in the VALU — no ds_bpermute round trips (measured: a __shfl_xor butterfly over the 32 row lanes of an
+// accumulator tile cost ~7 us per launch in the convolution epilogues).
+template <int CTRL>
+UDT_DEVINL float dpp_add(float v) {
+  const int t = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false);
+  return v + __builtin_bit_cast(float, t);
+}
+// sum over the 16 lanes of each DPP row (lanes 16k .. 16k+15), result in every lane of the row
+UDT_DEVINL float row16_sum(float v) {
+  v = dpp_add<0xB1>(v);       // quad_perm [1,0,3,2]: lane ^ 1
+  v = dpp_add<0x4E>(v);       // quad_perm [2,3,0,1]: lane ^ 2
+  v = dpp_add<0x124>(v);      // row_ror:4
+  v = dpp_add<0x128>(v);      // row_ror:8
+  return v;
+}
+// + the neighbouring row (lane ^ 16): v_permlane16_swap exchanges the odd rows of its first operand with the even
+// rows of the second; with both operands = v the two results are [r0 r0 r2 r2] and [r1 r1 r3 r3]
+UDT_DEVINL float xor16_sum(float v) {
+  const auto r = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, v), __builtin_bit_cast(unsigned, v), false, false);
+  return __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
+}
+// + the other half of the wave (lane ^ 32)
+UDT_DEVINL float xor32_sum(float v) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, v), __builtin_bit_cast(unsigned, v), false, false);
+  return __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
 }
 
 // ---- host-side helpers -------------------------------------------------------------------------

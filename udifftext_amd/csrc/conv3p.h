@@ -21,9 +21,9 @@ using g8::Params;
 using g8::raw_barrier;
 
 // max pixel rows of a staged patch: 400 (4 x 10 x 10, the four-image 8x8 tile) with 128-channel weight tiles; the
-// 160-channel configuration (N = 320) has 20 KiB weight stages, so its patches are capped at 344 rows (34 x 10 and
-// 18 x 18 tiles) to leave room for the GroupNorm scale/shift stage
-constexpr int patch_rows(int TN) { return TN == 5 ? 344 : 400; }
+// 160-channel configuration (N = 320) has 20 KiB weight stages, so with GroupNorm on the patch its patches are capped
+// at 344 rows (34 x 10 and 18 x 18 tiles) to leave room for the scale/shift stage
+constexpr int patch_rows(int TN, bool GN) { return (TN == 5 && GN) ? 344 : 400; }
 constexpr int SCSH_BYTES = 2 * 4 * 512;            // [2 chunks in flight][<= 4 images][64 scale | 64 shift] fp32
 
 struct Geo {            // spatial tiling of the output (= input) map
@@ -62,10 +62,67 @@ UDT_DEVINL void wait_vmcnt_dyn(int n) {          // n is wave-uniform
   }
 }
 
-// epilogue with an explicit output-row table: mrow[tm] = global NHWC pixel index of this lane's row, or -1.
-// `stats` (optional): this wave block's row of the column statistics, fp32 [N][2], offset to the wave's first column
+// epilogue with an explicit output-row table: mrow[tm] = global NHWC pixel index of this lane's row, or -1
 template <int TM, int TN>
-UDT_DEVINL void epilogue_rows(const GemmParams& p, f32x16 (&acc)[TM][TN], const long long (&mrow)[TM], int n0, int col0,
+UDT_DEVINL void epilogue_rows_plain(const GemmParams& p, f32x16 (&acc)[TM][TN], const long long (&mrow)[TM], int n0, int col0,
+                              int lane) {
+  const int hi = lane >> 5;
+  const int flags = p.flags;
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm) {
+    const long long m = mrow[tm];
+    if (m < 0) continue;
+    const int b = (p.rowvec != nullptr) ? (int)(m / p.rows_per_batch) : 0;
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int n = n0 + col0 + tn * 32 + q * 8 + hi * 4;
+        if (n < p.N) {
+          float v[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = acc[tm][tn][q * 4 + r] * p.alpha;
+          if (p.bias) {
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + n);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] += bv[r];
+          }
+          if (p.rowvec) {
+            const f32x4 rv = *reinterpret_cast<const f32x4*>(p.rowvec + (long long)b * p.ldrv + n);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] += rv[r];
+          }
+          if (p.res) {
+            const u32x2 rr = *reinterpret_cast<const u32x2*>(p.res + m * p.ldr + n);
+            v[0] += bf16_lo(rr[0]);
+            v[1] += bf16_hi(rr[0]);
+            v[2] += bf16_lo(rr[1]);
+            v[3] += bf16_hi(rr[1]);
+          }
+          if (flags & UDT_GEMM_RELU) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+          }
+          if (flags & UDT_GEMM_SILU_OUT) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = silu_f(v[r]);
+          }
+          if (flags & UDT_GEMM_OUT_F32) {
+            f32x4 ov = {v[0], v[1], v[2], v[3]};
+            *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + m * p.ldo + n) = ov;
+          } else {
+            u32x2 pk = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+            *reinterpret_cast<u32x2*>(reinterpret_cast<uint16_t*>(p.out) + m * p.ldo + n) = pk;
+          }
+        }
+      }
+  }
+}
+
+// the same with column statistics of the stored values (tn-outer so that one 32-column tile's sums are live at a time).
+// `stats`: this wave block's row of the column statistics, fp32 [N][2], offset to the wave's first column
+template <int TM, int TN>
+UDT_DEVINL void epilogue_rows_stats(const GemmParams& p, f32x16 (&acc)[TM][TN], const long long (&mrow)[TM], int n0, int col0,
                               int lane, float* stats) {
   const int hi = lane >> 5;
   const int flags = p.flags;
@@ -153,15 +210,18 @@ using g8::OOB;
 // staged — in-image rows only, the zero padding stays zero — as y = act(x * scale + shift) in fp32, rounded to bf16
 // once.  The patch of chunk c+1 lands during taps 0..2 of chunk c; its pieces are transformed one per tap behind the
 // MFMAs of taps 3..8 (VALU beside the other wave's matrix work), so only the first chunk of a segment pays for it.
-template <int WGM, int WGN, int TM, int TN, bool GN>
+// STATS = true: the epilogue also emits the output's per-(row slot, column) partial sums (udt_gemm_desc.colstats).
+// The four (GN, STATS) combinations are separate kernels: the plain one is the round-1 kernel instruction for
+// instruction (this kernel's register allocation is tight: extra code anywhere in it costs 5-10 % of the launch).
+template <int WGM, int WGN, int TM, int TN, bool GN, bool STATS>
 __global__ void __launch_bounds__(NTHREADS) conv3p_kernel(const CParams cp) {
   static_assert(WGM * WGN == 8 && WGM * TM * 32 == 256, "8 waves, 256 output pixels");
   constexpr int BN = WGN * TN * 32;
   constexpr int W_BYTES = BN * ROW_BYTES;
   constexpr int W_PIECES = BN / 8;                  // 16 or 20
   constexpr int NWP = (W_PIECES + 7) / 8;           // weight pieces per wave and K-tile (2 or 3, padded with duplicates)
-  constexpr int PATCH_BYTES = patch_rows(TN) * ROW_BYTES;
-  constexpr int PP = (patch_rows(TN) / 8 + 7) / 8;  // patch pieces per wave and chunk (6 or 7, padded with duplicates)
+  constexpr int PATCH_BYTES = patch_rows(TN, GN) * ROW_BYTES;
+  constexpr int PP = (patch_rows(TN, GN) / 8 + 7) / 8;  // patch pieces per wave and chunk (6 or 7, padded with duplicates)
   constexpr int PPL = PP + (GN ? 1 : 0);            // + the scale/shift piece
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const wring = smem;                              // NSTAGE weight stages
@@ -213,7 +273,8 @@ __global__ void __launch_bounds__(NTHREADS) conv3p_kernel(const CParams cp) {
     w_piece[i] = idx;
   }
   int p_piece[PP];
-  int p_info[PP];                      // input pixel index of this lane's patch row | image-in-tile << 28, or -1 (padding)
+  unsigned p_voff[PP];                 // !GN: byte offset of this lane's 16 bytes of the patch row in the (single) source
+  int p_info[PP];                      // GN: input pixel index of this lane's patch row | image-in-tile << 28, or -1 (padding)
 #pragma unroll
   for (int i = 0; i < PP; ++i) {
     int idx = wave + 8 * i;
@@ -250,7 +311,8 @@ __global__ void __launch_bounds__(NTHREADS) conv3p_kernel(const CParams cp) {
       const int xx = rem - yy * ge.prow_w;
       const int gy = y0 + yy - 1, gx = x0 + xx - 1, b = b0 + img;
       const bool ok = (img < ge.NI) && (b < ge.B) && ((unsigned)gy < (unsigned)ge.H) && ((unsigned)gx < (unsigned)ge.W);
-      p_info[i] = ok ? ((((b * ge.H + gy) * ge.W + gx)) | (img << 28)) : -1;
+      if constexpr (GN) p_info[i] = ok ? ((((b * ge.H + gy) * ge.W + gx)) | (img << 28)) : -1;
+      else p_voff[i] = ok ? (unsigned)(((((long long)b * ge.H + gy) * ge.W + gx) * ge.C + koff) * 2) : OOB;
     }
     if constexpr (GN) {
       // scale/shift stage of a chunk: [image][64 scale | 64 shift] = 512 B per image; piece (wave & 1) of 1 KiB
@@ -280,15 +342,21 @@ __global__ void __launch_bounds__(NTHREADS) conv3p_kernel(const CParams cp) {
   };
   auto issue_patch = [&](int c) {
     char* pbuf = patches + (c & 1) * PATCH_BYTES;
-    const bool second = c >= nch1;                   // wave-uniform: the chunk lies in source 2
-    const int cs = second ? ge.C2 : ge.C1;
-    const int soff = (second ? c - nch1 : c) * 128;
+    if constexpr (GN) {
+      const bool second = c >= nch1;                   // wave-uniform: the chunk lies in source 2
+      const int cs = second ? ge.C2 : ge.C1;
+      const int soff = (second ? c - nch1 : c) * 128;
 #pragma unroll
-    for (int i = 0; i < PP; ++i) {
-      const unsigned voff = (p_info[i] >= 0) ? (unsigned)(((long long)(p_info[i] & 0x0fffffff) * cs + koff) * 2) : OOB;
-      buf_lds16(second ? rsrc_a2 : rsrc_a, pbuf + p_piece[i] * 1024, voff, soff);
+      for (int i = 0; i < PP; ++i) {
+        const unsigned voff = (p_info[i] >= 0) ? (unsigned)(((long long)(p_info[i] & 0x0fffffff) * cs + koff) * 2) : OOB;
+        buf_lds16(second ? rsrc_a2 : rsrc_a, pbuf + p_piece[i] * 1024, voff, soff);
+      }
+      buf_lds16(rsrc_s, scsh_lds + (c & 1) * 2048 + (wave & 1) * 1024, s_voff, c * 512);
+    } else {
+      const int soff = c * 128;
+#pragma unroll
+      for (int i = 0; i < PP; ++i) buf_lds16(rsrc_a, pbuf + p_piece[i] * 1024, p_voff[i], soff);
     }
-    if constexpr (GN) buf_lds16(rsrc_s, scsh_lds + (c & 1) * 2048 + (wave & 1) * 1024, s_voff, c * 512);
   };
   // GN: rewrite piece i of chunk c's patch (staged by THIS wave, already landed) as act(x * scale + shift).  A lane's 8
   // channels are the same for every piece (koff), so with one image per tile the chunk's 16 scale / shift values are
@@ -543,8 +611,12 @@ __global__ void __launch_bounds__(NTHREADS) conv3p_kernel(const CParams cp) {
       // (the row-coalesced LDS epilogue of gemm8.h was measured here too: 109 vs 95 us per launch — the cross-lane
       //  row table and the extra live state cost more than the whole-line stores return; direct stores stay)
       // column statistics: one slot per wave row block (TM * 32 pixels of one image), slots in tile order
-      float* stats = p.colstats ? p.colstats + (((long long)cur_tile_m * WGM + wm) * p.N + cur_n0 + col0) * 2 : nullptr;
-      epilogue_rows<TM, TN>(p, acc, cur_mrow, cur_n0, col0, lane, stats);
+      if constexpr (STATS) {
+        float* stats = p.colstats + (((long long)cur_tile_m * WGM + wm) * p.N + cur_n0 + col0) * 2;
+        epilogue_rows_stats<TM, TN>(p, acc, cur_mrow, cur_n0, col0, lane, stats);
+      } else {
+        epilogue_rows_plain<TM, TN>(p, acc, cur_mrow, cur_n0, col0, lane);
+      }
     }
     if (!more) break;
   }

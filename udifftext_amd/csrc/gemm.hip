@@ -634,13 +634,13 @@ TilePlan plan_tiles8(const udt_gemm_desc* d) {
   return t;
 }
 
-template <int WGM, int WGN, int TM, int TN, bool CONV, bool TRANS>
+template <int WGM, int WGN, int TM, int TN, bool CONV, bool TRANS, bool STATS = false>
 hipError_t launch8(const g8::Params& pp, const TilePlan& t, hipStream_t s) {
   constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
   // the 256x128 configuration transposes its output through LDS: stage 2 plus 16 KiB above the ring (160 KiB total)
   constexpr int smem = (TM == 2 && TN == 2 && !TRANS) ? 160 * 1024 : g8::NSTAGE * (BM + BN) * ROW_BYTES;
   static AttrOnce once;
-  auto kern = g8::gemm8_kernel<WGM, WGN, TM, TN, CONV, TRANS>;
+  auto kern = g8::gemm8_kernel<WGM, WGN, TM, TN, CONV, TRANS, STATS>;
   hipError_t e = once.ensure(reinterpret_cast<const void*>(kern), smem);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(kern, dim3(t.G), dim3(g8::NTHREADS), smem, s, pp);
@@ -648,7 +648,8 @@ hipError_t launch8(const g8::Params& pp, const TilePlan& t, hipStream_t s) {
 }
 
 // ---- patch-staged 3x3 convolution: host side -------------------------------------------------------------------
-bool conv3p_geometry(const udt_gemm_desc* d, c3p::Geo& ge) {
+// gn: the launch applies GroupNorm on the staged patch (the only variant that reads a second source)
+bool conv3p_geometry(const udt_gemm_desc* d, c3p::Geo& ge, bool gn) {
   int on = g_conv3p.load(std::memory_order_relaxed);
   if (on < 0) {
     const char* e = getenv("UDT_CONV3P");
@@ -659,10 +660,10 @@ bool conv3p_geometry(const udt_gemm_desc* d, c3p::Geo& ge) {
   if (!(d->flags & UDT_GEMM_CONV) || d->ksize != 3 || d->stride != 1 || d->upsample) return false;
   if (d->pad_t != 1 || d->pad_l != 1 || d->Hout != d->Hin || d->Wout != d->Win || d->N <= 64) return false;
   if (d->flags & (UDT_GEMM_GEGLU | UDT_GEMM_TRANSPOSED)) return false;
-  if (d->C1 <= 0 || d->C1 % 64 != 0 || d->C2 < 0 || d->C2 % 64 != 0) return false;
+  if (d->C1 <= 0 || d->C1 % 64 != 0 || d->C2 < 0 || d->C2 % 64 != 0 || (d->C2 != 0 && !gn)) return false;
   const int H = d->Hin, W = d->Win;
   if (W % 32 == 0 && H % 8 == 0) { ge.TW = 32; ge.TH = 8; ge.NI = 1; }
-  else if (W == 16 && H % 16 == 0) { ge.TW = 16; ge.TH = 16; ge.NI = 1; }
+  else if (W % 16 == 0 && H % 16 == 0) { ge.TW = 16; ge.TH = 16; ge.NI = 1; }      // 16x16, 48x48 (768x768 inputs), ...
   else if (W == 8 && H == 8) { ge.TW = 8; ge.TH = 8; ge.NI = 4; }
   else return false;
   ge.B = d->M / (H * W);
@@ -679,7 +680,7 @@ bool conv3p_geometry(const udt_gemm_desc* d, c3p::Geo& ge) {
   if ((long long)d->N * (d->ldw > 0 ? d->ldw : d->K) * 2 >= (1LL << 31)) return false;
   if ((long long)ge.B * ge.chunks * 512 >= (1LL << 31)) return false;
   const int bn = (d->N % 160 == 0 && d->N % 128 != 0) ? 160 : 128;
-  return ge.n_pieces * 8 <= c3p::patch_rows(bn == 160 ? 5 : 2) && ge.n_pieces >= 8;
+  return ge.n_pieces * 8 <= c3p::patch_rows(bn == 160 ? 5 : 2, gn) && ge.n_pieces >= 8;
 }
 
 TilePlan plan_tiles3p(const udt_gemm_desc* d, const c3p::Geo& ge) {
@@ -702,13 +703,13 @@ TilePlan plan_tiles3p(const udt_gemm_desc* d, const c3p::Geo& ge) {
   return t;
 }
 
-template <int WGM, int WGN, int TM, int TN, bool GN>
+template <int WGM, int WGN, int TM, int TN, bool GN, bool STATS>
 hipError_t launch3p(const c3p::CParams& cp, const TilePlan& t, hipStream_t s) {
   constexpr int BN = WGN * TN * 32;
-  constexpr int smem = g8::NSTAGE * BN * ROW_BYTES + 2 * c3p::patch_rows(TN) * ROW_BYTES + (GN ? c3p::SCSH_BYTES : 0);
+  constexpr int smem = g8::NSTAGE * BN * ROW_BYTES + 2 * c3p::patch_rows(TN, GN) * ROW_BYTES + (GN ? c3p::SCSH_BYTES : 0);
   static_assert(smem <= 160 * 1024, "one workgroup per CU: at most the CU's 160 KiB of LDS");
   static AttrOnce once;
-  auto kern = c3p::conv3p_kernel<WGM, WGN, TM, TN, GN>;
+  auto kern = c3p::conv3p_kernel<WGM, WGN, TM, TN, GN, STATS>;
   hipError_t e = once.ensure(reinterpret_cast<const void*>(kern), smem);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(kern, dim3(t.G), dim3(g8::NTHREADS), smem, s, cp);
@@ -721,7 +722,7 @@ int colstats_rows(const udt_gemm_desc* d) {
   if ((d->batch > 1) || d->M <= 0 || d->N <= 0 || d->K <= 0 || d->K % BK != 0) return 0;
   int rows = 0;
   c3p::Geo ge;
-  if (conv3p_geometry(d, ge)) {
+  if (conv3p_geometry(d, ge, d->in_scsh != nullptr)) {
     rows = (d->N % 160 == 0 && d->N % 128 != 0) ? 32 : 64;
     if ((ge.TW * ge.TH) % rows != 0) return 0;                    // a wave row block lies in one image
   } else if (use_gemm8(d) && g_rows_epi.load(std::memory_order_relaxed)) {
@@ -737,7 +738,7 @@ int colstats_slots(const udt_gemm_desc* d) {
   const int rows = colstats_rows(d);
   if (rows == 0) return 0;
   c3p::Geo ge;
-  if (conv3p_geometry(d, ge)) return ge.img_groups * ge.tiles_y * ge.tiles_x * (256 / rows);
+  if (conv3p_geometry(d, ge, d->in_scsh != nullptr)) return ge.img_groups * ge.tiles_y * ge.tiles_x * (256 / rows);
   return ((d->M + 255) / 256) * (256 / rows);
 }
 
@@ -785,7 +786,7 @@ extern "C" int32_t udt_gemm_colstats_slots(const udt_gemm_desc* d) { return d ? 
 extern "C" int32_t udt_gemm_in_scsh_ok(const udt_gemm_desc* d) {
   if (!d || d->K <= 0 || d->K % BK != 0) return 0;
   c3p::Geo ge;
-  return conv3p_geometry(d, ge) ? 1 : 0;
+  return conv3p_geometry(d, ge, true) ? 1 : 0;
 }
 
 extern "C" int udt_gn_silu_conv3x3_fwd(const udt_gemm_desc* d, void* workspace, size_t workspace_bytes, void* stream) {
@@ -798,7 +799,7 @@ extern "C" size_t udt_gemm_workspace_bytes(const udt_gemm_desc* d) {
   if (!d || d->K <= 0 || d->M <= 0 || d->N <= 0 || d->K % BK != 0) return 0;
   {
     c3p::Geo ge;
-    if (conv3p_geometry(d, ge)) {
+    if (conv3p_geometry(d, ge, d->in_scsh != nullptr)) {
       TilePlan t3 = plan_tiles3p(d, ge);
       if (!t3.fixup) return 0;
       return G8_HEADER_BYTES + (size_t)t3.G * t3.bm * t3.bn * sizeof(float);
@@ -887,7 +888,7 @@ extern "C" int udt_gemm(const udt_gemm_desc* d, void* workspace, size_t workspac
   const int cls = (conv && d->ksize == 3) ? 0 : 1;
   {
     c3p::CParams cp;
-    if (conv3p_geometry(d, cp.geo)) {
+    if (conv3p_geometry(d, cp.geo, d->in_scsh != nullptr)) {
       const TilePlan t3 = plan_tiles3p(d, cp.geo);
       p.tiles_m = t3.tiles_m; p.tiles_n = t3.tiles_n; p.tiles_per_batch = t3.tiles_m * t3.tiles_n;
       p.n_ktiles = t3.nkt;
@@ -915,8 +916,14 @@ extern "C" int udt_gemm(const udt_gemm_desc* d, void* workspace, size_t workspac
         udt_prof_tag(prof3.rec, tag);
       }
       hipError_t e3;
-      if (d->in_scsh) e3 = (t3.bn == 160) ? launch3p<8, 1, 1, 5, true>(cp, t3, s) : launch3p<4, 2, 2, 2, true>(cp, t3, s);
-      else e3 = (t3.bn == 160) ? launch3p<8, 1, 1, 5, false>(cp, t3, s) : launch3p<4, 2, 2, 2, false>(cp, t3, s);
+      const int variant = (d->in_scsh ? 2 : 0) | (d->colstats ? 1 : 0);
+      if (t3.bn == 160) {
+        e3 = variant == 3 ? launch3p<8, 1, 1, 5, true, true>(cp, t3, s) : variant == 2 ? launch3p<8, 1, 1, 5, true, false>(cp, t3, s)
+           : variant == 1 ? launch3p<8, 1, 1, 5, false, true>(cp, t3, s) : launch3p<8, 1, 1, 5, false, false>(cp, t3, s);
+      } else {
+        e3 = variant == 3 ? launch3p<4, 2, 2, 2, true, true>(cp, t3, s) : variant == 2 ? launch3p<4, 2, 2, 2, true, false>(cp, t3, s)
+           : variant == 1 ? launch3p<4, 2, 2, 2, false, true>(cp, t3, s) : launch3p<4, 2, 2, 2, false, false>(cp, t3, s);
+      }
       if (e3 != hipSuccess) return udt_set_hip_error(e3);
       return UDT_OK;
     }
@@ -957,10 +964,14 @@ extern "C" int udt_gemm(const udt_gemm_desc* d, void* workspace, size_t workspac
       udt_prof_tag(prof8.rec, tag);
     }
     hipError_t e8;
+    const bool st = d->colstats != nullptr;         // statistics-emitting epilogues are separate kernels
     if (t8.bn == 160) {
-      e8 = conv ? launch8<8, 1, 1, 5, true, false>(pp, t8, s) : launch8<8, 1, 1, 5, false, false>(pp, t8, s);
+      if (st) e8 = conv ? launch8<8, 1, 1, 5, true, false, true>(pp, t8, s) : launch8<8, 1, 1, 5, false, false, true>(pp, t8, s);
+      else e8 = conv ? launch8<8, 1, 1, 5, true, false>(pp, t8, s) : launch8<8, 1, 1, 5, false, false>(pp, t8, s);
     } else if (trans) {
       e8 = launch8<4, 2, 2, 2, false, true>(pp, t8, s);
+    } else if (st) {
+      e8 = conv ? launch8<4, 2, 2, 2, true, false, true>(pp, t8, s) : launch8<4, 2, 2, 2, false, false, true>(pp, t8, s);
     } else {
       e8 = conv ? launch8<4, 2, 2, 2, true, false>(pp, t8, s) : launch8<4, 2, 2, 2, false, false>(pp, t8, s);
     }

@@ -159,25 +159,46 @@ UDT_DEVINL void colstat_acc8(const u32x4 v, float (&s)[8], float (&q)[8]) {
     s[2 * j + 1] += b; q[2 * j + 1] += b * b;
   }
 }
-// rows layout (8 lanes x 16 B cover one 128-byte row; lane>>3 = row within a group of 8): reduce over the row lanes
+// rows layout (8 lanes x 16 B cover one 128-byte row; lane>>3 = row within a group of 8): sum over the 8 row lanes
+// (lane bits 3, 4, 5) with row_ror:8 + the row / half swaps; the lanes of row group 0 write their 8 columns
 UDT_DEVINL void colstat_emit_rows(float (&s)[8], float (&q)[8], int lane, float* dst, int ncols) {
-  lane_reduce_scatter<8, 32, 8>(s, lane);
-  lane_reduce_scatter<8, 32, 8>(q, lane);
-  const int col = (lane & 7) * 8 + ((lane >> 5) & 1) * 4 + ((lane >> 4) & 1) * 2 + ((lane >> 3) & 1);
-  if (col < ncols) {
-    f32x2 o = {s[0], q[0]};
-    *reinterpret_cast<f32x2*>(dst + col * 2) = o;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    s[j] = xor32_sum(xor16_sum(dpp_add<0x128>(s[j])));
+    q[j] = xor32_sum(xor16_sum(dpp_add<0x128>(q[j])));
+  }
+  const int col = (lane & 7) * 8;
+  if (lane < 8 && col < ncols) {
+#pragma unroll
+    for (int j = 0; j < 8; j += 2) {
+      f32x4 o = {s[j], q[j], s[j + 1], q[j + 1]};
+      *reinterpret_cast<f32x4*>(dst + (col + j) * 2) = o;
+    }
   }
 }
-// accumulator layout (lane = one row, 16 (q, r) columns of a 32-column MFMA tile): reduce over the 32 row lanes
-UDT_DEVINL void colstat_emit_acc(float (&s16)[16], float (&q16)[16], int lane, float* dst_tile, int ncols) {
-  lane_reduce_scatter<16, 16, 1>(s16, lane);
-  lane_reduce_scatter<16, 16, 1>(q16, lane);
-  const int idx = ((lane & 16) ? 8 : 0) + ((lane & 8) ? 4 : 0) + ((lane & 4) ? 2 : 0) + ((lane & 2) ? 1 : 0);
-  const int col = (idx >> 2) * 8 + (lane >> 5) * 4 + (idx & 3);
-  if (!(lane & 1) && col < ncols) {
-    f32x2 o = {s16[0], q16[0]};
-    *reinterpret_cast<f32x2*>(dst_tile + col * 2) = o;
+// accumulator layout (lane = one row, 16 (q, r) columns of a 32-column MFMA tile): sum over the 32 row lanes of each
+// half-wave; lane 0 / lane 32 write the 16 columns of their half
+// NOT inlined: inlined into the 512-thread, 256-VGPR convolution kernel this code produced launches that died with
+// HSA_STATUS_ERROR_MEMORY_APERTURE_VIOLATION in one or the other (GN, STATS) variant depending on unrelated code
+// layout (ROCm 7.2 hipcc; tools/probes/variants.py); behind a call boundary all variants are correct.
+__device__ __attribute__((noinline)) void colstat_emit_acc(float (&s16)[16], float (&q16)[16], int lane, float* dst_tile, int ncols) {
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    s16[j] = xor16_sum(row16_sum(s16[j]));
+    q16[j] = xor16_sum(row16_sum(q16[j]));
+  }
+  if ((lane & 31) == 0) {
+    const int hi = lane >> 5;
+#pragma unroll
+    for (int qd = 0; qd < 4; ++qd) {
+      const int col = qd * 8 + hi * 4;             // columns of (q = qd, r = 0..3)
+      if (col < ncols) {
+        f32x4 o0 = {s16[qd * 4 + 0], q16[qd * 4 + 0], s16[qd * 4 + 1], q16[qd * 4 + 1]};
+        f32x4 o1 = {s16[qd * 4 + 2], q16[qd * 4 + 2], s16[qd * 4 + 3], q16[qd * 4 + 3]};
+        *reinterpret_cast<f32x4*>(dst_tile + col * 2) = o0;
+        *reinterpret_cast<f32x4*>(dst_tile + col * 2 + 4) = o1;
+      }
+    }
   }
 }
 
@@ -714,7 +735,9 @@ UDT_DEVINL void buf_lds16(__amdgpu_buffer_rsrc_t rsrc, void* lds_wave_base, unsi
 constexpr unsigned OOB = 0x80000000u;
 
 // WGM x WGN waves, each TM x TN MFMA tiles of 32x32
-template <int WGM, int WGN, int TM, int TN, bool CONV, bool TRANS>
+// STATS: the row-coalesced epilogues also emit the output's column statistics (udt_gemm_desc.colstats) — a separate
+// kernel, so that the plain one keeps its instruction stream and register allocation
+template <int WGM, int WGN, int TM, int TN, bool CONV, bool TRANS, bool STATS>
 __global__ void __launch_bounds__(NTHREADS) gemm8_kernel(const Params pp) {
   static_assert(WGM * WGN == 8, "8 waves per workgroup");
   constexpr int BM = WGM * TM * 32;
@@ -1020,7 +1043,8 @@ __global__ void __launch_bounds__(NTHREADS) gemm8_kernel(const Params pp) {
           auto mof = [&](int row) -> long long { return (mwv + row < p.M) ? (long long)(mwv + row) : -1LL; };
           char* wl = smem + 2 * STAGE_BYTES + wave * EPI_WAVE_BYTES;
           const bool interior = (cur_m0 + BM <= p.M) && (cur_n0 + BN <= p.N);
-          float* stats = p.colstats ? p.colstats + ((long long)(mwv / (TM * 32)) * p.N + cur_n0 + col0) * 2 : nullptr;
+          float* stats = nullptr;
+          if constexpr (STATS) stats = p.colstats + ((long long)(mwv / (TM * 32)) * p.N + cur_n0 + col0) * 2;
           if (!epilogue8_fast_dispatch<TM, TN>(p, acc, mof, cur_n0 + col0, cur_batch, lane, wl, interior, stats))
             epilogue8_rows16<TN>(p, acc, mof, cur_n0 + col0, cur_batch, lane, wl, stats);
         } else {
@@ -1034,7 +1058,8 @@ __global__ void __launch_bounds__(NTHREADS) gemm8_kernel(const Params pp) {
           auto mof = [&](int row) -> long long { return (mwv + row < p.M) ? (long long)(mwv + row) : -1LL; };
           char* wl = smem + 2 * STAGE_BYTES + wave * EPI_WAVE_BYTES;
           const bool interior = (cur_m0 + BM <= p.M) && (cur_n0 + BN <= p.N);
-          float* stats = p.colstats ? p.colstats + ((long long)(mwv / (TM * 32)) * p.N + cur_n0 + col0) * 2 : nullptr;
+          float* stats = nullptr;
+          if constexpr (STATS) stats = p.colstats + ((long long)(mwv / (TM * 32)) * p.N + cur_n0 + col0) * 2;
           if (!epilogue8_fast_dispatch<TM, TN>(p, acc, mof, cur_n0 + col0, cur_batch, lane, wl, interior, stats))
             epilogue8_rows<TM>(p, acc, mof, cur_n0 + col0, cur_batch, lane, wl, stats);
         } else {

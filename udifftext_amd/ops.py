@@ -7,6 +7,7 @@ from __future__ import annotations
 
 import contextlib
 import ctypes as C
+import os
 import threading
 from typing import NamedTuple, Optional
 

@@ -102,7 +102,7 @@ class MemoryEfficientAttnBlock(H._Packed):
         s = ops.bmm_nt(qk[..., :C], qk[..., C:], alpha=C ** -0.5)                    # [B, N, N]
         ops.softmax_rows_(s)
         o = ops.bmm_nt(s, vt)                                                        # [B, N, C]
-        out = ops.linear(o.reshape(B * N, C), wo, bo, residual=x.reshape(B * N, C), rows_per_batch=N, colstats=True)
+        out = ops.linear(o.reshape(B * N, C), wo, bo, residual=x.reshape(B * N, C), rows_per_batch=N, colstats=H.FUSE_GN)
         return H.carry_stats(out.reshape(B, Hh, Ww, C), out)
 
 

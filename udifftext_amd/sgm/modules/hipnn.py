@@ -25,10 +25,13 @@ def count_flops(kind: str, flops: float) -> None:
     ops.count_work(kind, flops)
 
 
-# GroupNorm(+SiLU) in front of a 3x3 convolution runs ON THE CONVOLUTION'S STAGED INPUT PATCH whenever the producers
-# of the input emitted their column statistics and the library takes the shape (ops.conv2d(in_scsh=...)); 0 = always the
-# separate gn_stats / gn_apply kernels (A/B runs)
-FUSE_GN = os.environ.get("UDT_FUSE_GN", "1") != "0"
+# UDT_FUSE_GN=1: GroupNorm(+SiLU) in front of a 3x3 convolution runs ON THE CONVOLUTION'S STAGED INPUT PATCH whenever the
+# producers of the input emitted their column statistics and the library takes the shape (udt_gn_silu_conv3x3_fwd).
+# Default OFF: measured on one MI355X box against the separate gn_stats / gn_apply kernels (tools/compare_builds.sh,
+# profiles/r02_ab_fused_groupnorm.txt) the fused chain is SLOWER end to end (UNet step 14.3 vs 13.7 ms): the patch
+# transform costs ~7 % of a convolution and the per-column statistics in the convolution's accumulator-layout epilogue
+# (one pixel per lane: 32-lane reductions) cost more than the two HBM passes they replace.
+FUSE_GN = os.environ.get("UDT_FUSE_GN", "0") != "0"
 
 
 def carry_stats(dst: torch.Tensor, src: torch.Tensor) -> torch.Tensor:
@@ -93,7 +96,7 @@ class Linear(_Packed):
                 colstats: bool = False):
         w, b = self.packed()
         return ops.linear(x, w, b, residual=residual, flags=flags, out=out, rowvec=rowvec, rows_per_batch=rows_per_batch,
-                          colstats=colstats)
+                          colstats=colstats and FUSE_GN)
 
 
 class Conv2d(_Packed):
@@ -132,6 +135,7 @@ class Conv2d(_Packed):
             pad = (self.padding, self.padding)
         if colstats is None:
             colstats = self.emit_colstats
+        colstats = bool(colstats) and FUSE_GN          # statistics are only worth emitting for the fused chain
         kw = dict(ksize=self.kernel_size, stride=self.stride, pad=pad, upsample=upsample, out_hw=out_hw, residual=residual,
                   rowvec=rowvec, flags=flags, n_out=w.shape[0], colstats=colstats)
         in_scsh = None
@@ -142,6 +146,7 @@ class Conv2d(_Packed):
                 B = x.shape[0]
                 in_scsh = ops.gn_finalize(st1, x.shape[-1], st2, x2.shape[-1] if x2 is not None else 0, norm.weight,
                                           norm.bias, B, x.shape[1] * x.shape[2], norm.num_groups, norm.eps)
+                count_flops("fused_gn_convs", 1)
             else:
                 x, x2 = norm(x, x2=x2, silu=norm_silu), None
         out = ops.conv2d(x, w, b, x2=x2, in_scsh=in_scsh, in_act=1 if norm_silu else 0, **kw)
@@ -159,7 +164,7 @@ class Conv2d(_Packed):
             Hh, Ww = x.shape[1], x.shape[2]
             if (k == 3 and self.stride == 1 and not upsample and tuple(pad) == (1, 1)
                     and self.out_channels > 64 and not (flags & L.GEMM_OUT_F32)
-                    and ((Ww % 32 == 0 and Hh % 8 == 0) or (Ww == 16 and Hh % 16 == 0) or (Ww == 8 and Hh == 8))):
+                    and ((Ww % 32 == 0 and Hh % 8 == 0) or (Ww % 16 == 0 and Hh % 16 == 0) or (Ww == 8 and Hh == 8))):
                 # the launches udt_gemm routes to c3p::conv3p_kernel (same test as conv3p_geometry in gemm.hip)
                 count_flops("conv3p_bytes", nbytes)
                 count_flops("conv3p_launches", 1.0)
