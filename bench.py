@@ -66,6 +66,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-mode-table", action="store_true", help="skip the extra passes in the other launch modes")
     ap.add_argument("--in-flight", type=int, default=2, help="batches sampled concurrently per GPU, one launch stream each")
+    ap.add_argument("--fp8", action="store_true", help="BASELINE config #5 arithmetic: the transformer blocks' LayerNorm-fed "
+                    "linears on the fp8 (e4m3) MFMA path")
     ap.add_argument("--fuse", type=int, default=1, help="batches concatenated into one UNet call (1 = the on-config "
                     "batch per call; > 1 or 0 = throughput mode, never the headline value)")
     return ap.parse_args()
@@ -138,6 +140,9 @@ def main():
     import udifftext_amd  # noqa: F401
     from udifftext_amd import config as C, lib as L, ops, parallel, pipeline, synth
 
+    if args.fp8:
+        import sgm.modules.hipnn as Hnn
+        Hnn.FP8_LINEARS = True
     torch.set_grad_enabled(False)
     with contextlib.redirect_stdout(sys.stderr):          # the conditioner announces its embedders like the reference does;
         model = pipeline.build_engine(dev)                # stdout carries the ONE JSON line only
@@ -284,9 +289,10 @@ def main():
                     "algorithmic_hbm_gbps": nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0,
                     "share_of_mfma_class_time": ms / max(conv_ms + gemm_ms + attn_ms, 1e-9)}
 
-        conv = cls("3x3 convolution: c3p::conv3p_kernel (LDS-staged patches, GroupNorm+SiLU applied on the staged patch) + "
-                   "g8::gemm8_kernel<CONV> (stride-2 / upsampling gathers), UNet + VAE", conv_flops, conv_bytes, conv_ms,
-                   conv_launches)
+        import sgm.modules.hipnn as Hn
+        conv = cls("3x3 convolution: c3p::conv3p_kernel (LDS-staged patches" + (", GroupNorm+SiLU applied on the staged patch"
+                   if Hn.FUSE_GN else "") + ") + g8::gemm8_kernel<CONV> (stride-2 / upsampling gathers), UNet + VAE",
+                   conv_flops, conv_bytes, conv_ms, conv_launches)
         conv.update({"traffic": traffic, "traffic_source": traffic_file,
                      "traffic_hbm_gbps": (traffic / (conv["avg_launch_us"] * 1e-6) / 1e9) if traffic else None,
                      "traffic_frac_of_hbm_peak": (traffic / (conv["avg_launch_us"] * 1e-6) / PEAK_HBM) if traffic else None,
@@ -295,8 +301,10 @@ def main():
                      "measured_on": "one eager single-stream pass of one local batch right after the timed region: HIP "
                                     "events around every launch, each kernel alone on the chip (the timed region replays "
                                     "hipGraphs with batches in flight, where launches of two streams overlap)",
-                     "whole_path_frac_of_peak": value * fpi / (world * PEAK_BF16)})
-        cfg_id = ("BASELINE.json configs[1]" if (args.size, args.batch, args.chars, args.sampler_steps, G) == (512, 4, 9, 50, 4 * world)
+                     "whole_path_frac_of_peak": value * fpi / (world * PEAK_BF16),
+                     "whole_path_frac_of_fp8_peak": (value * fpi / (world * 2 * PEAK_BF16)) if args.fp8 else None})
+        cfg_id = ("BASELINE.json configs[1]" if (args.size, args.batch, args.chars, args.sampler_steps, G, args.fp8) == (512, 4, 9, 50, 4 * world, False)
+                  else "BASELINE.json configs[4]" if (args.fp8 and (args.size, args.sampler_steps, G, world) == (512, 50, 32, 8))
                   else "BASELINE.json configs[2]" if (args.size, args.sampler_steps, G, world) == (512, 50, 64, 8)
                   else "BASELINE.json configs[3]" if (args.size, args.batch, args.chars, args.sampler_steps) == (768, 8, 12, 50)
                   else "non-baseline shape")
@@ -306,7 +314,12 @@ def main():
                       f"{args.sampler_steps} CFG Euler steps + VAE decode)",
             "value": value, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak" if weak else "strong",
-            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "vs_baseline": None, "data": "synthetic",
+            "dtype": "fp8" if args.fp8 else "bf16",
+            "dtype_note": ("e4m3 MFMA (v_mfma_scale_f32_32x32x64_f8f6f4) for the LayerNorm-fed linears of the transformer blocks "
+                           "(q|k, v, t_attn.to_q, GEGLU: 60 % of the linear FLOPs); bf16 MFMA everywhere else; fp32 accumulation, "
+                           "statistics, softmax and sampler state") if args.fp8 else
+                          "bf16 storage + MFMA, fp32 accumulation / statistics / softmax / sampler state",
             "images_per_s_by_launch_mode": dict(other_modes, **{"value": value}),
             "unet_ms_per_sampler_step": unet_ms,
             "unet_ms_note": f"one batch of {args.batch} alone on the whole GPU (latency of one UNet call on its CFG pair + "

@@ -147,6 +147,36 @@ def test_unet_and_vae_with_fused_groupnorm_vs_reference_golden(engine, cond256, 
         H.FUSE_GN = prev
 
 
+def test_unet_call_fp8_linears_vs_reference_golden(engine, cond256, eg, cuda):
+    """BASELINE config #5's arithmetic (UDT_FP8=1): the LayerNorm-fed linears of every transformer block on the fp8 MFMA
+    path (e4m3 weights with per-channel scales, e4m3 activations with a static per-tensor scale, fp32 accumulation).
+    Stated tolerance against the fp32 reference golden: rel_rms <= 1e-1 (e4m3 keeps 3 mantissa bits: each quantised
+    product carries ~3 % error; bf16 path: 2e-2); the eps must also stay within 1e-1 of the bf16 path."""
+    import sgm.modules.hipnn as H
+    from udifftext_amd import ops
+    batch, _, _ = cond256
+    x7 = torch.from_numpy(eg["g7_x"]).to(cuda)
+    ucc, cc = torch.from_numpy(eg["g6_uc_concat"]).to(cuda), torch.from_numpy(eg["g6_c_concat"]).to(cuda)
+    le = engine.conditioner.embedders[0]
+    tctx = torch.cat([torch.zeros((1, 12, 2048), device=cuda), le(batch["label"])])
+    xin = torch.cat([torch.cat([x7, x7]), torch.cat([ucc, cc])], dim=1)
+    ts = torch.tensor([999, 999], device=cuda)
+    unet = engine.model.diffusion_model
+    ref_bf16 = unet(xin, timesteps=ts, t_context=tctx)
+    prev = H.FP8_LINEARS
+    H.FP8_LINEARS = True
+    try:
+        ops.WORK_COUNTER = {}
+        eps = unet(xin, timesteps=ts, t_context=tctx)
+        n8 = ops.WORK_COUNTER.get("gemm_fp8_launches", 0)
+        ops.WORK_COUNTER = None
+    finally:
+        H.FP8_LINEARS = prev
+    assert n8 >= 16 * 3, f"only {n8} fp8 GEMM launches"
+    _check("UNet eps with fp8 linears (config #5 arithmetic) vs reference", eps.cpu(), eg["g7_eps"], 1e-1)
+    _check("UNet eps with fp8 linears vs the bf16 path", eps.cpu(), ref_bf16.cpu(), 1e-1)
+
+
 def test_zero_context_shortcut_is_bit_exact(engine, cond256, cuda):
     """the sampler skips the t_attn GEMMs of the unconditional half (context == 0 -> x + to_out.bias); the eps must
     be bit-identical to running the full cross-attention on the zero context"""

@@ -1,16 +1,18 @@
 #!/bin/bash
-# run on the GPU box: bench line + rocprofv3 kernel stats (timed regime and single-stream regime) + PMC traffic
+# run on the GPU box: bench line + rocprofv3 kernel stats (timed regime and single-stream regime) + PMC traffic + MFMA util
+# usage: tools/collect_profiles.sh [round-tag]   -> gpurun_out/<tag>/ (copy what should be judged into profiles/)
 R=$GRAFT_REPO_ROOT; [ -z "$R" ] && R=/root/repo
-O=$R/gpurun_out/r01; mkdir -p $O
+TAG=${1:-r02}
+O=$R/gpurun_out/$TAG; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-# 1. the bench line (default flags)
+# 1. the bench line (default flags = what the driver runs)
 (cd $R && python bench.py 2>$O/bench.err | tail -1 > $O/bench.json)
-# 2. kernel trace + stats of the bench command (graphs, 2 batches in flight)
-rm -rf /tmp/rpA; rocprofv3 --kernel-trace --stats -d /tmp/rpA -o t -- python $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-mode-table 2>/dev/null | tail -1 > $O/bench_under_rocprof_inflight.json
+# 2. kernel trace + stats of the bench command (hipGraph replay, 2 batches in flight)
+rm -rf /tmp/rpA; rocprofv3 --kernel-trace --stats -d /tmp/rpA -o t -- python $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-mode-table 2>/dev/null | tail -1 > $O/bench_under_rocprof_inflight.json
 python $R/tools/rocpd_summary.py $(find /tmp/rpA -name "*.db" | head -1) > $O/kernel_stats_inflight.csv
 # 3. the regime the roofline events are taken in: eager launches, one stream, one batch at a time
 rm -rf /tmp/rpB; UDT_GRAPHS=0 UDT_DUAL_STREAM=0 rocprofv3 --kernel-trace --stats -d /tmp/rpB -o t -- python $R/bench.py --steps 1 --warmup 1 --in-flight 1 --fuse 1 --no-cpu-baseline --no-mode-table 2>/dev/null | tail -1 > $O/bench_under_rocprof_single.json
-python $R/tools/rocpd_summary.py $(find /tmp/rpB -name "*.db" | head -1) > $O/kernel_stats_single.csv
+python $R/tools/rocpd_summary.py $(find /tmp/rpB -name "*.db" | head -1) > $O/kernel_stats_single_stream.csv
 # 4. HBM traffic of the 3x3-conv kernels: PMC passes (no tracing domains) over one batch of the bench workload.
 #    rocprofv3's counter collection dies after ~6000 dispatches on this image, so a 2-step and a 10-step batch are
 #    profiled and extrapolated to 50 steps (tools/pmc_extrapolate.py)
@@ -23,4 +25,4 @@ python $R/tools/pmc_extrapolate.py /tmp/pmc_FETCH_SIZE_2/p_counter_collection.cs
 rm -rf /tmp/pmc_mfma
 UDT_GRAPHS=0 UDT_DUAL_STREAM=0 timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d /tmp/pmc_mfma -o p -- python $R/tools/predict_once.py 4 > /dev/null 2>&1
 python $R/tools/pmc_mfma.py /tmp/pmc_mfma/p_counter_collection.csv > $O/mfma_util.json
-ls -la $O; cat $O/bench.json | cut -c1-600; cat $O/traffic.json; head -40 $O/mfma_util.json
+ls -la $O; cut -c1-400 $O/bench.json; cat $O/traffic.json | head -30; head -30 $O/mfma_util.json

@@ -42,6 +42,7 @@ struct GemmParams {
   const uint16_t* res;
   const float* rowvec;
   void* out;
+  const float* colscale; // fp8: per-output-channel weight scale (multiplies the accumulators), or nullptr
   const float* in_scsh;  // patch-staged convolution: GroupNorm scale/shift table of the input (conv3p.h), or nullptr
   float* colstats;       // per-(row slot, column) partial sums of the output, or nullptr
   int in_act;
@@ -587,7 +588,9 @@ std::atomic<int> g_dbg_bits{0};  // cost-attribution modes that switch parts of 
 #endif
 constexpr int INTERNAL_DIRECT_EPI = 1 << 30;   // kernel-side flag bit, never part of the public flag set
 constexpr int PUBLIC_FLAGS = UDT_GEMM_OUT_F32 | UDT_GEMM_GEGLU | UDT_GEMM_RELU | UDT_GEMM_TRANSPOSED | UDT_GEMM_CONV |
-                             UDT_GEMM_SILU_OUT;
+                             UDT_GEMM_SILU_OUT | UDT_GEMM_FP8;
+inline int k_tile(const udt_gemm_desc* d) { return (d->flags & UDT_GEMM_FP8) ? 128 : BK; }   // K elements per 128-byte row
+inline int elem_bytes(const udt_gemm_desc* d) { return (d->flags & UDT_GEMM_FP8) ? 1 : 2; }
 
 int gemm_impl() {
   int v = g_impl.load(std::memory_order_relaxed);
@@ -603,8 +606,8 @@ bool use_gemm8(const udt_gemm_desc* d) {
   if (gemm_impl() == 4 || d->N <= 64) return false;
   const long long ldw = d->ldw > 0 ? d->ldw : d->K;
   // buffer-descriptor addressing uses 31-bit byte offsets per batch element
-  if (!(d->flags & UDT_GEMM_CONV) && (long long)d->M * d->lda * 2 >= (1LL << 31)) return false;
-  return (long long)d->N * ldw * 2 < (1LL << 31);
+  if (!(d->flags & UDT_GEMM_CONV) && (long long)d->M * d->lda * elem_bytes(d) >= (1LL << 31)) return false;
+  return (long long)d->N * ldw * elem_bytes(d) < (1LL << 31);
 }
 
 TilePlan plan_tiles8(const udt_gemm_desc* d) {
@@ -616,7 +619,7 @@ TilePlan plan_tiles8(const udt_gemm_desc* d) {
   t.tiles_m = (d->M + t.bm - 1) / t.bm;
   t.tiles_n = (d->N + t.bn - 1) / t.bn;
   t.tiles = t.tiles_m * t.tiles_n * batch;
-  t.nkt = d->K / BK;
+  t.nkt = d->K / k_tile(d);
   t.total = (long long)t.tiles * t.nkt;
   // one 8-wave workgroup per CU.  Whole-tile plans (shallow K, below) have no waits between workgroups, so they may
   // use every CU even when other launch streams share the device (cu_share): excess workgroups simply queue
@@ -634,13 +637,13 @@ TilePlan plan_tiles8(const udt_gemm_desc* d) {
   return t;
 }
 
-template <int WGM, int WGN, int TM, int TN, bool CONV, bool TRANS, bool STATS = false>
+template <int WGM, int WGN, int TM, int TN, bool CONV, bool TRANS, bool STATS = false, bool FP8 = false>
 hipError_t launch8(const g8::Params& pp, const TilePlan& t, hipStream_t s) {
   constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
   // the 256x128 configuration transposes its output through LDS: stage 2 plus 16 KiB above the ring (160 KiB total)
   constexpr int smem = (TM == 2 && TN == 2 && !TRANS) ? 160 * 1024 : g8::NSTAGE * (BM + BN) * ROW_BYTES;
   static AttrOnce once;
-  auto kern = g8::gemm8_kernel<WGM, WGN, TM, TN, CONV, TRANS, STATS>;
+  auto kern = g8::gemm8_kernel<WGM, WGN, TM, TN, CONV, TRANS, STATS, FP8>;
   hipError_t e = once.ensure(reinterpret_cast<const void*>(kern), smem);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(kern, dim3(t.G), dim3(g8::NTHREADS), smem, s, pp);
@@ -796,7 +799,7 @@ extern "C" int udt_gn_silu_conv3x3_fwd(const udt_gemm_desc* d, void* workspace, 
 }
 
 extern "C" size_t udt_gemm_workspace_bytes(const udt_gemm_desc* d) {
-  if (!d || d->K <= 0 || d->M <= 0 || d->N <= 0 || d->K % BK != 0) return 0;
+  if (!d || d->K <= 0 || d->M <= 0 || d->N <= 0 || d->K % k_tile(d) != 0) return 0;
   {
     c3p::Geo ge;
     if (conv3p_geometry(d, ge, d->in_scsh != nullptr)) {
@@ -819,8 +822,16 @@ extern "C" size_t udt_gemm_workspace_bytes(const udt_gemm_desc* d) {
 extern "C" int udt_gemm(const udt_gemm_desc* d, void* workspace, size_t workspace_bytes, void* stream) {
   if (!d || !d->a || !d->w || !d->out) return UDT_ERR_BAD_ARG;
   if (d->M <= 0 || d->N <= 0 || d->K <= 0) return UDT_ERR_BAD_SHAPE;
-  if (d->K % BK != 0) return UDT_ERR_BAD_SHAPE;
+  if (d->K % k_tile(d) != 0) return UDT_ERR_BAD_SHAPE;
   if (d->N % 4 != 0) return UDT_ERR_BAD_SHAPE;
+  const bool fp8 = (d->flags & UDT_GEMM_FP8) != 0;
+  if (fp8) {
+    // e4m3 operands: plain / GEGLU / transposed linears on the 8-wave kernel only
+    if ((d->flags & (UDT_GEMM_CONV | UDT_GEMM_OUT_F32)) || d->colstats || d->in_scsh || !use_gemm8(d)) return UDT_ERR_BAD_ARG;
+    if (d->lda % 16 != 0 || (d->ldw > 0 && d->ldw % 16 != 0)) return UDT_ERR_BAD_SHAPE;
+  } else if (d->colscale) {
+    return UDT_ERR_BAD_ARG;
+  }
   const bool conv = (d->flags & UDT_GEMM_CONV) != 0;
   const bool trans = (d->flags & UDT_GEMM_TRANSPOSED) != 0;
   const int batch = d->batch > 0 ? d->batch : 1;
@@ -862,6 +873,7 @@ extern "C" int udt_gemm(const udt_gemm_desc* d, void* workspace, size_t workspac
   p.res = reinterpret_cast<const uint16_t*>(d->residual);
   p.rowvec = d->rowvec;
   p.out = d->out;
+  p.colscale = d->colscale;
   p.in_scsh = d->in_scsh;
   p.in_act = d->in_act;
   p.colstats = d->colstats;
@@ -947,8 +959,8 @@ extern "C" int udt_gemm(const udt_gemm_desc* d, void* workspace, size_t workspac
     g8::Params pp;
     pp.g = p;
     pp.flags = nullptr; pp.err = nullptr; pp.slab_base = nullptr;
-    pp.a_bytes = conv ? 0u : (unsigned)((long long)d->M * d->lda * 2);
-    pp.w_bytes = (unsigned)((long long)d->N * p.ldw * 2);
+    pp.a_bytes = conv ? 0u : (unsigned)((long long)d->M * d->lda * elem_bytes(d));
+    pp.w_bytes = (unsigned)((long long)d->N * p.ldw * elem_bytes(d));
     if (t8.fixup) {
       const size_t need = G8_HEADER_BYTES + (size_t)t8.G * t8.bm * t8.bn * sizeof(float);
       if (!workspace || workspace_bytes < need) return UDT_ERR_WORKSPACE;
@@ -965,7 +977,11 @@ extern "C" int udt_gemm(const udt_gemm_desc* d, void* workspace, size_t workspac
     }
     hipError_t e8;
     const bool st = d->colstats != nullptr;         // statistics-emitting epilogues are separate kernels
-    if (t8.bn == 160) {
+    if (fp8) {
+      if (t8.bn == 160) e8 = launch8<8, 1, 1, 5, false, false, false, true>(pp, t8, s);
+      else if (trans) e8 = launch8<4, 2, 2, 2, false, true, false, true>(pp, t8, s);
+      else e8 = launch8<4, 2, 2, 2, false, false, false, true>(pp, t8, s);
+    } else if (t8.bn == 160) {
       if (st) e8 = conv ? launch8<8, 1, 1, 5, true, false, true>(pp, t8, s) : launch8<8, 1, 1, 5, false, false, true>(pp, t8, s);
       else e8 = conv ? launch8<8, 1, 1, 5, true, false>(pp, t8, s) : launch8<8, 1, 1, 5, false, false>(pp, t8, s);
     } else if (trans) {

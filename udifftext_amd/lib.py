@@ -18,6 +18,7 @@ GEMM_RELU = 1 << 2
 GEMM_TRANSPOSED = 1 << 3
 GEMM_CONV = 1 << 4
 GEMM_SILU_OUT = 1 << 5
+GEMM_FP8 = 1 << 6
 
 PROF_CONV3X3, PROF_GEMM, PROF_ATTN, PROF_XATTN, PROF_NORM, PROF_ELEMENTWISE = range(6)
 
@@ -34,7 +35,7 @@ class GemmDesc(C.Structure):
         ("Hout", C.c_int32), ("Wout", C.c_int32),
         ("ksize", C.c_int32), ("stride", C.c_int32), ("pad_t", C.c_int32), ("pad_l", C.c_int32),
         ("upsample", C.c_int32), ("rows_per_batch", C.c_int32), ("ld_rowvec", C.c_int32), ("flags", C.c_int32),
-        ("alpha", C.c_float), ("in_scsh", C.c_void_p), ("in_act", C.c_int32), ("colstats", C.c_void_p),
+        ("alpha", C.c_float), ("colscale", C.c_void_p), ("in_scsh", C.c_void_p), ("in_act", C.c_int32), ("colstats", C.c_void_p),
         ("cu_share", C.c_int32),
     ]
 
@@ -58,6 +59,8 @@ SYMBOLS = {
     "udt_gn_stats": (C.c_int, [_vp, _vp, _fp, _i32, _i64, _i32, _i32, _i32, _vp]),
     "udt_gn_apply": (C.c_int, [_vp, _vp, _vp, _fp, _fp, _fp, _i32, _i64, _i32, _i32, _i32, _f32, _i32, _vp]),
     "udt_layernorm": (C.c_int, [_vp, _vp, _fp, _fp, _i64, _i32, _f32, _vp]),
+    "udt_layernorm_fp8": (C.c_int, [_vp, _vp, _fp, _fp, _i64, _i32, _i32, _f32, _f32, _vp]),
+    "udt_quantize_fp8": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _f32, _vp]),
     "udt_unet_input": (C.c_int, [_fp, _vp, _i32, _i32, _i32, _f32, _vp]),
     "udt_cfg_euler_step": (C.c_int, [_fp, _fp, _fp, _i32, _i32, _i32, _f32, _f32, _f32, _f32, _vp]),
     "udt_posterior_sample": (C.c_int, [_fp, _fp, _fp, _i32, _i32, _i32, _f32, _vp]),

@@ -79,3 +79,32 @@ def pack_geglu(w: torch.Tensor, b: torch.Tensor):
     inner = w.shape[0] // 2
     perm = geglu_permutation(inner).to(w.device)
     return pack_linear(w[perm]), b[perm].float().contiguous()
+
+
+# ------------------------------------------------------------------------------------------------ fp8 (config #5)
+FP8_KPAD = 128          # K elements per 128-byte LDS row of the fp8 GEMM
+FP8_MAX = 448.0         # largest finite OCP e4m3 value
+
+
+def pack_linear_fp8(w: torch.Tensor, n_pad_to: int = 4):
+    """[N, K] fp32 -> (e4m3 bytes [Npad, Kpad128] as uint8, per-output-channel scale fp32 [Npad]):
+    w[n, k] ~= q[n, k] * scale[n] with scale[n] = max_k |w[n, k]| / 448 (per-channel weight scales, udt_gemm colscale)."""
+    N, K = w.shape
+    Np, Kp = _round_up(N, n_pad_to), _round_up(K, FP8_KPAD)
+    wf = w.float()
+    amax = wf.abs().amax(dim=1).clamp_min(1e-12)
+    scale = amax / FP8_MAX
+    q = (wf / scale[:, None]).clamp(-FP8_MAX, FP8_MAX).to(torch.float8_e4m3fn).view(torch.uint8)
+    out = torch.zeros((Np, Kp), dtype=torch.uint8, device=w.device)
+    out[:N, :K] = q
+    cs = torch.ones((Np,), dtype=torch.float32, device=w.device)
+    cs[:N] = scale
+    return out.contiguous(), cs
+
+
+def pack_geglu_fp8(w: torch.Tensor, b: torch.Tensor):
+    """GEGLU.proj [2*inner, C] -> permuted e4m3 weight, permuted per-channel scales, permuted fp32 bias"""
+    inner = w.shape[0] // 2
+    perm = geglu_permutation(inner).to(w.device)
+    wq, cs = pack_linear_fp8(w[perm])
+    return wq, cs, b[perm].float().contiguous()

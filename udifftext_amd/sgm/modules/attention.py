@@ -36,7 +36,13 @@ class GEGLU(H._Packed):
     def _pack(self):
         return packing.pack_geglu(self.proj.weight, self.proj.bias)
 
+    def _pack_fp8(self):
+        return packing.pack_geglu_fp8(self.proj.weight, self.proj.bias)
+
     def forward(self, x):
+        if isinstance(x, ops.Fp8Act):
+            wq, cs, b = self.packed_fp8()
+            return ops.linear_fp8(x, wq, cs, b, flags=H.GEMM_GEGLU)
         w, b = self.packed()
         return ops.linear(x, w, b, flags=H.GEMM_GEGLU)
 
@@ -83,11 +89,16 @@ class CrossAttention(H._Packed):
         return ops.linear(context_bf16.reshape(B * Lc, Dc), self.packed()).reshape(B, Lc, -1)
 
     def forward(self, x, context=None, kv=None, residual=None, emit_map: bool = False, out=None):
-        B, N, _ = x.shape
+        """x: bf16 [B, N, C], or an ops.Fp8Act of the [B * N, C] rows (then B, N come from the residual)"""
         inner = self.heads * self.dim_head
+        if isinstance(x, ops.Fp8Act):
+            B, N = residual.shape[0], residual.shape[1]
+            q = self.to_q(x).reshape(B, N, inner)
+        else:
+            B, N, _ = x.shape
+            q = self.to_q(x.reshape(B * N, -1)).reshape(B, N, inner)
         if kv is None:
             kv = self.project_context(context)
-        q = self.to_q(x.reshape(B * N, -1)).reshape(B, N, inner)
         probs = None
         if emit_map and self.attn_map_cache is not None:
             probs = torch.empty((B * self.heads, N, kv.shape[1]), dtype=torch.float32, device=x.device)
@@ -129,15 +140,25 @@ class MemoryEfficientCrossAttention(H._Packed):
     def _pack(self):
         return H.fuse_rows(self.to_q.weight, self.to_k.weight), packing.pack_linear(self.to_v.weight)
 
+    def _pack_fp8(self):
+        return (packing.pack_linear_fp8(torch.cat([self.to_q.weight, self.to_k.weight], 0)),
+                packing.pack_linear_fp8(self.to_v.weight))
+
     def forward(self, x, context=None, mask=None, residual=None):
         if context is not None or mask is not None:
             raise NotImplementedError("attn1 is pure self-attention on this path (reference attention.py:251-252)")
-        B, N, C = x.shape
         inner = self.heads * self.dim_head
-        wqk, wv = self.packed()
-        x2 = x.reshape(B * N, C)
-        qk = ops.linear(x2, wqk).reshape(B, N, 2 * inner)
-        vt = ops.linear(x2, wv, flags=H.GEMM_TRANSPOSED, rows_per_batch=N)           # [B, inner, N]
+        if isinstance(x, ops.Fp8Act):                     # LayerNorm output quantised for the fp8 linears
+            B, N = residual.shape[0], residual.shape[1]
+            (wqk, sqk), (wv, sv) = self.packed_fp8()
+            qk = ops.linear_fp8(x, wqk, sqk).reshape(B, N, 2 * inner)
+            vt = ops.linear_fp8(x, wv, sv, flags=H.GEMM_TRANSPOSED, rows_per_batch=N)
+        else:
+            B, N, C = x.shape
+            wqk, wv = self.packed()
+            x2 = x.reshape(B * N, C)
+            qk = ops.linear(x2, wqk).reshape(B, N, 2 * inner)
+            vt = ops.linear(x2, wv, flags=H.GEMM_TRANSPOSED, rows_per_batch=N)       # [B, inner, N]
         o = ops.attention(qk[..., :inner], qk[..., inner:], vt, self.heads, self.dim_head ** -0.5)
         res = residual.reshape(B * N, -1) if residual is not None else None
         return self.to_out[0](o.reshape(B * N, inner), residual=res).reshape(B, N, -1)
@@ -159,7 +180,9 @@ class BasicTransformerBlock(nn.Module):
     def forward(self, x, t_context=None, v_context=None, t_kv=None, emit_map: bool = False, zero_ctx_rows: int = 0):
         """zero_ctx_rows: the first n samples of the batch attend to an all-zero text context (the unconditional
         half of a CFG pair under force_uc_zero_embeddings) — their t_attn branch is x + to_out.bias, no GEMMs."""
-        x = self.attn1(self.norm1(x), residual=x)
+        fp8 = H.FP8_LINEARS
+        ln = (lambda norm, t: norm.forward_fp8(t.reshape(-1, t.shape[-1]))) if fp8 else (lambda norm, t: norm(t))
+        x = self.attn1(ln(self.norm1, x), residual=x)
         if hasattr(self, "t_attn"):
             n0 = 0 if emit_map else min(int(zero_ctx_rows), x.shape[0])
             if n0 > 0 and t_kv is not None:
@@ -167,13 +190,13 @@ class BasicTransformerBlock(nn.Module):
                 self.t_attn.zero_context_residual(x[:n0], y[:n0])
                 if n0 < x.shape[0]:
                     xc = x[n0:]
-                    self.t_attn(self.t_norm(xc), kv=t_kv[n0:], residual=xc, out=y[n0:])
+                    self.t_attn(ln(self.t_norm, xc), kv=t_kv[n0:], residual=xc, out=y[n0:])
                 x = y
             else:
-                x = self.t_attn(self.t_norm(x), context=t_context, kv=t_kv, residual=x, emit_map=emit_map)
+                x = self.t_attn(ln(self.t_norm, x), context=t_context, kv=t_kv, residual=x, emit_map=emit_map)
         B, N, C = x.shape
         x2 = x.reshape(B * N, C)
-        return self.ff(self.norm3(x2), residual=x2).reshape(B, N, C)
+        return self.ff(ln(self.norm3, x2), residual=x2).reshape(B, N, C)
 
 
 class SpatialTransformer(nn.Module):

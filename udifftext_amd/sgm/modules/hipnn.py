@@ -34,6 +34,13 @@ def count_flops(kind: str, flops: float) -> None:
 FUSE_GN = os.environ.get("UDT_FUSE_GN", "0") != "0"
 
 
+# UDT_FP8=1 (BASELINE config #5): the LayerNorm-fed linears of every transformer block (q|k, v, t_attn.to_q, GEGLU — 60 % of
+# the linear FLOPs) run on the fp8 MFMA path: e4m3 weights with per-output-channel scales, e4m3 activations quantised
+# inside the LayerNorm kernel with a static per-tensor scale, fp32 accumulation, bf16 results.  Everything else (residual
+# stream, attention, convolutions, norm statistics, softmax) is unchanged.
+FP8_LINEARS = os.environ.get("UDT_FP8", "0") != "0"
+
+
 def carry_stats(dst: torch.Tensor, src: torch.Tensor) -> torch.Tensor:
     """a reshape / view makes a new tensor object: hand the producer's column statistics over"""
     st = ops.gn_stats_of(src)
@@ -76,6 +83,18 @@ class _Packed(nn.Module):
     def _pack(self):
         raise NotImplementedError
 
+    def packed_fp8(self):
+        """the fp8 (e4m3 + per-channel scale) layout of the same weights, cached like ``packed()``"""
+        key = self._key()
+        if getattr(self, "_pk8_key", None) != key:
+            with torch.no_grad():
+                self._pk8 = self._pack_fp8()
+            self._pk8_key = key
+        return self._pk8
+
+    def _pack_fp8(self):
+        raise NotImplementedError(f"{type(self).__name__} has no fp8 layout")
+
 
 class Linear(_Packed):
     def __init__(self, in_features: int, out_features: int, bias: bool = True):
@@ -92,8 +111,15 @@ class Linear(_Packed):
     def _pack(self):
         return packing.pack_linear(self.weight), packing.pad_bias(self.bias)
 
+    def _pack_fp8(self):
+        wq, cs = packing.pack_linear_fp8(self.weight)
+        return wq, cs, packing.pad_bias(self.bias)
+
     def forward(self, x, residual=None, flags: int = 0, out=None, rowvec=None, rows_per_batch: int = 0,
                 colstats: bool = False):
+        if isinstance(x, ops.Fp8Act):
+            wq, cs, b = self.packed_fp8()
+            return ops.linear_fp8(x, wq, cs, b, residual=residual, flags=flags, out=out, rows_per_batch=rows_per_batch)
         w, b = self.packed()
         return ops.linear(x, w, b, residual=residual, flags=flags, out=out, rowvec=rowvec, rows_per_batch=rows_per_batch,
                           colstats=colstats and FUSE_GN)
@@ -191,6 +217,20 @@ class LayerNorm(nn.Module):
 
     def forward(self, x):
         return ops.layer_norm(x, self.weight, self.bias, self.eps)
+
+    def fp8_scale(self) -> float:
+        """static per-tensor activation scale of this norm's output: |LN(x)| <= 12 |gamma|_max + |beta|_max covers every
+        value but > 12-sigma outliers (those saturate at the e4m3 maximum); data independent, one host sync per weight set"""
+        key = (self.weight.data_ptr(), self.weight._version, self.bias.data_ptr(), self.bias._version)
+        if getattr(self, "_fp8_key", None) != key:
+            with torch.no_grad():
+                bound = 12.0 * float(self.weight.abs().max()) + float(self.bias.abs().max())
+            self._fp8_scale, self._fp8_key = packing.FP8_MAX / max(bound, 1e-6), key
+        return self._fp8_scale
+
+    def forward_fp8(self, x):
+        """LayerNorm -> e4m3 (ops.Fp8Act) for an fp8 linear"""
+        return ops.layer_norm_fp8(x, self.weight, self.bias, self.eps, self.fp8_scale())
 
 
 def fuse_rows(*weights: torch.Tensor) -> torch.Tensor:
