@@ -217,7 +217,7 @@ def main():
     S.DUAL_STREAM = dual_prev
     conv_flops, conv_bytes = W.get("conv3x3", 0.0), W.get("conv3x3_bytes", 0.0)
     c3p_bytes, c3p_launches = W.get("conv3p_bytes", 0.0), W.get("conv3p_launches", 0.0)
-    gemm_flops = W.get("gemm", 0.0) + W.get("conv1x1", 0.0)
+    gemm_flops = W.get("gemm", 0.0) + W.get("conv1x1", 0.0) + W.get("gemm_fp8", 0.0)
     gemm_bytes = W.get("gemm_bytes", 0.0) + W.get("conv1x1_bytes", 0.0)
     attn_flops, attn_bytes = W.get("attn", 0.0), W.get("attn_bytes", 0.0)
 

@@ -150,8 +150,9 @@ def test_unet_and_vae_with_fused_groupnorm_vs_reference_golden(engine, cond256, 
 def test_unet_call_fp8_linears_vs_reference_golden(engine, cond256, eg, cuda):
     """BASELINE config #5's arithmetic (UDT_FP8=1): the LayerNorm-fed linears of every transformer block on the fp8 MFMA
     path (e4m3 weights with per-channel scales, e4m3 activations with a static per-tensor scale, fp32 accumulation).
-    Stated tolerance against the fp32 reference golden: rel_rms <= 1e-1 (e4m3 keeps 3 mantissa bits: each quantised
-    product carries ~3 % error; bf16 path: 2e-2); the eps must also stay within 1e-1 of the bf16 path."""
+    Stated tolerance against the fp32 reference golden: rel_rms <= 8e-2 (e4m3 keeps 3 mantissa bits: each quantised
+    product carries ~3 % error; measured 4.2e-2 on MI355X; bf16 path: 2e-2 stated / 1.4e-2 measured); the eps must also
+    stay within 8e-2 of the bf16 path."""
     import sgm.modules.hipnn as H
     from udifftext_amd import ops
     batch, _, _ = cond256
@@ -173,8 +174,8 @@ def test_unet_call_fp8_linears_vs_reference_golden(engine, cond256, eg, cuda):
     finally:
         H.FP8_LINEARS = prev
     assert n8 >= 16 * 3, f"only {n8} fp8 GEMM launches"
-    _check("UNet eps with fp8 linears (config #5 arithmetic) vs reference", eps.cpu(), eg["g7_eps"], 1e-1)
-    _check("UNet eps with fp8 linears vs the bf16 path", eps.cpu(), ref_bf16.cpu(), 1e-1)
+    _check("UNet eps with fp8 linears (config #5 arithmetic) vs reference", eps.cpu(), eg["g7_eps"], 8e-2)
+    _check("UNet eps with fp8 linears vs the bf16 path", eps.cpu(), ref_bf16.cpu(), 8e-2)
 
 
 def test_zero_context_shortcut_is_bit_exact(engine, cond256, cuda):

@@ -397,7 +397,8 @@ def test_layer_norm_fp8(ops, cuda):
     assert ((got - ref).abs() <= 0.0625 * ref.abs() + 4e-3).all()
     # identical to quantising the bf16 LayerNorm output up to one e4m3 step (the fused kernel skips the bf16 rounding)
     two = ops.quantize_fp8(ops.layer_norm(x, g, b, 1e-5), scale)
-    assert (_deq(two.data) - _deq(q.data)).abs().max().item() <= 0.125 * 14.0 * scale / 448.0 * 32
+    a, bq = _deq(two.data), _deq(q.data)
+    assert ((a - bq).abs() <= 0.126 * torch.maximum(a.abs(), bq.abs()) + 1e-2).all()
 
 
 def test_conv_epilogue(ops, cuda):

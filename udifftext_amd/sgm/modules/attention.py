@@ -101,7 +101,7 @@ class CrossAttention(H._Packed):
             kv = self.project_context(context)
         probs = None
         if emit_map and self.attn_map_cache is not None:
-            probs = torch.empty((B * self.heads, N, kv.shape[1]), dtype=torch.float32, device=x.device)
+            probs = torch.empty((B * self.heads, N, kv.shape[1]), dtype=torch.float32, device=q.device)
             self.attn_map_cache["size"] = int(N ** 0.5)
             self.attn_map_cache["attn_map"] = probs
         o = ops.xattention(q, kv[..., :inner], kv[..., inner:], self.heads, self.dim_head, self.scale, probs=probs)
