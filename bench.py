@@ -14,8 +14,8 @@ timed region starts.  The global batch (--global-batch, default batch x N) is sh
 ``parallel.predict_sharded`` (per-image seeds: results do not depend on N) and the decoded frames are all-gathered
 once per global batch over RCCL.
 
-`value` is the on-config number: every UNet call runs on ONE batch of --batch images (its CFG pair); two such
-batches are in flight per GPU on two launch streams (--in-flight 2, stated in config.workload).  The other launch
+`value` is the on-config number: every UNet call runs on ONE batch of --batch images (its CFG pair); three such
+batches are in flight per GPU on three launch streams (--in-flight 3, stated in config.workload).  The other launch
 modes (one batch at a time; throughput mode with batches concatenated into larger UNet calls) are reported under
 `images_per_s_by_launch_mode` and are never `value`.
 
@@ -55,8 +55,8 @@ def flop_per_image(size: int, sampler_steps: int) -> float:
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=4)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=6)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=4, help="images per UNet call and GPU (BASELINE config #2: 4)")
     ap.add_argument("--global-batch", type=int, default=0, help="images per step over ALL GPUs (0 = batch x GPUs); "
                     "config #3: 64 on 8 GPUs")
@@ -65,7 +65,8 @@ def parse():
     ap.add_argument("--chars", type=int, default=9)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-mode-table", action="store_true", help="skip the extra passes in the other launch modes")
-    ap.add_argument("--in-flight", type=int, default=2, help="batches sampled concurrently per GPU, one launch stream each")
+    ap.add_argument("--in-flight", type=int, default=3, help="batches sampled concurrently per GPU, one launch stream each "
+                    "(same-box on MI355X: 1 -> 5.7, 2 -> 7.13, 3 -> 7.67, 4 -> 6.0 images/s)")
     ap.add_argument("--fp8", action="store_true", help="BASELINE config #5 arithmetic: the transformer blocks' LayerNorm-fed "
                     "linears on the fp8 (e4m3) MFMA path")
     ap.add_argument("--fuse", type=int, default=1, help="batches concatenated into one UNet call (1 = the on-config "
@@ -238,6 +239,8 @@ def main():
     if not args.no_mode_table:
         if not (args.in_flight == 1 and args.fuse == 1):
             other_modes["one_batch_at_a_time"] = timed_mode(1, 1)
+        if args.in_flight > 2 and args.fuse == 1:
+            other_modes["2_batches_in_flight"] = timed_mode(2, 1)
         if args.fuse == 1 and args.steps * (G // world) // args.batch >= 4:
             other_modes["throughput_mode_batches_concatenated_per_unet_call (off-config)"] = timed_mode(2, 0)
 

@@ -170,6 +170,23 @@ int udt_xattn_fwd(const void* q, const void* k, const void* v, void* o, float* p
                   int32_t batch, int32_t heads, int32_t head_dim, int32_t nq, int32_t L,
                   int32_t ldq, int32_t ldkv, int32_t ldo, float scale, void* stream);
 
+/* The text cross-attention branch of a transformer block as ONE kernel (csrc/tattn.hip):
+ *   out = x + to_out(softmax(to_q(LayerNorm(x)) K^T * scale) V) + bias        reference sgm/modules/attention.py:140-174,326-333
+ * The context is constant during sampling and has L <= 12 tokens, so udt_tattn_prepare folds it ONCE per batch into
+ * per-sample tables (exact re-association): A' [B][hp][C] bf16 (LayerNorm gamma, to_q and K folded; hp = udt_tattn_hp(heads)
+ * = 16 columns per head, rounded up to 32), sc [B][hp][2] fp32 (the LayerNorm mean / beta terms), BmT [B][C][hp] bf16 (V and
+ * to_out folded).  udt_tattn_fused then needs only the raw rows: x, out bf16 [B * n_tok, C] (C = 64 * heads <= 1280,
+ * n_tok % 64 == 0, or % 32 for C > 640); the first `zero_samples` samples attend to an all-zero context and get
+ * x + bias (no tables needed when zero_samples == B).
+ *   kv: bf16 [B, L, ldkv], k in columns [0, C), v in [C, 2C) (the hoisted to_k|to_v projection); wq: bf16 [C, ldwq] (to_q
+ *   weight, rows = output features), wo: bf16 [C, ldwo] (to_out weight); gamma / beta: t_norm; bias: to_out bias. */
+int32_t udt_tattn_hp(int32_t heads);
+int udt_tattn_prepare(const void* kv, int32_t ldkv, const void* wq, int32_t ldwq, const void* wo, int32_t ldwo,
+                      const float* gamma, const float* beta, void* A, float* sc, void* BmT, int32_t B, int32_t L,
+                      int32_t C, int32_t heads, float scale, void* stream);
+int udt_tattn_fused(const void* x, void* out, const void* A, const float* sc, const void* BmT, const float* bias,
+                    int32_t B, int32_t n_tok, int32_t C, int32_t heads, int32_t zero_samples, float eps, void* stream);
+
 /* Row softmax of a bf16 [rows, cols] matrix in place (ld elements between rows), fp32 math. */
 int udt_softmax_rows(void* x, int64_t rows, int32_t cols, int32_t ld, void* stream);
 

@@ -464,6 +464,45 @@ def test_xattention(ops, cuda, B, H, D, N, Lc):
     _close(probs, sim.reshape(B * H, N, Lc), atol=1e-4, rtol=1e-3, what="xattn probs")
 
 
+@pytest.mark.parametrize("B,N,heads,Lc,zero", [(3, 4096, 5, 12, 1), (2, 1024, 10, 12, 0), (4, 64, 20, 12, 2), (2, 256, 20, 9, 2)])
+def test_tattn_fused(ops, cuda, B, N, heads, Lc, zero):
+    """udt_tattn_prepare + udt_tattn_fused (LayerNorm, to_q, 12-token softmax attention, to_out, bias, residual in one
+    launch on folded tables) against the reference op sequence in torch fp32 (attention.py:140-174,326-333) on the same
+    bf16 inputs / weights; the first `zero` samples attend to an all-zero context (x + bias)"""
+    from udifftext_amd import packing
+    C = heads * 64
+    Dc = 256
+    x = (_rand((B, N, C), cuda, 1.5, seed=1) + 0.3).bfloat16()
+    ctx = _rand((B, Lc, Dc), cuda, seed=2).bfloat16()
+    ctx[:zero] = 0
+    g = _rand((C,), cuda, seed=3) * 0.2 + 1.0
+    be = _rand((C,), cuda, seed=4) * 0.2
+    wq = _rand((C, C), cuda, 1 / math.sqrt(C), seed=5)
+    wk = _rand((C, Dc), cuda, 1 / math.sqrt(Dc), seed=6)
+    wv = _rand((C, Dc), cuda, 1 / math.sqrt(Dc), seed=7)
+    wo = _rand((C, C), cuda, 1 / math.sqrt(C), seed=8)
+    bo = _rand((C,), cuda, seed=9) * 0.3
+    kvw = packing.pack_linear(torch.cat([wk, wv], 0))
+    kv = ops.linear(ctx.reshape(B * Lc, Dc), kvw).reshape(B, Lc, 2 * C)
+    tabs = ops.tattn_prepare(kv, packing.pack_linear(wq), packing.pack_linear(wo), g, be, heads, 64 ** -0.5)
+    out = ops.tattn_fused(x, tabs, bo, heads, zero, 1e-5)
+    # reference
+    xn = F.layer_norm(x.float(), (C,), g, be, 1e-5)
+    q = xn @ wq.bfloat16().float().t()
+    k, v = kv[..., :C].float(), kv[..., C:].float()
+    qh = q.reshape(B, N, heads, 64).permute(0, 2, 1, 3)
+    kh = k.reshape(B, Lc, heads, 64).permute(0, 2, 1, 3)
+    vh = v.reshape(B, Lc, heads, 64).permute(0, 2, 1, 3)
+    sim = (qh @ kh.transpose(-1, -2)) * 64 ** -0.5
+    pr = sim.softmax(-1)           # (a single-token context takes the reference's sigmoid branch: never folded, see attention.py)
+    o = (pr @ vh).permute(0, 2, 1, 3).reshape(B, N, C)
+    ref = o @ wo.bfloat16().float().t() + bo + x.float()
+    ref[:zero] = x[:zero].float() + bo
+    _close(out, ref, atol=3e-2, what=f"fused t_attn {B,N,heads,Lc,zero}")
+    # zero-context rows are bit-exact x + bias
+    assert torch.equal(out[:zero], (x[:zero].float() + bo).bfloat16())
+
+
 def test_softmax_rows(ops, cuda):
     x = _rand((300, 1024), cuda, 3.0, seed=1).bfloat16()
     ref = torch.softmax(x.float(), dim=-1)

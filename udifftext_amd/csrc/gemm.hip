@@ -944,10 +944,18 @@ extern "C" int udt_gemm(const udt_gemm_desc* d, void* workspace, size_t workspac
     const TilePlan t8 = plan_tiles8(d);
     p.tiles_m = t8.tiles_m; p.tiles_n = t8.tiles_n; p.tiles_per_batch = t8.tiles_m * t8.tiles_n;
     const int n_block_knob = g_n_block.load(std::memory_order_relaxed);
-    if (n_block_knob != 0 && !conv && (n_block_knob > 0 || t8.tiles_n >= 8)) {    // wide outputs only (measured: N = 640 loses)
-      // weight block of ~2 MiB: bn * K * 2 bytes per N-tile
-      const long long wt = (long long)t8.bn * d->K * 2;
-      long long nb = n_block_knob > 0 ? n_block_knob : (2LL << 20) / (wt > 0 ? wt : 1);
+    // Tile order of plain GEMMs (decode_tile): N-tiles in blocks of n_block, N-fastest inside a block.  Automatic rule,
+    // from the sweep over the UNet's shapes in profiles/r02_gemm_shapes_tile_order.txt (same-box, hipGraph-timed):
+    //   few M-tiles (<= 8: the 16x16 / 8x8 levels) or a transposed output -> one block (N-fastest): the 256-row A tile
+    //     stays in the XCD's L2 while its (half as large) weight tiles stream (2048x1280x5120: 64 -> 52 us);
+    //   wide outputs (>= 8 N-tiles)                                      -> weight blocks of ~4 MiB;
+    //   otherwise                                                          -> M-fastest (N = 640 at 64x64 measured slower blocked).
+    if (n_block_knob != 0 && !conv) {
+      const long long wt = (long long)t8.bn * d->K * elem_bytes(d);
+      long long nb = 1;
+      if (n_block_knob > 0) nb = n_block_knob;
+      else if (t8.tiles_m <= 8 || trans) nb = t8.tiles_n;
+      else if (t8.tiles_n >= 8) nb = (4LL << 20) / (wt > 0 ? wt : 1);
       if (nb < 1) nb = 1;
       if (nb > t8.tiles_n) nb = t8.tiles_n;
       p.n_block = (int)nb;

@@ -1,0 +1,364 @@
+// tattn.hip — the text cross-attention branch of a transformer block as ONE kernel.
+//
+// Reference: BasicTransformerBlock.forward  x = t_attn(t_norm(x), context) + x   (sgm/modules/attention.py:314-341) with
+// CrossAttention.forward (:140-174): q = to_q(LN(x)); sim = q k^T * d^-1/2 per head; softmax over the L <= 12 context
+// tokens; out = to_out(sim v) + bias.
+//
+// The context (the label embedding) does not change during sampling and has at most 12 tokens, so everything that
+// touches it is folded once per batch (udt_tattn_prepare; exact re-association in fp32, SURVEY.md §9b.1 taken further):
+//   scores of head h   S_h = LN(x) Wq_h^T K_h^T * scale = LN(x) A_h            A_h  = scale * Wq_h^T K_h^T   [C, 12]
+//   output             out = sum_h softmax(S_h) (V_h Wo_h^T) + b               Bm_h = V_h Wo_h^T             [12, C]
+// and the LayerNorm is folded as well: with A' = diag(gamma) A,  s_j = sum_k A'_kj,  c_j = sum_k beta_k A_kj,
+//   S_j = rstd * (x . A'_j - mean * s_j) + c_j
+// so the kernel multiplies the RAW token rows — no normalised copy, no q, no per-head attention launch:
+//   x tile (TT tokens, staged once in LDS: also the residual) -> row mean / rstd -> S = x A' on the MFMAs ->
+//   softmax over each head's 16-column group (12 real + 4 padded columns whose c_j = -1e30) -> P (bf16, LDS) ->
+//   out^T = Bm^T P^T on the MFMAs -> + bias + x -> store.
+// A head occupies 16 columns, so hp = 16 * heads (80 / 160 / 320 for the UNet's 5 / 10 / 20 heads, padded to a multiple
+// of 32).  Replaces, per transformer block and sampler step, layernorm + to_q GEMM + xattn + to_out GEMM (+ the
+// bias-add launch of the zero-context half: tiles of the first `zero_samples` samples just add the bias).
+// FLOPs drop 5x against the unfused chain (K = 12 per head instead of 64); the kernel is bound by reading x once.
+#include "common.h"
+#include <stdio.h>
+
+namespace {
+
+constexpr int TA_THREADS = 512;        // 8 waves: the MFMA phases are chains of L2-latency-bound steps, more waves hide more of it
+constexpr int TA_WAVES = TA_THREADS / 64;
+
+struct TattnParams {
+  const uint16_t* x;       // [M, C] bf16
+  uint16_t* out;           // [M, C] bf16 (may alias x)
+  const uint16_t* A;       // [B][hp][C] bf16: A' rows (K contiguous)
+  const float* sc;         // [B][hp][2]: (s_j, c_j)
+  const uint16_t* BmT;     // [B][C][hp] bf16
+  const float* bias;       // [C] to_out bias
+  const uint16_t* zero;
+  int M, C, hp, n_tok, zero_samples;
+  int nsplit;              // workgroups per token tile: each recomputes the (cheap) scores and owns 1/nsplit of the output channels
+  float eps;
+};
+
+UDT_DEVINL f32x16 zero16() {
+  f32x16 z;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) z[r] = 0.f;
+  return z;
+}
+
+// TT tokens per workgroup (64, or 32 for C = 1280 so that the x tile fits in LDS), 8 waves
+template <int TT>
+__global__ void __launch_bounds__(TA_THREADS) tattn_fused_kernel(const TattnParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int C = p.C, hp = p.hp;
+  const int nkt = C >> 6;                                   // 64-channel K-tiles of the x tile
+  char* const xs = smem;                                    // [nkt][TT][128 B], XOR-swizzled 16-byte slots
+  float* const stats = reinterpret_cast<float*>(smem + (size_t)nkt * TT * 128);        // [TT][2]: mean, rstd
+  const int prs = hp * 2 + 16;                              // padded row stride of the P tile (bytes)
+  char* const pl = reinterpret_cast<char*>(stats + TT * 2);                            // [TT][prs]
+
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = tid & 63;
+  const int l31 = lane & 31, hi = lane >> 5;
+  const long long tok0 = (long long)blockIdx.x * TT;
+  const int b = (int)(tok0 / p.n_tok);
+  const uint16_t* xg = p.x + tok0 * C;
+  uint16_t* og = p.out + tok0 * C;
+
+  // ---- x tile -> LDS by LDS-DMA: piece = (K-tile kt, 8-row group rg); lane -> row rg*8 + lane/8, slot lane%8 ----------
+  {
+    const int pieces = nkt * (TT / 8);
+    const int l3 = lane >> 3, ps = lane & 7;
+    for (int pc = wave; pc < pieces; pc += TA_WAVES) {
+      const int kt = pc / (TT / 8), rg = pc - kt * (TT / 8);
+      const int row = rg * 8 + l3;
+      const int slot = ps ^ ((row >> 1) & 7);
+      const uint16_t* src = (tok0 + row < p.M) ? (xg + (long long)row * C + kt * 64 + slot * 8) : p.zero;
+      glds16(src, xs + (size_t)pc * 1024);
+    }
+    wait_vmcnt0();
+  }
+  __syncthreads();
+
+  // ---- the zero-context half: x + to_out.bias (reference: k = v = 0 -> attention output 0 -> to_out reduces to its bias)
+  if (b < p.zero_samples) {
+    const int c8 = C >> 3;
+    const int ch_lo = (int)blockIdx.y * c8 / p.nsplit, ch_hi = ((int)blockIdx.y + 1) * c8 / p.nsplit;
+    for (int i = tid; i < TT * c8; i += TA_THREADS) {
+      const int row = i / c8, ch = i - row * c8;
+      if (tok0 + row >= p.M || ch < ch_lo || ch >= ch_hi) continue;
+      const int kt = ch >> 3, s = ch & 7;
+      const u32x4 v = *reinterpret_cast<const u32x4*>(xs + ((size_t)kt * TT + row) * 128 + ((s ^ ((row >> 1) & 7)) << 4));
+      const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.bias + ch * 8), b1 = *reinterpret_cast<const f32x4*>(p.bias + ch * 8 + 4);
+      u32x4 o = {pack_bf16x2(bf16_lo(v[0]) + b0[0], bf16_hi(v[0]) + b0[1]), pack_bf16x2(bf16_lo(v[1]) + b0[2], bf16_hi(v[1]) + b0[3]),
+                 pack_bf16x2(bf16_lo(v[2]) + b1[0], bf16_hi(v[2]) + b1[1]), pack_bf16x2(bf16_lo(v[3]) + b1[2], bf16_hi(v[3]) + b1[3])};
+      *reinterpret_cast<u32x4*>(og + (long long)row * C + ch * 8) = o;
+    }
+    return;
+  }
+
+  // ---- LayerNorm statistics of the raw rows: 256 / TT threads per row, fp32 -------------------------------------------
+  {
+    constexpr int TPR = TA_THREADS / TT;                    // 8 or 16 threads per row (consecutive lanes)
+    const int row = tid / TPR, part = tid - row * TPR;
+    const int swz = (row >> 1) & 7;
+    float s = 0.f, q = 0.f;
+    for (int ch = part; ch < nkt * 8; ch += TPR) {
+      const int kt = ch >> 3, sl = ch & 7;
+      const u32x4 v = *reinterpret_cast<const u32x4*>(xs + ((size_t)kt * TT + row) * 128 + ((sl ^ swz) << 4));
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float a = bf16_lo(v[j]), bb = bf16_hi(v[j]);
+        s += a + bb;
+        q += a * a + bb * bb;
+      }
+    }
+    s = dpp_add<0xB1>(s); q = dpp_add<0xB1>(q);             // lane ^ 1
+    s = dpp_add<0x4E>(s); q = dpp_add<0x4E>(q);             // lane ^ 2
+    s += __shfl_xor(s, 4); q += __shfl_xor(q, 4);           // lane ^ 4
+    if (TPR == 16) { s += __shfl_xor(s, 8); q += __shfl_xor(q, 8); }
+    if (part == 0) {
+      const float mean = s / (float)C;
+      float var = q / (float)C - mean * mean;
+      if (var < 0.f) var = 0.f;
+      stats[row * 2] = mean;
+      stats[row * 2 + 1] = rsqrtf(var + p.eps);
+    }
+  }
+  __syncthreads();
+
+  // ---- S^T = A' x^T  (D rows = score columns j, D cols = tokens: a lane owns one token) -> softmax -> P in LDS ---------
+  const uint16_t* Ab = p.A + (long long)b * hp * C;
+  const float* scb = p.sc + (long long)b * hp * 2;
+  const int jt = hp >> 5;                                   // 32-column tiles of the scores
+  const int tiles1 = jt * (TT / 32);
+  for (int t = wave; t < tiles1; t += TA_WAVES) {
+    const int rt = t % (TT / 32), ct = t / (TT / 32);
+    const int row = rt * 32 + l31;                          // this lane's token (as MFMA column)
+    const int swz = (l31 >> 1) & 7;                         // (row >> 1) & 7 with row = rt*32 + l31
+    const uint16_t* arow = Ab + (long long)(ct * 32 + l31) * C + hi * 8;
+    f32x16 acc = zero16();
+    // the A' fragments come straight from L2 (each is used once per workgroup): loads run one K-tile ahead of the MFMAs
+    bf16x8_t an[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) an[ks] = *reinterpret_cast<const bf16x8_t*>(arow + ks * 16);
+    for (int kt = 0; kt < nkt; ++kt) {
+      const char* xrow = xs + ((size_t)kt * TT + row) * 128;
+      bf16x8_t af[4], xf[4];
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        af[ks] = an[ks];
+        xf[ks] = lds_read_frag(xrow + (((ks * 2 + hi) ^ swz) << 4));
+      }
+      const int ktn = (kt + 1 < nkt) ? kt + 1 : kt;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) an[ks] = *reinterpret_cast<const bf16x8_t*>(arow + ktn * 64 + ks * 16);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) acc = mfma32(af[ks], xf[ks], acc);
+    }
+    const float mean = stats[row * 2], rstd = stats[row * 2 + 1];
+    // reg r <-> column j = ct*32 + (r&3) + 8*(r>>2) + 4*hi; regs 0..7 lie in the tile's first head, 8..15 in the second
+    float sv[16];
+#pragma unroll
+    for (int r4 = 0; r4 < 4; ++r4) {
+      const int j = ct * 32 + 8 * r4 + 4 * hi;
+      const f32x4 c0 = *reinterpret_cast<const f32x4*>(scb + j * 2), c1 = *reinterpret_cast<const f32x4*>(scb + j * 2 + 4);
+      sv[r4 * 4 + 0] = rstd * (acc[r4 * 4 + 0] - mean * c0[0]) + c0[1];
+      sv[r4 * 4 + 1] = rstd * (acc[r4 * 4 + 1] - mean * c0[2]) + c0[3];
+      sv[r4 * 4 + 2] = rstd * (acc[r4 * 4 + 2] - mean * c1[0]) + c1[1];
+      sv[r4 * 4 + 3] = rstd * (acc[r4 * 4 + 3] - mean * c1[2]) + c1[3];
+    }
+#pragma unroll
+    for (int h2 = 0; h2 < 2; ++h2) {                        // the two heads of this 32-column tile
+      float mx = sv[h2 * 8];
+#pragma unroll
+      for (int r = 1; r < 8; ++r) mx = fmaxf(mx, sv[h2 * 8 + r]);
+      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      float sum = 0.f;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        sv[h2 * 8 + r] = __expf(sv[h2 * 8 + r] - mx);
+        sum += sv[h2 * 8 + r];
+      }
+      sum += __shfl_xor(sum, 32);
+      const float inv = 1.0f / sum;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) sv[h2 * 8 + r] *= inv;
+    }
+#pragma unroll
+    for (int r4 = 0; r4 < 4; ++r4) {
+      const int j = ct * 32 + 8 * r4 + 4 * hi;
+      u32x2 pk = {pack_bf16x2(sv[r4 * 4], sv[r4 * 4 + 1]), pack_bf16x2(sv[r4 * 4 + 2], sv[r4 * 4 + 3])};
+      *reinterpret_cast<u32x2*>(pl + (size_t)row * prs + j * 2) = pk;
+    }
+  }
+  __syncthreads();
+
+  // ---- out^T = Bm^T P^T  (D rows = channels, D cols = tokens) + bias + residual -> store ---------------------------------
+  const uint16_t* Bb = p.BmT + (long long)b * C * hp;
+  const int ct_lo = (int)blockIdx.y * (C >> 5) / p.nsplit, ct_hi = ((int)blockIdx.y + 1) * (C >> 5) / p.nsplit;
+  const int tiles2 = (ct_hi - ct_lo) * (TT / 32);
+  const int nks = hp >> 4;                                  // 16-wide k-steps over the score columns
+  for (int t = wave; t < tiles2; t += TA_WAVES) {
+    const int rt = t % (TT / 32), ct = ct_lo + t / (TT / 32);
+    const int row = rt * 32 + l31;
+    const uint16_t* brow = Bb + (long long)(ct * 32 + l31) * hp + hi * 8;
+    const char* prow = pl + (size_t)row * prs + hi * 16;
+    f32x16 acc = zero16();
+    bf16x8_t bn[2];                                         // Bm^T fragments two k-steps ahead (L2 latency)
+    bn[0] = *reinterpret_cast<const bf16x8_t*>(brow);
+    bn[1] = *reinterpret_cast<const bf16x8_t*>(brow + 16);
+    for (int ks = 0; ks < nks; ks += 2) {
+      const bf16x8_t b0 = bn[0], b1 = bn[1];
+      const int k2 = (ks + 2 < nks) ? ks + 2 : ks;
+      bn[0] = *reinterpret_cast<const bf16x8_t*>(brow + k2 * 16);
+      bn[1] = *reinterpret_cast<const bf16x8_t*>(brow + k2 * 16 + 16);
+      const bf16x8_t p0 = *reinterpret_cast<const bf16x8_t*>(prow + ks * 32);
+      const bf16x8_t p1 = *reinterpret_cast<const bf16x8_t*>(prow + ks * 32 + 32);
+      acc = mfma32(b0, p0, acc);
+      acc = mfma32(b1, p1, acc);
+    }
+    if (tok0 + row < p.M) {
+      const int swz = (row >> 1) & 7;
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) {
+        const int c = ct * 32 + 8 * r4 + 4 * hi;            // 4 consecutive channels
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + c);
+        const int kt = c >> 6, sl = (c & 63) >> 3;
+        const u32x2 xr = *reinterpret_cast<const u32x2*>(xs + ((size_t)kt * TT + row) * 128 + ((sl ^ swz) << 4) + (c & 7) * 2);
+        u32x2 pk = {pack_bf16x2(acc[r4 * 4 + 0] + bv[0] + bf16_lo(xr[0]), acc[r4 * 4 + 1] + bv[1] + bf16_hi(xr[0])),
+                    pack_bf16x2(acc[r4 * 4 + 2] + bv[2] + bf16_lo(xr[1]), acc[r4 * 4 + 3] + bv[3] + bf16_hi(xr[1]))};
+        *reinterpret_cast<u32x2*>(og + (long long)row * C + c) = pk;
+      }
+    }
+  }
+}
+
+// ---- once per batch: fold the context into the per-sample tables ------------------------------------------------------
+// grid (hp, B): one workgroup per score column j = 16 h + i.  A'[b][j][k] = gamma_k * scale * sum_d Wq[h*64+d][k] K[b][i][h*64+d];
+// s_j = sum_k bf16(A'), c_j = scale * sum_k beta_k sum_d (...); padded columns (i >= L): A' = 0, s = 0, c = -1e30.
+__global__ void __launch_bounds__(256) tattn_prepare_a_kernel(const uint16_t* __restrict__ kv, int ldkv, const uint16_t* __restrict__ wq,
+                                                              int ldwq, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                              uint16_t* __restrict__ A, float* __restrict__ sc, int L, int C, int hp,
+                                                              int heads, float scale) {
+  __shared__ float kvec[64];
+  __shared__ float red[2][4];
+  const int j = blockIdx.x, b = blockIdx.y, t = threadIdx.x;
+  const int h = j >> 4, i = j & 15;
+  uint16_t* arow = A + ((long long)b * hp + j) * C;
+  float* scj = sc + ((long long)b * hp + j) * 2;
+  if (h >= heads || i >= L) {
+    for (int k = t; k < C; k += 256) arow[k] = 0;
+    if (t == 0) { scj[0] = 0.f; scj[1] = -1e30f; }
+    return;
+  }
+  if (t < 64) kvec[t] = bf16_bits_to_f32(kv[((long long)b * L + i) * ldkv + h * 64 + t]) * scale;
+  __syncthreads();
+  float s = 0.f, c = 0.f;
+  for (int k = t; k < C; k += 256) {
+    float a = 0.f;
+#pragma unroll 8
+    for (int d = 0; d < 64; ++d) a += bf16_bits_to_f32(wq[(long long)(h * 64 + d) * ldwq + k]) * kvec[d];
+    const uint32_t pk = pack_bf16x2(a * gamma[k], 0.f);
+    arow[k] = (uint16_t)(pk & 0xffffu);
+    s += bf16_lo(pk);
+    c += beta[k] * a;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { s += __shfl_xor(s, off); c += __shfl_xor(c, off); }
+  if ((t & 63) == 0) { red[0][t >> 6] = s; red[1][t >> 6] = c; }
+  __syncthreads();
+  if (t == 0) {
+    scj[0] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+    scj[1] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+  }
+}
+
+// BmT[b][c][j] = sum_d V[b][i][h*64+d] Wo[c][h*64+d]   (j = 16 h + i; padded columns 0).  One thread per element.
+__global__ void __launch_bounds__(256) tattn_prepare_b_kernel(const uint16_t* __restrict__ kv, int ldkv, int v_off,
+                                                              const uint16_t* __restrict__ wo, int ldwo, uint16_t* __restrict__ BmT,
+                                                              int B, int L, int C, int hp, int heads) {
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long long)B * C * hp) return;
+  const int j = (int)(idx % hp);
+  const long long bc = idx / hp;
+  const int c = (int)(bc % C), b = (int)(bc / C);
+  const int h = j >> 4, i = j & 15;
+  float a = 0.f;
+  if (h < heads && i < L) {
+    const uint16_t* vr = kv + ((long long)b * L + i) * ldkv + v_off + h * 64;
+    const uint16_t* wr = wo + (long long)c * ldwo + h * 64;
+#pragma unroll 8
+    for (int d = 0; d < 64; ++d) a += bf16_bits_to_f32(vr[d]) * bf16_bits_to_f32(wr[d]);
+  }
+  BmT[idx] = (uint16_t)(pack_bf16x2(a, 0.f) & 0xffffu);
+}
+
+}  // namespace
+
+extern "C" int32_t udt_tattn_hp(int32_t heads) { return ((heads * 16 + 31) / 32) * 32; }
+
+extern "C" int udt_tattn_prepare(const void* kv, int32_t ldkv, const void* wq, int32_t ldwq, const void* wo, int32_t ldwo,
+                                 const float* gamma, const float* beta, void* A, float* sc, void* BmT, int32_t B, int32_t L,
+                                 int32_t C, int32_t heads, float scale, void* stream) {
+  if (!kv || !wq || !wo || !gamma || !beta || !A || !sc || !BmT) return UDT_ERR_BAD_ARG;
+  if (B <= 0 || L <= 0 || L > 12 || heads <= 0 || C != heads * 64 || ldkv < 2 * C || ldwq < C || ldwo < C) return UDT_ERR_BAD_SHAPE;
+  const int hp = udt_tattn_hp(heads);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  UdtProfScope prof(3, s);
+  hipLaunchKernelGGL(tattn_prepare_a_kernel, dim3(hp, B), dim3(256), 0, s, reinterpret_cast<const uint16_t*>(kv), ldkv,
+                     reinterpret_cast<const uint16_t*>(wq), ldwq, gamma, beta, reinterpret_cast<uint16_t*>(A), sc, L, C, hp, heads, scale);
+  UDT_CHECK_LAUNCH();
+  const long long n = (long long)B * C * hp;
+  hipLaunchKernelGGL(tattn_prepare_b_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s,
+                     reinterpret_cast<const uint16_t*>(kv), ldkv, C, reinterpret_cast<const uint16_t*>(wo), ldwo,
+                     reinterpret_cast<uint16_t*>(BmT), B, L, C, hp, heads);
+  UDT_CHECK_LAUNCH();
+  return UDT_OK;
+}
+
+extern "C" int udt_tattn_fused(const void* x, void* out, const void* A, const float* sc, const void* BmT, const float* bias,
+                               int32_t B, int32_t n_tok, int32_t C, int32_t heads, int32_t zero_samples, float eps, void* stream) {
+  if (!x || !out || !bias || (zero_samples < B && (!A || !sc || !BmT))) return UDT_ERR_BAD_ARG;
+  if (B <= 0 || n_tok <= 0 || heads <= 0 || C != heads * 64 || C > 1280 || zero_samples < 0 || zero_samples > B) return UDT_ERR_BAD_SHAPE;
+  const int TT = (C > 640) ? 32 : 64;
+  if (n_tok % TT != 0) return UDT_ERR_BAD_SHAPE;             // a token tile lies in one sample
+  TattnParams p;
+  p.x = reinterpret_cast<const uint16_t*>(x); p.out = reinterpret_cast<uint16_t*>(out);
+  p.A = reinterpret_cast<const uint16_t*>(A); p.sc = sc; p.BmT = reinterpret_cast<const uint16_t*>(BmT); p.bias = bias;
+  p.zero = udt_zero_page();
+  if (!p.zero) return UDT_ERR_HIP;
+  p.M = B * n_tok; p.C = C; p.hp = udt_tattn_hp(heads); p.n_tok = n_tok; p.zero_samples = zero_samples; p.eps = eps;
+  const size_t smem = (size_t)TT * C * 2 + (size_t)TT * 2 * sizeof(float) + (size_t)TT * (p.hp * 2 + 16);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  UdtProfScope prof(3, s);
+  if (prof.rec) {
+    char tag[96];
+    snprintf(tag, sizeof(tag), "tattn_fused B=%d n=%d C=%d zero=%d", B, n_tok, C, zero_samples);
+    udt_prof_tag(prof.rec, tag);
+  }
+  static bool attr64 = false, attr32 = false;                // (max dynamic LDS; set once per process — one device per process)
+  const unsigned grid = (unsigned)(p.M / TT);
+  // few token tiles (the 16x16 / 8x8 levels): split the output channels over up to 4 workgroups per tile so that the
+  // launch covers >= ~128 CUs; every split recomputes the statistics and scores of its tile (a third of the work)
+  p.nsplit = 1;
+  while (p.nsplit < 4 && grid * p.nsplit < 128) p.nsplit *= 2;
+  if (TT == 64) {
+    if (!attr64) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(tattn_fused_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024);
+      if (e != hipSuccess) return udt_set_hip_error(e);
+      attr64 = true;
+    }
+    hipLaunchKernelGGL(tattn_fused_kernel<64>, dim3(grid, p.nsplit), dim3(TA_THREADS), smem, s, p);
+  } else {
+    if (!attr32) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(tattn_fused_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024);
+      if (e != hipSuccess) return udt_set_hip_error(e);
+      attr32 = true;
+    }
+    hipLaunchKernelGGL(tattn_fused_kernel<32>, dim3(grid, p.nsplit), dim3(TA_THREADS), smem, s, p);
+  }
+  UDT_CHECK_LAUNCH();
+  return UDT_OK;
+}

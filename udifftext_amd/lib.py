@@ -55,6 +55,9 @@ SYMBOLS = {
                                _i64, _i64, _i64, _i64, _f32, _vp]),
     "udt_xattn_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _fp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp]),
     "udt_softmax_rows": (C.c_int, [_vp, _i64, _i32, _i32, _vp]),
+    "udt_tattn_hp": (_i32, [_i32]),
+    "udt_tattn_prepare": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _i32, _fp, _fp, _vp, _fp, _vp, _i32, _i32, _i32, _i32, _f32, _vp]),
+    "udt_tattn_fused": (C.c_int, [_vp, _vp, _vp, _fp, _vp, _fp, _i32, _i32, _i32, _i32, _i32, _f32, _vp]),
     "udt_gn_nchunks": (_i32, [_i64, _i32]),
     "udt_gn_stats": (C.c_int, [_vp, _vp, _fp, _i32, _i64, _i32, _i32, _i32, _vp]),
     "udt_gn_apply": (C.c_int, [_vp, _vp, _vp, _fp, _fp, _fp, _i32, _i64, _i32, _i32, _i32, _f32, _i32, _vp]),

@@ -307,6 +307,51 @@ def xattention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, he
     return out
 
 
+class TattnTables(NamedTuple):
+    """per-sample tables of the fused text cross-attention (udt_tattn_prepare)"""
+    A: torch.Tensor          # bf16 [B, hp, C]
+    sc: torch.Tensor         # fp32 [B, hp, 2]
+    BmT: torch.Tensor        # bf16 [B, C, hp]
+
+    def rows(self, begin: int, end: Optional[int] = None) -> "TattnTables":
+        return TattnTables(self.A[begin:end], self.sc[begin:end], self.BmT[begin:end])
+
+
+def tattn_prepare(kv: torch.Tensor, wq: torch.Tensor, wo: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, heads: int,
+                  scale: float, out: Optional[TattnTables] = None) -> TattnTables:
+    """kv bf16 [B, L, 2*C] (hoisted k|v of the context), wq / wo packed bf16 [C, >=C] -> tables (in place into ``out``)"""
+    _bf16(kv); _bf16(wq); _bf16(wo)
+    B, Lc, two_c = kv.shape
+    Cc = heads * 64
+    assert two_c == 2 * Cc and kv.is_contiguous() and wq.is_contiguous() and wo.is_contiguous()
+    hp = L.load().udt_tattn_hp(heads)
+    if out is None:
+        out = TattnTables(torch.empty((B, hp, Cc), dtype=torch.bfloat16, device=kv.device),
+                          torch.empty((B, hp, 2), dtype=torch.float32, device=kv.device),
+                          torch.empty((B, Cc, hp), dtype=torch.bfloat16, device=kv.device))
+    L.check(L.load().udt_tattn_prepare(_ptr(kv), two_c, _ptr(wq), wq.stride(0), _ptr(wo), wo.stride(0), _ptr(gamma), _ptr(beta),
+                                       _ptr(out.A), _ptr(out.sc), _ptr(out.BmT), B, Lc, Cc, heads, scale, _stream()),
+            "udt_tattn_prepare")
+    return out
+
+
+def tattn_fused(x: torch.Tensor, tables: Optional[TattnTables], bias: torch.Tensor, heads: int, zero_samples: int, eps: float,
+                out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """x bf16 [B, N, C] -> x + t_attn(LayerNorm(x)) (+ bias); the first zero_samples samples see a zero context"""
+    _bf16(x)
+    assert x.is_contiguous()
+    B, N, Cc = x.shape
+    if out is None:
+        out = torch.empty_like(x)
+    assert out.is_contiguous()
+    if tables is not None:
+        assert tables.A.is_contiguous() and tables.sc.is_contiguous() and tables.BmT.is_contiguous() and tables.A.shape[0] == B
+    L.check(L.load().udt_tattn_fused(_ptr(x), _ptr(out), _ptr(tables.A) if tables else None, _ptr(tables.sc) if tables else None,
+                                     _ptr(tables.BmT) if tables else None, _ptr(bias), B, N, Cc, heads, zero_samples, eps, _stream()),
+            "udt_tattn_fused")
+    return out
+
+
 def softmax_rows_(x: torch.Tensor) -> torch.Tensor:
     _bf16(x)
     assert x.is_contiguous()

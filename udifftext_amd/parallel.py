@@ -64,7 +64,7 @@ def slice_batch(batch: dict, begin: int, end: int) -> dict:
 
 
 def predict_sharded(cfgs, model, sampler, global_batches: Sequence[dict], global_seeds: Sequence[int], dist=None,
-                    micro_batch: int = 4, in_flight: int = 2, fuse: int = 1, device=None,
+                    micro_batch: int = 4, in_flight: Optional[int] = None, fuse: int = 1, device=None,
                     predict_many: Optional[Callable] = None) -> List[torch.Tensor]:
     """Sample every global batch (a batch dict for ALL its images, CPU or device tensors) across the ranks of
     ``dist`` and return, on every rank, the frames ``[N, 3, H, W]`` of each global batch in global image order.

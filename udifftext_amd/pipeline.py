@@ -86,7 +86,8 @@ def predict(cfgs, model, sampler, batch: dict, device: Optional[torch.device] = 
     return torch.clamp((img + 1.0) / 2.0, min=0.0, max=1.0), z
 
 
-IN_FLIGHT = 2      # launch streams sampling concurrently in predict_many (measured optimum on MI355X; 1 = one at a time)
+IN_FLIGHT = 3      # launch streams sampling concurrently in predict_many (same-box on MI355X, batches of 4 at 512x512:
+#                    1 -> 5.7, 2 -> 7.13, 3 -> 7.67, 4 -> 6.0 images/s; 1 = one at a time)
 FUSE = 0           # batches concatenated into one sampling batch per stream; 0 = automatic: the list is spread over
 #                    the streams, at most 4 batches per sampling batch (dynamic batching: 8 images per UNet call
 #                    cost 2.87 ms per step and image against 3.6 ms for 4, MI355X; per-sample statistics only, so every

@@ -11,6 +11,7 @@ State-dict names and semantics follow reference sgm/modules/attention.py:
 """
 from __future__ import annotations
 
+import os
 from typing import List, Optional
 
 import torch
@@ -20,6 +21,11 @@ from udifftext_amd import ops, packing
 
 from . import hipnn as H
 from .diffusionmodules.util import zero_module
+
+
+# UDT_TATTN_FUSED=0: the text cross-attention branch runs as layernorm -> to_q GEMM -> short-context attention -> to_out GEMM
+# (the reference's op sequence); default: one udt_tattn_fused launch on per-batch folded tables (csrc/tattn.hip)
+TATTN_FUSED = os.environ.get("UDT_TATTN_FUSED", "1") != "0"
 
 
 class GEGLU(H._Packed):
@@ -109,6 +115,16 @@ class CrossAttention(H._Packed):
         out2 = out.reshape(B * N, -1) if out is not None else None
         return self.to_out[0](o.reshape(B * N, inner), residual=res, out=out2).reshape(B, N, -1)
 
+    def prepare_fused(self, kv: torch.Tensor, t_norm, out=None):
+        """fold the (step-invariant) context k|v, to_q, to_out and the LayerNorm in front of this module into the
+        per-sample tables of udt_tattn_fused (None for a single-token context: the reference then applies a sigmoid
+        instead of the softmax, attention.py:159-162 — that case stays on the unfused path)"""
+        if kv.shape[1] < 2:
+            return None
+        wq, _ = self.to_q.packed()
+        wo, _ = self.to_out[0].packed()
+        return ops.tattn_prepare(kv.contiguous(), wq, wo, t_norm.weight, t_norm.bias, self.heads, self.scale, out=out)
+
     def zero_context_residual(self, x, out):
         """x + t_attn(anything, context == 0): with k = v = 0 (to_k / to_v have no bias) the attention output is 0
         and to_out reduces to its bias — bit-identical to running the projections on zeros."""
@@ -177,15 +193,24 @@ class BasicTransformerBlock(nn.Module):
         self.norm3 = H.LayerNorm(dim)
         self.ff = FeedForward(dim, dropout=dropout, glu=gated_ff)
 
-    def forward(self, x, t_context=None, v_context=None, t_kv=None, emit_map: bool = False, zero_ctx_rows: int = 0):
+    def fused_tattn_ok(self, n_tokens: int) -> bool:
+        C = self.t_attn.heads * self.t_attn.dim_head
+        return (TATTN_FUSED and self.t_attn.dim_head == 64 and C <= 1280 and n_tokens % (32 if C > 640 else 64) == 0)
+
+    def forward(self, x, t_context=None, v_context=None, t_kv=None, emit_map: bool = False, zero_ctx_rows: int = 0,
+                t_fused=None):
         """zero_ctx_rows: the first n samples of the batch attend to an all-zero text context (the unconditional
-        half of a CFG pair under force_uc_zero_embeddings) — their t_attn branch is x + to_out.bias, no GEMMs."""
+        half of a CFG pair under force_uc_zero_embeddings) — their t_attn branch is x + to_out.bias, no GEMMs.
+        t_fused: the block's folded context tables (ops.TattnTables for the samples of x) -> one fused launch."""
         fp8 = H.FP8_LINEARS
         ln = (lambda norm, t: norm.forward_fp8(t.reshape(-1, t.shape[-1]))) if fp8 else (lambda norm, t: norm(t))
         x = self.attn1(ln(self.norm1, x), residual=x)
         if hasattr(self, "t_attn"):
             n0 = 0 if emit_map else min(int(zero_ctx_rows), x.shape[0])
-            if n0 > 0 and t_kv is not None:
+            if t_fused is not None and not emit_map and n0 < x.shape[0] and self.fused_tattn_ok(x.shape[1]):
+                _, bo = self.t_attn.to_out[0].packed()
+                x = ops.tattn_fused(x, t_fused, bo, self.t_attn.heads, n0, self.t_norm.eps)
+            elif n0 > 0 and t_kv is not None:
                 y = torch.empty_like(x)
                 self.t_attn.zero_context_residual(x[:n0], y[:n0])
                 if n0 < x.shape[0]:
@@ -218,15 +243,20 @@ class SpatialTransformer(nn.Module):
     def project_context(self, context_bf16) -> List[torch.Tensor]:
         return [blk.t_attn.project_context(context_bf16) for blk in self.transformer_blocks]
 
+    def prepare_fused(self, kv_list, out=None) -> list:
+        """per block: fold its hoisted k|v (+ to_q, to_out, t_norm) into the tables of udt_tattn_fused"""
+        return [blk.t_attn.prepare_fused(kv, blk.t_norm, out=(out[i] if out is not None else None))
+                for i, (blk, kv) in enumerate(zip(self.transformer_blocks, kv_list))]
+
     def forward(self, x, t_context=None, v_context=None, t_kv: Optional[list] = None, emit_map: bool = False,
-                zero_ctx_rows: int = 0):
+                zero_ctx_rows: int = 0, t_fused: Optional[list] = None):
         """x: bf16 NHWC [B, H, W, C]"""
         B, Hh, Ww, C = x.shape
         N = Hh * Ww
         t = self.proj_in(self.norm(x).reshape(B * N, C)).reshape(B, N, -1)
         for i, blk in enumerate(self.transformer_blocks):
             t = blk(t, t_context=t_context, t_kv=(t_kv[i] if t_kv is not None else None), emit_map=emit_map,
-                    zero_ctx_rows=zero_ctx_rows)
+                    zero_ctx_rows=zero_ctx_rows, t_fused=(t_fused[i] if t_fused is not None else None))
         # the output feeds a ResBlock's GroupNorm (and maybe a skip concat): statistics from the GEMM epilogue
         out = self.proj_out(t.reshape(B * N, -1), residual=x.reshape(B * N, C), rows_per_batch=N, colstats=True)
         return H.carry_stats(out.reshape(B, Hh, Ww, C), out)

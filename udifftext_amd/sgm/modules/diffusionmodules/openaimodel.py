@@ -106,14 +106,15 @@ class ResBlock(TimestepBlock):
 
 class TimestepEmbedSequential(nn.Sequential, TimestepBlock):
     def forward(self, x, emb_rows=None, t_context=None, v_context=None, x2=None, t_kv=None, emit_map=False,
-                zero_ctx_rows=0):
+                zero_ctx_rows=0, t_fused=None):
         for layer in self:
             if isinstance(layer, ResBlock):
                 x = layer(x, emb_rows, x2=x2)
                 x2 = None
             elif isinstance(layer, SpatialTransformer):
                 kv = t_kv[layer.st_index] if t_kv is not None else None
-                x = layer(x, t_context, v_context, t_kv=kv, emit_map=emit_map, zero_ctx_rows=zero_ctx_rows)
+                tf = t_fused[layer.st_index] if t_fused is not None else None
+                x = layer(x, t_context, v_context, t_kv=kv, emit_map=emit_map, zero_ctx_rows=zero_ctx_rows, t_fused=tf)
             else:
                 x = layer(x)
         return x
@@ -239,13 +240,19 @@ class UnifiedUNetModel(nn.Module):
         ctx = t_context.to(torch.bfloat16).contiguous()
         return [st.project_context(ctx) for st in self._transformers]
 
+    def prepare_fused_tattn(self, t_kv: List[list], out: Optional[List[list]] = None) -> List[list]:
+        """fold the hoisted context projections of all transformers into the tables of the fused text cross-attention
+        (udt_tattn_prepare); ``out``: refresh existing tables in place (static buffers of captured graphs)"""
+        return [st.prepare_fused(kv, out=(out[i] if out is not None else None))
+                for i, (st, kv) in enumerate(zip(self._transformers, t_kv))]
+
     def forward_nhwc(self, xin: torch.Tensor, emb_rows: torch.Tensor, t_kv: List[list], emit_maps: bool = False,
-                     zero_ctx_rows: int = 0) -> torch.Tensor:
+                     zero_ctx_rows: int = 0, t_fused: Optional[List[list]] = None) -> torch.Tensor:
         """xin: bf16 [B, h, w, 64] (9 real channels); returns eps fp32 [B, h, w, 4].
         zero_ctx_rows: leading samples whose text context is exactly zero (see BasicTransformerBlock.forward)."""
         hs = []
         h = xin
-        kw = dict(t_kv=t_kv, emit_map=emit_maps, zero_ctx_rows=zero_ctx_rows)
+        kw = dict(t_kv=t_kv, emit_map=emit_maps, zero_ctx_rows=zero_ctx_rows, t_fused=t_fused)
         for block in self.input_blocks:
             h = block(h, emb_rows, **kw)
             hs.append(h)

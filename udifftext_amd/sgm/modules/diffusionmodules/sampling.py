@@ -112,6 +112,7 @@ class _Stepper:
         self.table = model.denoiser.sigmas.detach().float().cpu()          # ascending 1000-entry table
         ctx = torch.cat((uc["t_crossattn"], cond["t_crossattn"]), 0)
         self.t_kv = self.unet.project_context(ctx)                        # hoisted k|v of all transformers
+        self.t_fused = self.unet.prepare_fused_tattn(self.t_kv)           # ... folded further into the fused t_attn tables
         # force_uc_zero_embeddings=["label"] (reference sample loop) makes the unconditional context exactly zero:
         # its cross-attention is then x + to_out.bias — one host sync per sampling run buys half of every t_attn
         self.zero_ctx_rows = batch_size if not bool(uc["t_crossattn"].any()) else 0
@@ -125,6 +126,8 @@ class _Stepper:
             self.eps = torch.empty((2 * batch_size, h, w, 4), dtype=torch.float32, device=dev)
             self.t_kv_u = [[kv[:batch_size] for kv in lst] for lst in self.t_kv]
             self.t_kv_c = [[kv[batch_size:] for kv in lst] for lst in self.t_kv]
+            self.t_fused_u = [[tb.rows(0, batch_size) if tb is not None else None for tb in lst] for lst in self.t_fused]
+            self.t_fused_c = [[tb.rows(batch_size) if tb is not None else None for tb in lst] for lst in self.t_fused]
         self.xin = torch.zeros((2 * batch_size, h, w, packing.KPAD), dtype=torch.bfloat16, device=dev)
         concat = torch.cat((uc["concat"], cond["concat"]), 0).float().contiguous()
         ops.nhwc_set_channels(concat, self.xin, 4)                         # channels 4..8: mask, masked latent
@@ -161,7 +164,7 @@ class _Stepper:
         else:
             with ops.launch_context(cu_share=self.cu_share, workspace=self.ws):
                 eps = self.unet.forward_nhwc(self.xin, emb, self.t_kv, emit_maps=emit_maps,
-                                             zero_ctx_rows=self.zero_ctx_rows)
+                                             zero_ctx_rows=self.zero_ctx_rows, t_fused=self.t_fused)
         ops.cfg_euler_step(x, eps, sigma, sigma_next, self.scale, c_out=-sq)
 
     def check(self) -> None:
@@ -178,10 +181,11 @@ class _Stepper:
         share = 2 * self.cu_share
         self.side.wait_stream(main)
         with torch.cuda.stream(self.side), ops.launch_context(cu_share=share, workspace=self.ws_side):
-            eps_c = self.unet.forward_nhwc(self.xin[B:], emb[B:], self.t_kv_c, zero_ctx_rows=0)
+            eps_c = self.unet.forward_nhwc(self.xin[B:], emb[B:], self.t_kv_c, zero_ctx_rows=0, t_fused=self.t_fused_c)
             self.eps[B:].copy_(eps_c)
         with ops.launch_context(cu_share=share, workspace=self.ws):
-            eps_u = self.unet.forward_nhwc(self.xin[:B], emb[:B], self.t_kv_u, zero_ctx_rows=self.zero_ctx_rows)
+            eps_u = self.unet.forward_nhwc(self.xin[:B], emb[:B], self.t_kv_u, zero_ctx_rows=self.zero_ctx_rows,
+                                           t_fused=self.t_fused_u)
             self.eps[:B].copy_(eps_u)
         main.wait_stream(self.side)
         return self.eps
@@ -220,6 +224,7 @@ class _GraphedSteps:
         for dst_list, src_list in zip(st.t_kv, st.unet.project_context(ctx)):
             for dst, src in zip(dst_list, src_list):
                 dst.copy_(src)
+        st.unet.prepare_fused_tattn(st.t_kv, out=st.t_fused)              # tables refreshed in place (views stay valid)
         concat = torch.cat((uc["concat"], cond["concat"]), 0).float().contiguous()
         ops.nhwc_set_channels(concat, st.xin, 4)
         return True
