@@ -203,6 +203,13 @@ int udt_gn_stats(const void* x, const void* x2, float* partials, int32_t B, int6
 int udt_gn_apply(const void* x, const void* x2, void* y, const float* partials, const float* gamma,
                  const float* beta, int32_t B, int64_t HW, int32_t C, int32_t C2, int32_t G, float eps, int32_t act,
                  void* stream);
+/* One-launch GroupNorm (+ optional SiLU) for shapes whose per-sample group strips fit the caches (udt_gn_strip_ok): a
+ * workgroup owns a few consecutive groups of one sample, reads them once for the statistics and again (out of L2) to
+ * normalise.  Same arguments and result as udt_gn_stats + udt_gn_apply (statistics summed in a different order). */
+int32_t udt_gn_strip_ok(int32_t B, int64_t HW, int32_t C1, int32_t C2, int32_t G);
+int udt_gn_strip(const void* x, const void* x2, void* y, const float* gamma, const float* beta, int32_t B, int64_t HW,
+                 int32_t C1, int32_t C2, int32_t G, float eps, int32_t act, void* stream);
+
 /* GroupNorm statistics from producer epilogues -> per-(sample, channel) scale / shift for udt_gemm's in_scsh.
  *   stats1 fp32 [B * slots1][C1][2] (+ optional stats2 [B * slots2][C2][2] for a channel concat x ‖ x2): the colstats of
  *   the layer(s) that produced the input; slotsN = slots per sample.  Groups run over the C1 + C2 concatenated channels.

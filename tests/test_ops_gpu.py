@@ -537,6 +537,30 @@ def test_group_norm_concat(ops, cuda, C1, C2):
     _close(out, ref, what=f"gn concat {C1}+{C2}")
 
 
+@pytest.mark.parametrize("B,HW,C1,C2", [(8, 256, 1280, 0), (8, 64, 1280, 1280), (4, 256, 1280, 640), (3, 64, 1280, 640), (2, 576, 640, 0),
+                                        (1, 64, 512, 0), (5, 256, 320, 320)])
+def test_group_norm_strip_matches_two_kernel_path(ops, cuda, B, HW, C1, C2):
+    """the one-launch strip kernel (udt_gn_strip) against udt_gn_stats + udt_gn_apply and the torch reference"""
+    import udifftext_amd.ops as O
+    x1 = (_rand((B, HW, C1), cuda, 2.0, seed=1) + 0.7).bfloat16()
+    x2 = (_rand((B, HW, C2), cuda, 0.5, seed=4) - 0.3).bfloat16() if C2 else None
+    g = _rand((C1 + C2,), cuda, seed=2) * 0.2 + 1.0
+    b = _rand((C1 + C2,), cuda, seed=3) * 0.2
+    assert O.L.load().udt_gn_strip_ok(B, HW, C1, C2, 32) == 1
+    prev = O.GN_STRIP
+    try:
+        O.GN_STRIP = False
+        two = ops.group_norm(x1, g, b, 32, 1e-5, True, x2=x2)
+        O.GN_STRIP = True
+        one = ops.group_norm(x1, g, b, 32, 1e-5, True, x2=x2)
+    finally:
+        O.GN_STRIP = prev
+    assert (one.float() - two.float()).abs().max().item() <= 2e-2 and (one != two).float().mean().item() < 0.02
+    cat = x1.float() if x2 is None else torch.cat([x1, x2], dim=-1).float()
+    ref = F.silu(F.group_norm(cat.permute(0, 2, 1), 32, g, b, 1e-5)).permute(0, 2, 1)
+    _close(one, ref, what=f"gn strip {B,HW,C1,C2}")
+
+
 @pytest.mark.parametrize("rows,Cc", [(1000, 320), (513, 640), (64, 1280), (36, 2048)])
 def test_layer_norm(ops, cuda, rows, Cc):
     x = (_rand((rows, Cc), cuda, 2.0, seed=1) + 0.3).bfloat16()

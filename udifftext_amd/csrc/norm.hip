@@ -252,6 +252,137 @@ __global__ void __launch_bounds__(256) layernorm_kernel(const uint16_t* __restri
 }
 
 
+// ---- one-launch GroupNorm for strips that fit the caches -----------------------------------------------------------
+// A group's statistics only need the group's own channels, so a workgroup can own a STRIP = `gw` consecutive groups of one
+// sample (gw chosen so that the strip is a whole number of 16-byte chunks per pixel: 80 .. 240 bytes for the UNet's
+// channel counts), read it once for the statistics and a second time — now out of L2 — to normalise.  One launch and
+// one HBM read instead of gn_stats + gn_apply's two launches and two HBM reads.  grid (G / gw, B), 512 threads;
+// thread = (chunk j of the strip, pixel lane); deterministic reductions (no atomics): per-lane partial sums -> LDS
+// matrix -> one thread per channel -> one thread per group (fp64 combine, as gn_apply).
+constexpr int GNS_THREADS = 512;
+
+__global__ void __launch_bounds__(GNS_THREADS) gn_strip_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ x2,
+                                                               uint16_t* __restrict__ y, const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta, long long HW, int C1, int C2, int G,
+                                                               int gw, float eps, int act) {
+  extern __shared__ __attribute__((aligned(16))) float gss[];
+  const int C = C1 + C2;
+  const int cpg = C / G;
+  const int cw = gw * cpg;                         // channels of the strip (multiple of 8)
+  const int nch = cw >> 3;                         // 16-byte chunks per pixel
+  const int pstep = GNS_THREADS / nch;             // pixel lanes
+  float* psum = gss;                               // [pstep][cw]
+  float* psq = gss + pstep * cw;                   // [pstep][cw]
+  float* scl = psq + pstep * cw;                   // [cw] scale, then [cw] shift
+  float* shf = scl + cw;
+  double* csum = reinterpret_cast<double*>(shf + cw + (cw & 1));   // [cw] channel totals (fp64), [cw] squares
+  double* csq = csum + cw;
+  const int t = threadIdx.x;
+  const int b = blockIdx.y;
+  const int c_base = blockIdx.x * cw;
+  const int j = t % nch, pl = t / nch;
+  const bool active = pl < pstep;
+  const int c = c_base + 8 * j;                    // first of this thread's 8 channels (one source: C1 % 8 == 0)
+  const bool second = c >= C1;
+  const int cs = second ? C2 : C1;
+  const uint16_t* src = (second ? x2 : x) + (long long)b * HW * cs + (second ? c - C1 : c);
+  float s[8], q[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) s[i] = q[i] = 0.f;
+  auto acc8 = [&](const u32x4 v) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float a = bf16_lo(v[i]), bb = bf16_hi(v[i]);
+      s[2 * i] += a; q[2 * i] += a * a;
+      s[2 * i + 1] += bb; q[2 * i + 1] += bb * bb;
+    }
+  };
+  if (active) {
+    long long p = pl;
+    for (; p + 3LL * pstep < HW; p += 4LL * pstep) {           // 4 loads in flight per lane
+      const u32x4 v0 = *reinterpret_cast<const u32x4*>(src + p * cs);
+      const u32x4 v1 = *reinterpret_cast<const u32x4*>(src + (p + pstep) * cs);
+      const u32x4 v2 = *reinterpret_cast<const u32x4*>(src + (p + 2LL * pstep) * cs);
+      const u32x4 v3 = *reinterpret_cast<const u32x4*>(src + (p + 3LL * pstep) * cs);
+      acc8(v0); acc8(v1); acc8(v2); acc8(v3);
+    }
+    for (; p < HW; p += pstep) acc8(*reinterpret_cast<const u32x4*>(src + p * cs));
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      psum[pl * cw + 8 * j + i] = s[i];
+      psq[pl * cw + 8 * j + i] = q[i];
+    }
+  }
+  __syncthreads();
+  if (t < cw) {
+    double a = 0.0, qq = 0.0;
+    for (int r = 0; r < pstep; ++r) { a += (double)psum[r * cw + t]; qq += (double)psq[r * cw + t]; }
+    csum[t] = a;
+    csq[t] = qq;
+  }
+  __syncthreads();
+  if (t < cw) {
+    const int g0 = (t / cpg) * cpg;                // every channel thread re-adds its group's cpg totals (<= 80 adds)
+    double a = 0.0, qq = 0.0;
+    for (int k = 0; k < cpg; ++k) { a += csum[g0 + k]; qq += csq[g0 + k]; }
+    const double n = (double)HW * (double)cpg;
+    const double mean = a / n;
+    double var = qq / n - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float sc = rstd * gamma[c_base + t];
+    scl[t] = sc;
+    shf[t] = beta[c_base + t] - (float)mean * sc;
+  }
+  __syncthreads();
+  if (!active) return;
+  float sc8[8], sh8[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { sc8[i] = scl[8 * j + i]; sh8[i] = shf[8 * j + i]; }
+  uint16_t* dst = y + (long long)b * HW * C + c;
+  auto norm8 = [&](const u32x4 v) {
+    u32x4 o;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float a = bf16_lo(v[i]) * sc8[2 * i] + sh8[2 * i];
+      float bb = bf16_hi(v[i]) * sc8[2 * i + 1] + sh8[2 * i + 1];
+      if (act == 1) { a = silu_f(a); bb = silu_f(bb); }
+      o[i] = pack_bf16x2(a, bb);
+    }
+    return o;
+  };
+  long long p = pl;
+  for (; p + 3LL * pstep < HW; p += 4LL * pstep) {
+    const u32x4 v0 = *reinterpret_cast<const u32x4*>(src + p * cs);
+    const u32x4 v1 = *reinterpret_cast<const u32x4*>(src + (p + pstep) * cs);
+    const u32x4 v2 = *reinterpret_cast<const u32x4*>(src + (p + 2LL * pstep) * cs);
+    const u32x4 v3 = *reinterpret_cast<const u32x4*>(src + (p + 3LL * pstep) * cs);
+    *reinterpret_cast<u32x4*>(dst + p * C) = norm8(v0);
+    *reinterpret_cast<u32x4*>(dst + (p + pstep) * C) = norm8(v1);
+    *reinterpret_cast<u32x4*>(dst + (p + 2LL * pstep) * C) = norm8(v2);
+    *reinterpret_cast<u32x4*>(dst + (p + 3LL * pstep) * C) = norm8(v3);
+  }
+  for (; p < HW; p += pstep) *reinterpret_cast<u32x4*>(dst + p * C) = norm8(*reinterpret_cast<const u32x4*>(src + p * cs));
+}
+
+// groups per strip so that a strip is a whole number of 16-byte chunks per pixel; 0 = shape not served by the strip kernel
+int gn_strip_groups(long long HW, int C1, int C2, int G) {
+  const int C = C1 + C2;
+  if (G <= 0 || C % G != 0 || C1 % 8 != 0 || C2 % 8 != 0) return 0;
+  const int cpg = C / G;
+  int gw = 1;
+  while ((gw * cpg) % 8 != 0) gw *= 2;
+  if (gw > 8 || G % gw != 0) return 0;
+  const int cw = gw * cpg;
+  if (cw > 256) return 0;
+  // Measured on MI355X (B = 4, one launch stream): 64x64x320 strips (320 KiB) 41 us vs 28 us for the stats + apply pair,
+  // 32x32x640 (80 KiB) 22 vs 23.5, 16x16x1280 (20 KiB) 12 vs 20.6, 8x8x1280 (5 KiB) 12 vs 20: a strip is walked by ONE
+  // workgroup, so only small strips (the launch-latency-bound levels) take this kernel
+  const long long bytes = HW * cw * 2;
+  if (bytes > (64LL << 10)) return 0;
+  return gw;
+}
+
 // ---- fp8 (OCP e4m3) activations for UDT_GEMM_FP8 consumers ---------------------------------------------------------
 // 8 fp32 -> 8 saturated e4m3 bytes (v_cvt_pk_fp8_f32 converts to the OCP format on gfx950; values are clamped to the
 // largest finite e4m3, 448, first: the conversion itself does not saturate)
@@ -445,6 +576,40 @@ extern "C" int udt_gn_finalize(const float* stats1, int32_t slots1, int32_t C1, 
   }
   hipLaunchKernelGGL(gn_finalize_kernel, dim3(G, B), dim3(256), 0, s, stats1, slots1, C1, stats2, slots2, C2, gamma, beta, scsh,
                      (long long)HW, G, eps);
+  UDT_CHECK_LAUNCH();
+  return UDT_OK;
+}
+
+extern "C" int32_t udt_gn_strip_ok(int32_t B, int64_t HW, int32_t C1, int32_t C2, int32_t G) {
+  return (B > 0 && gn_strip_groups(HW, C1, C2, G) > 0) ? 1 : 0;
+}
+
+extern "C" int udt_gn_strip(const void* x, const void* x2, void* y, const float* gamma, const float* beta, int32_t B, int64_t HW,
+                            int32_t C1, int32_t C2, int32_t G, float eps, int32_t act, void* stream) {
+  if (!x || !y || !gamma || !beta || (C2 > 0 && !x2)) return UDT_ERR_BAD_ARG;
+  if (B <= 0 || HW <= 0 || C1 <= 0 || C2 < 0) return UDT_ERR_BAD_SHAPE;
+  const int gw = gn_strip_groups(HW, C1, C2, G);
+  if (gw <= 0) return UDT_ERR_BAD_SHAPE;
+  const int C = C1 + C2;
+  const int cw = gw * (C / G);
+  const int pstep = GNS_THREADS / (cw / 8);
+  const size_t smem = (size_t)(2 * pstep * cw + 2 * cw + 1) * sizeof(float) + (size_t)2 * cw * sizeof(double) + 8;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  UdtProfScope prof(4, s);
+  if (prof.rec) {
+    char tag[96];
+    snprintf(tag, sizeof(tag), "gn_strip B=%d HW=%lld C=%d+%d gw=%d", B, (long long)HW, C1, C2, gw);
+    udt_prof_tag(prof.rec, tag);
+  }
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gn_strip_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    if (e != hipSuccess) return udt_set_hip_error(e);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(gn_strip_kernel, dim3(G / gw, B), dim3(GNS_THREADS), smem, s, reinterpret_cast<const uint16_t*>(x),
+                     reinterpret_cast<const uint16_t*>(x2), reinterpret_cast<uint16_t*>(y), gamma, beta, (long long)HW, C1, C2, G, gw,
+                     eps, act);
   UDT_CHECK_LAUNCH();
   return UDT_OK;
 }

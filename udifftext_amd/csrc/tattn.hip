@@ -139,21 +139,25 @@ __global__ void __launch_bounds__(TA_THREADS) tattn_fused_kernel(const TattnPara
     const int swz = (l31 >> 1) & 7;                         // (row >> 1) & 7 with row = rt*32 + l31
     const uint16_t* arow = Ab + (long long)(ct * 32 + l31) * C + hi * 8;
     f32x16 acc = zero16();
-    // the A' fragments come straight from L2 (each is used once per workgroup): loads run one K-tile ahead of the MFMAs
-    bf16x8_t an[4];
+    // the A' fragments come straight from L2 (each is used once per workgroup): loads run TWO K-tiles ahead of the MFMAs
+    bf16x8_t a0[4], a1[4];
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) an[ks] = *reinterpret_cast<const bf16x8_t*>(arow + ks * 16);
+    for (int ks = 0; ks < 4; ++ks) {
+      a0[ks] = *reinterpret_cast<const bf16x8_t*>(arow + ks * 16);
+      a1[ks] = *reinterpret_cast<const bf16x8_t*>(arow + (nkt > 1 ? 64 : 0) + ks * 16);
+    }
     for (int kt = 0; kt < nkt; ++kt) {
       const char* xrow = xs + ((size_t)kt * TT + row) * 128;
       bf16x8_t af[4], xf[4];
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
-        af[ks] = an[ks];
+        af[ks] = a0[ks];
+        a0[ks] = a1[ks];
         xf[ks] = lds_read_frag(xrow + (((ks * 2 + hi) ^ swz) << 4));
       }
-      const int ktn = (kt + 1 < nkt) ? kt + 1 : kt;
+      const int ktn = (kt + 2 < nkt) ? kt + 2 : kt;
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) an[ks] = *reinterpret_cast<const bf16x8_t*>(arow + ktn * 64 + ks * 16);
+      for (int ks = 0; ks < 4; ++ks) a1[ks] = *reinterpret_cast<const bf16x8_t*>(arow + ktn * 64 + ks * 16);
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) acc = mfma32(af[ks], xf[ks], acc);
     }
@@ -206,14 +210,16 @@ __global__ void __launch_bounds__(TA_THREADS) tattn_fused_kernel(const TattnPara
     const uint16_t* brow = Bb + (long long)(ct * 32 + l31) * hp + hi * 8;
     const char* prow = pl + (size_t)row * prs + hi * 16;
     f32x16 acc = zero16();
-    bf16x8_t bn[2];                                         // Bm^T fragments two k-steps ahead (L2 latency)
-    bn[0] = *reinterpret_cast<const bf16x8_t*>(brow);
-    bn[1] = *reinterpret_cast<const bf16x8_t*>(brow + 16);
+    bf16x8_t bn[4];                                         // Bm^T fragments four k-steps ahead (L2 latency)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) bn[i] = *reinterpret_cast<const bf16x8_t*>(brow + (i < nks ? i : 0) * 16);
     for (int ks = 0; ks < nks; ks += 2) {
       const bf16x8_t b0 = bn[0], b1 = bn[1];
-      const int k2 = (ks + 2 < nks) ? ks + 2 : ks;
-      bn[0] = *reinterpret_cast<const bf16x8_t*>(brow + k2 * 16);
-      bn[1] = *reinterpret_cast<const bf16x8_t*>(brow + k2 * 16 + 16);
+      bn[0] = bn[2];
+      bn[1] = bn[3];
+      const int k2 = (ks + 4 < nks) ? ks + 4 : ks;
+      bn[2] = *reinterpret_cast<const bf16x8_t*>(brow + k2 * 16);
+      bn[3] = *reinterpret_cast<const bf16x8_t*>(brow + k2 * 16 + 16);
       const bf16x8_t p0 = *reinterpret_cast<const bf16x8_t*>(prow + ks * 32);
       const bf16x8_t p1 = *reinterpret_cast<const bf16x8_t*>(prow + ks * 32 + 32);
       acc = mfma32(b0, p0, acc);

@@ -61,6 +61,8 @@ SYMBOLS = {
     "udt_gn_nchunks": (_i32, [_i64, _i32]),
     "udt_gn_stats": (C.c_int, [_vp, _vp, _fp, _i32, _i64, _i32, _i32, _i32, _vp]),
     "udt_gn_apply": (C.c_int, [_vp, _vp, _vp, _fp, _fp, _fp, _i32, _i64, _i32, _i32, _i32, _f32, _i32, _vp]),
+    "udt_gn_strip_ok": (_i32, [_i32, _i64, _i32, _i32, _i32]),
+    "udt_gn_strip": (C.c_int, [_vp, _vp, _vp, _fp, _fp, _i32, _i64, _i32, _i32, _i32, _f32, _i32, _vp]),
     "udt_layernorm": (C.c_int, [_vp, _vp, _fp, _fp, _i64, _i32, _f32, _vp]),
     "udt_layernorm_fp8": (C.c_int, [_vp, _vp, _fp, _fp, _i64, _i32, _i32, _f32, _f32, _vp]),
     "udt_quantize_fp8": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _f32, _vp]),

@@ -134,6 +134,9 @@ def run_gemm(d: L.GemmDesc, device, fused_gn: bool = False) -> None:
         L.check(lib.udt_gemm(C.byref(d), ws_ptr, ws_bytes, _stream()), "udt_gemm")
 
 
+GN_STRIP = os.environ.get("UDT_GN_STRIP", "1") != "0"       # one-launch strip GroupNorm where the shape allows (A/B switch)
+
+
 class GnStats(NamedTuple):
     """column statistics a producer's epilogue emitted for its output (udt_gemm_desc.colstats): fp32
     [slots, C, 2] = per-(row slot, channel) (sum, sum of squares); a sample owns ``slots_per_sample`` consecutive slots"""
@@ -377,6 +380,10 @@ def group_norm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, groups:
     lib = L.load()
     if out is None:
         out = torch.empty(x.shape[:-1] + (C1 + C2,), dtype=torch.bfloat16, device=x.device)
+    if GN_STRIP and lib.udt_gn_strip_ok(B, HW, C1, C2, groups):      # one launch, second read out of L2
+        L.check(lib.udt_gn_strip(_ptr(x), _ptr(x2), _ptr(out), _ptr(gamma), _ptr(beta), B, HW, C1, C2, groups, eps,
+                                 1 if silu else 0, _stream()), "udt_gn_strip")
+        return out
     nch = lib.udt_gn_nchunks(HW, C1 + C2)
     part = torch.empty((B, nch, groups, 2), dtype=torch.float32, device=x.device)
     L.check(lib.udt_gn_stats(_ptr(x), _ptr(x2), _ptr(part), B, HW, C1, C2, groups, _stream()), "udt_gn_stats")
