@@ -610,6 +610,16 @@ bool use_gemm8(const udt_gemm_desc* d) {
   return (long long)d->N * ldw * elem_bytes(d) < (1LL << 31);
 }
 
+
+// Launch a multiple of 8 workgroups so that range_index() can hand every XCD (block b runs on XCD b % 8) one contiguous
+// slice of the iteration space: neighbouring tiles then share one L2 (the patch / A rows across N tiles, the weight
+// column tile across M tiles, and the stream-K slabs between neighbours).  The padding workgroups own empty ranges and
+// exit at once.  UDT_G_ROUND8=0 restores the exact count (A/B measurements).
+int round_workgroups(int G) {
+  static const int on = [] { const char* e = getenv("UDT_G_ROUND8"); return (e && e[0] == '0') ? 0 : 1; }();
+  return (on && G > 8) ? ((G + 7) & ~7) : G;
+}
+
 TilePlan plan_tiles8(const udt_gemm_desc* d) {
   TilePlan t;
   const int batch = d->batch > 0 ? d->batch : 1;
@@ -632,7 +642,7 @@ TilePlan plan_tiles8(const udt_gemm_desc* d) {
   // shallow K (< 24 K-tiles): cutting a tile costs more (slab round trip + the finisher's wait) than the imbalance it
   // removes — measured on MI355X: 2048x1280x1280 33.7 -> 28.6 us, 8192x640x640 32.4 -> 20.2 us with whole tiles
   if (whole) t.ipw = ((t.ipw + t.nkt - 1) / t.nkt) * t.nkt;
-  t.G = (int)((t.total + t.ipw - 1) / t.ipw);
+  t.G = round_workgroups((int)((t.total + t.ipw - 1) / t.ipw));
   t.fixup = (t.ipw % t.nkt) != 0;
   return t;
 }
@@ -701,7 +711,7 @@ TilePlan plan_tiles3p(const udt_gemm_desc* d, const c3p::Geo& ge) {
   if (G > slots) G = slots;
   t.ipw = (int)((t.total + G - 1) / G);
   if (whole) t.ipw = ((t.ipw + t.nkt - 1) / t.nkt) * t.nkt;             // shallow K: whole tiles
-  t.G = (int)((t.total + t.ipw - 1) / t.ipw);
+  t.G = round_workgroups((int)((t.total + t.ipw - 1) / t.ipw));
   t.fixup = (t.ipw % t.nkt) != 0;
   return t;
 }
