@@ -1,14 +1,14 @@
 #!/bin/bash
 # usage (on the GPU box): tools/compare_builds.sh spec spec ...   with spec = dir[:ENV=VAL[,ENV=VAL]]
 # Same-box A/B (box-to-box variation on the pool is ~10 %): every spec is benchmarked REPS times, interleaved; one line
-# per run: images/s (on-config value), ms per step, UNet ms per sampler step, conv TF/s, conv us/launch, GEMM TF/s
+# (extra bench flags: BENCH_ARGS="--in-flight 4");  per run: images/s (on-config value), ms per step, UNet ms per sampler step, conv TF/s, conv us/launch, GEMM TF/s
 cd "$(dirname "$0")/.."
 REPS=${REPS:-2}
 for rep in $(seq $REPS); do
 for spec in "$@"; do
   d=${spec%%:*}; envs=""
   [ "$spec" != "$d" ] && envs=$(echo "${spec#*:}" | tr ',' ' ')
-  (cd "$d" && env $envs python bench.py --steps 6 --warmup 3 --no-cpu-baseline --no-mode-table 2>/dev/null | tail -1 | python -c "
+  (cd "$d" && env $envs python bench.py --steps 6 --warmup 3 --no-cpu-baseline --no-mode-table $BENCH_ARGS 2>/dev/null | tail -1 | python -c "
 import json,sys
 d=json.loads(sys.stdin.read())
 g=d.get('roofline_classes',{}).get('gemm',{}).get('achieved',0)

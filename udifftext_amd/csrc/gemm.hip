@@ -620,6 +620,19 @@ int round_workgroups(int G) {
   return (on && G > 8) ? ((G + 7) & ~7) : G;
 }
 
+// Several launch streams in flight (cu_share > 1): what counts is the CU-time a launch consumes, not its latency.  Cutting
+// tiles (stream-K) buys latency with CU-time — slab round trips, two prologues per tile, and all partners resident at
+// once: measured alone on the chip, 8x32x32 640->640 costs 256 x 90 us of CU-time at full width but 32 x 340 us on 32
+// workgroups (tools/bench_cu_share.py).  Whole tiles need no residency (nobody waits), so they queue on whatever CU is
+// free.  Used when there are at least ~3/4 as many tiles as the stream's share of workgroup slots.
+// UDT_WHOLE_NUM / UDT_WHOLE_DEN override the 3/4 (A/B measurements); cu_share 1 keeps the latency plans.
+bool prefer_whole_tiles(const udt_gemm_desc* d, int tiles) {
+  static const int num = [] { const char* e = getenv("UDT_WHOLE_NUM"); return e ? atoi(e) : 3; }();
+  static const int den = [] { const char* e = getenv("UDT_WHOLE_DEN"); return (e && atoi(e) > 0) ? atoi(e) : 4; }();
+  if (d->cu_share <= 1 || num <= 0) return false;
+  return (long long)tiles * den >= (long long)(resident_slots(d) / 2) * num;
+}
+
 TilePlan plan_tiles8(const udt_gemm_desc* d) {
   TilePlan t;
   const int batch = d->batch > 0 ? d->batch : 1;
@@ -633,7 +646,7 @@ TilePlan plan_tiles8(const udt_gemm_desc* d) {
   t.total = (long long)t.tiles * t.nkt;
   // one 8-wave workgroup per CU.  Whole-tile plans (shallow K, below) have no waits between workgroups, so they may
   // use every CU even when other launch streams share the device (cu_share): excess workgroups simply queue
-  const bool whole = t.nkt < 24;
+  const bool whole = t.nkt < 24 || prefer_whole_tiles(d, t.tiles);
   int slots = (whole ? resident_slots_all() : resident_slots(d)) / 2;
   long long G = t.total / 4;                       // >= 4 K-tiles per workgroup
   if (G < 1) G = 1;
@@ -705,7 +718,7 @@ TilePlan plan_tiles3p(const udt_gemm_desc* d, const c3p::Geo& ge) {
   t.tiles = t.tiles_m * t.tiles_n;
   t.nkt = ge.chunks;                               // iteration unit of this kernel: one 64-channel chunk (9 K-tiles)
   t.total = (long long)t.tiles * t.nkt;
-  const bool whole = t.nkt * 9 < 24;
+  const bool whole = t.nkt * 9 < 24 || prefer_whole_tiles(d, t.tiles);
   const int slots = (whole ? resident_slots_all() : resident_slots(d)) / 2;
   long long G = t.total;                           // >= one chunk per workgroup
   if (G > slots) G = slots;
