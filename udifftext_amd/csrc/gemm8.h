@@ -949,23 +949,36 @@ __global__ void __launch_bounds__(NTHREADS) gemm8_kernel(const Params pp) {
             }
         }
       } else {
+      // all fragment reads of the K-tile are issued ahead of its MFMAs (sched_group_barrier pins that order: left
+      // alone, the scheduler keeps three fragment registers and drains lgkmcnt to 0 twice per 16-wide step, exposing
+      // the LDS latency eight times per K-tile); the compiler's counted lgkmcnt waits then release the MFMAs as
+      // their operands land
+      bf16x8_t xf[4][TM], wf[4][TN];
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
         const int slot = ((ks * 2 + hi) ^ swz) << 4;
-        bf16x8_t xf[TM], wf[TN];
 #pragma unroll
-        for (int t = 0; t < TM; ++t) xf[t] = lds_read_frag(abuf + a_frag_row + t * 32 * ROW_BYTES + slot);
+        for (int t = 0; t < TM; ++t) xf[ks][t] = lds_read_frag(abuf + a_frag_row + t * 32 * ROW_BYTES + slot);
 #pragma unroll
-        for (int t = 0; t < TN; ++t) wf[t] = lds_read_frag(bbuf + b_frag_row + t * 32 * ROW_BYTES + slot);
+        for (int t = 0; t < TN; ++t) wf[ks][t] = lds_read_frag(bbuf + b_frag_row + t * 32 * ROW_BYTES + slot);
+      }
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
           for (int tn = 0; tn < TN; ++tn) {
             if constexpr (TRANS)
-              acc[tm][tn] = mfma32(xf[tm], wf[tn], acc[tm][tn]);
+              acc[tm][tn] = mfma32(xf[ks][tm], wf[ks][tn], acc[tm][tn]);
             else
-              acc[tm][tn] = mfma32(wf[tn], xf[tm], acc[tm][tn]);
+              acc[tm][tn] = mfma32(wf[ks][tn], xf[ks][tm], acc[tm][tn]);
           }
+      }
+      // (plain GEMMs: deep-K shapes +3..6 %, same-box; the gathered convolutions and conv3p measured 1..8 % slower
+      //  with the read burst, so they keep the scheduler's interleaving)
+      if constexpr (!CONV) {
+        __builtin_amdgcn_sched_group_barrier(0x100, 4 * (TM + TN), 0);    // DS reads
+        __builtin_amdgcn_sched_group_barrier(0x008, 4 * TM * TN, 0);      // MFMAs
       }
       }
       st = st + 1;

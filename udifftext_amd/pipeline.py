@@ -102,14 +102,28 @@ def _cat_cond(conds):
     return out
 
 
+_LANE_STREAMS: dict = {}
+
+
+def _lane_streams(device: torch.device, n: int):
+    key = (device.index, n)
+    if key not in _LANE_STREAMS:
+        _LANE_STREAMS[key] = [torch.cuda.Stream(device=device) for _ in range(n)]
+    return _LANE_STREAMS[key]
+
+
 def predict_many(cfgs, model, sampler, batches, device: Optional[torch.device] = None, in_flight: Optional[int] = None,
                  fuse: Optional[int] = None, image_seeds: Optional[list] = None):
     """``predict`` over a list of batches in throughput mode: ``fuse`` consecutive batches are concatenated into one
-    sampling batch, and up to ``in_flight`` such batches are sampled concurrently on separate launch streams
-    (EulerEDMSampler.sample_in_flight).  Conditioning and noise draws stay per input batch, in the order and from the
-    CPU generator that calling ``predict`` batch by batch would use; decoding runs on the fused batch.
+    sampling batch, and up to ``in_flight`` such batches are processed concurrently, each on its own launch stream
+    (a lane): conditioning (VAE encoder, label encoder) and the VAE decode run on the lane's stream next to the other
+    lanes' work, the sampling loops replay their hipGraphs side by side (EulerEDMSampler.sample_in_flight), and the
+    host only synchronises once, at the end — so the decodes of one group overlap the conditioning of the next.
+    Conditioning and noise draws stay per input batch, in the order and from the CPU generator that calling
+    ``predict`` batch by batch would use; decoding runs on the fused batch.
     ``image_seeds[k]`` (optional): one seed per image of batch k — its draws then come from per-image generators
     (``rng.per_image``), independent of batching and sharding.  Returns [(samples, z), ...] in input order."""
+    from udifftext_amd import ops
     device = device or next(model.parameters()).device
     n = max(1, int(in_flight if in_flight is not None else IN_FLIGHT))
     f = int(fuse if fuse is not None else FUSE)
@@ -117,37 +131,55 @@ def predict_many(cfgs, model, sampler, batches, device: Optional[torch.device] =
         f = min(4, max(1, -(-len(batches) // n)))
     if cfgs.aae_enabled or cfgs.detailed:
         raise NotImplementedError("attend-and-excite / detailed dumps are out of scope (see EulerEDMSampler.__call__)")
-    out = []
+    # (host logic only below; with a stub engine on the CPU — tests/test_parallel_cpu.py — there are no streams)
+    gpu = torch.device(device).type == "cuda"
+    main = torch.cuda.current_stream(device) if gpu else None
+    lanes = (_lane_streams(device, n) if n > 1 else [main]) if gpu else [None] * n
+    on = (lambda lane: torch.cuda.stream(lane)) if gpu else (lambda lane: contextlib.nullcontext())
+    after = (lambda a, b: a.wait_stream(b)) if gpu else (lambda a, b: None)       # stream a continues after stream b
+    out, checks, keep = [], [], []
     for k in range(0, len(batches), n * f):
         group = batches[k:k + n * f]
-        xs, cs, ucs, sizes = [], [], [], []
-        for gi, b in enumerate(group):
-            b, buc = prepare_batch(b, device)
-            seeds = image_seeds[k + gi] if image_seeds is not None else None
-            with (rng.per_image(seeds) if seeds is not None else contextlib.nullcontext()):
-                c, uc = model.conditioner.get_unconditional_conditioning(
-                    b, batch_uc=buc, force_uc_zero_embeddings=cfgs.force_uc_zero_embeddings)
-                xs.append(sampler.get_init_noise(cfgs, model, cond=c, batch=b, uc=uc))
-            cs.append(c)
-            ucs.append(uc)
-            sizes.append(xs[-1].shape[0])
-        # fuse consecutive batches (same latent shape) into one sampling batch per stream
         fx, fc, fuc, spans = [], [], [], []
-        i = 0
-        while i < len(group):
-            j = i + 1
-            while j < len(group) and j - i < f and xs[j].shape[1:] == xs[i].shape[1:]:
-                j += 1
-            fx.append(torch.cat(xs[i:j], 0) if j - i > 1 else xs[i])
-            fc.append(_cat_cond(cs[i:j]) if j - i > 1 else cs[i])
-            fuc.append(_cat_cond(ucs[i:j]) if j - i > 1 else ucs[i])
-            spans.append(sizes[i:j])
-            i = j
-        zs = sampler.sample_in_flight(model, fx, fc, fuc, init_step=cfgs.init_step)
-        for z, span in zip(zs, spans):
-            img = torch.clamp((model.decode_first_stage(z) + 1.0) / 2.0, min=0.0, max=1.0)
+        for lane, i in zip(lanes, range(0, len(group), f)):
+            # one lane: the conditioning of its (up to f) input batches, fused into one sampling batch
+            after(lane, main)
+            xs, cs, ucs, sizes = [], [], [], []
+            with on(lane), ops.launch_context(cu_share=n):
+                for gi in range(i, min(i + f, len(group))):
+                    b, buc = prepare_batch(group[gi], device)
+                    seeds = image_seeds[k + gi] if image_seeds is not None else None
+                    with (rng.per_image(seeds) if seeds is not None else contextlib.nullcontext()):
+                        c, uc = model.conditioner.get_unconditional_conditioning(
+                            b, batch_uc=buc, force_uc_zero_embeddings=cfgs.force_uc_zero_embeddings)
+                        xs.append(sampler.get_init_noise(cfgs, model, cond=c, batch=b, uc=uc))
+                    cs.append(c)
+                    ucs.append(uc)
+                    sizes.append(xs[-1].shape[0])
+                if any(x.shape[1:] != xs[0].shape[1:] for x in xs):
+                    raise ValueError("batches fused into one sampling batch need one image size (use fuse=1)")
+                fx.append(torch.cat(xs, 0) if len(xs) > 1 else xs[0])
+                fc.append(_cat_cond(cs) if len(cs) > 1 else cs[0])
+                fuc.append(_cat_cond(ucs) if len(ucs) > 1 else ucs[0])
+            spans.append(sizes)
+            keep.append((xs, cs, ucs))        # tensors of a lane stream that other streams read: alive until the sync
+        for lane in lanes:
+            after(main, lane)
+        zs = sampler.sample_in_flight(model, fx, fc, fuc, init_step=cfgs.init_step, deferred_checks=checks)
+        keep.append((fx, fc, fuc, zs))
+        for lane, z, span in zip(lanes, zs, spans):
+            after(lane, main)
+            with on(lane), ops.launch_context(cu_share=n):
+                img = torch.clamp((model.decode_first_stage(z) + 1.0) / 2.0, min=0.0, max=1.0)
             o = 0
             for nb in span:
                 out.append((img[o:o + nb], z[o:o + nb]))
                 o += nb
+    for lane in lanes:
+        after(main, lane)
+    for chk in checks:
+        chk()
+    if gpu:
+        ops.check_async_errors()
+    del keep
     return out

@@ -357,14 +357,18 @@ class EulerEDMSampler(EDMSampler):
         return x
 
     # ------------------------------------------------------------------------------- batches in flight
-    def sample_in_flight(self, model, xs, conds, ucs, init_step=0):
+    def sample_in_flight(self, model, xs, conds, ucs, init_step=0, deferred_checks: Optional[list] = None):
         """run the sampling loops of SEVERAL independent batches concurrently (one launch stream + one set of
         hipGraphs each, every stream planned for its share of the CUs) and return their latents.
 
         One launch stream cannot keep the chip busy through every kernel's ramp-up, epilogue and tail; measured on
         MI355X (512x512, batch 4): 14.0 ms per sampler step for one batch at a time, 10.9 ms per step and batch with
-        two batches in flight (three or more are slower again).  Falls back to one batch after the other when
-        graphs are unavailable."""
+        two batches in flight, 10.1 with three (pipeline.IN_FLIGHT).  Falls back to one batch after the other when
+        graphs are unavailable.
+
+        ``deferred_checks``: a list that receives the runners' error-word checks instead of running them here (each
+        check synchronises its stream) — a caller that keeps enqueuing work behind this call (pipeline.predict_many)
+        runs them once at its own synchronisation point."""
         n = len(xs)
         if n == 1 or not self.use_graphs:
             return [self(model, x, cond=c, uc=u, init_step=init_step) for x, c, u in zip(xs, conds, ucs)]
@@ -405,7 +409,10 @@ class EulerEDMSampler(EDMSampler):
             main.wait_stream(gs.capture_stream)
         outs = [gs.x.clone() for gs in runners]
         for gs in runners:
-            gs.st.check()
+            if deferred_checks is not None:
+                deferred_checks.append(gs.st.check)
+            else:
+                gs.st.check()
         return outs
 
     def _run_graphed(self, model, x, cond, uc, sig, init_step):
