@@ -409,8 +409,10 @@ __global__ void __launch_bounds__(NTHREADS) conv3p_kernel(const CParams cp) {
 
   int tile = (int)(it / chunks);
   int c0 = (int)(it - (long long)tile * chunks);
-  int tile_n = tile / p.tiles_m;
-  int tile_m = tile - tile_n * p.tiles_m;
+  // tile order: N-tiles in blocks of p.n_block (decode_tile in gemm.hip; 1 = M-fastest) — with each XCD walking one
+  // contiguous slice of the tile space, its L2 then serves (slice / n_block) patches to n_block weight tiles each
+  int tile_n, tile_m, tile_b;
+  decode_tile<1, 1>(p, tile, tile_b, tile_m, tile_n);
   int n0 = tile_n * BN;
   prepare(tile_m, n0);
   issue_patch(c0);
@@ -530,8 +532,7 @@ __global__ void __launch_bounds__(NTHREADS) conv3p_kernel(const CParams cp) {
       raw_barrier();
       tile = (int)(it / chunks);
       c0 = (int)(it - (long long)tile * chunks);
-      tile_n = tile / p.tiles_m;
-      tile_m = tile - tile_n * p.tiles_m;
+      decode_tile<1, 1>(p, tile, tile_b, tile_m, tile_n);
       n0 = tile_n * BN;
       prepare(tile_m, n0);
       issue_patch(c0);

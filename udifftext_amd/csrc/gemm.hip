@@ -30,6 +30,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <atomic>
+#include <cmath>
 
 namespace {
 
@@ -926,6 +927,19 @@ extern "C" int udt_gemm(const udt_gemm_desc* d, void* workspace, size_t workspac
     if (conv3p_geometry(d, cp.geo, d->in_scsh != nullptr)) {
       const TilePlan t3 = plan_tiles3p(d, cp.geo);
       p.tiles_m = t3.tiles_m; p.tiles_n = t3.tiles_n; p.tiles_per_batch = t3.tiles_m * t3.tiles_n;
+      {
+        // XCD-aware tile order.  An XCD's L2 sees ~S = min(tiles, workgroups) / 8 neighbouring tiles at a time; taking
+        // them as (S / nb) patches x nb weight tiles costs (S / nb) * patch + nb * weight-tile bytes of L2 fills:
+        // least at nb = sqrt(S * patch / weight tile).  UDT_C3P_NBLOCK forces a value (A/B measurements).
+        static const int knob = [] { const char* e = getenv("UDT_C3P_NBLOCK"); return e ? atoi(e) : -1; }();
+        const double patch = (double)cp.geo.prows_img * cp.geo.NI * cp.geo.C * 2.0;
+        const double wtile = 9.0 * t3.bn * cp.geo.C * 2.0;
+        const double S = (double)(t3.tiles < t3.G ? t3.tiles : t3.G) / 8.0;
+        int nb = knob > 0 ? knob : (int)(std::sqrt((S < 1.0 ? 1.0 : S) * patch / wtile) + 0.5);
+        if (nb < 1) nb = 1;
+        if (nb > t3.tiles_n) nb = t3.tiles_n;
+        p.n_block = nb;
+      }
       p.n_ktiles = t3.nkt;
       p.total_iters = t3.total;
       p.iters_per_wg = t3.ipw;
