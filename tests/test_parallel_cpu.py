@@ -95,7 +95,7 @@ class _StubSampler:
         assert cfgs.batch_size == cond["concat"].shape[0]
         return rng.randn((cfgs.batch_size, 4, 2, 2))              # draw 3: x0
 
-    def sample_in_flight(self, model, xs, conds, ucs, init_step=0, deferred_checks=None):
+    def sample_in_flight(self, model, xs, conds, ucs, init_step=0, deferred_checks=None, streams=None):
         return [x + 0.5 * c["concat"] - 0.25 * u["concat"] for x, c, u in zip(xs, conds, ucs)]
 
 

@@ -138,8 +138,14 @@ def predict_many(cfgs, model, sampler, batches, device: Optional[torch.device] =
     on = (lambda lane: torch.cuda.stream(lane)) if gpu else (lambda lane: contextlib.nullcontext())
     after = (lambda a, b: a.wait_stream(b)) if gpu else (lambda a, b: None)       # stream a continues after stream b
     out, checks, keep = [], [], []
-    for k in range(0, len(batches), n * f):
-        group = batches[k:k + n * f]
+    # groups of up to n lanes, balanced: 4 sampling batches on 3 lanes run as 2 + 2, not 3 + 1 (a lone batch runs at
+    # the one-at-a-time rate)
+    units = -(-len(batches) // f)
+    n_groups = max(1, -(-units // n))
+    sizes = [units // n_groups + (1 if g < units % n_groups else 0) for g in range(n_groups)]
+    starts = [f * sum(sizes[:g]) for g in range(n_groups)]
+    for k, lanes_used in zip(starts, sizes):
+        group = batches[k:k + lanes_used * f]
         fx, fc, fuc, spans = [], [], [], []
         for lane, i in zip(lanes, range(0, len(group), f)):
             # one lane: the conditioning of its (up to f) input batches, fused into one sampling batch
@@ -165,7 +171,8 @@ def predict_many(cfgs, model, sampler, batches, device: Optional[torch.device] =
             keep.append((xs, cs, ucs))        # tensors of a lane stream that other streams read: alive until the sync
         for lane in lanes:
             after(main, lane)
-        zs = sampler.sample_in_flight(model, fx, fc, fuc, init_step=cfgs.init_step, deferred_checks=checks)
+        zs = sampler.sample_in_flight(model, fx, fc, fuc, init_step=cfgs.init_step, deferred_checks=checks,
+                                      streams=lanes if gpu and n > 1 else None)
         keep.append((fx, fc, fuc, zs))
         for lane, z, span in zip(lanes, zs, spans):
             after(lane, main)

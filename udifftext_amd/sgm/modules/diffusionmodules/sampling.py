@@ -357,7 +357,8 @@ class EulerEDMSampler(EDMSampler):
         return x
 
     # ------------------------------------------------------------------------------- batches in flight
-    def sample_in_flight(self, model, xs, conds, ucs, init_step=0, deferred_checks: Optional[list] = None):
+    def sample_in_flight(self, model, xs, conds, ucs, init_step=0, deferred_checks: Optional[list] = None,
+                         streams: Optional[list] = None):
         """run the sampling loops of SEVERAL independent batches concurrently (one launch stream + one set of
         hipGraphs each, every stream planned for its share of the CUs) and return their latents.
 
@@ -368,7 +369,10 @@ class EulerEDMSampler(EDMSampler):
 
         ``deferred_checks``: a list that receives the runners' error-word checks instead of running them here (each
         check synchronises its stream) — a caller that keeps enqueuing work behind this call (pipeline.predict_many)
-        runs them once at its own synchronisation point."""
+        runs them once at its own synchronisation point.
+        ``streams``: launch streams to replay on, one per batch (default: the runners' capture streams).  A caller
+        that already owns one stream per batch passes them so that no further streams are active: hipStreams share a
+        small number of hardware queues (GPU_MAX_HW_QUEUES, 4 by default) and two busy streams on one queue serialise."""
         n = len(xs)
         if n == 1 or not self.use_graphs:
             return [self(model, x, cond=c, uc=u, init_step=init_step) for x, c, u in zip(xs, conds, ucs)]
@@ -399,14 +403,15 @@ class EulerEDMSampler(EDMSampler):
                     gs._capture(i)
             runners.append(gs)
         main = torch.cuda.current_stream()
-        for gs in runners:
-            gs.capture_stream.wait_stream(main)
-        for i in steps:                                  # interleaved launches: both queues stay fed
-            for gs in runners:
-                with torch.cuda.stream(gs.capture_stream):
+        lanes = list(streams[:n]) if streams is not None and len(streams) >= n else [gs.capture_stream for gs in runners]
+        for lane in lanes:
+            lane.wait_stream(main)
+        for i in steps:                                  # interleaved launches: every queue stays fed
+            for gs, lane in zip(runners, lanes):
+                with torch.cuda.stream(lane):
                     gs.graphs[i].replay()
-        for gs in runners:
-            main.wait_stream(gs.capture_stream)
+        for lane in lanes:
+            main.wait_stream(lane)
         outs = [gs.x.clone() for gs in runners]
         for gs in runners:
             if deferred_checks is not None:
