@@ -19,6 +19,7 @@
  *                         sgm/modules/encoders/modules.py:1103-1104 (nn.TransformerEncoderLayer linears)
  *   udt_attn_fwd        xformers.ops.memory_efficient_attention  sgm/modules/attention.py:246
  *   udt_xattn_fwd       einsum / softmax / einsum               sgm/modules/attention.py:152-172
+ *   udt_mattn_fwd       nn.MultiheadAttention (OCR scorer decoder)  src/parseq/strhub/models/parseq/modules.py:57-70
  *                       (also nn.MultiheadAttention inside nn.TransformerEncoderLayer,
  *                        sgm/modules/encoders/modules.py:1103-1104,1164)
  *   udt_softmax_rows    softmax of the VAE single-head attention  sgm/modules/diffusionmodules/model.py:246
@@ -169,6 +170,20 @@ int udt_attn_fwd(const void* q, const void* k, const void* vt, void* o,
 int udt_xattn_fwd(const void* q, const void* k, const void* v, void* o, float* probs,
                   int32_t batch, int32_t heads, int32_t head_dim, int32_t nq, int32_t L,
                   int32_t ldq, int32_t ldkv, int32_t ldo, float scale, void* stream);
+
+/* Masked small attention (the OCR scorer's decoder: nn.MultiheadAttention of PARSeq's DecoderLayer, reference
+ * src/parseq/strhub/models/parseq/modules.py:35-36,57-70 -> torch's scaled-dot-product with attn_mask and
+ * key_padding_mask).  Few queries against a short key set, any head_dim that is a multiple of 8 up to 64:
+ *   q : bf16 rows (b, i) at q + b*q_bstride + i*ldq + h*head_dim      i < nq
+ *   k, v : bf16 rows (b, l) at k + b*k_bstride + l*ldk + h*head_dim   l < lk, lk <= 256, lk*head_dim <= 8192
+ *   o : bf16 rows (b, i) at o + b*o_bstride + i*ldo + h*head_dim
+ *   mask (optional): fp32 [nq, ldmask] added to the scaled scores (-inf = masked), shared by batch and heads
+ *   kpm  (optional): uint8 [batch, lk], non-zero = the key is padding (ignored)
+ * fp32 scores, softmax and accumulation.  A query whose keys are all masked yields zeros (torch yields NaN). */
+int udt_mattn_fwd(const void* q, const void* k, const void* v, void* o, const float* mask, const uint8_t* kpm,
+                  int32_t batch, int32_t heads, int32_t head_dim, int32_t nq, int32_t lk,
+                  int32_t ldq, int32_t ldk, int32_t ldv, int32_t ldo, int32_t ldmask,
+                  int64_t q_bstride, int64_t k_bstride, int64_t v_bstride, int64_t o_bstride, float scale, void* stream);
 
 /* The text cross-attention branch of a transformer block as ONE kernel (csrc/tattn.hip):
  *   out = x + to_out(softmax(to_q(LayerNorm(x)) K^T * scale) V) + bias        reference sgm/modules/attention.py:140-174,326-333

@@ -1,0 +1,160 @@
+"""OCR scorer on the GPU: udt_mattn_fwd against a plain torch fp32 reference, and the HIP-backed
+ParseqPredictor / PARSeq against the CPU oracle (oracle/parseq.py, pinned by the reference's own classes —
+tests/test_parseq_cpu.py) with the same synthetic weights.  Stated tolerance: relative RMS 2e-2 on activations and
+logits (bf16 storage, fp32 accumulation), as for the denoising path."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+G = np.load(os.path.join(os.path.dirname(__file__), "golden", "parseq_golden.npz"))
+TOL = 2e-2
+
+
+def _rel(a, b):
+    a, b = a.detach().double().cpu(), torch.as_tensor(b).double()
+    return float((a - b).pow(2).mean().sqrt() / b.pow(2).mean().sqrt())
+
+
+@pytest.fixture(scope="module")
+def sd():
+    from udifftext_amd import synth
+    keys, shapes = list(G["state_dict_keys"]), [eval(s) for s in G["state_dict_shapes"]]
+    return {k: synth.synthetic_tensor("parseq." + k, sh) for k, sh in zip(keys, shapes)}
+
+
+@pytest.fixture(scope="module")
+def predictor(cuda, sd):
+    import udifftext_amd  # noqa: F401
+    from sgm.modules.predictors.model import ParseqPredictor
+    from sgm.util import skip_param_init
+    with skip_param_init():
+        m = ParseqPredictor(ckpt_path=None)
+    missing, unexpected = m.parseq.load_state_dict(sd, strict=True)
+    assert not missing and not unexpected
+    return m.to(cuda).eval()
+
+
+@pytest.mark.parametrize("B,H,D,nq,lk,masked", [(2, 12, 32, 1, 1, False), (3, 12, 32, 9, 9, True), (2, 12, 32, 26, 26, True),
+                                                  (2, 12, 32, 5, 128, False), (2, 6, 64, 128, 128, False), (1, 4, 16, 7, 160, True)])
+def test_masked_attention_matches_torch(cuda, B, H, D, nq, lk, masked):
+    from udifftext_amd import ops
+    g = torch.Generator().manual_seed(B * 1000 + nq * 10 + lk)
+    C = H * D
+    q = torch.randn((B, nq, C), generator=g).bfloat16().to(cuda)
+    kv = torch.randn((B, lk, 2 * C), generator=g).bfloat16().to(cuda)
+    mask = kpm = None
+    if masked:
+        mask = torch.zeros((nq, lk))
+        mask[torch.rand((nq, lk), generator=g) < 0.3] = float("-inf")
+        mask[:, 0] = 0.0                                          # every query keeps one key
+        mask = mask.to(cuda)
+        kpm = (torch.rand((B, lk), generator=g) < 0.2)
+        kpm[:, 0] = False
+        kpm = kpm.to(cuda)
+    o = ops.masked_attention(q, kv[..., :C], kv[..., C:], H, D ** -0.5, mask=mask, key_padding_mask=kpm)
+    qf = q.float().reshape(B, nq, H, D).transpose(1, 2)
+    kf = kv[..., :C].float().reshape(B, lk, H, D).transpose(1, 2)
+    vf = kv[..., C:].float().reshape(B, lk, H, D).transpose(1, 2)
+    s = qf @ kf.transpose(-2, -1) * D ** -0.5
+    if masked:
+        s = s + mask
+        s = s.masked_fill(kpm[:, None, None, :], float("-inf"))
+    ref = (torch.softmax(s, -1) @ vf).transpose(1, 2).reshape(B, nq, C)
+    assert (o.float() - ref).abs().max().item() < 2e-2 + 1.5e-2 * ref.abs().max().item()
+
+
+def test_encoder_vs_oracle(predictor, sd, cuda):
+    from oracle import parseq as OP
+    img = torch.from_numpy(G["images"])
+    mem = predictor.parseq.encode(img.to(cuda))
+    r = _rel(mem, OP.vit_encode(sd, img))
+    assert r < TOL, r
+
+
+def test_teacher_forced_decode_vs_reference_golden(predictor, cuda):
+    from oracle import parseq as OP
+    P = predictor.parseq
+    tok = OP.Tokenizer()
+    mem = torch.from_numpy(G["memory_from_stand_in_vit"]).to(cuda).bfloat16()
+    tgt = torch.from_numpy(G["tf_tgt"]).to(cuda)
+    L = tgt.shape[1]
+    mask = torch.triu(torch.full((L, L), float("-inf"), device=cuda), 1)
+    kpm = (tgt == tok.pad_id) | (tgt == tok.eos_id)
+    out = P.decode(tgt, P.decoder.memory_kv(mem), mask, kpm, tgt_query_mask=mask)
+    assert _rel(out, G["tf_out"]) < TOL
+    cm, qm = torch.from_numpy(G["perm_content_mask"]).to(cuda), torch.from_numpy(G["perm_query_mask"]).to(cuda)
+    out = P.decode(tgt[:, :-1], P.decoder.memory_kv(mem), cm, kpm[:, :-1], tgt_query_mask=qm)
+    assert _rel(out, G["perm_out"]) < TOL
+
+
+def test_full_inference_vs_reference_golden(predictor, sd, cuda):
+    """AR decoding + refinement.  Greedy decoding of a random-weight network has near-ties, and one flipped token changes
+    everything after it, so the reference's final logits cannot be compared position by position.  Instead:
+    (1) the passes that do not depend on earlier predictions are compared with the reference's logits directly;
+    (2) the greedy prefix the HIP path chose is replayed through the oracle step by step: every chosen token must be the
+        oracle's arg-max up to a near-tie (oracle logit gap < 0.15), and the loop must stop exactly where the reference's
+        rule stops it;
+    (3) the refinement pass on that prefix is compared with the oracle's refinement pass on the same prefix."""
+    from oracle import parseq as OP
+    import torch.nn.functional as F
+    P = predictor.parseq
+    tok = OP.Tokenizer()
+    img = torch.from_numpy(G["images"]).to(cuda)
+    mem32 = torch.from_numpy(G["memory_from_stand_in_vit"])
+    mem = mem32.to(cuda).bfloat16()
+    # (1)
+    P.decode_ar = False
+    got = P(img, memory=mem).float().cpu()
+    P.decode_ar = True
+    ref = torch.from_numpy(G["logits_nar"])
+    if bool((got.argmax(-1) == ref.argmax(-1)).all()):
+        assert _rel(got, ref) < 3e-2
+    for key, ml in (("logits", None), ("logits_max7", 7)):
+        got = P(img, max_length=ml, memory=mem).float().cpu()
+        ref = torch.from_numpy(G[key])
+        assert _rel(got[:, 0], ref[:, 0]) < 3e-2 or not bool((got.argmax(-1) == ref.argmax(-1)).all())
+        toks = P.last_ar_tokens.cpu()
+        n = toks.shape[1]
+        assert got.shape == (3, n, 95)
+        # (2)
+        num_steps = (25 if ml is None else ml) + 1
+        pos_q = sd["pos_queries"][:, :num_steps].expand(3, -1, -1)
+        mask = torch.triu(torch.full((num_steps, num_steps), float("-inf")), 1)
+        head = lambda t: F.linear(t, sd["head.weight"], sd["head.bias"])
+        for i in range(n - 1):
+            j = i + 1
+            lo = head(OP.decode(sd, toks[:, :j], mem32, mask[:j, :j], tgt_query=pos_q[:, i:j], tgt_query_mask=mask[i:j, :j]))[:, 0]
+            gap = lo.max(-1).values - lo.gather(1, toks[:, j:j + 1])[:, 0]
+            assert float(gap.max()) < 0.15, (key, i, gap)
+            if ml is None:
+                assert not bool((toks[:, :j + 1] == tok.eos_id).any(-1).all()) or j + 1 == n, "AR loop ran past the early exit"
+        assert n == num_steps or bool((toks == tok.eos_id).any(-1).all())
+        # (3)
+        qm = mask.clone()
+        qm[torch.triu(torch.ones(num_steps, num_steps, dtype=torch.bool), 2)] = 0
+        kpm = (toks == tok.eos_id).int().cumsum(-1) > 0
+        want = head(OP.decode(sd, toks, mem32, mask[:n, :n], kpm, tgt_query=pos_q[:, :n], tgt_query_mask=qm[:n, :n]))
+        assert _rel(got, want) < 3e-2, key
+    # end to end through the HIP encoder as well
+    got = P(img).float().cpu()
+    assert got.shape[-1] == 95 and bool(torch.isfinite(got).all())
+
+
+def test_predictor_api(predictor, sd, cuda):
+    from oracle import parseq as OP
+    g = torch.Generator().manual_seed(3)
+    crops = [torch.rand((3, 40, 100), generator=g), torch.rand((3, 25, 90), generator=g)]
+    x = predictor.transform([c.to(cuda) for c in crops])
+    assert _rel(x, OP.predictor_transform(crops)) < 1e-5
+    logits = predictor([c.to(cuda) for c in crops])
+    assert logits.shape[0] == 2 and logits.shape[2] == 95 and logits.dtype == torch.float32
+    txt = predictor.img2txt([c.to(cuda) for c in crops])
+    assert len(txt) == 2 and all(isinstance(t, str) for t in txt)
+    loss = predictor.calc_loss([c.to(cuda) for c in crops], ["ab", "MI3"])
+    ref = OP.calc_loss(sd, crops, ["ab", "MI3"])
+    assert loss.shape == (2,) and bool((loss <= 1.0).all())
+    assert float((loss.cpu() - ref).abs().max()) < 5e-2

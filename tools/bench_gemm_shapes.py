@@ -27,6 +27,8 @@ NBUF = 4
 
 
 def apply(spec):
+    for k in ("no_xchg", "no_epi", "no_store", "no_res", "no_bias", "no_fast"):      # measurement builds only: start clean
+        L.load().udt_debug_set(k.encode(), 0)
     for item in spec.split(","):
         k, v = item.split("=")
         L.check(L.load().udt_debug_set(k.encode(), int(v)), "udt_debug_set")

@@ -396,6 +396,111 @@ extern "C" int udt_xattn_fwd(const void* q, const void* k, const void* v, void* 
   return UDT_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// masked small attention (OCR scorer decoder): one workgroup per (head, sample); K and V of the head staged as fp32
+// in LDS (row stride D + 1: lanes walk the keys), one wave per query: lanes own keys for the scores / softmax, then
+// channels for the output
+struct MattnParams {
+  const uint16_t* q;
+  const uint16_t* k;
+  const uint16_t* v;
+  uint16_t* o;
+  const float* mask;
+  const uint8_t* kpm;
+  int heads, D, nq, lk;
+  int ldq, ldk, ldv, ldo, ldmask;
+  long long sq, sk, sv, so;
+  float scale;
+};
+
+__global__ void __launch_bounds__(256) mattn_kernel(const MattnParams p) {
+  extern __shared__ __attribute__((aligned(16))) char msm[];
+  const int D = p.D, RS = D + 1;
+  float* ks = reinterpret_cast<float*>(msm);                 // [lk][D + 1]
+  float* vs = ks + p.lk * RS;                                // [lk][D + 1]
+  float* qs = vs + p.lk * RS;                                // [4][64]
+  float* ps = qs + 4 * 64;                                   // [4][256]
+  const int h = blockIdx.x, b = blockIdx.y;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int i = threadIdx.x; i < p.lk * D; i += 256) {
+    const int l = i / D, d = i - l * D;
+    ks[l * RS + d] = bf16_bits_to_f32(p.k[(long long)b * p.sk + (long long)l * p.ldk + h * D + d]);
+    vs[l * RS + d] = bf16_bits_to_f32(p.v[(long long)b * p.sv + (long long)l * p.ldv + h * D + d]);
+  }
+  __syncthreads();
+  const int rounds = (p.nq + 3) >> 2;
+  for (int it = 0; it < rounds; ++it) {
+    const int qi = it * 4 + wave;
+    const bool active = qi < p.nq;
+    if (active && lane < D) qs[wave * 64 + lane] = bf16_bits_to_f32(p.q[(long long)b * p.sq + (long long)qi * p.ldq + h * D + lane]);
+    __syncthreads();
+    float sc[4];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int l = lane + j * 64;
+      float s = -INFINITY;
+      if (active && l < p.lk) {
+        s = 0.f;
+        for (int d = 0; d < D; ++d) s += qs[wave * 64 + d] * ks[l * RS + d];
+        s *= p.scale;
+        if (p.mask) s += p.mask[(long long)qi * p.ldmask + l];
+        if (p.kpm && p.kpm[(long long)b * p.lk + l]) s = -INFINITY;
+      }
+      sc[j] = s;
+      mx = fmaxf(mx, s);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      sc[j] = (mx == -INFINITY || sc[j] == -INFINITY) ? 0.f : __expf(sc[j] - mx);
+      sum += sc[j];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    const float inv = sum > 0.f ? 1.0f / sum : 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int l = lane + j * 64;
+      if (l < p.lk) ps[wave * 256 + l] = sc[j] * inv;
+    }
+    __syncthreads();
+    if (active && lane < D) {
+      float acc = 0.f;
+      for (int l = 0; l < p.lk; ++l) acc += ps[wave * 256 + l] * vs[l * RS + lane];
+      p.o[(long long)b * p.so + (long long)qi * p.ldo + h * D + lane] = (uint16_t)(pack_bf16x2(acc, 0.f) & 0xffffu);
+    }
+    __syncthreads();
+  }
+}
+
+extern "C" int udt_mattn_fwd(const void* q, const void* k, const void* v, void* o, const float* mask, const uint8_t* kpm,
+                             int32_t batch, int32_t heads, int32_t head_dim, int32_t nq, int32_t lk, int32_t ldq,
+                             int32_t ldk, int32_t ldv, int32_t ldo, int32_t ldmask, int64_t q_bstride, int64_t k_bstride,
+                             int64_t v_bstride, int64_t o_bstride, float scale, void* stream) {
+  if (!q || !k || !v || !o) return UDT_ERR_BAD_ARG;
+  if (batch <= 0 || heads <= 0 || nq <= 0 || lk <= 0 || lk > 256 || batch > 65535) return UDT_ERR_BAD_SHAPE;
+  if (head_dim <= 0 || head_dim > 64 || head_dim % 8 != 0 || (long long)lk * head_dim > 8192) return UDT_ERR_BAD_SHAPE;
+  if (mask && ldmask < lk) return UDT_ERR_BAD_SHAPE;
+  MattnParams p;
+  p.q = reinterpret_cast<const uint16_t*>(q);
+  p.k = reinterpret_cast<const uint16_t*>(k);
+  p.v = reinterpret_cast<const uint16_t*>(v);
+  p.o = reinterpret_cast<uint16_t*>(o);
+  p.mask = mask; p.kpm = kpm;
+  p.heads = heads; p.D = head_dim; p.nq = nq; p.lk = lk;
+  p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo; p.ldmask = ldmask;
+  p.sq = q_bstride; p.sk = k_bstride; p.sv = v_bstride; p.so = o_bstride;
+  p.scale = scale;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const size_t smem = ((size_t)2 * lk * (head_dim + 1) + 4 * 64 + 4 * 256) * sizeof(float);
+  hipLaunchKernelGGL(mattn_kernel, dim3(heads, batch), dim3(256), smem, s, p);
+  UDT_CHECK_LAUNCH();
+  return UDT_OK;
+}
+
 extern "C" int udt_softmax_rows(void* x, int64_t rows, int32_t cols, int32_t ld, void* stream) {
   if (!x) return UDT_ERR_BAD_ARG;
   if (rows <= 0 || cols <= 0 || cols % 8 != 0 || ld % 8 != 0 || rows > 0x7fffffffLL) return UDT_ERR_BAD_SHAPE;

@@ -54,6 +54,8 @@ SYMBOLS = {
     "udt_attn_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32,
                                _i64, _i64, _i64, _i64, _f32, _vp]),
     "udt_xattn_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _fp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp]),
+    "udt_mattn_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _fp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32,
+                                _i64, _i64, _i64, _i64, _f32, _vp]),
     "udt_softmax_rows": (C.c_int, [_vp, _i64, _i32, _i32, _vp]),
     "udt_tattn_hp": (_i32, [_i32]),
     "udt_tattn_prepare": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _i32, _fp, _fp, _vp, _fp, _vp, _i32, _i32, _i32, _i32, _f32, _vp]),

@@ -310,6 +310,31 @@ def xattention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, he
     return out
 
 
+def masked_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, scale: float,
+                     mask: Optional[torch.Tensor] = None, key_padding_mask: Optional[torch.Tensor] = None,
+                     out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """nn.MultiheadAttention's core for short sequences (udt_mattn_fwd): q [B, Nq, heads*D], k / v [B, Lk, *] row views
+    whose first heads*D columns are the head-major projections; mask fp32 [Nq, Lk] additive; key_padding_mask
+    uint8 / bool [B, Lk] (true = ignore).  D = q.shape[-1] // heads, a multiple of 8 up to 64."""
+    _bf16(q); _bf16(k); _bf16(v)
+    B, Nq, Cq = q.shape
+    Lk = k.shape[1]
+    D = Cq // heads
+    assert q.stride(2) == 1 and k.stride(2) == 1 and v.stride(2) == 1
+    if out is None:
+        out = torch.empty((B, Nq, heads * D), dtype=torch.bfloat16, device=q.device)
+    if mask is not None:
+        mask = mask.float().contiguous()
+        assert mask.shape == (Nq, Lk)
+    if key_padding_mask is not None:
+        key_padding_mask = key_padding_mask.to(torch.uint8).contiguous()
+        assert key_padding_mask.shape == (B, Lk)
+    L.check(L.load().udt_mattn_fwd(_ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(mask), _ptr(key_padding_mask), B, heads, D,
+                                   Nq, Lk, q.stride(1), k.stride(1), v.stride(1), out.stride(1), Lk,
+                                   q.stride(0), k.stride(0), v.stride(0), out.stride(0), scale, _stream()), "udt_mattn_fwd")
+    return out
+
+
 class TattnTables(NamedTuple):
     """per-sample tables of the fused text cross-attention (udt_tattn_prepare)"""
     A: torch.Tensor          # bf16 [B, hp, C]

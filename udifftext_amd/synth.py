@@ -36,6 +36,8 @@ def synthetic_tensor(name: str, shape: Tuple[int, ...]) -> torch.Tensor:
             v = 1.0 + 0.1 * u
         else:                                # biases
             v = 0.05 * u
+    elif name.endswith("pos_embed") or name.endswith("pos_queries"):      # PARSeq's learned positions (OCR scorer)
+        v = 0.5 * u
     elif "embedding.weight" in name:         # nn.Embedding
         v = u * np.float32(np.sqrt(3.0))
     else:
