@@ -13,6 +13,10 @@
 #pragma once
 #include <type_traits>
 
+#ifndef UDT_C3P_PIPE
+#define UDT_C3P_PIPE 1
+#endif
+
 namespace c3p {
 
 using g8::NSTAGE;
@@ -509,6 +513,68 @@ __global__ void __launch_bounds__(NTHREADS) conv3p_kernel(const CParams cp) {
     };
     // (the lead/lag wave-role split of gemm8.h measured no gain once the per-K-tile instruction overhead was gone, and
     //  holding a K-tile of operands across the barrier cost spills here — all waves run the same straight loop)
+#if UDT_C3P_PIPE
+    if constexpr (!GN) {
+      // Software-pipelined taps: tap t+1 reads its A fragments from the SAME staged patch as tap t (tap 8 -> the next
+      // chunk's patch, complete since the tap-3 barrier), so they are fetched into a second fragment set while tap t's
+      // MFMAs run; only the weight fragments are read behind the tap's barrier.  (profiles/r02_conv3p_loop_decomposition:
+      // the fragment reads otherwise add 0.29 us to a 0.46 us K-tile instead of hiding under its MFMAs.)
+      bf16x8_t fy[4][TM];
+      auto read_a = [&](auto dx_c, int c, int dy, bf16x8_t (&dst)[4][TM]) {
+        constexpr int DX = decltype(dx_c)::value;
+        const char* pbuf = patches + (c & 1) * PATCH_BYTES;
+#pragma unroll
+        for (int t = 0; t < TM; ++t) {
+          const int prow = a_prow[t] + dy * ge.prow_w + DX;
+          const int arow = prow * ROW_BYTES, aswz = (prow >> 1) & 7;
+#pragma unroll
+          for (int ks = 0; ks < 4; ++ks) dst[ks][t] = lds_read_frag(pbuf + arow + (((ks * 2 + hi) ^ aswz) << 4));
+        }
+      };
+      auto read_w = [&](auto dx_c) {
+        constexpr int DX = decltype(dx_c)::value;
+        const char* wbuf = wring + DX * W_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          const int slot = ((ks * 2 + hi) ^ swz_w) << 4;
+#pragma unroll
+          for (int t = 0; t < TN; ++t) fw[ks][t] = lds_read_frag(wbuf + w_frag_row + t * 32 * ROW_BYTES + slot);
+        }
+      };
+      auto mfma_from = [&](bf16x8_t (&src)[4][TM]) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+          for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = mfma32(fw[ks][tn], src[ks][tm], acc[tm][tn]);
+        // order: the tap's weight fragments, then its MFMAs with the next tap's A reads spread between them
+        __builtin_amdgcn_sched_group_barrier(0x100, 4 * TN, 0);
+#pragma unroll
+        for (int i = 0; i < 4 * TM; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, TN, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+      };
+      for (int c = c0; c < c1; ++c) {
+        const bool nxt = (c + 1 < c1);
+        for (int dy = 0; dy < 3; ++dy) {
+          head(I0{}, c, dy, nxt);
+          if (c == c0 && dy == 0) read_a(I0{}, c, 0, fx);          // first tap of the segment: nothing was prefetched
+          read_w(I0{}); read_a(I1{}, c, dy, fy); mfma_from(fx);
+          head(I1{}, c, dy, nxt);
+          read_w(I1{}); read_a(I2{}, c, dy, fx); mfma_from(fy);
+          head(I2{}, c, dy, nxt);
+          // next tap: (c, dy + 1, 0), or tap 0 of the next chunk (a stale but in-range read after the last chunk)
+          read_w(I2{}); read_a(I0{}, c + (dy == 2 ? 1 : 0), dy == 2 ? 0 : dy + 1, fy); mfma_from(fx);
+#pragma unroll
+          for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int t = 0; t < TM; ++t) fx[ks][t] = fy[ks][t];
+        }
+      }
+    } else
+#endif
     for (int c = c0; c < c1; ++c) {
       const bool nxt = (c + 1 < c1);
       for (int dy = 0; dy < 3; ++dy) {
