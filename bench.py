@@ -55,7 +55,7 @@ def flop_per_image(size: int, sampler_steps: int) -> float:
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=6)
+    ap.add_argument("--steps", type=int, default=12)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=4, help="images per UNet call and GPU (BASELINE config #2: 4)")
     ap.add_argument("--global-batch", type=int, default=0, help="images per step over ALL GPUs (0 = batch x GPUs); "

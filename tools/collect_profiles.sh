@@ -29,7 +29,8 @@ python $R/tools/pmc_mfma.py /tmp/pmc_mfma/p_counter_collection.csv > $O/mfma_uti
 (cd $R && python bench.py --size 768 --batch 8 --chars 12 --steps 3 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_config4_768.json)
 (cd $R && python bench.py --fp8 --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_fp8.json)
 # 7. launch-mode sweeps on this box: batches in flight, and one convolution / GEMM planned for 1/s of the CUs
-(cd $R && for n in 1 2 3 4; do python bench.py --in-flight $n --steps 12 --warmup 3 --no-cpu-baseline --no-mode-table 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('in_flight $n: %.3f images/s, %.1f ms per batch of 4' % (d['value'], d['ms_per_step']))"; done > $O/in_flight_sweep.txt)
+(cd $R && for n in 1 2 3 4 5 6; do python bench.py --in-flight $n --steps 12 --warmup 3 --no-cpu-baseline --no-mode-table 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('in_flight $n: %.3f images/s, %.1f ms per batch of 4' % (d['value'], d['ms_per_step']))"; done > $O/in_flight_sweep.txt)
 (cd $R && python tools/bench_cu_share.py 2>/dev/null > $O/cu_share_sweep.txt)
+(cd $R && python tools/probes/stream_queues.py 12 2>/dev/null > $O/stream_queue_probe.txt)
 (cd $R && python tools/phase_times.py 2>/dev/null | grep -E "alone|predict_many|sampling only" > $O/phase_times.txt)
 ls -la $O; cut -c1-400 $O/bench.json; cat $O/traffic.json | head -30; head -30 $O/mfma_util.json
