@@ -162,6 +162,12 @@ CONV_CASES = [
     (2, 32, 32, 640, 320, 640, 3, 1, (1, 1), False),     # patch-staged, two sources (skip concat), 15 chunks
     (4, 8, 8, 1280, 1280, 1280, 3, 1, (1, 1), False),    # 8x8 maps, two sources
     (1, 64, 64, 320, 320, 320, 3, 1, (1, 1), False),     # bn 160, two sources
+    # patch-staged kernel with the nearest x2 upsampling folded in: 16x16 and 32x8 output tiles, stream-K / whole tiles
+    (3, 16, 16, 640, 0, 640, 3, 1, (1, 1), True),        # -> 32x32
+    (1, 32, 32, 128, 0, 256, 3, 1, (1, 1), True),        # -> 64x64
+    (2, 24, 24, 192, 0, 128, 3, 1, (1, 1), True),        # -> 48x48 (16x16 tiles), 3 chunks
+    (1, 16, 48, 128, 0, 128, 3, 1, (1, 1), True),        # non-square -> 32x96
+    (2, 8, 8, 1280, 0, 320, 3, 1, (1, 1), True),         # N = 320 (bn 160): stays on the gather kernel
 ]
 
 

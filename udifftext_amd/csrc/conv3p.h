@@ -217,8 +217,14 @@ using g8::OOB;
 // STATS = true: the epilogue also emits the output's per-(row slot, column) partial sums (udt_gemm_desc.colstats).
 // The four (GN, STATS) combinations are separate kernels: the plain one is the round-1 kernel instruction for
 // instruction (this kernel's register allocation is tight: extra code anywhere in it costs 5-10 % of the launch).
-template <int WGM, int WGN, int TM, int TN, bool GN, bool STATS>
+// UPS = true: nearest x2 upsampling folded into the convolution (reference Upsample.forward, openaimodel.py:99-101 /
+// model.py:64-68: F.interpolate(scale 2, nearest) then conv3x3 pad 1).  The tile is 256 pixels of the UPSAMPLED map; the
+// staged patch is the low-resolution region under it with its halo ((TW/2 + 2) x (TH/2 + 2) rows), and the tap (dy, dx)
+// of output pixel (py, px) reads patch row ((py + dy - 1) >> 1) + 1, column ((px + dx - 1) >> 1) + 1.  ge.H / ge.W are the
+// INPUT dimensions.  One source, no GroupNorm, no statistics (a separate kernel instance: the others are unchanged).
+template <int WGM, int WGN, int TM, int TN, bool GN, bool STATS, bool UPS = false>
 __global__ void __launch_bounds__(NTHREADS) conv3p_kernel(const CParams cp) {
+  static_assert(!UPS || (!GN && !STATS && UDT_C3P_PIPE), "the upsampling variant covers the plain (pipelined) convolution");
   static_assert(WGM * WGN == 8 && WGM * TM * 32 == 256, "8 waves, 256 output pixels");
   constexpr int BN = WGN * TN * 32;
   constexpr int W_BYTES = BN * ROW_BYTES;
@@ -313,7 +319,7 @@ __global__ void __launch_bounds__(NTHREADS) conv3p_kernel(const CParams cp) {
       const int rem = prow - img * ge.prows_img;
       const int yy = rem / ge.prow_w;
       const int xx = rem - yy * ge.prow_w;
-      const int gy = y0 + yy - 1, gx = x0 + xx - 1, b = b0 + img;
+      const int gy = (UPS ? (y0 >> 1) : y0) + yy - 1, gx = (UPS ? (x0 >> 1) : x0) + xx - 1, b = b0 + img;
       const bool ok = (img < ge.NI) && (b < ge.B) && ((unsigned)gy < (unsigned)ge.H) && ((unsigned)gx < (unsigned)ge.W);
       if constexpr (GN) p_info[i] = ok ? ((((b * ge.H + gy) * ge.W + gx)) | (img << 28)) : -1;
       else p_voff[i] = ok ? (unsigned)(((((long long)b * ge.H + gy) * ge.W + gx) * ge.C + koff) * 2) : OOB;
@@ -332,9 +338,10 @@ __global__ void __launch_bounds__(NTHREADS) conv3p_kernel(const CParams cp) {
       const int rem = ml - img * per;
       const int py = rem / ge.TW;
       const int px = rem - py * ge.TW;
-      a_prow[tm] = img * ge.prows_img + py * ge.prow_w + px;
+      a_prow[tm] = UPS ? (py | (px << 16)) : (img * ge.prows_img + py * ge.prow_w + px);
       const int b = b0 + img;
-      mrow[tm] = (b < ge.B) ? (((long long)b * ge.H + (y0 + py)) * ge.W + (x0 + px)) : -1;
+      if constexpr (UPS) mrow[tm] = (b < ge.B) ? (((long long)b * (2 * ge.H) + (y0 + py)) * (2 * ge.W) + (x0 + px)) : -1;
+      else mrow[tm] = (b < ge.B) ? (((long long)b * ge.H + (y0 + py)) * ge.W + (x0 + px)) : -1;
     }
   };
 
@@ -525,7 +532,13 @@ __global__ void __launch_bounds__(NTHREADS) conv3p_kernel(const CParams cp) {
         const char* pbuf = patches + (c & 1) * PATCH_BYTES;
 #pragma unroll
         for (int t = 0; t < TM; ++t) {
-          const int prow = a_prow[t] + dy * ge.prow_w + DX;
+          int prow;
+          if constexpr (UPS) {
+            const int py = a_prow[t] & 0xffff, px = a_prow[t] >> 16;
+            prow = (((py + dy - 1) >> 1) + 1) * ge.prow_w + (((px + DX - 1) >> 1) + 1);
+          } else {
+            prow = a_prow[t] + dy * ge.prow_w + DX;
+          }
           const int arow = prow * ROW_BYTES, aswz = (prow >> 1) & 7;
 #pragma unroll
           for (int ks = 0; ks < 4; ++ks) dst[ks][t] = lds_read_frag(pbuf + arow + (((ks * 2 + hi) ^ aswz) << 4));

@@ -676,6 +676,11 @@ hipError_t launch8(const g8::Params& pp, const TilePlan& t, hipStream_t s) {
 
 // ---- patch-staged 3x3 convolution: host side -------------------------------------------------------------------
 // gn: the launch applies GroupNorm on the staged patch (the only variant that reads a second source)
+bool upsample3p_enabled() {      // UDT_CONV3P_UPS=0: upsampling convolutions stay on the gather kernel (A/B measurements)
+  static const int on = [] { const char* e = getenv("UDT_CONV3P_UPS"); return (e && e[0] == '0') ? 0 : 1; }();
+  return on != 0;
+}
+
 bool conv3p_geometry(const udt_gemm_desc* d, c3p::Geo& ge, bool gn) {
   int on = g_conv3p.load(std::memory_order_relaxed);
   if (on < 0) {
@@ -684,22 +689,26 @@ bool conv3p_geometry(const udt_gemm_desc* d, c3p::Geo& ge, bool gn) {
     g_conv3p.store(on, std::memory_order_relaxed);
   }
   if (!on || gemm_impl() == 4) return false;
-  if (!(d->flags & UDT_GEMM_CONV) || d->ksize != 3 || d->stride != 1 || d->upsample) return false;
-  if (d->pad_t != 1 || d->pad_l != 1 || d->Hout != d->Hin || d->Wout != d->Win || d->N <= 64) return false;
+  if (!(d->flags & UDT_GEMM_CONV) || d->ksize != 3 || d->stride != 1) return false;
+  const bool ups = d->upsample != 0;
+  // nearest x2 upsampling folded in: the 256x128 plain variant only (one source, no GroupNorm / statistics)
+  if (ups && (gn || d->colstats || d->C2 != 0 || (d->N % 160 == 0 && d->N % 128 != 0) || !upsample3p_enabled())) return false;
+  if (d->pad_t != 1 || d->pad_l != 1 || d->N <= 64) return false;
+  if (d->Hout != (d->Hin << (ups ? 1 : 0)) || d->Wout != (d->Win << (ups ? 1 : 0))) return false;
   if (d->flags & (UDT_GEMM_GEGLU | UDT_GEMM_TRANSPOSED)) return false;
   if (d->C1 <= 0 || d->C1 % 64 != 0 || d->C2 < 0 || d->C2 % 64 != 0 || (d->C2 != 0 && !gn)) return false;
-  const int H = d->Hin, W = d->Win;
+  const int H = d->Hout, W = d->Wout;              // the tile lives in the OUTPUT map (= input map unless upsampling)
   if (W % 32 == 0 && H % 8 == 0) { ge.TW = 32; ge.TH = 8; ge.NI = 1; }
   else if (W % 16 == 0 && H % 16 == 0) { ge.TW = 16; ge.TH = 16; ge.NI = 1; }      // 16x16, 48x48 (768x768 inputs), ...
-  else if (W == 8 && H == 8) { ge.TW = 8; ge.TH = 8; ge.NI = 4; }
+  else if (W == 8 && H == 8 && !ups) { ge.TW = 8; ge.TH = 8; ge.NI = 4; }
   else return false;
   ge.B = d->M / (H * W);
-  ge.H = H; ge.W = W; ge.C1 = d->C1; ge.C2 = d->C2; ge.C = d->C1 + d->C2;
+  ge.H = d->Hin; ge.W = d->Win; ge.C1 = d->C1; ge.C2 = d->C2; ge.C = d->C1 + d->C2;
   ge.tiles_x = W / ge.TW;
   ge.tiles_y = H / ge.TH;
   ge.img_groups = (ge.B + ge.NI - 1) / ge.NI;
-  ge.prow_w = ge.TW + 2;
-  ge.prows_img = (ge.TH + 2) * (ge.TW + 2);
+  ge.prow_w = (ups ? ge.TW / 2 : ge.TW) + 2;
+  ge.prows_img = ((ups ? ge.TH / 2 : ge.TH) + 2) * ge.prow_w;
   ge.n_pieces = (ge.NI * ge.prows_img + 7) / 8;
   ge.chunks = ge.C / 64;
   // buffer-descriptor addressing: 31-bit byte offsets (bit 31 marks zero padding); pixel indices are kept in 28 bits
@@ -730,13 +739,13 @@ TilePlan plan_tiles3p(const udt_gemm_desc* d, const c3p::Geo& ge) {
   return t;
 }
 
-template <int WGM, int WGN, int TM, int TN, bool GN, bool STATS>
+template <int WGM, int WGN, int TM, int TN, bool GN, bool STATS, bool UPS = false>
 hipError_t launch3p(const c3p::CParams& cp, const TilePlan& t, hipStream_t s) {
   constexpr int BN = WGN * TN * 32;
   constexpr int smem = g8::NSTAGE * BN * ROW_BYTES + 2 * c3p::patch_rows(TN, GN) * ROW_BYTES + (GN ? c3p::SCSH_BYTES : 0);
   static_assert(smem <= 160 * 1024, "one workgroup per CU: at most the CU's 160 KiB of LDS");
   static AttrOnce once;
-  auto kern = c3p::conv3p_kernel<WGM, WGN, TM, TN, GN, STATS>;
+  auto kern = c3p::conv3p_kernel<WGM, WGN, TM, TN, GN, STATS, UPS>;
   hipError_t e = once.ensure(reinterpret_cast<const void*>(kern), smem);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(kern, dim3(t.G), dim3(g8::NTHREADS), smem, s, cp);
@@ -944,7 +953,8 @@ extern "C" int udt_gemm(const udt_gemm_desc* d, void* workspace, size_t workspac
       p.total_iters = t3.total;
       p.iters_per_wg = t3.ipw;
       p.G = t3.G;
-      cp.base.a_bytes = (unsigned)((long long)d->M * d->C1 * 2);
+      const long long in_px = (long long)cp.geo.B * d->Hin * d->Win;       // (= M unless the launch upsamples)
+      cp.base.a_bytes = (unsigned)(in_px * d->C1 * 2);
       cp.a2_bytes = (unsigned)((long long)d->M * d->C2 * 2);
       cp.scsh_bytes = (unsigned)((long long)cp.geo.B * cp.geo.chunks * 512);
       cp.base.w_bytes = (unsigned)((long long)d->N * p.ldw * 2);
@@ -960,13 +970,15 @@ extern "C" int udt_gemm(const udt_gemm_desc* d, void* workspace, size_t workspac
       UdtProfScope prof3(cls, s);
       if (prof3.rec) {
         char tag[96];
-        snprintf(tag, sizeof(tag), "conv3p%s M=%d N=%d K=%d %dx%d tile=%dx%dx%d bn=%d G=%d ipw=%d", d->in_scsh ? "+gn" : "", d->M,
+        snprintf(tag, sizeof(tag), "conv3p%s%s M=%d N=%d K=%d %dx%d tile=%dx%dx%d bn=%d G=%d ipw=%d", d->in_scsh ? "+gn" : "", d->upsample ? "+up" : "", d->M,
                  d->N, d->K, d->Hin, d->Win, cp.geo.TW, cp.geo.TH, cp.geo.NI, t3.bn, t3.G, t3.ipw);
         udt_prof_tag(prof3.rec, tag);
       }
       hipError_t e3;
       const int variant = (d->in_scsh ? 2 : 0) | (d->colstats ? 1 : 0);
-      if (t3.bn == 160) {
+      if (d->upsample) {
+        e3 = launch3p<4, 2, 2, 2, false, false, true>(cp, t3, s);
+      } else if (t3.bn == 160) {
         e3 = variant == 3 ? launch3p<8, 1, 1, 5, true, true>(cp, t3, s) : variant == 2 ? launch3p<8, 1, 1, 5, true, false>(cp, t3, s)
            : variant == 1 ? launch3p<8, 1, 1, 5, false, true>(cp, t3, s) : launch3p<8, 1, 1, 5, false, false>(cp, t3, s);
       } else {
