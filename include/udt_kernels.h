@@ -171,6 +171,14 @@ int udt_xattn_fwd(const void* q, const void* k, const void* v, void* o, float* p
                   int32_t batch, int32_t heads, int32_t head_dim, int32_t nq, int32_t L,
                   int32_t ldq, int32_t ldkv, int32_t ldo, float scale, void* stream);
 
+/* The same with V row-major like K (row (b, tok) at v + b*v_bstride + tok*ldv + h*64): q, k and v may then be column
+ * ranges of ONE q|k|v projection output (reference attention.py:193-199: to_q / to_k / to_v on the same input). */
+int udt_attn_rowv_fwd(const void* q, const void* k, const void* v, void* o,
+                      int32_t batch, int32_t heads, int32_t nq, int32_t nk,
+                      int32_t ldq, int32_t ldk, int32_t ldv, int32_t ldo,
+                      int64_t q_bstride, int64_t k_bstride, int64_t v_bstride, int64_t o_bstride,
+                      float scale, void* stream);
+
 /* Masked small attention (the OCR scorer's decoder: nn.MultiheadAttention of PARSeq's DecoderLayer, reference
  * src/parseq/strhub/models/parseq/modules.py:35-36,57-70 -> torch's scaled-dot-product with attn_mask and
  * key_padding_mask).  Few queries against a short key set, any head_dim that is a multiple of 8 up to 64:

@@ -100,9 +100,9 @@ def test_prepare_packs_dedups_and_frees(small_engine):
     # packed layouts exist for every evaluated module; fused children were not packed on their own
     blk = eng.model.diffusion_model.input_blocks[1][1].transformer_blocks[0]
     assert getattr(blk.attn1, "_pk", None) is not None and getattr(blk.attn1.to_q, "_pk", None) is None
-    wqk, wv = blk.attn1.packed()
-    ref_qk = torch.cat([blk.attn1.to_q.weight, blk.attn1.to_k.weight]).to(torch.bfloat16)
-    assert torch.equal(wqk, ref_qk)
+    wqk, wv = blk.attn1.packed()                  # one fused q|k|v matrix (the flash kernel reads V row-major)
+    ref_qk = torch.cat([blk.attn1.to_q.weight, blk.attn1.to_k.weight, blk.attn1.to_v.weight]).to(torch.bfloat16)
+    assert torch.equal(wqk, ref_qk) and wv is None
     # release the fp32 masters: the caches keep serving, the parameters are gone
     before = sum(p.numel() for p in eng.parameters())
     rep = eng.prepare(free_masters=True)

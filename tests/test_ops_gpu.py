@@ -436,6 +436,10 @@ def test_flash_attention(ops, cuda, B, H, N, Nk):
     vh = v.float().reshape(B, Nk, H, 64).permute(0, 2, 1, 3)
     ref = F.scaled_dot_product_attention(qh, kh, vh).permute(0, 2, 1, 3).reshape(B, N, Cc)
     _close(out, ref, what=f"attn {B,H,N,Nk}")
+    # V row-major (column range of the same q|k|v rows): LDS transpose reads instead of a transposed V
+    out2 = ops.attention_rowv(q, k, v, H, 0.125)
+    _close(out2, ref, what=f"attn rowv {B,H,N,Nk}")
+    assert torch.equal(out2, out), "both V layouts feed the MFMAs the same fragments"
 
 
 def test_flash_attention_spike(ops, cuda):

@@ -38,6 +38,12 @@ struct AttnParams {
 constexpr int KV_TILE = 64;
 constexpr int TILE_BYTES = 64 * 128;   // 64 rows x 128 B (K tile, and V^T tile)
 
+// VROW = true: V is row-major like K (row (b, tok) at vt + b*svt + tok*ldvt + h*64 — the q|k|v output of ONE GEMM, no
+// transposed-epilogue GEMM in front of the kernel): the V tile is staged exactly like the K tile, and the V^T fragments
+// of the P·V step come from ds_read_b64_tr_b16, gfx950's LDS transpose read — each 16-lane group passes the addresses of a
+// [4 keys][16 dims] block (lane i: key i/4, dims 4*(i%4)..+3) and lane i receives dim i of the four keys, which is the
+// A-operand order the swapped S^T left P in (layout verified by tools/probes/tr_read.cpp).
+template <bool VROW>
 __global__ void __launch_bounds__(256, 4) attn_d64_kernel(const AttnParams p) {
   __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];   // [buf][K | VT]
   const int tid = threadIdx.x;
@@ -51,7 +57,7 @@ __global__ void __launch_bounds__(256, 4) attn_d64_kernel(const AttnParams p) {
 
   const uint16_t* __restrict__ Q = p.q + (long long)b * p.sq + h * 64;
   const uint16_t* __restrict__ K = p.k + (long long)b * p.sk + h * 64;
-  const uint16_t* __restrict__ VT = p.vt + (long long)b * p.svt + (long long)h * 64 * p.ldvt;
+  const uint16_t* __restrict__ VT = p.vt + (long long)b * p.svt + (VROW ? (long long)h * 64 : (long long)h * 64 * p.ldvt);
   uint16_t* __restrict__ O = p.o + (long long)b * p.so + h * 64;
 
   // this lane's query
@@ -87,11 +93,25 @@ __global__ void __launch_bounds__(256, 4) attn_d64_kernel(const AttnParams p) {
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const int kcol = key0 + st_koff[i];          // first of 8 keys of this 16-byte chunk
-      const uint16_t* g = (kcol < p.nk) ? (VT + (long long)st_row[i] * p.ldvt + kcol) : p.zero;
-      glds16(g, vbuf + (wave * 2 + i) * 1024);
+      if constexpr (VROW) {
+        const int key = key0 + st_row[i];
+        const uint16_t* g = (key < p.nk) ? (VT + (long long)key * p.ldvt + st_koff[i]) : p.zero;
+        glds16(g, vbuf + (wave * 2 + i) * 1024);
+      } else {
+        const int kcol = key0 + st_koff[i];          // first of 8 keys of this 16-byte chunk
+        const uint16_t* g = (kcol < p.nk) ? (VT + (long long)st_row[i] * p.ldvt + kcol) : p.zero;
+        glds16(g, vbuf + (wave * 2 + i) * 1024);
+      }
     }
   };
+  // VROW: per-lane pieces of the transpose-read addresses.  Block of 16-key step s4, dim tile dt: keys 16*s4 + 4*hi (+8)
+  // .. + 3, dims dt*32 + 16*g1 .. + 15 (g1 = second 16-lane group of the half-wave); this lane points at key + (i >> 2),
+  // dims + 4 * (i & 3).  The tile's XOR swizzle ((row >> 1) & 7 on the 16-byte chunk) does not depend on s4.
+  const int tr_i = lane & 15, tr_g1 = (lane >> 4) & 1;
+  const int tr_row = 4 * hi + (tr_i >> 2);
+  const int tr_swz = (tr_row >> 1) & 7;                       // rows + 8 flip bit 2 of it
+  const int tr_chunk = 2 * tr_g1 + ((tr_i & 3) >> 1);         // + 4 * dt
+  const int tr_base = tr_row * 128 + (tr_i & 1) * 8;
 
   f32x16 o_acc[2];
 #pragma unroll
@@ -179,9 +199,21 @@ __global__ void __launch_bounds__(256, 4) attn_d64_kernel(const AttnParams p) {
       const bf16x8_t pf = __builtin_bit_cast(bf16x8_t, pk);
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt) {
-        const char* row = vbuf + (dt * 32 + l31) * 128;
-        const u32x2 lo = *reinterpret_cast<const u32x2*>(row + (((2 * s4) ^ swz) << 4) + 8 * hi);
-        const u32x2 hh = *reinterpret_cast<const u32x2*>(row + (((2 * s4 + 1) ^ swz) << 4) + 8 * hi);
+        u32x2 lo, hh;
+        if constexpr (VROW) {
+          typedef short v4s __attribute__((ext_vector_type(4)));
+          typedef __attribute__((address_space(3))) v4s* lds_v4s;
+          const char* blk = vbuf + s4 * 2048 + tr_base;
+          const int c = dt * 4 + tr_chunk;
+          const v4s a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s)(blk + ((c ^ tr_swz) << 4)));
+          const v4s b8 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s)(blk + 1024 + ((c ^ tr_swz ^ 4) << 4)));
+          lo = __builtin_bit_cast(u32x2, a);
+          hh = __builtin_bit_cast(u32x2, b8);
+        } else {
+          const char* row = vbuf + (dt * 32 + l31) * 128;
+          lo = *reinterpret_cast<const u32x2*>(row + (((2 * s4) ^ swz) << 4) + 8 * hi);
+          hh = *reinterpret_cast<const u32x2*>(row + (((2 * s4 + 1) ^ swz) << 4) + 8 * hi);
+        }
         u32x4 vv = {lo[0], lo[1], hh[0], hh[1]};
         o_acc[dt] = mfma32(__builtin_bit_cast(bf16x8_t, vv), pf, o_acc[dt]);
       }
@@ -341,10 +373,10 @@ __global__ void __launch_bounds__(256) softmax_rows_kernel(uint16_t* x, int cols
 
 }  // namespace
 
-extern "C" int udt_attn_fwd(const void* q, const void* k, const void* vt, void* o, int32_t batch, int32_t heads,
-                            int32_t nq, int32_t nk, int32_t ldq, int32_t ldk, int32_t ldvt, int32_t ldo,
-                            int64_t q_bstride, int64_t k_bstride, int64_t vt_bstride, int64_t o_bstride,
-                            float scale, void* stream) {
+static int attn_fwd_impl(bool vrow, const void* q, const void* k, const void* vt, void* o, int32_t batch, int32_t heads,
+                         int32_t nq, int32_t nk, int32_t ldq, int32_t ldk, int32_t ldvt, int32_t ldo,
+                         int64_t q_bstride, int64_t k_bstride, int64_t vt_bstride, int64_t o_bstride,
+                         float scale, void* stream) {
   if (!q || !k || !vt || !o) return UDT_ERR_BAD_ARG;
   if (batch <= 0 || heads <= 0 || nq <= 0 || nk <= 0) return UDT_ERR_BAD_SHAPE;
   if (nk % 8 != 0 || ldq % 8 != 0 || ldk % 8 != 0 || ldvt % 8 != 0 || ldo % 4 != 0) return UDT_ERR_BAD_SHAPE;
@@ -367,9 +399,26 @@ extern "C" int udt_attn_fwd(const void* q, const void* k, const void* vt, void* 
     udt_prof_tag(prof.rec, tag);
   }
   dim3 grid((nq + 127) / 128, batch * heads);
-  hipLaunchKernelGGL(attn_d64_kernel, grid, dim3(256), 0, s, p);
+  if (vrow) hipLaunchKernelGGL(attn_d64_kernel<true>, grid, dim3(256), 0, s, p);
+  else hipLaunchKernelGGL(attn_d64_kernel<false>, grid, dim3(256), 0, s, p);
   UDT_CHECK_LAUNCH();
   return UDT_OK;
+}
+
+extern "C" int udt_attn_fwd(const void* q, const void* k, const void* vt, void* o, int32_t batch, int32_t heads,
+                            int32_t nq, int32_t nk, int32_t ldq, int32_t ldk, int32_t ldvt, int32_t ldo,
+                            int64_t q_bstride, int64_t k_bstride, int64_t vt_bstride, int64_t o_bstride,
+                            float scale, void* stream) {
+  return attn_fwd_impl(false, q, k, vt, o, batch, heads, nq, nk, ldq, ldk, ldvt, ldo, q_bstride, k_bstride, vt_bstride,
+                       o_bstride, scale, stream);
+}
+
+extern "C" int udt_attn_rowv_fwd(const void* q, const void* k, const void* v, void* o, int32_t batch, int32_t heads,
+                                 int32_t nq, int32_t nk, int32_t ldq, int32_t ldk, int32_t ldv, int32_t ldo,
+                                 int64_t q_bstride, int64_t k_bstride, int64_t v_bstride, int64_t o_bstride,
+                                 float scale, void* stream) {
+  return attn_fwd_impl(true, q, k, v, o, batch, heads, nq, nk, ldq, ldk, ldv, ldo, q_bstride, k_bstride, v_bstride,
+                       o_bstride, scale, stream);
 }
 
 extern "C" int udt_xattn_fwd(const void* q, const void* k, const void* v, void* o, float* probs, int32_t batch,

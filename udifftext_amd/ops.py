@@ -292,6 +292,27 @@ def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, heads: int, sc
     return out
 
 
+def attention_rowv(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, scale: float,
+                   out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """flash attention with V row-major like K: q, k, v [B, N, *] row views (e.g. the column ranges of one q|k|v
+    projection) whose first heads*64 columns are the head-major projections.  Returns o [B, Nq, heads*64]."""
+    _bf16(q); _bf16(k); _bf16(v)
+    B, Nq = q.shape[0], q.shape[1]
+    Nk = k.shape[1]
+    assert q.stride(2) == 1 and k.stride(2) == 1 and v.stride(2) == 1 and v.shape[1] == Nk
+    if out is None:
+        out = torch.empty((B, Nq, heads * 64), dtype=torch.bfloat16, device=q.device)
+    L.check(L.load().udt_attn_rowv_fwd(_ptr(q), _ptr(k), _ptr(v), _ptr(out), B, heads, Nq, Nk,
+                                       q.stride(1), k.stride(1), v.stride(1), out.stride(1),
+                                       q.stride(0), k.stride(0), v.stride(0), out.stride(0), scale, _stream()),
+            "udt_attn_rowv_fwd")
+    if WORK_COUNTER is not None:
+        count_work("attn", 4.0 * B * heads * Nq * Nk * 64)
+        count_work("attn_bytes", 2.0 * B * heads * 64 * (2 * Nq + 2 * Nk))
+        count_work("attn_launches", 1.0)
+    return out
+
+
 def xattention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, head_dim: int, scale: float,
                probs: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """q [B, Nq, heads*head_dim]; k, v row views [B, L, *] sharing one row stride; probs fp32 [B*heads, Nq, L]."""

@@ -132,6 +132,11 @@ class CrossAttention(H._Packed):
         return ops.bias_add(x, b, out=out)
 
 
+# One q|k|v GEMM per self-attention (reference attention.py:193-199 applies three bias-free Linears to the same input) and
+# the flash kernel reads V row-major (udt_attn_rowv_fwd).  UDT_QKV_ONE_GEMM=0: q|k GEMM + transposed-output V GEMM.
+QKV_ONE_GEMM = os.environ.get("UDT_QKV_ONE_GEMM", "1") != "0"
+
+
 class MemoryEfficientCrossAttention(H._Packed):
     """self-attention (flash kernel, head_dim 64)"""
 
@@ -154,9 +159,13 @@ class MemoryEfficientCrossAttention(H._Packed):
         return [self.to_q, self.to_k, self.to_v]
 
     def _pack(self):
+        if QKV_ONE_GEMM:                 # one q|k|v projection; the flash kernel transposes V tiles out of LDS itself
+            return H.fuse_rows(self.to_q.weight, self.to_k.weight, self.to_v.weight), None
         return H.fuse_rows(self.to_q.weight, self.to_k.weight), packing.pack_linear(self.to_v.weight)
 
     def _pack_fp8(self):
+        if QKV_ONE_GEMM:
+            return packing.pack_linear_fp8(torch.cat([self.to_q.weight, self.to_k.weight, self.to_v.weight], 0)), None
         return (packing.pack_linear_fp8(torch.cat([self.to_q.weight, self.to_k.weight], 0)),
                 packing.pack_linear_fp8(self.to_v.weight))
 
@@ -164,18 +173,30 @@ class MemoryEfficientCrossAttention(H._Packed):
         if context is not None or mask is not None:
             raise NotImplementedError("attn1 is pure self-attention on this path (reference attention.py:251-252)")
         inner = self.heads * self.dim_head
-        if isinstance(x, ops.Fp8Act):                     # LayerNorm output quantised for the fp8 linears
+        fp8 = isinstance(x, ops.Fp8Act)                   # LayerNorm output quantised for the fp8 linears
+        if fp8:
             B, N = residual.shape[0], residual.shape[1]
-            (wqk, sqk), (wv, sv) = self.packed_fp8()
-            qk = ops.linear_fp8(x, wqk, sqk).reshape(B, N, 2 * inner)
-            vt = ops.linear_fp8(x, wv, sv, flags=H.GEMM_TRANSPOSED, rows_per_batch=N)
         else:
             B, N, C = x.shape
-            wqk, wv = self.packed()
             x2 = x.reshape(B * N, C)
-            qk = ops.linear(x2, wqk).reshape(B, N, 2 * inner)
-            vt = ops.linear(x2, wv, flags=H.GEMM_TRANSPOSED, rows_per_batch=N)       # [B, inner, N]
-        o = ops.attention(qk[..., :inner], qk[..., inner:], vt, self.heads, self.dim_head ** -0.5)
+        if QKV_ONE_GEMM:
+            if fp8:
+                (wqkv, sqkv), _ = self.packed_fp8()
+                qkv = ops.linear_fp8(x, wqkv, sqkv).reshape(B, N, 3 * inner)
+            else:
+                qkv = ops.linear(x2, self.packed()[0]).reshape(B, N, 3 * inner)
+            o = ops.attention_rowv(qkv[..., :inner], qkv[..., inner:2 * inner], qkv[..., 2 * inner:], self.heads,
+                                   self.dim_head ** -0.5)
+        else:
+            if fp8:
+                (wqk, sqk), (wv, sv) = self.packed_fp8()
+                qk = ops.linear_fp8(x, wqk, sqk).reshape(B, N, 2 * inner)
+                vt = ops.linear_fp8(x, wv, sv, flags=H.GEMM_TRANSPOSED, rows_per_batch=N)
+            else:
+                wqk, wv = self.packed()
+                qk = ops.linear(x2, wqk).reshape(B, N, 2 * inner)
+                vt = ops.linear(x2, wv, flags=H.GEMM_TRANSPOSED, rows_per_batch=N)       # [B, inner, N]
+            o = ops.attention(qk[..., :inner], qk[..., inner:], vt, self.heads, self.dim_head ** -0.5)
         res = residual.reshape(B * N, -1) if residual is not None else None
         return self.to_out[0](o.reshape(B * N, inner), residual=res).reshape(B, N, -1)
 
