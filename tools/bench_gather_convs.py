@@ -37,4 +37,4 @@ for share in (1, 3):
                 xr = torch.randn((B, Ho, Ho, C), device=dev).bfloat16()
                 ref = timed(lambda: ops.conv2d(xr, w, b))
         fl = 2.0 * B * Ho * Ho * N * C * 9
-        print(f"  {mode} {B}x{Hin}x{Hin} {C}->{N} (out {Ho}x{Ho}): gathered {us:7.1f} us {fl/us/1e6:5.0f} TF | staged-patch conv of the same output {ref:7.1f} us {fl/ref/1e6:5.0f} TF", flush=True)
+        print(f"  {mode} {B}x{Hin}x{Hin} {C}->{N} (out {Ho}x{Ho}): this launch {us:7.1f} us {fl/us/1e6:5.0f} TF | staged-patch conv of the same output {ref:7.1f} us {fl/ref/1e6:5.0f} TF", flush=True)
