@@ -123,6 +123,12 @@ typedef struct {
                            The persistent stream-K kernels wait on partner workgroups, so all their
                            workgroups must be resident: the launch is planned for 1/cu_share of the CUs.
                            udt_gemm_workspace_bytes must be asked with the same value.                  */
+  /* LayerNorm prologue (udt_ln_gemm_fwd; reference attention.py:310-339 `attn1(norm1(x))` / `ff(norm3(x))`): `a` holds
+     the RAW rows x, `w` = gamma o W (LayerNorm scale folded into the weight columns), `bias` = c_n = sum_k beta_k W_nk
+     + linear bias, ln_colsum = s_n = sum_k w_nk (fp32 [N], of the bf16-rounded folded weights); the kernel takes every
+     row's mean / rstd from the A tiles it streams and computes out = rstd (x w^T - mean s) + c.  K = normalised width. */
+  const float* ln_colsum;
+  float ln_eps;
 } udt_gemm_desc;
 
 /* workspace (bytes) udt_gemm needs for this problem (split-K slabs); 0 if none.  The first 4 KiB of a workspace are
@@ -143,6 +149,11 @@ int32_t udt_gemm_in_scsh_ok(const udt_gemm_desc* d);
  * epilogue (bias, time-embedding row vector, residual) -> optional statistics of the output.  Same as udt_gemm with a
  * descriptor that has UDT_GEMM_CONV, ksize 3, stride 1, pad 1 and in_scsh set; anything else is UDT_ERR_BAD_ARG. */
 int udt_gn_silu_conv3x3_fwd(const udt_gemm_desc* d, void* workspace, size_t workspace_bytes, void* stream);
+/* LayerNorm -> linear in one launch (SURVEY.md §8b `udt_ln_gemm_fwd`; reference attention.py:310-339: `attn1(norm1(x))`,
+ * `ff(norm3(x))`, LayerNorm over the last dimension = the GEMM's K).  Descriptor as for udt_gemm with the ln_colsum /
+ * ln_eps fields set (see udt_gemm_desc); plain or GEGLU epilogue, optional residual.  UDT_ERR_BAD_SHAPE when the
+ * problem is outside the lean GEMM family (N <= 64, fp32 / transposed outputs, batched, fp8). */
+int udt_ln_gemm_fwd(const udt_gemm_desc* d, void* workspace, size_t workspace_bytes, void* stream);
 /* Synchronises `stream` and reports (UDT_ERR_ASYNC) whether any udt_gemm launch that used `workspace` gave up waiting
  * for a partner workgroup since the last check; in that case the header is re-zeroed so the workspace stays usable.
  * Callers check at their natural sync points (the sampler: once per sampling loop). */

@@ -6,6 +6,7 @@ from seeds / the name-keyed synthetic weight recipe, expected outputs are stored
 
     python tests/golden/make_golden.py            # ~3-4 minutes, needs /root/reference
     python tests/golden/make_golden.py --g11      # only the 50-step trajectory (engine_golden_50.npz), ~3 minutes
+    python tests/golden/make_golden.py --g12      # only BASELINE config #2 end to end (engine_golden_512.npz), ~10 minutes
 
 Import recipe: import transformers first; stub the absent third-party modules
 (pytorch_lightning, omegaconf, kornia, open_clip, imageio, seaborn, torchvision, timm); replace xformers'
@@ -108,7 +109,52 @@ def stats(t: torch.Tensor) -> np.ndarray:
     return np.array([f.sum().item(), f.abs().sum().item(), (f * f).sum().item()], dtype=np.float64)
 
 
-def main(only_g11: bool = False):
+def g12(model, S, t0):
+    """G12 — BASELINE config #2 end to end on ONE image: 512x512, the 9-character label "Diffusion", 50 Euler steps
+    through the real EulerEDMSampler.__call__ (reference sampling.py:355-420), CFG 5, noise_iters 0; conditioning from the
+    real GeneralConditioner under torch.manual_seed(1234) (draw order pinned), x0 under torch.manual_seed(512).  Stored:
+    conditioning sub-samples, x0, the latent after steps 10 / 25 / 50 and a sub-sample of the decoded image."""
+    import io, contextlib
+    batch = synth.synthetic_batch(1, 512, 512, 9, seed=12)
+    torch.manual_seed(1234)
+    buc = {k: (v.clone() if isinstance(v, torch.Tensor) else list(v)) for k, v in batch.items()}
+    buc["label"] = ["" for _ in batch["label"]]
+    buc["txt"] = ["" for _ in batch["txt"]]
+    c, uc = model.conditioner.get_unconditional_conditioning(batch, batch_uc=buc, force_uc_zero_embeddings=["label"])
+    print(f"[golden] G12 conditioning done ({time.time() - t0:.1f}s)")
+    sampler = S.EulerEDMSampler(
+        num_steps=50,
+        discretization_config={"target": "sgm.modules.diffusionmodules.discretizer.LegacyDDPMDiscretization"},
+        guider_config={"target": "sgm.modules.diffusionmodules.guiders.VanillaCFG", "params": {"scale": 5.0}},
+        s_churn=0.0, s_tmin=0.0, s_tmax=999.0, s_noise=1.0, verbose=False, device="cpu")
+    traj = []
+    orig_step = sampler.sampler_step
+
+    def recording_step(*a, **k):
+        r = orig_step(*a, **k)
+        traj.append(r[0].clone())
+        if len(traj) % 10 == 0:
+            print(f"[golden] G12 step {len(traj)} ({time.time() - t0:.1f}s)", flush=True)
+        return r
+
+    sampler.sampler_step = recording_step
+    cfgs = types.SimpleNamespace(batch_size=1, channel=4, factor=8, gpu=0, noise_iters=0)
+    torch.manual_seed(512)
+    x0 = sampler.get_init_noise(cfgs, model, cond=c, batch=batch, uc=uc)
+    with contextlib.redirect_stdout(io.StringIO()):
+        z50 = sampler(model, x0.clone(), cond=c, batch=batch, uc=uc, init_step=0, aae_enabled=False, detailed=False)
+    assert len(traj) == 50 and torch.equal(traj[-1], z50)
+    dec = model.decode_first_stage(z50)
+    out = {"g12_c_concat": c["concat"].numpy(), "g12_uc_concat": uc["concat"].numpy(),
+           "g12_c_txt_sub": c["t_crossattn"][:, :, ::16].numpy(), "g12_x0": x0.numpy(),
+           "g12_latent_10": traj[9].numpy(), "g12_latent_25": traj[24].numpy(), "g12_latent_50": z50.numpy(),
+           "g12_decoded_sub": dec[:, :, ::8, ::8].numpy(),
+           "g12_latent_rms": np.array([t.pow(2).mean().sqrt().item() for t in traj])}
+    np.savez_compressed(os.path.join(HERE, "engine_golden_512.npz"), **out)
+    print(f"[golden] G12 512x512 50-step trajectory done ({time.time() - t0:.1f}s)")
+
+
+def main(only_g11: bool = False, only_g12: bool = False):
     t0 = time.time()
     torch.set_grad_enabled(False)
     import_reference()
@@ -229,6 +275,9 @@ def main(only_g11: bool = False):
             return torch.device("cpu")
 
     S.torch = _TorchProxy()
+    if only_g12:
+        g12(model, S, t0)
+        return
     sampler = S.EulerEDMSampler(
         num_steps=10,
         discretization_config={"target": "sgm.modules.diffusionmodules.discretizer.LegacyDDPMDiscretization"},
@@ -340,4 +389,6 @@ def main(only_g11: bool = False):
 
 
 if __name__ == "__main__":
-    main(only_g11="--g11" in sys.argv)
+    main(only_g11="--g11" in sys.argv, only_g12="--g12" in sys.argv)
+    if "--all" in sys.argv:
+        main(only_g12=True)

@@ -13,14 +13,15 @@ GEGLU, TRANS = L.GEMM_GEGLU, L.GEMM_TRANSPOSED
 # (M, N, K, flags, residual, rows_per_batch, name)
 SHAPES = [
     (32768, 2560, 320, GEGLU, False, 0, "L0 geglu"), (32768, 320, 1280, 0, True, 0, "L0 ff-out"),
-    (32768, 320, 320, 0, True, 0, "L0 to_out/proj"), (32768, 640, 320, 0, False, 0, "L0 q|k"),
+    (32768, 320, 320, 0, True, 0, "L0 to_out/proj"), (32768, 640, 320, 0, False, 0, "L0 q|k"), (32768, 960, 320, 0, False, 0, "L0 q|k|v"),
     (32768, 320, 320, TRANS, False, 4096, "L0 v^T"), (16384, 320, 320, 0, False, 0, "L0 t_attn q"),
     (8192, 5120, 640, GEGLU, False, 0, "L1 geglu"), (8192, 640, 2560, 0, True, 0, "L1 ff-out"),
-    (8192, 640, 640, 0, True, 0, "L1 to_out/proj"), (8192, 1280, 640, 0, False, 0, "L1 q|k"),
+    (8192, 640, 640, 0, True, 0, "L1 to_out/proj"), (8192, 1280, 640, 0, False, 0, "L1 q|k"), (8192, 1920, 640, 0, False, 0, "L1 q|k|v"),
     (4096, 640, 640, 0, False, 0, "L1 t_attn q"),
     (2048, 10240, 1280, GEGLU, False, 0, "L2 geglu"), (2048, 1280, 5120, 0, True, 0, "L2 ff-out"),
-    (2048, 1280, 1280, 0, True, 0, "L2 to_out/proj"), (2048, 2560, 1280, 0, False, 0, "L2 q|k"),
+    (2048, 1280, 1280, 0, True, 0, "L2 to_out/proj"), (2048, 2560, 1280, 0, False, 0, "L2 q|k"), (2048, 3840, 1280, 0, False, 0, "L2 q|k|v"),
     (1024, 1280, 1280, 0, False, 0, "L2 t_attn q"), (512, 1280, 1280, 0, True, 0, "L3 to_out/proj"),
+    (512, 10240, 1280, GEGLU, False, 0, "L3 geglu"), (512, 1280, 5120, 0, True, 0, "L3 ff-out"), (512, 3840, 1280, 0, False, 0, "L3 q|k|v"),
 ]
 settings = sys.argv[1:] or ["n_block=-1"]
 NBUF = 4
@@ -29,6 +30,8 @@ NBUF = 4
 def apply(spec):
     for k in ("no_xchg", "no_epi", "no_store", "no_res", "no_bias", "no_fast"):      # measurement builds only: start clean
         L.load().udt_debug_set(k.encode(), 0)
+    for k in ("lean", "lean_splitk", "n_block"):
+        L.load().udt_debug_set(k.encode(), -1)
     for item in spec.split(","):
         k, v = item.split("=")
         L.check(L.load().udt_debug_set(k.encode(), int(v)), "udt_debug_set")
@@ -72,4 +75,4 @@ for M, N, K, flags, res, rpb, name in SHAPES:
         us = time_shape(M, N, K, flags, res, rpb)
         row += f"{us:10.1f} us {2.0 * M * N * K / us / 1e6:6.0f} TF"
     print(row, flush=True)
-apply("n_block=-1")
+apply("n_block=-1,lean=-1,lean_splitk=-1")

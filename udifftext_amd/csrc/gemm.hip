@@ -462,6 +462,7 @@ __global__ void __launch_bounds__(256) gemm_fixup_kernel(const GemmParams p) {
 
 #include "gemm8.h"
 #include "conv3p.h"
+#include "lean.h"
 
 struct TilePlan {
   int bm, bn;
@@ -778,6 +779,105 @@ int colstats_slots(const udt_gemm_desc* d) {
   return ((d->M + 255) / 256) * (256 / rows);
 }
 
+
+// ---- lean co-resident GEMM family (lean.h): host side --------------------------------------------------------------
+// udt_debug_set("lean", v): -1 automatic (default), 0 off, 1 = 4 waves / 128x128 / 2 stages (two workgroups per CU),
+// 2 = 8 waves / 256x128 / 3 stages (one per CU), 3 = 4 waves / 128x128 / 3 stages (one per CU) — every setting gives
+// the same results up to fp32 summation order (split-K); A/B measurements (tools/bench_gemm_shapes.py)
+std::atomic<int> g_lean{-1};
+std::atomic<int> g_lean_splitk{-1};   // -1 automatic, 1 = never split, n = force n slices where K allows
+
+struct LeanPlan {
+  int cfg;                 // 1, 2, 3 as above; 5 = 4 waves / 128x160 / 2 stages (N = 320, 960)
+  int bm, bn, nw, smem;
+  int tiles_m, tiles_n, tiles, nkt, splitk, kt_per, G, n_block;
+};
+
+int lean_mode() {
+  int v = g_lean.load(std::memory_order_relaxed);
+  if (v == -1) {
+    const char* e = getenv("UDT_LEAN");
+    v = e ? atoi(e) : -2;                                  // -2: automatic
+    g_lean.store(v, std::memory_order_relaxed);
+  }
+  return v;
+}
+
+bool lean_plan(const udt_gemm_desc* d, LeanPlan& t) {
+  const int mode = lean_mode();
+  if (mode == 0 || gemm_impl() == 4) return false;
+  constexpr int unsupported = UDT_GEMM_OUT_F32 | UDT_GEMM_RELU | UDT_GEMM_TRANSPOSED | UDT_GEMM_CONV | UDT_GEMM_SILU_OUT |
+                              UDT_GEMM_FP8;
+  if (d->flags & unsupported) return false;
+  if (d->batch > 1 || d->colstats || d->in_scsh || d->colscale) return false;
+  const bool geglu = (d->flags & UDT_GEMM_GEGLU) != 0;
+  const bool ln = d->ln_colsum != nullptr;
+  if (d->N <= 64 || d->N % 8 != 0 || d->K % BK != 0 || d->lda % 8 != 0 || d->ldo % 8 != 0) return false;
+  if (d->residual && d->ldr % 8 != 0) return false;
+  if (geglu && (d->N % 64 != 0 || d->residual || d->rowvec)) return false;
+  const long long ldw = d->ldw > 0 ? d->ldw : d->K;
+  if ((long long)d->M * d->lda * 2 >= (1LL << 31) || (long long)d->N * ldw * 2 >= (1LL << 31)) return false;
+  if ((reinterpret_cast<uintptr_t>(d->out) | reinterpret_cast<uintptr_t>(d->residual) | reinterpret_cast<uintptr_t>(d->bias) |
+       reinterpret_cast<uintptr_t>(d->rowvec) | reinterpret_cast<uintptr_t>(d->ln_colsum)) & 15) return false;
+  if (d->rowvec && ((d->ld_rowvec > 0 ? d->ld_rowvec : d->N) % 4 != 0)) return false;
+  t.cfg = (mode > 0) ? mode : 1;
+  if (!geglu && d->N % 160 == 0 && d->N % 128 != 0 && t.cfg == 1) t.cfg = 5;
+  switch (t.cfg) {
+    case 1: t.nw = 4; t.bm = 128; t.bn = 128; t.smem = 2 * (128 + 128) * ROW_BYTES; break;
+    case 2: t.nw = 8; t.bm = 256; t.bn = 128; t.smem = 3 * (256 + 128) * ROW_BYTES; break;
+    case 3: t.nw = 4; t.bm = 128; t.bn = 128; t.smem = 3 * (128 + 128) * ROW_BYTES; break;
+    case 5: t.nw = 4; t.bm = 128; t.bn = 160; t.smem = 128 * 160 * 4; break;          // the fp32 staging rows exceed the ring
+    default: return false;
+  }
+  if (ln && t.cfg != 5) {                                  // [BM][mean, rstd] behind the fp32 staging rows
+    if (t.smem < t.bm * t.bn * 4) t.smem = t.bm * t.bn * 4;
+    t.smem += t.bm * 8;
+  }
+  t.tiles_m = (d->M + t.bm - 1) / t.bm;
+  t.tiles_n = (d->N + t.bn - 1) / t.bn;
+  t.tiles = t.tiles_m * t.tiles_n;
+  t.nkt = d->K / BK;
+  // split K when the tiles alone leave most of the chip idle: slices of >= 4 K-tiles, ~1.5 units per workgroup slot
+  const int slots = device_cus() * (t.nw == 4 ? 2 : 1);
+  int sk = 1;
+  const int knob = g_lean_splitk.load(std::memory_order_relaxed);
+  if (!ln && t.tiles <= 1023) {
+    if (knob > 1) sk = knob;
+    else if (knob < 0 && t.tiles * 2 <= slots && t.nkt >= 8) sk = (slots * 3 / 2 + t.tiles - 1) / t.tiles;
+    if (sk > t.nkt / 4) sk = t.nkt / 4;
+    if (sk < 1) sk = 1;
+  }
+  t.kt_per = (t.nkt + sk - 1) / sk;
+  t.splitk = (t.nkt + t.kt_per - 1) / t.kt_per;
+  const int units = t.tiles * t.splitk;
+  t.G = round_workgroups(units);
+  // tile order: an XCD's slice of ~64 concurrently resident tiles should be ~8 M-tiles x 8 N-tiles
+  int nb = g_n_block.load(std::memory_order_relaxed);
+  if (nb <= 0) nb = (t.tiles_m <= 8) ? t.tiles_n : 8;
+  if (nb > t.tiles_n) nb = t.tiles_n;
+  t.n_block = nb;
+  return true;
+}
+
+size_t lean_workspace(const LeanPlan& t) {
+  return t.splitk > 1 ? G8_HEADER_BYTES + (size_t)t.tiles * t.splitk * t.bm * t.bn * sizeof(float) : 0;
+}
+
+template <int NW, int WGM, int WGN, int TM, int TN, int NST>
+hipError_t launch_lean(const lg::LParams& lp, const LeanPlan& t, bool geglu, bool ln, hipStream_t s) {
+  static AttrOnce once[4];
+  const void* fn;
+  if constexpr (TN == 2) {
+    fn = geglu ? (ln ? (const void*)lg::lgemm_kernel<NW, WGM, WGN, TM, TN, NST, true, true> : (const void*)lg::lgemm_kernel<NW, WGM, WGN, TM, TN, NST, true, false>)
+               : (ln ? (const void*)lg::lgemm_kernel<NW, WGM, WGN, TM, TN, NST, false, true> : (const void*)lg::lgemm_kernel<NW, WGM, WGN, TM, TN, NST, false, false>);
+  } else {
+    fn = ln ? (const void*)lg::lgemm_kernel<NW, WGM, WGN, TM, TN, NST, false, true> : (const void*)lg::lgemm_kernel<NW, WGM, WGN, TM, TN, NST, false, false>;
+  }
+  hipError_t e = once[(geglu ? 2 : 0) + (ln ? 1 : 0)].ensure(fn, t.smem);
+  if (e != hipSuccess) return e;
+  void* args[] = {const_cast<lg::LParams*>(&lp)};
+  return hipLaunchKernel(fn, dim3(t.G), dim3(NW * 64), args, t.smem, s);
+}
 }  // namespace
 
 extern "C" int udt_debug_set(const char* key, int32_t value) {
@@ -786,6 +886,8 @@ extern "C" int udt_debug_set(const char* key, int32_t value) {
   if (!strcmp(key, "conv3p")) { g_conv3p.store(value ? 1 : 0); return UDT_OK; }
   if (!strcmp(key, "n_block")) { g_n_block.store(value); return UDT_OK; }
   if (!strcmp(key, "rows_epi")) { g_rows_epi.store(value ? 1 : 0); return UDT_OK; }
+  if (!strcmp(key, "lean")) { g_lean.store(value < 0 ? -2 : value); return UDT_OK; }
+  if (!strcmp(key, "lean_splitk")) { g_lean_splitk.store(value); return UDT_OK; }
 #ifdef UDT_MEASURE
   static const struct { const char* k; int bit; } bits[] = {{"no_xchg", 28}, {"no_epi", 27}, {"no_store", 26}, {"no_res", 25},
                                                             {"no_bias", 24}, {"no_fast", 22}};
@@ -831,8 +933,19 @@ extern "C" int udt_gn_silu_conv3x3_fwd(const udt_gemm_desc* d, void* workspace, 
   return udt_gemm(d, workspace, workspace_bytes, stream);
 }
 
+extern "C" int udt_ln_gemm_fwd(const udt_gemm_desc* d, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!d || !d->ln_colsum || !d->bias || !(d->ln_eps > 0.f)) return UDT_ERR_BAD_ARG;
+  LeanPlan lt;
+  if (!lean_plan(d, lt)) return UDT_ERR_BAD_SHAPE;
+  return udt_gemm(d, workspace, workspace_bytes, stream);
+}
+
 extern "C" size_t udt_gemm_workspace_bytes(const udt_gemm_desc* d) {
   if (!d || d->K <= 0 || d->M <= 0 || d->N <= 0 || d->K % k_tile(d) != 0) return 0;
+  {
+    LeanPlan lt;
+    if (lean_plan(d, lt)) return lean_workspace(lt);
+  }
   {
     c3p::Geo ge;
     if (conv3p_geometry(d, ge, d->in_scsh != nullptr)) {
@@ -931,6 +1044,46 @@ extern "C" int udt_gemm(const udt_gemm_desc* d, void* workspace, size_t workspac
   p.n_block = 1;
   p.alpha = d->alpha;
   const int cls = (conv && d->ksize == 3) ? 0 : 1;
+  {
+    LeanPlan lt;
+    if (lean_plan(d, lt)) {
+      lg::LParams lp;
+      lp.a = p.a; lp.w = p.w; lp.bias = p.bias; lp.res = p.res; lp.rowvec = p.rowvec; lp.ln_s = d->ln_colsum;
+      lp.out = reinterpret_cast<uint16_t*>(d->out);
+      lp.M = d->M; lp.N = d->N; lp.K = d->K;
+      lp.lda = p.lda; lp.ldw = p.ldw; lp.ldo = p.ldo; lp.ldr = p.ldr; lp.ldrv = p.ldrv; lp.rows_per_batch = p.rows_per_batch;
+      lp.alpha = d->alpha; lp.ln_eps = d->ln_eps;
+      lp.tiles_m = lt.tiles_m; lp.tiles_n = lt.tiles_n; lp.n_block = lt.n_block; lp.tiles = lt.tiles;
+      lp.nkt = lt.nkt; lp.splitk = lt.splitk; lp.kt_per = lt.kt_per;
+      lp.a_bytes = (unsigned)((long long)d->M * d->lda * 2);
+      lp.w_bytes = (unsigned)((long long)d->N * p.ldw * 2);
+      lp.G = lt.G;
+      lp.counters = nullptr; lp.slabs = nullptr;
+      if (lt.splitk > 1) {
+        if (!workspace || workspace_bytes < lean_workspace(lt)) return UDT_ERR_WORKSPACE;
+        lp.counters = reinterpret_cast<int*>(workspace);
+        lp.slabs = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + G8_HEADER_BYTES);
+      }
+      UdtProfScope profl(cls, s);
+      if (profl.rec) {
+        char tag[96];
+        snprintf(tag, sizeof(tag), "lean%d M=%d N=%d K=%d fl=0x%x ln=%d tile=%dx%d units=%d splitk=%d", lt.cfg, d->M, d->N, d->K, d->flags,
+                 d->ln_colsum ? 1 : 0, lt.bm, lt.bn, lt.tiles * lt.splitk, lt.splitk);
+        udt_prof_tag(profl.rec, tag);
+      }
+      const bool geglu = (d->flags & UDT_GEMM_GEGLU) != 0, ln = d->ln_colsum != nullptr;
+      hipError_t el;
+      switch (lt.cfg) {
+        case 1: el = launch_lean<4, 2, 2, 2, 2, 2>(lp, lt, geglu, ln, s); break;
+        case 2: el = launch_lean<8, 4, 2, 2, 2, 3>(lp, lt, geglu, ln, s); break;
+        case 3: el = launch_lean<4, 2, 2, 2, 2, 3>(lp, lt, geglu, ln, s); break;
+        default: el = launch_lean<4, 4, 1, 1, 5, 2>(lp, lt, false, ln, s); break;
+      }
+      if (el != hipSuccess) return udt_set_hip_error(el);
+      return UDT_OK;
+    }
+  }
+  if (d->ln_colsum) return UDT_ERR_BAD_ARG;            // the LayerNorm-folded form exists on the lean kernels only
   {
     c3p::CParams cp;
     if (conv3p_geometry(d, cp.geo, d->in_scsh != nullptr)) {

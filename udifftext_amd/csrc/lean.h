@@ -1,0 +1,447 @@
+// lean.h — whole-tile MFMA GEMM with CO-RESIDENT workgroups (included by gemm.hip, round 3).
+//
+// Why a second GEMM family.  The 8-wave kernels of gemm8.h own a CU (160 KiB of LDS, 256 VGPRs + 60..150 spilled
+// dwords: one template carries stream-K finishing, six epilogue forms, statistics, fp8 and the gathered convolution),
+// so nothing overlaps a workgroup's prologue (HBM latency), its epilogue (LDS transposition, residual loads, GELU) or
+// its barrier skew: profiles/r02_gemm_shapes_tile_order.txt — 32768x320x320 takes 29 us against a 7 us HBM floor, the
+// class runs at 16 % of the MFMA peak.  This family is the opposite trade:
+//   * 4 waves, a 128x128 (or 128x160) tile, a TWO-stage ring: 64 (80) KiB of LDS -> TWO workgroups per CU, which fall
+//     into anti-phase on their own (one waits for its LDS-DMA / runs its epilogue while the other owns the matrix
+//     pipe), and co-reside with the workgroups of OTHER launch streams (three batches in flight);
+//   * one tile (or one K slice of a tile) per workgroup, no waiting between workgroups anywhere: split-K slices park
+//     fp32 slabs (write-through stores) and draw a ticket; the LAST arriver sums all slabs in slice order
+//     (deterministic) and runs the epilogue — no residency requirement, no spin, no time-out path;
+//   * one epilogue: the accumulators go through LDS as fp32 rows, so bias / per-sample row vector / residual are
+//     added in the ROW layout (a lane owns 8 consecutive columns: their bias lives in 8 registers) before the single
+//     bf16 rounding, and every store is 16 bytes per lane with whole 128-byte lines per row;
+//   * separate kernels per feature set (plain / GEGLU, LayerNorm-folded) instead of run-time flags: ~150 VGPRs, no
+//     scratch.
+// LayerNorm prologue (udt_ln_gemm_fwd, reference attention.py:310-339 `attn1(norm1(x))`, `ff(norm3(x))`): LayerNorm is
+// affine per row, so  LN(x) W^T = rstd_m * (x W'^T - mean_m * s) + c  with W' = gamma o W (folded when the weights are
+// packed), s_n = sum_k W'_nk, c_n = sum_k beta_k W_nk + bias_n.  The kernel multiplies the RAW rows and accumulates
+// every row's sum and sum of squares from the A fragments it reads anyway (v_dot2_f32_bf16: 2 VALU ops per 8
+// elements, beside the MFMAs); the epilogue applies rstd / mean.  The normalised activation never exists in memory.
+#pragma once
+
+namespace lg {
+
+using g8::raw_barrier;
+using g8::wait_vm;
+using g8::buf_lds16;
+using g8::OOB;
+
+struct LParams {
+  const uint16_t* a;
+  const uint16_t* w;
+  const float* bias;       // [N] fp32 or nullptr (LN: c_n)
+  const uint16_t* res;     // bf16 [M, ldr] or nullptr
+  const float* rowvec;     // fp32 [M / rows_per_batch, ldrv] or nullptr
+  const float* ln_s;       // LN: s_n = sum_k W'_nk, fp32 [N]
+  uint16_t* out;
+  int M, N, K;
+  int lda, ldw, ldo, ldr, ldrv, rows_per_batch;
+  float alpha, ln_eps;
+  int tiles_m, tiles_n, n_block, tiles;
+  int nkt;                 // K tiles of the problem
+  int splitk, kt_per;      // K slices per tile, K tiles per slice
+  unsigned a_bytes, w_bytes;
+  int G;                   // launched workgroups (a multiple of 8 when > 8)
+  int* counters;           // split-K: [tiles] arrival tickets, zero between launches
+  float* slabs;            // split-K: [tiles * splitk][BM * BN] fp32
+};
+
+typedef __attribute__((ext_vector_type(2))) __bf16 bf2_t;
+UDT_DEVINL float dot2_bf16(uint32_t a, uint32_t b, float c) {
+  return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2_t, a), __builtin_bit_cast(bf2_t, b), c, false);
+}
+
+// NW waves as WGM x WGN, each TM x TN MFMA tiles of 32x32; NST ring stages; GEGLU: weight rows packed [32 x | 32 gate]
+// per 64-column wave block (TN == 2); LN: LayerNorm folded into the weights, row statistics from the A fragments
+template <int NW, int WGM, int WGN, int TM, int TN, int NST, bool GEGLU, bool LN>
+__global__ void __launch_bounds__(NW * 64, 2) lgemm_kernel(const LParams p) {
+  static_assert(WGM * WGN == NW, "wave grid");
+  static_assert(!GEGLU || TN == 2, "GEGLU pairs the two 32-column tiles of a wave");
+  constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
+  constexpr int A_BYTES = BM * ROW_BYTES, B_BYTES = BN * ROW_BYTES, STAGE_BYTES = A_BYTES + B_BYTES;
+  constexpr int A_PIECES = BM / 8, B_PIECES = BN / 8;
+  constexpr int A_INSTR = (A_PIECES + NW - 1) / NW, B_INSTR = (B_PIECES + NW - 1) / NW;
+  constexpr int LPT = A_INSTR + B_INSTR;
+  constexpr int WROWS = TM * 32, WCOLS = TN * 32;
+  constexpr int EROW = WCOLS * 4;                       // bytes of one fp32 row of the wave block
+  constexpr int EPI_WAVE = WROWS * EROW;                // (LN: + [BM][mean, rstd] behind the NW wave blocks)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = tid & 63;
+  const int l31 = lane & 31;
+  const int hi = lane >> 5;
+  const int l3 = lane >> 3;
+  const int pslot = lane & 7;
+  const int wm = wave / WGN;
+  const int wn = wave - wm * WGN;
+  const int row0 = wm * WROWS;
+  const int col0 = wn * WCOLS;
+  const int swz = (l31 >> 1) & 7;
+
+  const int unit = range_index(blockIdx.x, p.G);
+  if (unit >= p.tiles * p.splitk) return;
+  const int tile = unit / p.splitk;
+  const int slice = unit - tile * p.splitk;
+  int m0, n0;
+  {
+    // blocked tile order (decode_tile of gemm.hip): N-tiles in blocks of n_block, N-fastest inside a block
+    const int per_block = p.tiles_m * p.n_block;
+    const int blk = tile / per_block;
+    const int r = tile - blk * per_block;
+    int nbw = p.tiles_n - blk * p.n_block;
+    if (nbw > p.n_block) nbw = p.n_block;
+    const int tmi = r / nbw;
+    m0 = tmi * BM;
+    n0 = (blk * p.n_block + (r - tmi * nbw)) * BN;
+  }
+  const int kt0 = slice * p.kt_per;
+  int kt1 = kt0 + p.kt_per;
+  if (kt1 > p.nkt) kt1 = p.nkt;
+
+  const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.a), 0, p.a_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.w), 0, p.w_bytes, 0x00020000);
+  unsigned a_voff[A_INSTR], w_voff[B_INSTR];
+  int a_piece[A_INSTR], w_piece[B_INSTR];
+#pragma unroll
+  for (int i = 0; i < A_INSTR; ++i) {
+    int idx = wave + NW * i;
+    while (idx >= A_PIECES) idx -= NW;                   // duplicate piece (re-writes identical bytes): uniform load count
+    a_piece[i] = idx;
+    const int row = idx * 8 + l3;
+    const int koff = (pslot ^ ((row >> 1) & 7)) * 8;
+    const int m = m0 + row;
+    a_voff[i] = (m < p.M) ? (unsigned)(((long long)m * p.lda + koff) * 2) : OOB;
+  }
+#pragma unroll
+  for (int i = 0; i < B_INSTR; ++i) {
+    int idx = wave + NW * i;
+    while (idx >= B_PIECES) idx -= NW;
+    w_piece[i] = idx;
+    const int row = idx * 8 + l3;
+    const int koff = (pslot ^ ((row >> 1) & 7)) * 8;
+    const int n = n0 + row;
+    w_voff[i] = (n < p.N) ? (unsigned)(((long long)n * p.ldw + koff) * 2) : OOB;
+  }
+  auto stage = [&](int st, int kt) {
+    char* abuf = smem + st * STAGE_BYTES;
+    char* bbuf = abuf + A_BYTES;
+#pragma unroll
+    for (int i = 0; i < A_INSTR; ++i) buf_lds16(rsrc_a, abuf + a_piece[i] * 1024, a_voff[i], kt * ROW_BYTES);
+#pragma unroll
+    for (int i = 0; i < B_INSTR; ++i) buf_lds16(rsrc_w, bbuf + w_piece[i] * 1024, w_voff[i], kt * ROW_BYTES);
+  };
+
+#pragma unroll
+  for (int s = 0; s < NST - 1; ++s)
+    if (kt0 + s < kt1) stage(s, kt0 + s);
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  float rs[TM], rq[TM];                                 // LN: this lane's half-K share of sum x, sum x^2 of its rows
+#pragma unroll
+  for (int i = 0; i < TM; ++i) rs[i] = rq[i] = 0.f;
+
+  const int a_frag_row = (row0 + l31) * ROW_BYTES;
+  const int b_frag_row = (col0 + l31) * ROW_BYTES;
+  int st = 0;
+  for (int kt = kt0; kt < kt1; ++kt) {
+    if (NST > 2 && kt + NST - 2 < kt1) wait_vm<LPT*(NST > 2 ? NST - 2 : 0)>();
+    else wait_vm<0>();
+    raw_barrier();                    // K-tile kt visible to all waves; the stage read in the previous iteration is free
+    if (kt + NST - 1 < kt1) {
+      int s2 = st + NST - 1;
+      if (s2 >= NST) s2 -= NST;
+      stage(s2, kt + NST - 1);
+    }
+    const char* abuf = smem + st * STAGE_BYTES;
+    const char* bbuf = abuf + A_BYTES;
+    bf16x8_t xf[4][TM], wf[4][TN];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int slot = ((ks * 2 + hi) ^ swz) << 4;
+#pragma unroll
+      for (int t = 0; t < TM; ++t) xf[ks][t] = lds_read_frag(abuf + a_frag_row + t * 32 * ROW_BYTES + slot);
+#pragma unroll
+      for (int t = 0; t < TN; ++t) wf[ks][t] = lds_read_frag(bbuf + b_frag_row + t * 32 * ROW_BYTES + slot);
+    }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = mfma32(wf[ks][tn], xf[ks][tm], acc[tm][tn]);
+      if constexpr (LN) {
+        if (wn == 0) {
+#pragma unroll
+          for (int tm = 0; tm < TM; ++tm) {
+            const u32x4 v = __builtin_bit_cast(u32x4, xf[ks][tm]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              rs[tm] = dot2_bf16(v[j], 0x3f803f80u, rs[tm]);      // (1.0, 1.0)
+              rq[tm] = dot2_bf16(v[j], v[j], rq[tm]);
+            }
+          }
+        }
+      }
+    }
+    __builtin_amdgcn_sched_group_barrier(0x100, 4 * (TM + TN), 0);    // all fragment reads of the K-tile ...
+    __builtin_amdgcn_sched_group_barrier(0x008, 4 * TM * TN, 0);      // ... ahead of its MFMAs (gemm8.h)
+    st = st + 1;
+    if (st >= NST) st = 0;
+  }
+  raw_barrier();                      // every wave is done with the ring: it becomes the epilogue's staging space
+
+  // ---- split-K: park the slice, draw a ticket; the last arriver sums all slices in order ----------------------------
+  if (p.splitk > 1) {
+    f32x4* slab = reinterpret_cast<f32x4*>(p.slabs + (long long)unit * (BM * BN));
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          f32x4 v = {acc[tm][tn][q * 4 + 0], acc[tm][tn][q * 4 + 1], acc[tm][tn][q * 4 + 2], acc[tm][tn][q * 4 + 3]};
+          store16_sc1(slab + ((tm * TN + tn) * 4 + q) * (NW * 64) + tid, v);
+        }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every storing wave drains its write-through stores
+    __syncthreads();
+    int* const bcast = reinterpret_cast<int*>(smem);
+    if (tid == 0) {
+      const int t = __hip_atomic_fetch_add(p.counters + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int last = (t == p.splitk - 1) ? 1 : 0;
+      if (last) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        __hip_atomic_store(p.counters + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // clean for the next launch
+      }
+      *bcast = last;
+    }
+    __syncthreads();
+    const bool last = *bcast != 0;
+    __syncthreads();                                      // (bcast lives in the staging space)
+    if (!last) return;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    for (int s = 0; s < p.splitk; ++s) {
+      const f32x4* sl = reinterpret_cast<const f32x4*>(p.slabs + ((long long)tile * p.splitk + s) * (BM * BN));
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const f32x4 v = sl[((tm * TN + tn) * 4 + q) * (NW * 64) + tid];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[tm][tn][q * 4 + r] += v[r];
+          }
+    }
+  }
+
+  // ---- epilogue: accumulators -> this wave's fp32 rows in LDS (16-byte chunks XOR-swizzled by row & 7) ----------------
+  char* const wl = smem + wave * EPI_WAVE;
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm) {
+    const int row = tm * 32 + l31;
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int chunk = (tn * 8 + q * 2 + hi) ^ (row & 7);
+        f32x4 v = {acc[tm][tn][q * 4 + 0], acc[tm][tn][q * 4 + 1], acc[tm][tn][q * 4 + 2], acc[tm][tn][q * 4 + 3]};
+        *reinterpret_cast<f32x4*>(wl + row * EROW + chunk * 16) = v;
+      }
+  }
+  // LN row statistics: the two half-waves hold the two halves of K.  One wave column (WGN == 1): every wave owns the
+  // statistics of its rows in registers (row r of block tm in lanes r and r + 32) and the row-layout pass fetches them
+  // with a lane shuffle; otherwise the wn == 0 wave of each wave row publishes [BM][mean, rstd] behind the wave blocks.
+  float ln_mean[TM], ln_rstd[TM];
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm) ln_mean[tm] = 0.f, ln_rstd[tm] = 1.f;
+  if constexpr (LN) {
+    float* const rst = reinterpret_cast<float*>(smem + NW * EPI_WAVE);
+    if (WGN == 1 || wn == 0) {
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm) {
+        const float s = xor32_sum(rs[tm]), q = xor32_sum(rq[tm]);
+        const float mean = s / (float)p.K;
+        const float var = fmaxf(q / (float)p.K - mean * mean, 0.f);
+        ln_mean[tm] = mean;
+        ln_rstd[tm] = __builtin_amdgcn_rsqf(var + p.ln_eps);
+        if constexpr (WGN > 1) {
+          if (hi == 0) {
+            f32x2 o = {ln_mean[tm], ln_rstd[tm]};
+            *reinterpret_cast<f32x2*>(rst + (row0 + tm * 32 + l31) * 2) = o;
+          }
+        }
+      }
+    }
+    if constexpr (WGN > 1) __syncthreads();
+  }
+  auto row_stats = [&](int row, float& mean, float& rstd) {       // called by all lanes (shuffle)
+    if constexpr (WGN == 1) {
+      mean = __shfl(ln_mean[0], row & 31);
+      rstd = __shfl(ln_rstd[0], row & 31);
+#pragma unroll
+      for (int tm = 1; tm < TM; ++tm) {
+        const float m2 = __shfl(ln_mean[tm], row & 31), r2 = __shfl(ln_rstd[tm], row & 31);
+        if ((row >> 5) == tm) mean = m2, rstd = r2;
+      }
+    } else {
+      const f32x2 ms = *reinterpret_cast<const f32x2*>(reinterpret_cast<const float*>(smem + NW * EPI_WAVE) + (row0 + row) * 2);
+      mean = ms[0];
+      rstd = ms[1];
+    }
+  };
+
+  if constexpr (GEGLU) {
+    // fp32 row = [32 x | 32 gate]; 4 lanes per row (8 output columns each), 16 rows per instruction
+    const int c8 = lane & 3;
+    const int n_in = n0 + col0 + c8 * 8;                 // packed index of this lane's x columns
+    const int n_out = ((n0 + col0) >> 1) + c8 * 8;
+    f32x4 bx0 = {0.f, 0.f, 0.f, 0.f}, bx1 = bx0, bg0 = bx0, bg1 = bx0;
+    if (p.bias && n_in < p.N) {
+      bx0 = *reinterpret_cast<const f32x4*>(p.bias + n_in);
+      bx1 = *reinterpret_cast<const f32x4*>(p.bias + n_in + 4);
+      bg0 = *reinterpret_cast<const f32x4*>(p.bias + n_in + 32);
+      bg1 = *reinterpret_cast<const f32x4*>(p.bias + n_in + 36);
+    }
+    f32x4 ls0 = {0.f, 0.f, 0.f, 0.f}, ls1 = ls0, lg0 = ls0, lg1 = ls0;
+    if constexpr (LN) {
+      if (n_in < p.N) {
+        ls0 = *reinterpret_cast<const f32x4*>(p.ln_s + n_in);
+        ls1 = *reinterpret_cast<const f32x4*>(p.ln_s + n_in + 4);
+        lg0 = *reinterpret_cast<const f32x4*>(p.ln_s + n_in + 32);
+        lg1 = *reinterpret_cast<const f32x4*>(p.ln_s + n_in + 36);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < WROWS / 16; ++i) {
+      const int row = i * 16 + (lane >> 2);
+      const int m = m0 + row0 + row;
+      const char* rp = wl + row * EROW;
+      const int sw = row & 7;
+      f32x4 x0 = *reinterpret_cast<const f32x4*>(rp + (((2 * c8) ^ sw) << 4));
+      f32x4 x1 = *reinterpret_cast<const f32x4*>(rp + (((2 * c8 + 1) ^ sw) << 4));
+      f32x4 g0 = *reinterpret_cast<const f32x4*>(rp + (((8 + 2 * c8) ^ sw) << 4));
+      f32x4 g1 = *reinterpret_cast<const f32x4*>(rp + (((8 + 2 * c8 + 1) ^ sw) << 4));
+      float mean = 0.f, rstd = 1.f;
+      if constexpr (LN) row_stats(row, mean, rstd);
+      float o[8];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float xa = x0[j], xb = x1[j], ga = g0[j], gb = g1[j];
+        if constexpr (LN) {
+          xa = rstd * (xa - mean * ls0[j]);
+          xb = rstd * (xb - mean * ls1[j]);
+          ga = rstd * (ga - mean * lg0[j]);
+          gb = rstd * (gb - mean * lg1[j]);
+        }
+        o[j] = (xa * p.alpha + bx0[j]) * gelu_erf_f(ga * p.alpha + bg0[j]);
+        o[4 + j] = (xb * p.alpha + bx1[j]) * gelu_erf_f(gb * p.alpha + bg1[j]);
+      }
+      if (m < p.M && n_in < p.N) {
+        u32x4 pk = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7])};
+        *reinterpret_cast<u32x4*>(p.out + (long long)m * p.ldo + n_out) = pk;
+      }
+    }
+  } else {
+    constexpr int CPR = TN * 4;                          // 8-column groups per wave row
+    constexpr int RPI = 64 / CPR;                        // rows per instruction (8, or 3 with 4 idle lanes)
+    constexpr int NIT = (WROWS + RPI - 1) / RPI;
+    const int rl = lane / CPR;
+    const int c8 = lane - rl * CPR;
+    const int n = n0 + col0 + c8 * 8;
+    const bool col_ok = (rl < RPI) && (n < p.N);
+    f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = b0, s0 = b0, s1 = b0;
+    if (p.bias && col_ok) {
+      b0 = *reinterpret_cast<const f32x4*>(p.bias + n);
+      b1 = *reinterpret_cast<const f32x4*>(p.bias + n + 4);
+    }
+    if constexpr (LN) {
+      if (col_ok) {
+        s0 = *reinterpret_cast<const f32x4*>(p.ln_s + n);
+        s1 = *reinterpret_cast<const f32x4*>(p.ln_s + n + 4);
+      }
+    }
+    // residual rows first (whole lines, all loads in flight together)
+    u32x4 rv[NIT];
+    if (p.res) {
+#pragma unroll
+      for (int i = 0; i < NIT; ++i) {
+        const int row = i * RPI + rl;
+        const int m = m0 + row0 + row;
+        u32x4 z = {0u, 0u, 0u, 0u};
+        rv[i] = z;
+        if (col_ok && row < WROWS && m < p.M) rv[i] = *reinterpret_cast<const u32x4*>(p.res + (long long)m * p.ldr + n);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+      const int row = i * RPI + rl;
+      const int m = m0 + row0 + row;
+      const bool ok = col_ok && row < WROWS && m < p.M;
+      const int rr = row < WROWS ? row : 0;
+      const char* rp = wl + rr * EROW;
+      const int sw = rr & 7;
+      const f32x4 v0 = *reinterpret_cast<const f32x4*>(rp + (((2 * c8) ^ sw) << 4));
+      const f32x4 v1 = *reinterpret_cast<const f32x4*>(rp + (((2 * c8 + 1) ^ sw) << 4));
+      float o[8];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        o[j] = v0[j];
+        o[4 + j] = v1[j];
+      }
+      if constexpr (LN) {
+        float mean, rstd;
+        row_stats(rr, mean, rstd);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          o[j] = rstd * (o[j] - mean * s0[j]);
+          o[4 + j] = rstd * (o[4 + j] - mean * s1[j]);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        o[j] = o[j] * p.alpha + b0[j];
+        o[4 + j] = o[4 + j] * p.alpha + b1[j];
+      }
+      if (p.rowvec && ok) {
+        const float* rvp = p.rowvec + (long long)(m / p.rows_per_batch) * p.ldrv + n;
+        const f32x4 r0 = *reinterpret_cast<const f32x4*>(rvp);
+        const f32x4 r1 = *reinterpret_cast<const f32x4*>(rvp + 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          o[j] += r0[j];
+          o[4 + j] += r1[j];
+        }
+      }
+      if (p.res) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          o[2 * j] += bf16_lo(rv[i][j]);
+          o[2 * j + 1] += bf16_hi(rv[i][j]);
+        }
+      }
+      if (ok) {
+        u32x4 pk = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7])};
+        *reinterpret_cast<u32x4*>(p.out + (long long)m * p.ldo + n) = pk;
+      }
+    }
+  }
+}
+
+}  // namespace lg

@@ -36,7 +36,7 @@ class GemmDesc(C.Structure):
         ("ksize", C.c_int32), ("stride", C.c_int32), ("pad_t", C.c_int32), ("pad_l", C.c_int32),
         ("upsample", C.c_int32), ("rows_per_batch", C.c_int32), ("ld_rowvec", C.c_int32), ("flags", C.c_int32),
         ("alpha", C.c_float), ("colscale", C.c_void_p), ("in_scsh", C.c_void_p), ("in_act", C.c_int32), ("colstats", C.c_void_p),
-        ("cu_share", C.c_int32),
+        ("cu_share", C.c_int32), ("ln_colsum", C.c_void_p), ("ln_eps", C.c_float),
     ]
 
 
@@ -50,6 +50,7 @@ SYMBOLS = {
     "udt_gemm_colstats_slots": (_i32, [C.POINTER(GemmDesc)]),
     "udt_gemm_in_scsh_ok": (_i32, [C.POINTER(GemmDesc)]),
     "udt_gn_silu_conv3x3_fwd": (C.c_int, [C.POINTER(GemmDesc), _vp, C.c_size_t, _vp]),
+    "udt_ln_gemm_fwd": (C.c_int, [C.POINTER(GemmDesc), _vp, C.c_size_t, _vp]),
     "udt_gn_finalize": (C.c_int, [_fp, _i32, _i32, _fp, _i32, _i32, _fp, _fp, _fp, _i32, _i64, _i32, _f32, _vp]),
     "udt_attn_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32,
                                _i64, _i64, _i64, _i64, _f32, _vp]),

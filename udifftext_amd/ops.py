@@ -199,6 +199,38 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
     return out
 
 
+def ln_linear(x: torch.Tensor, w_folded: torch.Tensor, c: torch.Tensor, s: torch.Tensor, *, eps: float = 1e-5,
+              out: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None, flags: int = 0,
+              n_out: Optional[int] = None) -> torch.Tensor:
+    """out = epilogue(LayerNorm(x) @ W^T + b) in ONE launch (udt_ln_gemm_fwd): x holds the raw rows, (w_folded, c, s) come
+    from packing.pack_ln_linear; the row statistics are taken inside the GEMM (reference attention.py:310-339)."""
+    _bf16(x); _bf16(w_folded)
+    K = x.shape[-1]
+    x2 = x.reshape(-1, K) if x.is_contiguous() else x
+    assert x2.dim() == 2 and x2.stride(1) == 1 and w_folded.shape[1] == K and w_folded.is_contiguous()
+    M = x2.shape[0]
+    N = w_folded.shape[0] if n_out is None else n_out
+    n_cols = N // 2 if (flags & L.GEMM_GEGLU) else N
+    if out is None:
+        out = torch.empty((M, n_cols), dtype=torch.bfloat16, device=x.device)
+    d = gemm_desc(a=_ptr(x2), w=_ptr(w_folded), bias=_ptr(c), residual=_ptr(residual), out=_ptr(out), M=M, N=N, K=K,
+                  lda=x2.stride(0), ldo=out.stride(0), ldr=(residual.stride(0) if residual is not None else 0), flags=flags,
+                  ln_colsum=_ptr(s), ln_eps=eps)
+    lib = L.load()
+    need = lib.udt_gemm_workspace_bytes(C.byref(d))
+    ws_ptr, ws_bytes = None, 0
+    if need:
+        ws = _ws(need, x.device)
+        ws_ptr, ws_bytes = ws.data_ptr(), ws.numel()
+    L.check(lib.udt_ln_gemm_fwd(C.byref(d), ws_ptr, ws_bytes, _stream()), "udt_ln_gemm_fwd")
+    if WORK_COUNTER is not None:
+        count_work("gemm", 2.0 * M * N * K)
+        count_work("gemm_bytes", 2.0 * (M * K + N * K) + out.numel() * out.element_size()
+                   + (2.0 * M * n_cols if residual is not None else 0.0))
+        count_work("gemm_launches", 1.0)
+    return out
+
+
 def bmm_nt(a: torch.Tensor, w: torch.Tensor, *, out: Optional[torch.Tensor] = None, alpha: float = 1.0) -> torch.Tensor:
     """Batched out[b] = a[b] @ w[b]^T with a [B, M, K], w [B, N, K] bf16 (row-strided views allowed)."""
     _bf16(a); _bf16(w)

@@ -81,6 +81,22 @@ def pack_geglu(w: torch.Tensor, b: torch.Tensor):
     return pack_linear(w[perm]), b[perm].float().contiguous()
 
 
+def pack_ln_linear(w: torch.Tensor, b, gamma: torch.Tensor, beta: torch.Tensor, geglu: bool = False):
+    """LayerNorm(gamma, beta) followed by a linear [N, K] (+ bias), folded for udt_ln_gemm_fwd:
+        LN(x) W^T + b = rstd * (x W'^T - mean * s) + c,   W' = W * gamma (bf16),  s_n = sum_k W'_nk (of the ROUNDED
+    weights, so the mean term cancels exactly what the MFMA accumulates),  c_n = sum_k beta_k W_nk + b_n.
+    Returns (W' bf16 [N, Kpad], c fp32 [N], s fp32 [N]); GEGLU projections are row-permuted like pack_geglu."""
+    wf = w.float()
+    bf = torch.zeros((w.shape[0],), dtype=torch.float32, device=w.device) if b is None else b.float()
+    if geglu:
+        perm = geglu_permutation(w.shape[0] // 2).to(w.device)
+        wf, bf = wf[perm], bf[perm]
+    wp = pack_linear(wf * gamma.float()[None, :])
+    s = wp[:, :w.shape[1]].float().sum(dim=1).contiguous()
+    c = (wf @ beta.float() + bf).contiguous()
+    return wp, c, s
+
+
 # ------------------------------------------------------------------------------------------------ fp8 (config #5)
 FP8_KPAD = 128          # K elements per 128-byte LDS row of the fp8 GEMM
 FP8_MAX = 448.0         # largest finite OCP e4m3 value
