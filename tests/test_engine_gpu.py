@@ -271,6 +271,41 @@ def test_fifty_step_sampling_vs_reference_golden(engine, cond256, cuda):
     _check("decoded image of the 50-step latent vs reference", dec[:, :, ::8, ::8].cpu(), g11["g11_decoded_sub"], 4e-2)
 
 
+def test_config2_512_fifty_steps_vs_reference_golden(engine, cuda):
+    """BASELINE config #2 end to end on one image: 512x512, the 9-character label, 50 Euler steps, CFG 5 — conditioning,
+    x0 (CPU RNG contract, bit-exact) and the latent after 10 / 25 / 50 steps against the trajectory of the REAL reference's
+    EulerEDMSampler.__call__ (tests/golden/engine_golden_512.npz, make_golden.py --g12), then the decoded image.
+    Stated tolerances as for the 256x256 trajectory: rel_rms <= 3e-2 at every horizon, decoded image <= 4e-2."""
+    from udifftext_amd import config as C, pipeline, synth
+    g12 = np.load(os.path.join(GOLD, "engine_golden_512.npz"))
+    batch = synth.synthetic_batch(1, 512, 512, 9, seed=12)
+    torch.manual_seed(1234)
+    batch, buc = pipeline.prepare_batch(batch, cuda)
+    c, uc = engine.conditioner.get_unconditional_conditioning(batch, batch_uc=buc, force_uc_zero_embeddings=["label"])
+    _check("512x512 conditioner c.concat vs reference", c["concat"].cpu(), g12["g12_c_concat"], 2e-2, 8e-2)
+    _check("512x512 conditioner uc.concat vs reference", uc["concat"].cpu(), g12["g12_uc_concat"], 2e-2, 8e-2)
+    _check("512x512 conditioner c.t_crossattn vs reference", c["t_crossattn"][:, :, ::16].cpu(), g12["g12_c_txt_sub"], 2e-2, 8e-2)
+    cfgs = C.default_runtime_config(steps=50, batch_size=1, noise_iters=0)
+    for horizon in (10, 25, 50):
+        sampler = pipeline.init_sampling(50, 5.0, cuda)
+        torch.manual_seed(512)
+        x0 = sampler.get_init_noise(cfgs, engine, cond=c, batch=batch, uc=uc)
+        np.testing.assert_array_equal(x0.cpu().numpy(), g12["g12_x0"])
+        if horizon == 50:
+            z = sampler(engine, x0.clone(), cond=c, batch=batch, uc=uc)
+        else:
+            from sgm.modules.diffusionmodules.sampling import _Stepper
+            sig = sampler._host_sigmas()
+            z = x0.clone().float() * (1.0 + sig[0] ** 2.0) ** 0.5
+            st = _Stepper(engine, c, uc, 1, z.shape[2:], 5.0)
+            for i in range(horizon):
+                st.step(z, sig[i], sig[i + 1])
+            st.check()
+        _check(f"512x512, 50-step schedule, latent after {horizon} steps vs reference", z.cpu(), g12[f"g12_latent_{horizon}"], 3e-2)
+    dec = engine.decode_first_stage(z)
+    _check("512x512 decoded image of the 50-step latent vs reference", dec[:, :, ::8, ::8].cpu(), g12["g12_decoded_sub"], 4e-2)
+
+
 def test_unet_call_at_benchmarked_shape_vs_oracle(engine, cuda):
     """BASELINE config #2's UNet call: 64x64 latents, batch 4 -> 8 samples (uc half first, zero text context), the
     tile / stream-K plans of the benchmarked shape — against the fp32 CPU oracle on the same weights.  The oracle

@@ -1,0 +1,97 @@
+"""Lean 3x3 convolution (csrc/lean.h lconv3_kernel) against the 8-wave conv3p kernel and a torch fp32 reference, then
+timing in two regimes: `indep` = 20 back-to-back launches on rotating buffers inside a hipGraph (successive launches may
+overlap head / tail), `chain` = 20 DEPENDENT launches (each convolution reads the previous one's output: what a network
+step looks like).   python tools/check_lean_conv.py"""
+import math, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import torch.nn.functional as F
+import udifftext_amd
+from udifftext_amd import lib as L, ops, packing
+
+dev = torch.device("cuda", 0)
+torch.manual_seed(0)
+
+
+def dbg(k, v):
+    L.check(L.load().udt_debug_set(k.encode(), int(v)), "udt_debug_set " + k)
+
+
+def rel(a, b):
+    a, b = a.float(), b.float()
+    return ((a - b).pow(2).mean().sqrt() / b.pow(2).mean().sqrt().clamp_min(1e-30)).item()
+
+
+bad = 0
+for B, H, W, C, N, res, rvec in [(2, 16, 16, 128, 128, True, True), (1, 8, 16, 64, 256, False, False), (3, 24, 32, 192, 128, True, False),
+                                 (8, 16, 16, 1280, 1280, True, True), (8, 32, 32, 640, 640, False, True), (2, 64, 64, 320, 640, True, False)]:
+    x = torch.randn((B, H, W, C), device=dev).bfloat16()
+    w4 = torch.randn((N, C, 3, 3), device=dev) / math.sqrt(C * 9)
+    w = packing.pack_conv(w4)
+    b = torch.randn((N,), device=dev)
+    r = torch.randn((B, H, W, N), device=dev).bfloat16() if res else None
+    rv = torch.randn((B, N), device=dev) if rvec else None
+    y = F.conv2d(x.float().permute(0, 3, 1, 2), w4.bfloat16().float(), b, padding=1).permute(0, 2, 3, 1)
+    if rv is not None:
+        y = y + rv[:, None, None, :]
+    if r is not None:
+        y = y + r.float()
+    line = f"B{B} {H}x{W} {C}->{N} res={int(res)} rv={int(rvec)}:"
+    outs = {}
+    for mode, sk in ((0, -1), (1, -1), (1, 2)):
+        dbg("lean_conv", mode); dbg("lean_splitk", sk)
+        o = ops.conv2d(x, w, b, residual=r, rowvec=rv)
+        torch.cuda.synchronize()
+        e = rel(o, y)
+        ok = e < 6e-3 and math.isfinite(e)
+        bad += 0 if ok else 1
+        outs[(mode, sk)] = o
+        line += f"  lean_conv={mode}{'/sk2' if sk > 0 else ''} {e:.2e}{'' if ok else ' BAD'}"
+    line += f"  maxdiff(lean, conv3p) {(outs[(1, -1)].float() - outs[(0, -1)].float()).abs().max().item():.1e}"
+    dbg("lean_splitk", -1)
+    print(line, flush=True)
+print("FAILED" if bad else "ALL OK", bad)
+
+
+def graph_time(fn_list, reps=5):
+    for f in fn_list[:3]:
+        f()
+    torch.cuda.synchronize()
+    s = torch.cuda.Stream()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=s):
+        for f in fn_list:
+            f()
+    g.replay(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        g.replay()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / (reps * len(fn_list)) * 1e3
+
+
+print(f"{'conv (B HxW C->N)':28s}" + "".join(f"{h:>26s}" for h in ("conv3p indep", "lean indep", "conv3p chain", "lean chain")))
+for B, H, C, N in [(8, 32, 640, 640), (8, 32, 1280, 640), (8, 16, 1280, 1280), (8, 16, 2560, 1280), (8, 64, 320, 640), (4, 32, 640, 640),
+                   (4, 16, 1280, 1280), (1, 256, 256, 256), (1, 512, 128, 128)]:
+    xs = [torch.randn((B, H, H, C), device=dev).bfloat16() for _ in range(4)]
+    w = packing.pack_conv(torch.randn((N, C, 3, 3), device=dev) / math.sqrt(C * 9))
+    b = torch.zeros((N,), device=dev)
+    outs = [torch.empty((B, H, H, N), dtype=torch.bfloat16, device=dev) for _ in range(4)]
+    fl = 2.0 * B * H * H * N * C * 9
+    row = f"{B:2d} {H:3d}x{H:<3d} {C:4d}->{N:4d}        "
+    cols = []
+    for regime in ("indep", "chain"):
+        for mode in (0, 1):
+            dbg("lean_conv", mode)
+            if regime == "indep":
+                fns = [(lambda i=i: ops.conv2d(xs[i % 4], w, b, out=outs[i % 4])) for i in range(20)]
+            elif C == N:
+                bufs = [xs[0], outs[0]]
+                fns = [(lambda i=i: ops.conv2d(bufs[i % 2], w, b, out=bufs[(i + 1) % 2])) for i in range(20)]
+            else:       # C != N: alternate C->N with a same-size N->C convolution is not this shape; chain through the residual input
+                fns = [(lambda i=i: ops.conv2d(xs[0], w, b, residual=outs[i % 2], out=outs[(i + 1) % 2])) for i in range(20)]
+            us = graph_time(fns)
+            cols.append(f"{us:9.1f} us {fl / us / 1e6:6.0f} TF")
+    print(row + "".join(f"{c:>26s}" for c in cols), flush=True)
+dbg("lean_conv", -1)

@@ -24,7 +24,7 @@ ops.prof_reset(); lib.udt_prof_trace(1); ops.prof_enable(0x3f)
 st.step(x, sig[3], sig[4])
 torch.cuda.synchronize()
 ops.prof_enable(0)
-out = os.path.join("gpurun_out", "trace_step.csv")
+out = os.path.join("gpurun_out", os.environ.get("TRACE_OUT", "trace_step.csv"))
 lib.udt_prof_dump(out.encode())
 agg = collections.OrderedDict()
 tot = 0.0
@@ -37,7 +37,7 @@ print(f"total traced {tot:.3f} ms")
 rows = sorted(agg.items(), key=lambda kv: -kv[1][1])
 for tag, (n, ms) in rows[:70]:
     tf = ""
-    m = re.match(r"gemm M=(\d+) N=(\d+) K=(\d+)", tag)
+    m = re.match(r"(?:gemm8?|lean\d|conv3p\S*) M=(\d+) N=(\d+) K=(\d+)", tag)
     if m:
         M, N, K = map(int, m.groups()); tf = f"{2.0*M*N*K*n/ms/1e9:7.0f} TF/s"
     m = re.match(r"attn B=(\d+) H=(\d+) nq=(\d+) nk=(\d+)", tag)

@@ -786,11 +786,13 @@ int colstats_slots(const udt_gemm_desc* d) {
 // the same results up to fp32 summation order (split-K); A/B measurements (tools/bench_gemm_shapes.py)
 std::atomic<int> g_lean{-1};
 std::atomic<int> g_lean_splitk{-1};   // -1 automatic, 1 = never split, n = force n slices where K allows
+std::atomic<int> g_lean_pf{1};        // look-ahead L2 touch of the two-stage configurations (lean.h PF)
 
 struct LeanPlan {
   int cfg;                 // 1, 2, 3 as above; 5 = 4 waves / 128x160 / 2 stages (N = 320, 960)
   int bm, bn, nw, smem;
   int tiles_m, tiles_n, tiles, nkt, splitk, kt_per, G, n_block;
+  bool pf;
 };
 
 int lean_mode() {
@@ -829,22 +831,28 @@ bool lean_plan(const udt_gemm_desc* d, LeanPlan& t) {
     case 5: t.nw = 4; t.bm = 128; t.bn = 160; t.smem = 128 * 160 * 4; break;          // the fp32 staging rows exceed the ring
     default: return false;
   }
-  if (ln && t.cfg != 5) {                                  // [BM][mean, rstd] behind the fp32 staging rows
-    if (t.smem < t.bm * t.bn * 4) t.smem = t.bm * t.bn * 4;
-    t.smem += t.bm * 8;
+  t.pf = (t.cfg == 1 || t.cfg == 5) && g_lean_pf.load(std::memory_order_relaxed) != 0;
+  if (t.pf) t.smem += t.nw * 256;                           // scratch rows of the look-ahead touch, behind the ring
+  {
+    // the epilogue's fp32 staging rows re-use the ring (+ [BM][mean, rstd] behind them when two wave columns share rows)
+    const int epi = t.bm * t.bn * 4 + ((ln && t.cfg != 5) ? t.bm * 8 : 0);
+    if (t.smem < epi) t.smem = epi;
   }
   t.tiles_m = (d->M + t.bm - 1) / t.bm;
   t.tiles_n = (d->N + t.bn - 1) / t.bn;
   t.tiles = t.tiles_m * t.tiles_n;
   t.nkt = d->K / BK;
   // split K when the tiles alone leave most of the chip idle: slices of >= 4 K-tiles, ~1.5 units per workgroup slot
-  const int slots = device_cus() * (t.nw == 4 ? 2 : 1);
+  const int slots = device_cus() * ((t.cfg == 1 || t.cfg == 5) ? 2 : 1);
   int sk = 1;
   const int knob = g_lean_splitk.load(std::memory_order_relaxed);
   if (!ln && t.tiles <= 1023) {
     if (knob > 1) sk = knob;
-    else if (knob < 0 && t.tiles * 2 <= slots && t.nkt >= 8) sk = (slots * 3 / 2 + t.tiles - 1) / t.tiles;
+    // measured (profiles/r03_gemm_shapes_lean_splitk.txt): a slice costs ~10 us of slab round trip + ticket, so K is cut
+    // only when it is deep (>= 40 K-tiles) and the tiles leave more than half of the workgroup slots idle
+    else if (knob < 0 && t.tiles * 2 <= slots && t.nkt >= 40) { sk = slots / t.tiles; if (sk > t.nkt / 16) sk = t.nkt / 16; }
     if (sk > t.nkt / 4) sk = t.nkt / 4;
+    while (sk > 1 && (long long)t.tiles * sk * t.bm * t.bn * 4 > (64LL << 20)) --sk;    // slabs stay inside the workspace
     if (sk < 1) sk = 1;
   }
   t.kt_per = (t.nkt + sk - 1) / sk;
@@ -863,20 +871,79 @@ size_t lean_workspace(const LeanPlan& t) {
   return t.splitk > 1 ? G8_HEADER_BYTES + (size_t)t.tiles * t.splitk * t.bm * t.bn * sizeof(float) : 0;
 }
 
-template <int NW, int WGM, int WGN, int TM, int TN, int NST>
+template <int NW, int WGM, int WGN, int TM, int TN, int NST, bool PF>
 hipError_t launch_lean(const lg::LParams& lp, const LeanPlan& t, bool geglu, bool ln, hipStream_t s) {
   static AttrOnce once[4];
   const void* fn;
   if constexpr (TN == 2) {
-    fn = geglu ? (ln ? (const void*)lg::lgemm_kernel<NW, WGM, WGN, TM, TN, NST, true, true> : (const void*)lg::lgemm_kernel<NW, WGM, WGN, TM, TN, NST, true, false>)
-               : (ln ? (const void*)lg::lgemm_kernel<NW, WGM, WGN, TM, TN, NST, false, true> : (const void*)lg::lgemm_kernel<NW, WGM, WGN, TM, TN, NST, false, false>);
+    fn = geglu ? (ln ? (const void*)lg::lgemm_kernel<NW, WGM, WGN, TM, TN, NST, true, true, PF> : (const void*)lg::lgemm_kernel<NW, WGM, WGN, TM, TN, NST, true, false, PF>)
+               : (ln ? (const void*)lg::lgemm_kernel<NW, WGM, WGN, TM, TN, NST, false, true, PF> : (const void*)lg::lgemm_kernel<NW, WGM, WGN, TM, TN, NST, false, false, PF>);
   } else {
-    fn = ln ? (const void*)lg::lgemm_kernel<NW, WGM, WGN, TM, TN, NST, false, true> : (const void*)lg::lgemm_kernel<NW, WGM, WGN, TM, TN, NST, false, false>;
+    fn = ln ? (const void*)lg::lgemm_kernel<NW, WGM, WGN, TM, TN, NST, false, true, PF> : (const void*)lg::lgemm_kernel<NW, WGM, WGN, TM, TN, NST, false, false, PF>;
   }
   hipError_t e = once[(geglu ? 2 : 0) + (ln ? 1 : 0)].ensure(fn, t.smem);
   if (e != hipSuccess) return e;
   void* args[] = {const_cast<lg::LParams*>(&lp)};
   return hipLaunchKernel(fn, dim3(t.G), dim3(NW * 64), args, t.smem, s);
+}
+
+// ---- lean 3x3 convolution (lean.h lconv3_kernel): host side ------------------------------------------------------------
+// udt_debug_set("lean_conv", v): -1 automatic (default: on), 0 off, 1 on
+std::atomic<int> g_lean_conv{-1};
+struct LeanConvPlan { lg::C3Params cp; };
+
+bool lean_conv_plan(const udt_gemm_desc* d, lg::C3Params& c) {
+  int on = g_lean_conv.load(std::memory_order_relaxed);
+  if (on < 0) {
+    const char* e = getenv("UDT_LEAN_CONV");
+    on = (e && e[0] == '0') ? 0 : 1;
+    g_lean_conv.store(on, std::memory_order_relaxed);
+  }
+  if (!on || gemm_impl() == 4 || lean_mode() == 0) return false;
+  if (d->flags != UDT_GEMM_CONV || d->ksize != 3 || d->stride != 1 || d->pad_t != 1 || d->pad_l != 1 || d->upsample) return false;
+  if (d->C2 != 0 || d->in_scsh || d->colstats || d->colscale || d->batch > 1) return false;
+  if (d->N % 128 != 0 || d->C1 <= 0 || d->C1 % 64 != 0) return false;
+  if (d->Hout != d->Hin || d->Wout != d->Win || d->Win % lg::C3_TW != 0 || d->Hin % lg::C3_TH != 0) return false;
+  if (d->ldo % 8 != 0 || (d->residual && d->ldr % 8 != 0)) return false;
+  const long long ldw = d->ldw > 0 ? d->ldw : d->K;
+  if ((long long)d->M * d->C1 * 2 >= (1LL << 31) || (long long)d->N * ldw * 2 >= (1LL << 31)) return false;
+  if ((reinterpret_cast<uintptr_t>(d->out) | reinterpret_cast<uintptr_t>(d->residual) | reinterpret_cast<uintptr_t>(d->bias) |
+       reinterpret_cast<uintptr_t>(d->rowvec)) & 15) return false;
+  if (d->rowvec && ((d->ld_rowvec > 0 ? d->ld_rowvec : d->N) % 4 != 0)) return false;
+  c.N = d->N; c.C = d->C1; c.H = d->Hin; c.W = d->Win; c.B = d->M / (d->Hin * d->Win);
+  c.ldw = (int)ldw; c.ldo = d->ldo; c.ldr = d->ldr; c.ldrv = d->ld_rowvec > 0 ? d->ld_rowvec : d->N;
+  c.alpha = d->alpha;
+  c.tiles_x = c.W / lg::C3_TW; c.tiles_y = c.H / lg::C3_TH;
+  c.tiles_m = c.B * c.tiles_x * c.tiles_y;
+  c.tiles_n = d->N / 128;
+  c.tiles = c.tiles_m * c.tiles_n;
+  c.chunks = c.C / 64;
+  const int slots = 2 * device_cus();
+  int sk = 1;
+  const int knob = g_lean_splitk.load(std::memory_order_relaxed);
+  if (c.tiles <= 1023) {
+    if (knob > 1) sk = knob;
+    else if (knob < 0 && c.tiles * 2 <= slots && c.chunks >= 10) sk = slots / c.tiles;
+    if (sk > c.chunks / 5) sk = c.chunks / 5;
+    while (sk > 1 && (long long)c.tiles * sk * 128 * 128 * 4 > (64LL << 20)) --sk;
+    if (sk < 1) sk = 1;
+  }
+  c.ch_per = (c.chunks + sk - 1) / sk;
+  c.splitk = (c.chunks + c.ch_per - 1) / c.ch_per;
+  c.G = round_workgroups(c.tiles * c.splitk);
+  // tile order: ~64 concurrently resident tiles per XCD; n_block weight tiles per patch (conv3p's rule)
+  {
+    const double patch = (double)lg::C3_PROWS * c.C * 2.0, wtile = 9.0 * 128 * c.C * 2.0;
+    int nb = g_n_block.load(std::memory_order_relaxed);
+    if (nb <= 0) nb = (int)(std::sqrt(64.0 * patch / wtile) + 0.5);
+    if (nb < 1) nb = 1;
+    if (nb > c.tiles_n) nb = c.tiles_n;
+    c.n_block = nb;
+  }
+  c.a_bytes = (unsigned)((long long)d->M * d->C1 * 2);
+  c.w_bytes = (unsigned)((long long)d->N * ldw * 2);
+  c.counters = nullptr; c.slabs = nullptr;
+  return true;
 }
 }  // namespace
 
@@ -888,6 +955,8 @@ extern "C" int udt_debug_set(const char* key, int32_t value) {
   if (!strcmp(key, "rows_epi")) { g_rows_epi.store(value ? 1 : 0); return UDT_OK; }
   if (!strcmp(key, "lean")) { g_lean.store(value < 0 ? -2 : value); return UDT_OK; }
   if (!strcmp(key, "lean_splitk")) { g_lean_splitk.store(value); return UDT_OK; }
+  if (!strcmp(key, "lean_conv")) { g_lean_conv.store(value < 0 ? -1 : (value ? 1 : 0)); return UDT_OK; }
+  if (!strcmp(key, "lean_pf")) { g_lean_pf.store(value != 0 ? 1 : 0); return UDT_OK; }
 #ifdef UDT_MEASURE
   static const struct { const char* k; int bit; } bits[] = {{"no_xchg", 28}, {"no_epi", 27}, {"no_store", 26}, {"no_res", 25},
                                                             {"no_bias", 24}, {"no_fast", 22}};
@@ -945,6 +1014,8 @@ extern "C" size_t udt_gemm_workspace_bytes(const udt_gemm_desc* d) {
   {
     LeanPlan lt;
     if (lean_plan(d, lt)) return lean_workspace(lt);
+    lg::C3Params c3;
+    if (lean_conv_plan(d, c3)) return c3.splitk > 1 ? G8_HEADER_BYTES + (size_t)c3.tiles * c3.splitk * 128 * 128 * sizeof(float) : 0;
   }
   {
     c3p::Geo ge;
@@ -1074,16 +1145,42 @@ extern "C" int udt_gemm(const udt_gemm_desc* d, void* workspace, size_t workspac
       const bool geglu = (d->flags & UDT_GEMM_GEGLU) != 0, ln = d->ln_colsum != nullptr;
       hipError_t el;
       switch (lt.cfg) {
-        case 1: el = launch_lean<4, 2, 2, 2, 2, 2>(lp, lt, geglu, ln, s); break;
-        case 2: el = launch_lean<8, 4, 2, 2, 2, 3>(lp, lt, geglu, ln, s); break;
-        case 3: el = launch_lean<4, 2, 2, 2, 2, 3>(lp, lt, geglu, ln, s); break;
-        default: el = launch_lean<4, 4, 1, 1, 5, 2>(lp, lt, false, ln, s); break;
+        case 1: el = lt.pf ? launch_lean<4, 2, 2, 2, 2, 2, true>(lp, lt, geglu, ln, s) : launch_lean<4, 2, 2, 2, 2, 2, false>(lp, lt, geglu, ln, s); break;
+        case 2: el = launch_lean<8, 4, 2, 2, 2, 3, false>(lp, lt, geglu, ln, s); break;
+        case 3: el = launch_lean<4, 2, 2, 2, 2, 3, false>(lp, lt, geglu, ln, s); break;
+        default: el = lt.pf ? launch_lean<4, 4, 1, 1, 5, 2, true>(lp, lt, false, ln, s) : launch_lean<4, 4, 1, 1, 5, 2, false>(lp, lt, false, ln, s); break;
       }
       if (el != hipSuccess) return udt_set_hip_error(el);
       return UDT_OK;
     }
   }
   if (d->ln_colsum) return UDT_ERR_BAD_ARG;            // the LayerNorm-folded form exists on the lean kernels only
+  {
+    lg::C3Params c3;
+    if (lean_conv_plan(d, c3)) {
+      c3.a = p.a; c3.w = p.w; c3.bias = p.bias; c3.res = p.res; c3.rowvec = p.rowvec; c3.out = reinterpret_cast<uint16_t*>(d->out);
+      if (c3.splitk > 1) {
+        const size_t need = G8_HEADER_BYTES + (size_t)c3.tiles * c3.splitk * 128 * 128 * sizeof(float);
+        if (!workspace || workspace_bytes < need) return UDT_ERR_WORKSPACE;
+        c3.counters = reinterpret_cast<int*>(workspace);
+        c3.slabs = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + G8_HEADER_BYTES);
+      }
+      UdtProfScope profc(cls, s);
+      if (profc.rec) {
+        char tag[96];
+        snprintf(tag, sizeof(tag), "lconv3 M=%d N=%d K=%d %dx%d units=%d splitk=%d nb=%d", d->M, d->N, d->K, d->Hin, d->Win,
+                 c3.tiles * c3.splitk, c3.splitk, c3.n_block);
+        udt_prof_tag(profc.rec, tag);
+      }
+      static AttrOnce once3;
+      hipError_t ec = once3.ensure(reinterpret_cast<const void*>(lg::lconv3_kernel), lg::C3_SMEM);
+      if (ec != hipSuccess) return udt_set_hip_error(ec);
+      hipLaunchKernelGGL(lg::lconv3_kernel, dim3(c3.G), dim3(256), lg::C3_SMEM, s, c3);
+      ec = hipGetLastError();
+      if (ec != hipSuccess) return udt_set_hip_error(ec);
+      return UDT_OK;
+    }
+  }
   {
     c3p::CParams cp;
     if (conv3p_geometry(d, cp.geo, d->in_scsh != nullptr)) {

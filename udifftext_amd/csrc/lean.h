@@ -57,7 +57,7 @@ UDT_DEVINL float dot2_bf16(uint32_t a, uint32_t b, float c) {
 
 // NW waves as WGM x WGN, each TM x TN MFMA tiles of 32x32; NST ring stages; GEGLU: weight rows packed [32 x | 32 gate]
 // per 64-column wave block (TN == 2); LN: LayerNorm folded into the weights, row statistics from the A fragments
-template <int NW, int WGM, int WGN, int TM, int TN, int NST, bool GEGLU, bool LN>
+template <int NW, int WGM, int WGN, int TM, int TN, int NST, bool GEGLU, bool LN, bool PF = false>
 __global__ void __launch_bounds__(NW * 64, 2) lgemm_kernel(const LParams p) {
   static_assert(WGM * WGN == NW, "wave grid");
   static_assert(!GEGLU || TN == 2, "GEGLU pairs the two 32-column tiles of a wave");
@@ -69,6 +69,7 @@ __global__ void __launch_bounds__(NW * 64, 2) lgemm_kernel(const LParams p) {
   constexpr int WROWS = TM * 32, WCOLS = TN * 32;
   constexpr int EROW = WCOLS * 4;                       // bytes of one fp32 row of the wave block
   constexpr int EPI_WAVE = WROWS * EROW;                // (LN: + [BM][mean, rstd] behind the NW wave blocks)
+  constexpr int PF_OFF = NST * STAGE_BYTES;             // scratch rows of the look-ahead touch: behind the ring (K loop only)
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x;
@@ -137,9 +138,41 @@ __global__ void __launch_bounds__(NW * 64, 2) lgemm_kernel(const LParams p) {
     for (int i = 0; i < B_INSTR; ++i) buf_lds16(rsrc_w, bbuf + w_piece[i] * 1024, w_voff[i], kt * ROW_BYTES);
   };
 
+  // PF: one lane per tile row touches the row's 128-byte line of the K-tile AFTER the one being staged (a 4-byte load
+  // whose result is never used): the line is pulled into this XCD's L2 one more K-tile ahead than the two-stage ring
+  // can hold, so the LDS-DMA that follows finds it there (HBM-cold activations).  Loads return in order: the counted
+  // wait of the next iteration (vmcnt(1)) covers the LDS-DMA issued before the touch and leaves the touch in flight.
+  // (the touch is a 4-byte LDS-DMA into a 256-byte scratch row per wave behind the ring: no VGPR destination that a
+  //  late return could clobber)
+  unsigned pf_voff = OOB;
+  const bool pf_is_a = __builtin_amdgcn_readfirstlane(tid) < BM;       // wave-uniform: BM is a multiple of 64
+  char* const pf_lds = smem + PF_OFF + wave * 256;
+  if constexpr (PF) {
+    static_assert(NST == 2, "the look-ahead touch complements the two-stage ring");
+    if (pf_is_a) {
+      const int m = m0 + tid;
+      if (m < p.M) pf_voff = (unsigned)((long long)m * p.lda * 2);
+    } else if (tid < BM + BN) {
+      const int n = n0 + tid - BM;
+      if (n < p.N) pf_voff = (unsigned)((long long)n * p.ldw * 2);
+    }
+  }
+  auto touch = [&](int kt) {
+    if constexpr (PF) {
+      if (pf_is_a)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (__attribute__((address_space(3))) void*)pf_lds, 4, pf_voff, kt * ROW_BYTES, 0, 0);
+      else
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (__attribute__((address_space(3))) void*)pf_lds, 4, pf_voff, kt * ROW_BYTES, 0, 0);
+    }
+  };
+
 #pragma unroll
   for (int s = 0; s < NST - 1; ++s)
     if (kt0 + s < kt1) stage(s, kt0 + s);
+  bool touched = false;
+  if constexpr (PF) {
+    if (kt0 + 1 < kt1) { touch(kt0 + 1); touched = true; }
+  }
 
   f32x16 acc[TM][TN];
 #pragma unroll
@@ -157,12 +190,17 @@ __global__ void __launch_bounds__(NW * 64, 2) lgemm_kernel(const LParams p) {
   int st = 0;
   for (int kt = kt0; kt < kt1; ++kt) {
     if (NST > 2 && kt + NST - 2 < kt1) wait_vm<LPT*(NST > 2 ? NST - 2 : 0)>();
+    else if (PF && touched) wait_vm<1>();
     else wait_vm<0>();
     raw_barrier();                    // K-tile kt visible to all waves; the stage read in the previous iteration is free
     if (kt + NST - 1 < kt1) {
       int s2 = st + NST - 1;
       if (s2 >= NST) s2 -= NST;
       stage(s2, kt + NST - 1);
+    }
+    if constexpr (PF) {
+      touched = (kt + 2 < kt1);
+      if (touched) touch(kt + 2);
     }
     const char* abuf = smem + st * STAGE_BYTES;
     const char* bbuf = abuf + A_BYTES;
@@ -251,20 +289,6 @@ __global__ void __launch_bounds__(NW * 64, 2) lgemm_kernel(const LParams p) {
     }
   }
 
-  // ---- epilogue: accumulators -> this wave's fp32 rows in LDS (16-byte chunks XOR-swizzled by row & 7) ----------------
-  char* const wl = smem + wave * EPI_WAVE;
-#pragma unroll
-  for (int tm = 0; tm < TM; ++tm) {
-    const int row = tm * 32 + l31;
-#pragma unroll
-    for (int tn = 0; tn < TN; ++tn)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int chunk = (tn * 8 + q * 2 + hi) ^ (row & 7);
-        f32x4 v = {acc[tm][tn][q * 4 + 0], acc[tm][tn][q * 4 + 1], acc[tm][tn][q * 4 + 2], acc[tm][tn][q * 4 + 3]};
-        *reinterpret_cast<f32x4*>(wl + row * EROW + chunk * 16) = v;
-      }
-  }
   // LN row statistics: the two half-waves hold the two halves of K.  One wave column (WGN == 1): every wave owns the
   // statistics of its rows in registers (row r of block tm in lanes r and r + 32) and the row-layout pass fetches them
   // with a lane shuffle; otherwise the wn == 0 wave of each wave row publishes [BM][mean, rstd] behind the wave blocks.
@@ -308,57 +332,76 @@ __global__ void __launch_bounds__(NW * 64, 2) lgemm_kernel(const LParams p) {
   };
 
   if constexpr (GEGLU) {
-    // fp32 row = [32 x | 32 gate]; 4 lanes per row (8 output columns each), 16 rows per instruction
-    const int c8 = lane & 3;
-    const int n_in = n0 + col0 + c8 * 8;                 // packed index of this lane's x columns
-    const int n_out = ((n0 + col0) >> 1) + c8 * 8;
-    f32x4 bx0 = {0.f, 0.f, 0.f, 0.f}, bx1 = bx0, bg0 = bx0, bg1 = bx0;
-    if (p.bias && n_in < p.N) {
-      bx0 = *reinterpret_cast<const f32x4*>(p.bias + n_in);
-      bx1 = *reinterpret_cast<const f32x4*>(p.bias + n_in + 4);
-      bg0 = *reinterpret_cast<const f32x4*>(p.bias + n_in + 32);
-      bg1 = *reinterpret_cast<const f32x4*>(p.bias + n_in + 36);
-    }
-    f32x4 ls0 = {0.f, 0.f, 0.f, 0.f}, ls1 = ls0, lg0 = ls0, lg1 = ls0;
-    if constexpr (LN) {
-      if (n_in < p.N) {
-        ls0 = *reinterpret_cast<const f32x4*>(p.ln_s + n_in);
-        ls1 = *reinterpret_cast<const f32x4*>(p.ln_s + n_in + 4);
-        lg0 = *reinterpret_cast<const f32x4*>(p.ln_s + n_in + 32);
-        lg1 = *reinterpret_cast<const f32x4*>(p.ln_s + n_in + 36);
+    // x and its gate sit in the SAME lane and register index of acc[tm][0] / acc[tm][1]: GEGLU is applied in the
+    // accumulator layout and only the bf16 result (32 columns = 64 bytes per row) is transposed through LDS
+    if constexpr (LN && WGN > 1) {
+      if (wn != 0) {
+        const float* rst = reinterpret_cast<const float*>(smem + NW * EPI_WAVE);
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) {
+          const f32x2 ms = *reinterpret_cast<const f32x2*>(rst + (row0 + tm * 32 + l31) * 2);
+          ln_mean[tm] = ms[0];
+          ln_rstd[tm] = ms[1];
+        }
       }
     }
+    char* const wb = smem + wave * (WROWS * 64);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {                         // (q outer: one column group's constants live at a time)
+      const int n = n0 + col0 + q * 8 + hi * 4;
+      f32x4 bx = {0.f, 0.f, 0.f, 0.f}, bg = bx, sx = bx, sg = bx;
+      if (n < p.N) {
+        if (p.bias) {
+          bx = *reinterpret_cast<const f32x4*>(p.bias + n);
+          bg = *reinterpret_cast<const f32x4*>(p.bias + n + 32);
+        }
+        if constexpr (LN) {
+          sx = *reinterpret_cast<const f32x4*>(p.ln_s + n);
+          sg = *reinterpret_cast<const f32x4*>(p.ln_s + n + 32);
+        }
+      }
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm) {
+        const int row = tm * 32 + l31;
+        float o[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float x = acc[tm][0][q * 4 + r], g = acc[tm][1][q * 4 + r];
+          if constexpr (LN) {
+            x = ln_rstd[tm] * (x - ln_mean[tm] * sx[r]);
+            g = ln_rstd[tm] * (g - ln_mean[tm] * sg[r]);
+          }
+          o[r] = (x * p.alpha + bx[r]) * gelu_erf_f(g * p.alpha + bg[r]);
+        }
+        u32x2 pk = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
+        *reinterpret_cast<u32x2*>(wb + row * 64 + ((q ^ (row & 3)) << 4) + hi * 8) = pk;
+      }
+    }
+    const int ch = lane & 3;
+    const int n_out = ((n0 + col0) >> 1) + ch * 8;
+    const bool col_ok = (n0 + col0 + ch * 8) < p.N;
 #pragma unroll
     for (int i = 0; i < WROWS / 16; ++i) {
       const int row = i * 16 + (lane >> 2);
       const int m = m0 + row0 + row;
-      const char* rp = wl + row * EROW;
-      const int sw = row & 7;
-      f32x4 x0 = *reinterpret_cast<const f32x4*>(rp + (((2 * c8) ^ sw) << 4));
-      f32x4 x1 = *reinterpret_cast<const f32x4*>(rp + (((2 * c8 + 1) ^ sw) << 4));
-      f32x4 g0 = *reinterpret_cast<const f32x4*>(rp + (((8 + 2 * c8) ^ sw) << 4));
-      f32x4 g1 = *reinterpret_cast<const f32x4*>(rp + (((8 + 2 * c8 + 1) ^ sw) << 4));
-      float mean = 0.f, rstd = 1.f;
-      if constexpr (LN) row_stats(row, mean, rstd);
-      float o[8];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        float xa = x0[j], xb = x1[j], ga = g0[j], gb = g1[j];
-        if constexpr (LN) {
-          xa = rstd * (xa - mean * ls0[j]);
-          xb = rstd * (xb - mean * ls1[j]);
-          ga = rstd * (ga - mean * lg0[j]);
-          gb = rstd * (gb - mean * lg1[j]);
-        }
-        o[j] = (xa * p.alpha + bx0[j]) * gelu_erf_f(ga * p.alpha + bg0[j]);
-        o[4 + j] = (xb * p.alpha + bx1[j]) * gelu_erf_f(gb * p.alpha + bg1[j]);
-      }
-      if (m < p.M && n_in < p.N) {
-        u32x4 pk = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7])};
-        *reinterpret_cast<u32x4*>(p.out + (long long)m * p.ldo + n_out) = pk;
-      }
+      const u32x4 v = *reinterpret_cast<const u32x4*>(wb + row * 64 + ((ch ^ (row & 3)) << 4));
+      if (m < p.M && col_ok) *reinterpret_cast<u32x4*>(p.out + (long long)m * p.ldo + n_out) = v;
     }
   } else {
+    // ---- epilogue: accumulators -> this wave's fp32 rows in LDS (16-byte chunks XOR-swizzled by row & 7) ----------------
+    char* const wl = smem + wave * EPI_WAVE;
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+      const int row = tm * 32 + l31;
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int chunk = (tn * 8 + q * 2 + hi) ^ (row & 7);
+          f32x4 v = {acc[tm][tn][q * 4 + 0], acc[tm][tn][q * 4 + 1], acc[tm][tn][q * 4 + 2], acc[tm][tn][q * 4 + 3]};
+          *reinterpret_cast<f32x4*>(wl + row * EROW + chunk * 16) = v;
+        }
+    }
     constexpr int CPR = TN * 4;                          // 8-column groups per wave row
     constexpr int RPI = 64 / CPR;                        // rows per instruction (8, or 3 with 4 idle lanes)
     constexpr int NIT = (WROWS + RPI - 1) / RPI;
@@ -440,6 +483,297 @@ __global__ void __launch_bounds__(NW * 64, 2) lgemm_kernel(const LParams p) {
         u32x4 pk = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7])};
         *reinterpret_cast<u32x4*>(p.out + (long long)m * p.ldo + n) = pk;
       }
+    }
+  }
+}
+
+
+// ---- lean 3x3 / stride 1 / pad 1 convolution (LDS-staged patches, co-resident workgroups) -----------------------------
+// The patch-staged formulation of conv3p.h (a workgroup stages the input patch of its pixel tile WITH ITS HALO once per
+// 64-channel chunk; the nine taps read their A fragments from it at shifted rows, only the weight tile streams per tap)
+// in the lean form: 4 waves, 128 output pixels (16 x 8) x 128 output channels, two patch buffers (23 KiB each) + a
+// TWO-stage weight ring (16 KiB each) = 78 KiB -> two workgroups per CU, from the same or from different launch streams;
+// whole tiles (or, for the few-tile deep layers, chunk slices with the ticket split-K of lgemm_kernel); the fp32-row
+// epilogue of lgemm_kernel (bias + time-embedding row vector + residual before the single bf16 rounding, 16-byte stores of
+// whole 128-byte lines).  ~190 VGPRs, no scratch, no stream-K residency contract.
+// Replaces nn.Conv2d(k=3, pad=1) of ResBlock / ResnetBlock (reference openaimodel.py:183-187,218-231; model.py:128-148).
+struct C3Params {
+  const uint16_t* a;
+  const uint16_t* w;
+  const float* bias;
+  const uint16_t* res;
+  const float* rowvec;
+  uint16_t* out;
+  int N, C;                // output / input channels (C a multiple of 64)
+  int B, H, W;             // map (input = output size)
+  int ldw, ldo, ldr, ldrv;
+  float alpha;
+  int tiles_x, tiles_y, tiles_m, tiles_n, n_block, tiles;
+  int chunks, splitk, ch_per;
+  unsigned a_bytes, w_bytes;
+  int G;
+  int* counters;
+  float* slabs;
+};
+
+constexpr int C3_TW = 16, C3_TH = 8, C3_PW = C3_TW + 2, C3_PROWS = (C3_TH + 2) * C3_PW;       // 180 patch rows
+constexpr int C3_PIECES = (C3_PROWS + 7) / 8;                                                    // 23
+constexpr int C3_PATCH_BYTES = C3_PIECES * 1024;
+constexpr int C3_W_BYTES = 128 * ROW_BYTES;
+constexpr int C3_SMEM = 2 * C3_W_BYTES + 2 * C3_PATCH_BYTES;                                     // 79872
+
+__global__ void __launch_bounds__(256, 2) lconv3_kernel(const C3Params p) {
+  constexpr int NW = 4, TM = 2, TN = 2, BN = 128, BMPX = 128;
+  constexpr int WP = 4;                                  // weight pieces per wave and tap (16 / 4)
+  constexpr int PP = (C3_PIECES + NW - 1) / NW;          // patch pieces per wave and chunk (6, padded with duplicates)
+  constexpr int EROW = 64 * 4;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const wring = smem;
+  char* const patches = smem + 2 * C3_W_BYTES;
+
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = tid & 63;
+  const int l31 = lane & 31;
+  const int hi = lane >> 5;
+  const int l3 = lane >> 3;
+  const int pslot = lane & 7;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int row0 = wm * 64, col0 = wn * 64;
+  const int swz_w = (l31 >> 1) & 7;
+  const int w_frag_row = (col0 + l31) * ROW_BYTES;
+
+  const int unit = range_index(blockIdx.x, p.G);
+  if (unit >= p.tiles * p.splitk) return;
+  const int tile = unit / p.splitk;
+  const int slice = unit - tile * p.splitk;
+  int tile_m, n0;
+  {
+    const int per_block = p.tiles_m * p.n_block;
+    const int blk = tile / per_block;
+    const int r = tile - blk * per_block;
+    int nbw = p.tiles_n - blk * p.n_block;
+    if (nbw > p.n_block) nbw = p.n_block;
+    tile_m = r / nbw;
+    n0 = (blk * p.n_block + (r - tile_m * nbw)) * BN;
+  }
+  const int per_img = p.tiles_x * p.tiles_y;
+  const int b = tile_m / per_img;
+  const int rt = tile_m - b * per_img;
+  const int ty = rt / p.tiles_x;
+  const int y0 = ty * C3_TH, x0 = (rt - ty * p.tiles_x) * C3_TW;
+  const int c0 = slice * p.ch_per;
+  int c1 = c0 + p.ch_per;
+  if (c1 > p.chunks) c1 = p.chunks;
+
+  const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.a), 0, p.a_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.w), 0, p.w_bytes, 0x00020000);
+  unsigned w_voff[WP], p_voff[PP];
+  int p_piece[PP];
+#pragma unroll
+  for (int i = 0; i < WP; ++i) {
+    const int row = (wave + NW * i) * 8 + l3;
+    const int kw = (pslot ^ ((row >> 1) & 7)) * 8;
+    const int n = n0 + row;
+    w_voff[i] = (n < p.N) ? (unsigned)(((long long)n * p.ldw + kw) * 2) : OOB;
+  }
+#pragma unroll
+  for (int i = 0; i < PP; ++i) {
+    int idx = wave + NW * i;
+    while (idx >= C3_PIECES) idx -= NW;
+    p_piece[i] = idx;
+    const int prow = idx * 8 + l3;
+    const int yy = prow / C3_PW;
+    const int xx = prow - yy * C3_PW;
+    const int gy = y0 + yy - 1, gx = x0 + xx - 1;
+    const bool ok = (prow < C3_PROWS) && ((unsigned)gy < (unsigned)p.H) && ((unsigned)gx < (unsigned)p.W);
+    const int koff = (pslot ^ ((prow >> 1) & 7)) * 8;
+    p_voff[i] = ok ? (unsigned)(((((long long)b * p.H + gy) * p.W + gx) * p.C + koff) * 2) : OOB;
+  }
+  int a_prow[TM];
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm) {
+    const int ml = row0 + tm * 32 + l31;
+    a_prow[tm] = (ml >> 4) * C3_PW + (ml & 15);          // patch row of this lane's pixel at tap (0, 0)
+  }
+  auto issue_w = [&](int st, int c, int tap) {
+    const int soff = (tap * p.C + c * 64) * 2;
+    char* wbuf = wring + st * C3_W_BYTES;
+#pragma unroll
+    for (int i = 0; i < WP; ++i) buf_lds16(rsrc_w, wbuf + (wave + NW * i) * 1024, w_voff[i], soff);
+  };
+  auto issue_patch = [&](int c) {
+    char* pbuf = patches + (c & 1) * C3_PATCH_BYTES;
+#pragma unroll
+    for (int i = 0; i < PP; ++i) buf_lds16(rsrc_a, pbuf + p_piece[i] * 1024, p_voff[i], c * 128);
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  issue_patch(c0);
+  issue_w(0, c0, 0);
+  int st = 0;
+  for (int c = c0; c < c1; ++c) {
+    const bool nxt = (c + 1 < c1);
+    const char* pbuf = patches + (c & 1) * C3_PATCH_BYTES;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      // queue ahead of this wait (in order): tap 1: [W(c,1), patch(c+1)] -> leave the patch in flight; otherwise the
+      // weight tile of this tap is the youngest load
+      if (tap == 1 && nxt) wait_vm<PP>(); else wait_vm<0>();
+      raw_barrier();
+      if (tap < 8) issue_w(st ^ 1, c, tap + 1);
+      else if (nxt) issue_w(st ^ 1, c + 1, 0);
+      if (tap == 0 && nxt) issue_patch(c + 1);
+      const int dy = tap / 3, dx = tap - dy * 3;
+      const char* wbuf = wring + st * C3_W_BYTES;
+      bf16x8_t fx[4][TM], fw[4][TN];
+#pragma unroll
+      for (int t = 0; t < TM; ++t) {
+        const int prow = a_prow[t] + dy * C3_PW + dx;
+        const int arow = prow * ROW_BYTES, aswz = (prow >> 1) & 7;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) fx[ks][t] = lds_read_frag(pbuf + arow + (((ks * 2 + hi) ^ aswz) << 4));
+      }
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const int slot = ((ks * 2 + hi) ^ swz_w) << 4;
+#pragma unroll
+        for (int t = 0; t < TN; ++t) fw[ks][t] = lds_read_frag(wbuf + w_frag_row + t * 32 * ROW_BYTES + slot);
+      }
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+          for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = mfma32(fw[ks][tn], fx[ks][tm], acc[tm][tn]);
+      st ^= 1;
+    }
+  }
+  raw_barrier();
+
+  if (p.splitk > 1) {
+    f32x4* slab = reinterpret_cast<f32x4*>(p.slabs + (long long)unit * (BMPX * BN));
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          f32x4 v = {acc[tm][tn][q * 4 + 0], acc[tm][tn][q * 4 + 1], acc[tm][tn][q * 4 + 2], acc[tm][tn][q * 4 + 3]};
+          store16_sc1(slab + ((tm * TN + tn) * 4 + q) * 256 + tid, v);
+        }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int* const bcast = reinterpret_cast<int*>(smem);
+    if (tid == 0) {
+      const int t = __hip_atomic_fetch_add(p.counters + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int last = (t == p.splitk - 1) ? 1 : 0;
+      if (last) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        __hip_atomic_store(p.counters + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      *bcast = last;
+    }
+    __syncthreads();
+    const bool last = *bcast != 0;
+    __syncthreads();
+    if (!last) return;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    for (int s = 0; s < p.splitk; ++s) {
+      const f32x4* sl = reinterpret_cast<const f32x4*>(p.slabs + ((long long)tile * p.splitk + s) * (BMPX * BN));
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const f32x4 v = sl[((tm * TN + tn) * 4 + q) * 256 + tid];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[tm][tn][q * 4 + r] += v[r];
+          }
+    }
+  }
+
+  // ---- epilogue: fp32 rows through LDS (as lgemm_kernel), one pixel = one row ---------------------------------------
+  char* const wl = smem + wave * (64 * EROW);
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm) {
+    const int row = tm * 32 + l31;
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int chunk = (tn * 8 + q * 2 + hi) ^ (row & 7);
+        f32x4 v = {acc[tm][tn][q * 4 + 0], acc[tm][tn][q * 4 + 1], acc[tm][tn][q * 4 + 2], acc[tm][tn][q * 4 + 3]};
+        *reinterpret_cast<f32x4*>(wl + row * EROW + chunk * 16) = v;
+      }
+  }
+  const int rl = lane >> 3, c8 = lane & 7;
+  const int n = n0 + col0 + c8 * 8;
+  const bool col_ok = n < p.N;
+  f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = b0;
+  if (col_ok) {
+    if (p.bias) {
+      b0 = *reinterpret_cast<const f32x4*>(p.bias + n);
+      b1 = *reinterpret_cast<const f32x4*>(p.bias + n + 4);
+    }
+    if (p.rowvec) {                                      // one image per tile: the time-embedding row is a per-lane constant
+      const float* rvp = p.rowvec + (long long)b * p.ldrv + n;
+      const f32x4 r0 = *reinterpret_cast<const f32x4*>(rvp), r1 = *reinterpret_cast<const f32x4*>(rvp + 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b0[j] += r0[j], b1[j] += r1[j];
+    }
+  }
+  long long mrow[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int ml = row0 + i * 8 + rl;
+    mrow[i] = ((long long)b * p.H + (y0 + (ml >> 4))) * p.W + (x0 + (ml & 15));
+  }
+  u32x4 rv[8];
+  if (p.res) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      u32x4 z = {0u, 0u, 0u, 0u};
+      rv[i] = z;
+      if (col_ok) rv[i] = *reinterpret_cast<const u32x4*>(p.res + mrow[i] * p.ldr + n);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int row = i * 8 + rl;
+    const char* rp = wl + row * EROW;
+    const int sw = row & 7;
+    const f32x4 v0 = *reinterpret_cast<const f32x4*>(rp + (((2 * c8) ^ sw) << 4));
+    const f32x4 v1 = *reinterpret_cast<const f32x4*>(rp + (((2 * c8 + 1) ^ sw) << 4));
+    float o[8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      o[j] = v0[j] * p.alpha + b0[j];
+      o[4 + j] = v1[j] * p.alpha + b1[j];
+    }
+    if (p.res) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        o[2 * j] += bf16_lo(rv[i][j]);
+        o[2 * j + 1] += bf16_hi(rv[i][j]);
+      }
+    }
+    if (col_ok) {
+      u32x4 pk = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7])};
+      *reinterpret_cast<u32x4*>(p.out + mrow[i] * p.ldo + n) = pk;
     }
   }
 }

@@ -60,6 +60,12 @@ def prepare(engine, free_masters: bool = False, dedup_vae: bool = True) -> Dict[
                     report["packed_bytes"] += t.numel() * t.element_size()
         w, b = unet._emb_pack()
         report["packed_bytes"] += w.numel() * w.element_size() + b.numel() * b.element_size()
+        # ---- LayerNorm-folded layouts of the q|k|v and GEGLU projections (udt_ln_gemm_fwd)
+        from sgm.modules.attention import BasicTransformerBlock
+        if H.LN_GEMM and not H.FP8_LINEARS:
+            for m in unet.modules():
+                if isinstance(m, BasicTransformerBlock):
+                    report["packed_bytes"] += m.prepare_ln(freeze=free_masters)
         # ---- release the masters
         if free_masters:
             victims = []

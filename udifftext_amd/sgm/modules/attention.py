@@ -45,7 +45,14 @@ class GEGLU(H._Packed):
     def _pack_fp8(self):
         return packing.pack_geglu_fp8(self.proj.weight, self.proj.bias)
 
-    def forward(self, x):
+    def _pack_ln(self, gamma, beta):
+        return packing.pack_ln_linear(self.proj.weight, self.proj.bias, gamma, beta, geglu=True)
+
+    def forward(self, x, ln=None):
+        """ln: the LayerNorm in front of this projection, folded into the GEMM (x is then the RAW activation)"""
+        if ln is not None:
+            wf, c, s = self.packed_ln(ln)
+            return ops.ln_linear(x, wf, c, s, eps=ln.eps, flags=H.GEMM_GEGLU)
         if isinstance(x, ops.Fp8Act):
             wq, cs, b = self.packed_fp8()
             return ops.linear_fp8(x, wq, cs, b, flags=H.GEMM_GEGLU)
@@ -61,8 +68,8 @@ class FeedForward(nn.Module):
         inner = int(dim * mult)
         self.net = nn.Sequential(GEGLU(dim, inner), nn.Identity(), H.Linear(inner, dim_out or dim))
 
-    def forward(self, x, residual=None):
-        return self.net[2](self.net[0](x), residual=residual)
+    def forward(self, x, residual=None, ln=None):
+        return self.net[2](self.net[0](x, ln=ln), residual=residual)
 
 
 class CrossAttention(H._Packed):
@@ -169,7 +176,11 @@ class MemoryEfficientCrossAttention(H._Packed):
         return (packing.pack_linear_fp8(torch.cat([self.to_q.weight, self.to_k.weight], 0)),
                 packing.pack_linear_fp8(self.to_v.weight))
 
-    def forward(self, x, context=None, mask=None, residual=None):
+    def _pack_ln(self, gamma, beta):
+        return packing.pack_ln_linear(torch.cat([self.to_q.weight, self.to_k.weight, self.to_v.weight], 0), None, gamma, beta)
+
+    def forward(self, x, context=None, mask=None, residual=None, ln=None):
+        """ln: the LayerNorm in front of the q|k|v projection, folded into that GEMM (x is then the RAW activation)"""
         if context is not None or mask is not None:
             raise NotImplementedError("attn1 is pure self-attention on this path (reference attention.py:251-252)")
         inner = self.heads * self.dim_head
@@ -183,6 +194,9 @@ class MemoryEfficientCrossAttention(H._Packed):
             if fp8:
                 (wqkv, sqkv), _ = self.packed_fp8()
                 qkv = ops.linear_fp8(x, wqkv, sqkv).reshape(B, N, 3 * inner)
+            elif ln is not None:
+                wf, c, sv = self.packed_ln(ln)
+                qkv = ops.ln_linear(x2, wf, c, sv, eps=ln.eps).reshape(B, N, 3 * inner)
             else:
                 qkv = ops.linear(x2, self.packed()[0]).reshape(B, N, 3 * inner)
             o = ops.attention_rowv(qkv[..., :inner], qkv[..., inner:2 * inner], qkv[..., 2 * inner:], self.heads,
@@ -224,8 +238,9 @@ class BasicTransformerBlock(nn.Module):
         half of a CFG pair under force_uc_zero_embeddings) — their t_attn branch is x + to_out.bias, no GEMMs.
         t_fused: the block's folded context tables (ops.TattnTables for the samples of x) -> one fused launch."""
         fp8 = H.FP8_LINEARS
+        fold = H.LN_GEMM and not fp8 and QKV_ONE_GEMM          # LayerNorm inside the consuming GEMM (udt_ln_gemm_fwd)
         ln = (lambda norm, t: norm.forward_fp8(t.reshape(-1, t.shape[-1]))) if fp8 else (lambda norm, t: norm(t))
-        x = self.attn1(ln(self.norm1, x), residual=x)
+        x = self.attn1(x, residual=x, ln=self.norm1) if fold else self.attn1(ln(self.norm1, x), residual=x)
         if hasattr(self, "t_attn"):
             n0 = 0 if emit_map else min(int(zero_ctx_rows), x.shape[0])
             if t_fused is not None and not emit_map and n0 < x.shape[0] and self.fused_tattn_ok(x.shape[1]):
@@ -242,7 +257,19 @@ class BasicTransformerBlock(nn.Module):
                 x = self.t_attn(ln(self.t_norm, x), context=t_context, kv=t_kv, residual=x, emit_map=emit_map)
         B, N, C = x.shape
         x2 = x.reshape(B * N, C)
+        if fold:
+            return self.ff(x2, residual=x2, ln=self.norm3).reshape(B, N, C)
         return self.ff(ln(self.norm3, x2), residual=x2).reshape(B, N, C)
+
+    def prepare_ln(self, freeze: bool = False) -> int:
+        """build (and optionally freeze) the LayerNorm-folded layouts; returns their bytes"""
+        n = 0
+        for mod, norm in ((self.attn1, self.norm1), (self.ff.net[0], self.norm3)):
+            for t in mod.packed_ln(norm):
+                n += t.numel() * t.element_size()
+            if freeze:
+                mod._pkln_frozen = True
+        return n
 
 
 class SpatialTransformer(nn.Module):

@@ -40,6 +40,13 @@ FUSE_GN = os.environ.get("UDT_FUSE_GN", "0") != "0"
 # stream, attention, convolutions, norm statistics, softmax) is unchanged.
 FP8_LINEARS = os.environ.get("UDT_FP8", "0") != "0"
 
+# LayerNorm folded into the GEMM that consumes it (udt_ln_gemm_fwd, csrc/lean.h): `attn1(norm1(x))` and `ff(norm3(x))` of
+# every transformer block (reference attention.py:310-339) run as ONE launch on the raw residual stream — the normalised
+# activation never exists in memory.  UDT_LN_GEMM=0 restores layernorm kernel + GEMM (A/B measurements); the fp8 path
+# keeps its own LayerNorm -> e4m3 kernel.
+LN_GEMM = os.environ.get("UDT_LN_GEMM", "1") != "0" and os.environ.get("UDT_LEAN", "") != "0" \
+    and os.environ.get("UDT_GEMM_IMPL", "") != "4"
+
 
 def carry_stats(dst: torch.Tensor, src: torch.Tensor) -> torch.Tensor:
     """a reshape / view makes a new tensor object: hand the producer's column statistics over"""
@@ -94,6 +101,22 @@ class _Packed(nn.Module):
 
     def _pack_fp8(self):
         raise NotImplementedError(f"{type(self).__name__} has no fp8 layout")
+
+    def packed_ln(self, norm):
+        """the LayerNorm-folded layout (packing.pack_ln_linear) of these weights behind ``norm`` for udt_ln_gemm_fwd:
+        (gamma o W as bf16, c = W beta + bias, s = row sums of the folded weights); cached like ``packed()`` and frozen
+        with it by ``prepare(free_masters=True)``"""
+        if getattr(self, "_pkln_frozen", False):
+            return self._pkln
+        key = (self._key(), norm.weight.data_ptr(), norm.weight._version, norm.bias.data_ptr(), norm.bias._version)
+        if getattr(self, "_pkln_key", None) != key:
+            with torch.no_grad():
+                self._pkln = self._pack_ln(norm.weight, norm.bias)
+            self._pkln_key = key
+        return self._pkln
+
+    def _pack_ln(self, gamma, beta):
+        raise NotImplementedError(f"{type(self).__name__} has no LayerNorm-folded layout")
 
 
 class Linear(_Packed):
