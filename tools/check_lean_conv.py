@@ -23,24 +23,30 @@ def rel(a, b):
 
 
 bad = 0
-for B, H, W, C, N, res, rvec in [(2, 16, 16, 128, 128, True, True), (1, 8, 16, 64, 256, False, False), (3, 24, 32, 192, 128, True, False),
-                                 (8, 16, 16, 1280, 1280, True, True), (8, 32, 32, 640, 640, False, True), (2, 64, 64, 320, 640, True, False)]:
+for B, H, W, C, N, res, rvec, up in [(2, 16, 16, 128, 128, True, True, 0), (1, 8, 16, 64, 256, False, False, 0), (3, 24, 32, 192, 128, True, False, 0),
+                                     (8, 16, 16, 1280, 1280, True, True, 0), (8, 32, 32, 640, 640, False, True, 0), (2, 64, 64, 320, 640, True, False, 0),
+                                     (8, 8, 8, 1280, 1280, True, True, 0), (3, 24, 24, 128, 320, True, False, 0), (2, 64, 64, 320, 320, True, True, 0),
+                                     (2, 16, 16, 640, 640, False, False, 1), (1, 8, 8, 128, 136, True, False, 1), (8, 8, 8, 2560, 1280, False, True, 0)]:
     x = torch.randn((B, H, W, C), device=dev).bfloat16()
+    Ho, Wo = (2 * H, 2 * W) if up else (H, W)
     w4 = torch.randn((N, C, 3, 3), device=dev) / math.sqrt(C * 9)
     w = packing.pack_conv(w4)
     b = torch.randn((N,), device=dev)
-    r = torch.randn((B, H, W, N), device=dev).bfloat16() if res else None
+    r = torch.randn((B, Ho, Wo, N), device=dev).bfloat16() if res else None
     rv = torch.randn((B, N), device=dev) if rvec else None
-    y = F.conv2d(x.float().permute(0, 3, 1, 2), w4.bfloat16().float(), b, padding=1).permute(0, 2, 3, 1)
+    xin = x.float().permute(0, 3, 1, 2)
+    if up:
+        xin = F.interpolate(xin, scale_factor=2, mode="nearest")
+    y = F.conv2d(xin, w4.bfloat16().float(), b, padding=1).permute(0, 2, 3, 1)
     if rv is not None:
         y = y + rv[:, None, None, :]
     if r is not None:
         y = y + r.float()
-    line = f"B{B} {H}x{W} {C}->{N} res={int(res)} rv={int(rvec)}:"
+    line = f"B{B} {H}x{W} {C}->{N} res={int(res)} rv={int(rvec)} up={up}:"
     outs = {}
     for mode, sk in ((0, -1), (1, -1), (1, 2)):
         dbg("lean_conv", mode); dbg("lean_splitk", sk)
-        o = ops.conv2d(x, w, b, residual=r, rowvec=rv)
+        o = ops.conv2d(x, w, b, residual=r, rowvec=rv, upsample=bool(up))
         torch.cuda.synchronize()
         e = rel(o, y)
         ok = e < 6e-3 and math.isfinite(e)
@@ -72,25 +78,27 @@ def graph_time(fn_list, reps=5):
 
 
 print(f"{'conv (B HxW C->N)':28s}" + "".join(f"{h:>26s}" for h in ("conv3p indep", "lean indep", "conv3p chain", "lean chain")))
-for B, H, C, N in [(8, 32, 640, 640), (8, 32, 1280, 640), (8, 16, 1280, 1280), (8, 16, 2560, 1280), (8, 64, 320, 640), (4, 32, 640, 640),
-                   (4, 16, 1280, 1280), (1, 256, 256, 256), (1, 512, 128, 128)]:
+for B, H, C, N, up in [(8, 32, 640, 640, 0), (8, 32, 1280, 640, 0), (8, 16, 1280, 1280, 0), (8, 16, 2560, 1280, 0), (8, 64, 320, 640, 0),
+                       (8, 64, 320, 320, 0), (8, 64, 640, 320, 0), (8, 8, 1280, 1280, 0), (8, 8, 2560, 1280, 0), (8, 32, 640, 640, 1),
+                       (8, 16, 1280, 1280, 1), (4, 32, 640, 640, 0), (4, 16, 1280, 1280, 0), (1, 256, 256, 256, 0), (1, 512, 128, 128, 0)]:
+    Ho = 2 * H if up else H
     xs = [torch.randn((B, H, H, C), device=dev).bfloat16() for _ in range(4)]
     w = packing.pack_conv(torch.randn((N, C, 3, 3), device=dev) / math.sqrt(C * 9))
     b = torch.zeros((N,), device=dev)
-    outs = [torch.empty((B, H, H, N), dtype=torch.bfloat16, device=dev) for _ in range(4)]
-    fl = 2.0 * B * H * H * N * C * 9
-    row = f"{B:2d} {H:3d}x{H:<3d} {C:4d}->{N:4d}        "
+    outs = [torch.empty((B, Ho, Ho, N), dtype=torch.bfloat16, device=dev) for _ in range(4)]
+    fl = 2.0 * B * Ho * Ho * N * C * 9
+    row = f"{B:2d} {H:3d}x{H:<3d} {C:4d}->{N:4d} up={up}   "
     cols = []
     for regime in ("indep", "chain"):
         for mode in (0, 1):
             dbg("lean_conv", mode)
             if regime == "indep":
-                fns = [(lambda i=i: ops.conv2d(xs[i % 4], w, b, out=outs[i % 4])) for i in range(20)]
-            elif C == N:
+                fns = [(lambda i=i: ops.conv2d(xs[i % 4], w, b, out=outs[i % 4], upsample=bool(up))) for i in range(20)]
+            elif C == N and not up:
                 bufs = [xs[0], outs[0]]
                 fns = [(lambda i=i: ops.conv2d(bufs[i % 2], w, b, out=bufs[(i + 1) % 2])) for i in range(20)]
             else:       # C != N: alternate C->N with a same-size N->C convolution is not this shape; chain through the residual input
-                fns = [(lambda i=i: ops.conv2d(xs[0], w, b, residual=outs[i % 2], out=outs[(i + 1) % 2])) for i in range(20)]
+                fns = [(lambda i=i: ops.conv2d(xs[0], w, b, residual=outs[i % 2], out=outs[(i + 1) % 2], upsample=bool(up))) for i in range(20)]
             us = graph_time(fns)
             cols.append(f"{us:9.1f} us {fl / us / 1e6:6.0f} TF")
     print(row + "".join(f"{c:>26s}" for c in cols), flush=True)

@@ -785,7 +785,16 @@ int colstats_slots(const udt_gemm_desc* d) {
 // 2 = 8 waves / 256x128 / 3 stages (one per CU), 3 = 4 waves / 128x128 / 3 stages (one per CU) — every setting gives
 // the same results up to fp32 summation order (split-K); A/B measurements (tools/bench_gemm_shapes.py)
 std::atomic<int> g_lean{-1};
-std::atomic<int> g_lean_splitk{-1};   // -1 automatic, 1 = never split, n = force n slices where K allows
+std::atomic<int> g_lean_splitk{-2};   // -1 automatic, 1 = never split, n = force n slices where K allows (-2: read UDT_LEAN_SPLITK)
+int lean_splitk_knob() {
+  int v = g_lean_splitk.load(std::memory_order_relaxed);
+  if (v == -2) {
+    const char* e = getenv("UDT_LEAN_SPLITK");
+    v = e ? atoi(e) : -1;
+    g_lean_splitk.store(v, std::memory_order_relaxed);
+  }
+  return v;
+}
 std::atomic<int> g_lean_pf{1};        // look-ahead L2 touch of the two-stage configurations (lean.h PF)
 
 struct LeanPlan {
@@ -845,7 +854,7 @@ bool lean_plan(const udt_gemm_desc* d, LeanPlan& t) {
   // split K when the tiles alone leave most of the chip idle: slices of >= 4 K-tiles, ~1.5 units per workgroup slot
   const int slots = device_cus() * ((t.cfg == 1 || t.cfg == 5) ? 2 : 1);
   int sk = 1;
-  const int knob = g_lean_splitk.load(std::memory_order_relaxed);
+  const int knob = lean_splitk_knob();
   if (!ln && t.tiles <= 1023) {
     if (knob > 1) sk = knob;
     // measured (profiles/r03_gemm_shapes_lean_splitk.txt): a slice costs ~10 us of slab round trip + ticket, so K is cut
@@ -900,32 +909,37 @@ bool lean_conv_plan(const udt_gemm_desc* d, lg::C3Params& c) {
     g_lean_conv.store(on, std::memory_order_relaxed);
   }
   if (!on || gemm_impl() == 4 || lean_mode() == 0) return false;
-  if (d->flags != UDT_GEMM_CONV || d->ksize != 3 || d->stride != 1 || d->pad_t != 1 || d->pad_l != 1 || d->upsample) return false;
+  if (d->flags != UDT_GEMM_CONV || d->ksize != 3 || d->stride != 1 || d->pad_t != 1 || d->pad_l != 1) return false;
   if (d->C2 != 0 || d->in_scsh || d->colstats || d->colscale || d->batch > 1) return false;
-  if (d->N % 128 != 0 || d->C1 <= 0 || d->C1 % 64 != 0) return false;
-  if (d->Hout != d->Hin || d->Wout != d->Win || d->Win % lg::C3_TW != 0 || d->Hin % lg::C3_TH != 0) return false;
+  if (d->N < 128 || d->N % 8 != 0 || d->C1 <= 0 || d->C1 % 64 != 0) return false;
+  const bool ups = d->upsample != 0;
+  if (d->Hout != (d->Hin << (ups ? 1 : 0)) || d->Wout != (d->Win << (ups ? 1 : 0))) return false;
+  // pixel tile: 16 x 8 (two MFMA row tiles per wave), or 8 x 8 for the small maps (8 x 8, 24 x 24, ...)
+  if (d->Wout % 16 == 0 && d->Hout % 8 == 0) { c.geo = ups ? 2 : 0; c.tw = 16; c.th = 8; }
+  else if (!ups && d->Wout % 8 == 0 && d->Hout % 8 == 0) { c.geo = 1; c.tw = 8; c.th = 8; }
+  else return false;
   if (d->ldo % 8 != 0 || (d->residual && d->ldr % 8 != 0)) return false;
   const long long ldw = d->ldw > 0 ? d->ldw : d->K;
   if ((long long)d->M * d->C1 * 2 >= (1LL << 31) || (long long)d->N * ldw * 2 >= (1LL << 31)) return false;
   if ((reinterpret_cast<uintptr_t>(d->out) | reinterpret_cast<uintptr_t>(d->residual) | reinterpret_cast<uintptr_t>(d->bias) |
        reinterpret_cast<uintptr_t>(d->rowvec)) & 15) return false;
   if (d->rowvec && ((d->ld_rowvec > 0 ? d->ld_rowvec : d->N) % 4 != 0)) return false;
-  c.N = d->N; c.C = d->C1; c.H = d->Hin; c.W = d->Win; c.B = d->M / (d->Hin * d->Win);
+  c.N = d->N; c.C = d->C1; c.H = d->Hin; c.W = d->Win; c.B = d->M / (d->Hout * d->Wout);
   c.ldw = (int)ldw; c.ldo = d->ldo; c.ldr = d->ldr; c.ldrv = d->ld_rowvec > 0 ? d->ld_rowvec : d->N;
   c.alpha = d->alpha;
-  c.tiles_x = c.W / lg::C3_TW; c.tiles_y = c.H / lg::C3_TH;
+  c.tiles_x = d->Wout / c.tw; c.tiles_y = d->Hout / c.th;
   c.tiles_m = c.B * c.tiles_x * c.tiles_y;
-  c.tiles_n = d->N / 128;
+  c.tiles_n = (d->N + 127) / 128;
   c.tiles = c.tiles_m * c.tiles_n;
   c.chunks = c.C / 64;
   const int slots = 2 * device_cus();
   int sk = 1;
-  const int knob = g_lean_splitk.load(std::memory_order_relaxed);
+  const int knob = lean_splitk_knob();
   if (c.tiles <= 1023) {
     if (knob > 1) sk = knob;
     else if (knob < 0 && c.tiles * 2 <= slots && c.chunks >= 10) sk = slots / c.tiles;
     if (sk > c.chunks / 5) sk = c.chunks / 5;
-    while (sk > 1 && (long long)c.tiles * sk * 128 * 128 * 4 > (64LL << 20)) --sk;
+    while (sk > 1 && (long long)c.tiles * sk * c.tw * c.th * 128 * 4 > (64LL << 20)) --sk;
     if (sk < 1) sk = 1;
   }
   c.ch_per = (c.chunks + sk - 1) / sk;
@@ -933,17 +947,31 @@ bool lean_conv_plan(const udt_gemm_desc* d, lg::C3Params& c) {
   c.G = round_workgroups(c.tiles * c.splitk);
   // tile order: ~64 concurrently resident tiles per XCD; n_block weight tiles per patch (conv3p's rule)
   {
-    const double patch = (double)lg::C3_PROWS * c.C * 2.0, wtile = 9.0 * 128 * c.C * 2.0;
+    const double patch = (double)((ups ? c.tw / 2 : c.tw) + 2) * ((ups ? c.th / 2 : c.th) + 2) * c.C * 2.0, wtile = 9.0 * 128 * c.C * 2.0;
     int nb = g_n_block.load(std::memory_order_relaxed);
     if (nb <= 0) nb = (int)(std::sqrt(64.0 * patch / wtile) + 0.5);
     if (nb < 1) nb = 1;
     if (nb > c.tiles_n) nb = c.tiles_n;
     c.n_block = nb;
   }
-  c.a_bytes = (unsigned)((long long)d->M * d->C1 * 2);
+  c.a_bytes = (unsigned)((long long)c.B * d->Hin * d->Win * d->C1 * 2);
   c.w_bytes = (unsigned)((long long)d->N * ldw * 2);
   c.counters = nullptr; c.slabs = nullptr;
   return true;
+}
+
+size_t lean_conv_workspace(const lg::C3Params& c) {
+  return c.splitk > 1 ? G8_HEADER_BYTES + (size_t)c.tiles * c.splitk * c.tw * c.th * 128 * sizeof(float) : 0;
+}
+
+template <int TW, int TH, bool UPS>
+hipError_t launch_lconv3(const lg::C3Params& c3, hipStream_t s) {
+  static AttrOnce once;
+  constexpr int smem = lg::C3Geo<TW, TH, UPS>::SMEM;
+  hipError_t e = once.ensure(reinterpret_cast<const void*>(lg::lconv3_kernel<TW, TH, UPS>), smem);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL((lg::lconv3_kernel<TW, TH, UPS>), dim3(c3.G), dim3(256), smem, s, c3);
+  return hipGetLastError();
 }
 }  // namespace
 
@@ -1015,7 +1043,7 @@ extern "C" size_t udt_gemm_workspace_bytes(const udt_gemm_desc* d) {
     LeanPlan lt;
     if (lean_plan(d, lt)) return lean_workspace(lt);
     lg::C3Params c3;
-    if (lean_conv_plan(d, c3)) return c3.splitk > 1 ? G8_HEADER_BYTES + (size_t)c3.tiles * c3.splitk * 128 * 128 * sizeof(float) : 0;
+    if (lean_conv_plan(d, c3)) return lean_conv_workspace(c3);
   }
   {
     c3p::Geo ge;
@@ -1160,23 +1188,19 @@ extern "C" int udt_gemm(const udt_gemm_desc* d, void* workspace, size_t workspac
     if (lean_conv_plan(d, c3)) {
       c3.a = p.a; c3.w = p.w; c3.bias = p.bias; c3.res = p.res; c3.rowvec = p.rowvec; c3.out = reinterpret_cast<uint16_t*>(d->out);
       if (c3.splitk > 1) {
-        const size_t need = G8_HEADER_BYTES + (size_t)c3.tiles * c3.splitk * 128 * 128 * sizeof(float);
-        if (!workspace || workspace_bytes < need) return UDT_ERR_WORKSPACE;
+        if (!workspace || workspace_bytes < lean_conv_workspace(c3)) return UDT_ERR_WORKSPACE;
         c3.counters = reinterpret_cast<int*>(workspace);
         c3.slabs = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + G8_HEADER_BYTES);
       }
       UdtProfScope profc(cls, s);
       if (profc.rec) {
         char tag[96];
-        snprintf(tag, sizeof(tag), "lconv3 M=%d N=%d K=%d %dx%d units=%d splitk=%d nb=%d", d->M, d->N, d->K, d->Hin, d->Win,
-                 c3.tiles * c3.splitk, c3.splitk, c3.n_block);
+        snprintf(tag, sizeof(tag), "lconv3%s M=%d N=%d K=%d %dx%d tile=%dx%d units=%d splitk=%d nb=%d", d->upsample ? "+up" : "", d->M, d->N, d->K,
+                 d->Hin, d->Win, c3.tw, c3.th, c3.tiles * c3.splitk, c3.splitk, c3.n_block);
         udt_prof_tag(profc.rec, tag);
       }
-      static AttrOnce once3;
-      hipError_t ec = once3.ensure(reinterpret_cast<const void*>(lg::lconv3_kernel), lg::C3_SMEM);
-      if (ec != hipSuccess) return udt_set_hip_error(ec);
-      hipLaunchKernelGGL(lg::lconv3_kernel, dim3(c3.G), dim3(256), lg::C3_SMEM, s, c3);
-      ec = hipGetLastError();
+      const hipError_t ec = c3.geo == 2 ? launch_lconv3<16, 8, true>(c3, s) : c3.geo == 1 ? launch_lconv3<8, 8, false>(c3, s)
+                                                                                          : launch_lconv3<16, 8, false>(c3, s);
       if (ec != hipSuccess) return udt_set_hip_error(ec);
       return UDT_OK;
     }

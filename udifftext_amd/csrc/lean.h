@@ -25,8 +25,18 @@
 
 namespace lg {
 
-using g8::raw_barrier;
 using g8::wait_vm;
+// Workgroup barrier of the lean kernels.  hipcc sinks the MFMAs that consume a K-tile's LAST fragment reads below a bare
+// s_barrier (register-only instructions are not ordered by the memory clobber), so those ds_reads would still be in
+// flight when, right behind the barrier, another wave's LDS-DMA starts refilling the very stage they read — a rare,
+// timing-dependent corruption that showed up as run-to-run differences with two launch streams sharing the CUs.  Every
+// wave therefore drains its LDS reads (lgkmcnt only — never vmcnt: the prefetched K-tiles stay in flight) before it
+// arrives (cdna_hip_programming.md §5 "Pipelining across barriers").
+UDT_DEVINL void raw_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
 using g8::buf_lds16;
 using g8::OOB;
 
@@ -514,18 +524,38 @@ struct C3Params {
   int G;
   int* counters;
   float* slabs;
+  int geo, tw, th;         // host side: kernel instance (0: 16x8, 1: 8x8, 2: 16x8 upsampling) and its pixel tile
 };
 
-constexpr int C3_TW = 16, C3_TH = 8, C3_PW = C3_TW + 2, C3_PROWS = (C3_TH + 2) * C3_PW;       // 180 patch rows
-constexpr int C3_PIECES = (C3_PROWS + 7) / 8;                                                    // 23
-constexpr int C3_PATCH_BYTES = C3_PIECES * 1024;
-constexpr int C3_W_BYTES = 128 * ROW_BYTES;
-constexpr int C3_SMEM = 2 * C3_W_BYTES + 2 * C3_PATCH_BYTES;                                     // 79872
+// tile geometry: TW x TH output pixels (128 = 16 x 8: two 32-pixel MFMA tiles per wave; 64 = 8 x 8 for the 8 x 8 maps: one),
+// UPS: nearest x2 upsampling folded in (reference Upsample.forward, openaimodel.py:99-101 / model.py:64-68): the tile lives
+// in the UPSAMPLED map, the staged patch is the low-resolution region under it with its halo, and tap (dy, dx) of output
+// pixel (py, px) reads patch row ((py + dy - 1) >> 1) + 1, column ((px + dx - 1) >> 1) + 1; p.H / p.W are the INPUT size
+template <int TW, int TH, bool UPS>
+struct C3Geo {
+  static constexpr int PX = TW * TH;
+  static constexpr int TM = PX / 64;                       // 32-pixel MFMA tiles per wave (wave grid 2 x 2)
+  static constexpr int PW = (UPS ? TW / 2 : TW) + 2, PH = (UPS ? TH / 2 : TH) + 2;
+  static constexpr int PROWS = PW * PH;
+  static constexpr int PIECES = (PROWS + 7) / 8;
+  static constexpr int PATCH_BYTES = PIECES * 1024;
+  static constexpr int W_BYTES = 128 * ROW_BYTES;
+  static constexpr int RING = 2 * W_BYTES + 2 * PATCH_BYTES;
+  static constexpr int STAGING = 4 * TM * 32 * 256;        // fp32 rows of the epilogue
+  static constexpr int SMEM = RING > STAGING ? RING : STAGING;
+  static_assert(PX == 128 || PX == 64, "128 or 64 output pixels per workgroup");
+  static_assert(SMEM <= 80 * 1024, "two workgroups per CU");
+};
 
+template <int TW, int TH, bool UPS>
 __global__ void __launch_bounds__(256, 2) lconv3_kernel(const C3Params p) {
-  constexpr int NW = 4, TM = 2, TN = 2, BN = 128, BMPX = 128;
+  using Geo = C3Geo<TW, TH, UPS>;
+  constexpr int NW = 4, TM = Geo::TM, TN = 2, BN = 128, BMPX = Geo::PX;
+  constexpr int C3_PW = Geo::PW, C3_PROWS = Geo::PROWS, C3_PIECES = Geo::PIECES, C3_PATCH_BYTES = Geo::PATCH_BYTES;
+  constexpr int C3_W_BYTES = Geo::W_BYTES, C3_TW = TW, C3_TH = TH;
+  constexpr int WROWS = TM * 32;                         // pixels per wave
   constexpr int WP = 4;                                  // weight pieces per wave and tap (16 / 4)
-  constexpr int PP = (C3_PIECES + NW - 1) / NW;          // patch pieces per wave and chunk (6, padded with duplicates)
+  constexpr int PP = (C3_PIECES + NW - 1) / NW;          // patch pieces per wave and chunk (padded with duplicates)
   constexpr int EROW = 64 * 4;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const wring = smem;
@@ -539,7 +569,7 @@ __global__ void __launch_bounds__(256, 2) lconv3_kernel(const C3Params p) {
   const int l3 = lane >> 3;
   const int pslot = lane & 7;
   const int wm = wave >> 1, wn = wave & 1;
-  const int row0 = wm * 64, col0 = wn * 64;
+  const int row0 = wm * WROWS, col0 = wn * 64;
   const int swz_w = (l31 >> 1) & 7;
   const int w_frag_row = (col0 + l31) * ROW_BYTES;
 
@@ -585,7 +615,7 @@ __global__ void __launch_bounds__(256, 2) lconv3_kernel(const C3Params p) {
     const int prow = idx * 8 + l3;
     const int yy = prow / C3_PW;
     const int xx = prow - yy * C3_PW;
-    const int gy = y0 + yy - 1, gx = x0 + xx - 1;
+    const int gy = (UPS ? (y0 >> 1) : y0) + yy - 1, gx = (UPS ? (x0 >> 1) : x0) + xx - 1;
     const bool ok = (prow < C3_PROWS) && ((unsigned)gy < (unsigned)p.H) && ((unsigned)gx < (unsigned)p.W);
     const int koff = (pslot ^ ((prow >> 1) & 7)) * 8;
     p_voff[i] = ok ? (unsigned)(((((long long)b * p.H + gy) * p.W + gx) * p.C + koff) * 2) : OOB;
@@ -594,7 +624,8 @@ __global__ void __launch_bounds__(256, 2) lconv3_kernel(const C3Params p) {
 #pragma unroll
   for (int tm = 0; tm < TM; ++tm) {
     const int ml = row0 + tm * 32 + l31;
-    a_prow[tm] = (ml >> 4) * C3_PW + (ml & 15);          // patch row of this lane's pixel at tap (0, 0)
+    const int py = ml / TW, px = ml - py * TW;
+    a_prow[tm] = UPS ? (py | (px << 16)) : (py * C3_PW + px);      // patch row of this lane's pixel at tap (0, 0)
   }
   auto issue_w = [&](int st, int c, int tap) {
     const int soff = (tap * p.C + c * 64) * 2;
@@ -636,7 +667,13 @@ __global__ void __launch_bounds__(256, 2) lconv3_kernel(const C3Params p) {
       bf16x8_t fx[4][TM], fw[4][TN];
 #pragma unroll
       for (int t = 0; t < TM; ++t) {
-        const int prow = a_prow[t] + dy * C3_PW + dx;
+        int prow;
+        if constexpr (UPS) {
+          const int py = a_prow[t] & 0xffff, px = a_prow[t] >> 16;
+          prow = (((py + dy - 1) >> 1) + 1) * C3_PW + (((px + dx - 1) >> 1) + 1);
+        } else {
+          prow = a_prow[t] + dy * C3_PW + dx;
+        }
         const int arow = prow * ROW_BYTES, aswz = (prow >> 1) & 7;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) fx[ks][t] = lds_read_frag(pbuf + arow + (((ks * 2 + hi) ^ aswz) << 4));
@@ -707,7 +744,7 @@ __global__ void __launch_bounds__(256, 2) lconv3_kernel(const C3Params p) {
   }
 
   // ---- epilogue: fp32 rows through LDS (as lgemm_kernel), one pixel = one row ---------------------------------------
-  char* const wl = smem + wave * (64 * EROW);
+  char* const wl = smem + wave * (WROWS * EROW);
 #pragma unroll
   for (int tm = 0; tm < TM; ++tm) {
     const int row = tm * 32 + l31;
@@ -736,23 +773,26 @@ __global__ void __launch_bounds__(256, 2) lconv3_kernel(const C3Params p) {
       for (int j = 0; j < 4; ++j) b0[j] += r0[j], b1[j] += r1[j];
     }
   }
-  long long mrow[8];
+  constexpr int NIT = TM * 4;                            // 8 pixel rows per instruction
+  const int Ho = UPS ? 2 * p.H : p.H, Wo = UPS ? 2 * p.W : p.W;
+  long long mrow[NIT];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
+  for (int i = 0; i < NIT; ++i) {
     const int ml = row0 + i * 8 + rl;
-    mrow[i] = ((long long)b * p.H + (y0 + (ml >> 4))) * p.W + (x0 + (ml & 15));
+    const int py = ml / TW, px = ml - py * TW;
+    mrow[i] = ((long long)b * Ho + (y0 + py)) * Wo + (x0 + px);
   }
-  u32x4 rv[8];
+  u32x4 rv[NIT];
   if (p.res) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < NIT; ++i) {
       u32x4 z = {0u, 0u, 0u, 0u};
       rv[i] = z;
       if (col_ok) rv[i] = *reinterpret_cast<const u32x4*>(p.res + mrow[i] * p.ldr + n);
     }
   }
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
+  for (int i = 0; i < NIT; ++i) {
     const int row = i * 8 + rl;
     const char* rp = wl + row * EROW;
     const int sw = row & 7;
