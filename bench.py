@@ -69,6 +69,12 @@ def parse():
                     "(same-box on MI355X: 1 -> 5.7, 2 -> 7.13, 3 -> 7.67, 4 -> 6.0 images/s)")
     ap.add_argument("--fp8", action="store_true", help="BASELINE config #5 arithmetic: the transformer blocks' LayerNorm-fed "
                     "linears on the fp8 (e4m3) MFMA path")
+    ap.add_argument("--noise-iters", type=int, default=10, help="noise search iterations of the reference-default measurement "
+                    "(configs/test.yaml:14 noise_iters: 10, batch_size 1): reported as images_per_s_reference_default")
+    ap.add_argument("--no-reference-default", action="store_true", help="skip the reference-default (B = 1, noise search) pass")
+    ap.add_argument("--master-port", type=int, default=0, help="rendezvous port when bench.py launches its own ranks")
+    ap.add_argument("--stub", action="store_true", help="host-logic self-test on the CPU (gloo, a stub engine): rank spawning, "
+                    "image sharding, the single all-gather per global batch and the JSON line; the numbers mean nothing")
     ap.add_argument("--fuse", type=int, default=1, help="batches concatenated into one UNet call (1 = the on-config "
                     "batch per call; > 1 or 0 = throughput mode, never the headline value)")
     return ap.parse_args()
@@ -121,13 +127,105 @@ def cpu_baseline(model, size: int, chars: int, sampler_steps: int) -> dict:
                       "calls per image"}
 
 
+def self_launch(args) -> int:
+    """spawn --gpus ranks of this script with torch.distributed.run's environment contract (RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_ADDR / MASTER_PORT); stdout of rank 0 (the ONE JSON line) is passed through"""
+    import socket
+    import subprocess
+    port = args.master_port
+    if port <= 0:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    for pr in procs:
+        rc = pr.wait() or rc
+    return rc
+
+
+def stub_main(args, world: int, rank: int) -> None:
+    """--stub: the multi-rank plumbing of this script with a stub engine on the CPU (tests/test_bench_cpu.py)"""
+    import torch.distributed as dist
+    from udifftext_amd import config as C, parallel, rng
+
+    class Cond:
+        def get_unconditional_conditioning(self, batch, batch_uc=None, force_uc_zero_embeddings=None):
+            B = batch["image"].shape[0]
+            f = batch["image"].mean(dim=(1, 2, 3)).reshape(B, 1, 1, 1)
+            return {"concat": rng.randn((B, 4, 2, 2)) + f}, {"concat": rng.randn((B, 4, 2, 2)) + f}
+
+    class Model:
+        conditioner = Cond()
+
+        def decode_first_stage(self, z):
+            return z[:, :3].repeat_interleave(2, -1).repeat_interleave(2, -2) * 0.1
+
+    class Sampler:
+        def get_init_noise(self, cfgs, model, cond, batch, uc=None):
+            return rng.randn((cfgs.batch_size, 4, 2, 2))
+
+        def sample_in_flight(self, model, xs, conds, ucs, init_step=0, deferred_checks=None, streams=None):
+            return [x + 0.5 * c["concat"] - 0.25 * u["concat"] for x, c, u in zip(xs, conds, ucs)]
+
+    on = world > 1
+    if on:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    G = args.global_batch if args.global_batch > 0 else args.batch * world
+    cfgs = C.default_runtime_config(steps=2, batch_size=args.batch, noise_iters=0)
+
+    def gb(i):
+        g = torch.Generator().manual_seed(1000 + i)
+        return {"image": torch.rand((G, 3, 8, 8), generator=g), "label": [f"i{k}" for k in range(G)], "txt": [""] * G,
+                "name": [str(k) for k in range(G)], "target_size_as_tuple": torch.tensor([[4, 4]] * G)}
+
+    batches = [gb(i) for i in range(args.warmup + args.steps)]
+    seeds = [77 + i for i in range(len(batches))]
+    run = lambda b, sd: parallel.predict_sharded(cfgs, Model(), Sampler(), b, sd, dist=dist if on else None, micro_batch=args.batch,
+                                                 in_flight=args.in_flight, fuse=1, device=torch.device("cpu"))
+    if args.warmup:
+        run(batches[:args.warmup], seeds[:args.warmup])
+    if on:
+        dist.barrier()
+    t0 = time.perf_counter()
+    frames = run(batches[args.warmup:], seeds[args.warmup:])[-1]
+    if on:
+        dist.barrier()
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    if on:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    assert frames.shape[0] == G
+    if rank == 0:
+        print(json.dumps({"metric": "stub (host logic only)", "value": args.steps * G / float(t.item()), "unit": "images/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": float(t.item()) / args.steps * 1e3,
+                          "higher_is_better": True, "scaling": "weak" if args.global_batch <= 0 else "strong", "vs_baseline": None,
+                          "data": "stub", "dtype": "f32", "config": {"workload": "stub engine on the CPU", "global_batch": G}}), flush=True)
+    if on:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # not under torchrun: launch the N ranks ourselves (one process per GPU, RCCL rendezvous on 127.0.0.1) and relay
+        # rank 0's JSON line — `python bench.py --gpus 8` and `python -m torch.distributed.run ... bench.py --gpus 8` are
+        # the same measurement
+        raise SystemExit(self_launch(args))
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus} (WORLD_SIZE={world})")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus}")
+    if args.stub:
+        return stub_main(args, world, rank)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -277,6 +375,30 @@ def main():
         torch.cuda.synchronize()
         unet_ms = e0.elapsed_time(e1) / n_meas
 
+    # ---- the reference's DEFAULT workload (configs/test.yaml:14,22: batch_size 1, noise_iters 10 -> 2 x 10 + 50 = 70 UNet
+    # calls per image on one CFG pair): one image at a time through pipeline.predict, noise search included
+    ref_default = None
+    if rank == 0 and not args.no_reference_default and args.noise_iters > 0:
+        cfg_r = C.default_runtime_config(steps=args.sampler_steps, batch_size=1, noise_iters=args.noise_iters, gpu=local_rank)
+        one = [parallel.slice_batch(batches[i % len(batches)], i % max(G, 1), i % max(G, 1) + 1) for i in range(5)]
+        with contextlib.redirect_stdout(sys.stderr):                       # get_init_noise prints the scores like the reference
+            for b in one[:2]:
+                pipeline.predict(cfg_r, model, sampler, dict(b), dev)      # warm: captures the B = 1 graphs
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for b in one[2:]:
+                pipeline.predict(cfg_r, model, sampler, dict(b), dev)
+            torch.cuda.synchronize()
+            dt_ref = (time.perf_counter() - t1) / len(one[2:])
+        unet_g, enc_g, dec_g = WORK.get(args.size, WORK[512])
+        calls = args.sampler_steps + 2 * args.noise_iters
+        fpi_ref = (calls * unet_g + enc_g + dec_g + 7.2) * 1e9
+        ref_default = {"images_per_s": 1.0 / dt_ref, "s_per_image": dt_ref, "unet_calls_per_image": calls,
+                       "tflop_per_image": fpi_ref / 1e12, "frac_of_peak": fpi_ref / dt_ref / PEAK_BF16,
+                       "workload": f"{args.size}x{args.size}, batch_size 1, noise_iters {args.noise_iters} (2 Euler steps + local "
+                                   f"attention loss per candidate), {args.sampler_steps} steps, one image at a time "
+                                   "(reference configs/test.yaml defaults)"}
+
     if rank == 0:
         images = args.steps * G
         value = images / elapsed
@@ -293,8 +415,8 @@ def main():
                     "share_of_mfma_class_time": ms / max(conv_ms + gemm_ms + attn_ms, 1e-9)}
 
         import sgm.modules.hipnn as Hn
-        conv = cls("3x3 convolution: c3p::conv3p_kernel (LDS-staged patches" + (", GroupNorm+SiLU applied on the staged patch"
-                   if Hn.FUSE_GN else "") + ") + g8::gemm8_kernel<CONV> (stride-2 / upsampling gathers), UNet + VAE",
+        conv = cls("3x3 convolution: lg::lconv3_kernel (lean co-resident, LDS-staged patches) / c3p::conv3p_kernel (" + ("GroupNorm+SiLU "
+                   "on the staged patch" if Hn.FUSE_GN else "remaining geometries") + ") + g8::gemm8_kernel<CONV> (stride-2 gathers), UNet + VAE",
                    conv_flops, conv_bytes, conv_ms, conv_launches)
         conv.update({"traffic": traffic, "traffic_source": traffic_file,
                      "traffic_hbm_gbps": (traffic / (conv["avg_launch_us"] * 1e-6) / 1e9) if traffic else None,
@@ -323,6 +445,10 @@ def main():
                            "(q|k, v, t_attn.to_q, GEGLU: 60 % of the linear FLOPs); bf16 MFMA everywhere else; fp32 accumulation, "
                            "statistics, softmax and sampler state") if args.fp8 else
                           "bf16 storage + MFMA, fp32 accumulation / statistics / softmax / sampler state",
+            "value_one_batch": (value if (args.in_flight == 1 and args.fuse == 1) else other_modes.get("one_batch_at_a_time")),
+            "value_one_batch_note": "the same K steps with ONE batch of --batch images on the GPU at a time (no batches in "
+                                    "flight): the number that does not depend on how launch streams share the chip",
+            "images_per_s_reference_default": ref_default,
             "images_per_s_by_launch_mode": dict(other_modes, **{"value": value}),
             "unet_ms_per_sampler_step": unet_ms,
             "unet_ms_note": f"one batch of {args.batch} alone on the whole GPU (latency of one UNet call on its CFG pair + "
@@ -339,7 +465,8 @@ def main():
                        "in_flight": args.in_flight, "batches_per_unet_call": max(args.fuse, 1) if args.fuse else "auto"},
             "roofline": conv,
             "roofline_classes": {
-                "gemm": cls("linears + 1x1 convolutions: g8::gemm8_kernel (plain / GEGLU / transposed epilogues)", gemm_flops,
+                "gemm": cls("linears + 1x1 convolutions: lg::lgemm_kernel (lean co-resident family; plain / GEGLU / LayerNorm-folded) "
+                            "+ g8::gemm8_kernel (two-source 1x1, transposed, fp32 outputs)", gemm_flops,
                             gemm_bytes, gemm_ms, gemm_launches),
                 "attention": cls("flash self-attention: attn_d64_kernel", attn_flops, attn_bytes, attn_ms, attn_launches)},
         }

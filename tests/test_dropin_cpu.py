@@ -213,3 +213,33 @@ def test_reference_util_and_predict_run_against_the_new_sgm():
     finally:
         sys.path.remove(REF)
         _restore(saved)
+
+
+def test_sd2_inpainting_key_map():
+    """the LDM-named SD-2 inpainting checkpoint the reference's training starts from (configs/train.yaml:5): UNet keys load
+    straight except attn2 / norm2, the autoencoder also fills the LatentEncoder's twin, CLIP / EMA / schedule entries drop"""
+    from udifftext_amd import ckpt
+    ref = json.load(open(os.path.join(GOLD, "state_dict_keys.json")))
+    engine_keys = list(ref.keys())
+    unet = [k for k in engine_keys if k.startswith("model.diffusion_model.")]
+    vae = [k for k in engine_keys if k.startswith("first_stage_model.")]
+    sd = {}
+    for k in unet:                                         # an SD-2 file has attn2 / norm2 where UDiffText has t_attn / t_norm
+        k2 = k.replace(".t_attn.", ".attn2.").replace(".t_norm.", ".norm2.")
+        sd[k2] = torch.zeros(1)
+    for k in vae:
+        sd[k] = torch.ones(1)
+    sd.update({"cond_stage_model.model.ln_final.weight": torch.zeros(1), "model_ema.decay": torch.zeros(1), "betas": torch.zeros(1),
+               "alphas_cumprod": torch.zeros(1), "sqrt_recip_alphas_cumprod": torch.zeros(1)})
+    mapped, rep = ckpt.map_sd2_inpainting(sd, engine_keys)
+    n_t = sum(1 for k in unet if ".t_attn." in k or ".t_norm." in k)
+    assert n_t > 0 and len(rep["dropped_text_cross_attention"]) == n_t
+    assert len(rep["loaded"]) == len(unet) - n_t + len(vae)
+    assert len(rep["duplicated_to_latent_encoder"]) == len(vae)
+    assert all(k in mapped for k in engine_keys if k.startswith("conditioner.embedders.2.model."))
+    assert set(rep["dropped_other"]) == {"cond_stage_model.model.ln_final.weight", "model_ema.decay", "betas", "alphas_cumprod",
+                                         "sqrt_recip_alphas_cumprod"}
+    missing = set(rep["missing"])
+    assert all((".t_attn." in k or ".t_norm." in k) for k in missing if k.startswith("model.diffusion_model."))
+    assert any(k.startswith("conditioner.embedders.0.") for k in missing)      # the LabelEncoder has its own checkpoint
+    assert set(mapped) <= set(engine_keys)

@@ -529,3 +529,126 @@ def test_predict_many_matches_predict(engine, cuda):
         assert s_got.shape == s_ref.shape and z_got.shape == z_ref.shape
         _check(f"predict_many latent of batch {i} vs predict", z_got.cpu(), z_ref.cpu(), 3e-2)
         _check(f"predict_many image of batch {i} vs predict", s_got.cpu(), s_ref.cpu(), 3e-2)
+
+
+def test_unet_call_fp8_linears_at_benchmarked_shape_vs_oracle(engine, cuda):
+    """config #5's arithmetic at the BENCHMARKED shape: 64x64 latents, 8 samples per UNet call (batch 4 with CFG) — the fp8
+    (e4m3) linears against the fp32 CPU oracle on 2 + 2 of the samples.  Stated tolerance as for the 32x32 golden: rel_rms
+    <= 8e-2 against the reference arithmetic and against the bf16 path."""
+    import sgm.modules.hipnn as H
+    from oracle import nets, spec
+    from udifftext_amd import synth
+    torch.manual_seed(31)
+    B = 4
+    le = engine.conditioner.embedders[0]
+    ctx = le(synth.synthetic_batch(B, 512, 512, 9, seed=6)["label"])
+    tctx = torch.cat([torch.zeros_like(ctx), ctx])
+    x = torch.randn((2 * B, 9, 64, 64), device=cuda)
+    ts = torch.full((2 * B,), 441, device=cuda)
+    unet = engine.model.diffusion_model
+    ref_bf16 = unet(x, timesteps=ts, t_context=tctx)
+    prev = H.FP8_LINEARS
+    H.FP8_LINEARS = True
+    try:
+        eps = unet(x, timesteps=ts, t_context=tctx)
+    finally:
+        H.FP8_LINEARS = prev
+    pick = [0, 3, 4, 7]
+    sd = {k: v.detach().float().cpu() for k, v in engine.state_dict().items() if k.startswith("model.")}
+    with torch.no_grad():
+        ref = nets.unet_forward(sd, x[pick].cpu(), ts[pick].cpu(), tctx[pick].float().cpu(), spec.EngineConfig().unet)
+    _check("UNet eps with fp8 linears at 64x64 latents, 8 samples vs oracle", eps[pick].cpu(), ref, 8e-2)
+    _check("UNet eps with fp8 linears at 64x64 latents vs the bf16 path", eps.cpu(), ref_bf16.cpu(), 8e-2)
+
+
+def test_noise_search_at_benchmarked_latent_size_vs_oracle(engine, cuda):
+    """the reference-default noise search (configs/test.yaml:14) at 64x64 latents with 4 candidates: every candidate's
+    local attention loss against the fp32 CPU oracle's (2 Euler steps + get_min_local_loss per candidate), the same
+    candidate wins, and the draws come from the CPU generator in the reference's order"""
+    from oracle import sampling as osamp, spec
+    from udifftext_amd import config as C, pipeline, synth
+    batch = synth.synthetic_batch(1, 512, 512, 9, seed=21)
+    torch.manual_seed(1234)
+    batch, buc = pipeline.prepare_batch(batch, cuda)
+    c, uc = engine.conditioner.get_unconditional_conditioning(batch, batch_uc=buc, force_uc_zero_embeddings=["label"])
+    sampler = pipeline.init_sampling(50, 5.0, cuda)
+    cfgs = C.default_runtime_config(steps=50, batch_size=1, noise_iters=4)
+    import io, contextlib
+    torch.manual_seed(2024)
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        x0 = sampler.get_init_noise(cfgs, engine, cond=c, batch=batch, uc=uc)
+    line = [l for l in buf.getvalue().splitlines() if l.startswith("Init local loss")][0]
+    best, worst = float(line.split("Best")[1].split("Worst")[0]), float(line.split("Worst")[1])
+    # oracle: the same conditioning tensors (so only the search is under test), the same CPU draws
+    sd = {k: v.detach().float().cpu() for k, v in engine.state_dict().items()}
+    cpu = lambda d: {k: (v.float().cpu() if isinstance(v, torch.Tensor) else v) for k, v in d.items()}
+    torch.manual_seed(2024)
+    with torch.no_grad():
+        want, scores = osamp.get_init_noise(sd, spec.EngineConfig(), (1, 4, 64, 64), cpu(c), cpu(uc), cpu(batch), 4, 5.0)
+    assert len(scores) == 4
+    np.testing.assert_array_equal(x0.cpu().numpy(), want.numpy())                         # same winner, bit-exact draw
+    _check("noise search: best local loss vs oracle", torch.tensor([best]), torch.tensor([min(scores)]), 3e-2)
+    _check("noise search: worst local loss vs oracle", torch.tensor([worst]), torch.tensor([max(scores)]), 3e-2)
+
+
+def test_predict_many_in_flight_with_noise_search(engine, cuda):
+    """three batches in flight WITH the noise search (noise_iters > 0: the init-noise stepper of every lane plans its
+    stream-K launches for the lane's share of the CUs — ADVICE round 2): same frames as predict() one batch at a time"""
+    from udifftext_amd import config as C, pipeline, synth
+    cfgs = C.default_runtime_config(steps=3, batch_size=1, noise_iters=2)
+    batches = [synth.synthetic_batch(1, 256, 256, 4, seed=40 + i) for i in range(3)]
+    sampler = pipeline.init_sampling(3, 5.0, cuda)
+    import io, contextlib
+    with contextlib.redirect_stdout(io.StringIO()):
+        torch.manual_seed(5)
+        seq = [pipeline.predict(cfgs, engine, sampler, {k: (v.clone() if isinstance(v, torch.Tensor) else list(v)) for k, v in b.items()}, cuda)
+               for b in batches]
+        torch.manual_seed(5)
+        many = pipeline.predict_many(cfgs, engine, sampler, batches, cuda, in_flight=3, fuse=1)
+    for i, ((s1, z1), (s2, z2)) in enumerate(zip(seq, many)):
+        _check(f"in flight + noise search, batch {i}: latent vs one at a time", z2.cpu(), z1.cpu(), 2e-2)
+        assert torch.isfinite(s2).all()
+
+
+def test_checkpoint_load_prepare_free_masters_matches_goldens(engine, cond256, eg, cuda, tmp_path):
+    """SURVEY §8f-3 on the GPU: write the engine's 1330 keys as .safetensors, build a FRESH engine, init_from_ckpt,
+    prepare(free_masters=True, dedup_vae=True) — packed layouts only, fp32 masters released — and re-run the reference
+    golden checks (VAE G5, UNet call G7, 10-step trajectory G9)"""
+    from safetensors.torch import save_file
+    from udifftext_amd import config as C, ops, pipeline
+    path = os.path.join(str(tmp_path), "engine.safetensors")
+    save_file({k: v.detach().cpu().contiguous() for k, v in engine.state_dict().items()}, path)
+    from sgm.util import instantiate_from_config, skip_param_init
+    with skip_param_init():                                 # uninitialised parameters: everything must come from the file
+        fresh = instantiate_from_config(C.default_model_config().model)
+    fresh.to(cuda).eval()
+    fresh.freeze()
+    missing, unexpected = fresh.init_from_ckpt(path)
+    assert not missing and not unexpected
+    rep = fresh.prepare(free_masters=True, dedup_vae=True)
+    assert rep["vae_deduplicated"] == 1 and rep["freed_bytes"] > 4e9
+    assert fresh.model.diffusion_model.input_blocks[1][0].in_layers[2].weight.numel() == 0          # masters are gone
+    g = torch.Generator().manual_seed(5)
+    img = torch.rand((1, 3, 64, 64), generator=g) * 2 - 1
+    mom = fresh.first_stage_model.encode_moments(img.to(cuda))
+    _check("ckpt -> prepare(free_masters): VAE moments vs reference", ops.nhwc_to_nchw(mom, 8).cpu(), eg["g5_moments"], 2e-2, 8e-2)
+    batch, _, _ = cond256
+    torch.manual_seed(1234)
+    b2, buc = pipeline.prepare_batch({k: (v.clone() if isinstance(v, torch.Tensor) else list(v)) for k, v in batch.items()}, cuda)
+    c, uc = fresh.conditioner.get_unconditional_conditioning(b2, batch_uc=buc, force_uc_zero_embeddings=["label"])
+    _check("ckpt -> prepare(free_masters): conditioner c.concat vs reference", c["concat"].cpu(), eg["g6_c_concat"], 2e-2, 8e-2)
+    x7 = torch.from_numpy(eg["g7_x"]).to(cuda)
+    ucc, cc = torch.from_numpy(eg["g6_uc_concat"]).to(cuda), torch.from_numpy(eg["g6_c_concat"]).to(cuda)
+    tctx = torch.cat([torch.zeros((1, 12, 2048), device=cuda), fresh.conditioner.embedders[0](batch["label"])])
+    xin = torch.cat([torch.cat([x7, x7]), torch.cat([ucc, cc])], dim=1)
+    eps = fresh.model.diffusion_model(xin, timesteps=torch.tensor([999, 999], device=cuda), t_context=tctx)
+    _check("ckpt -> prepare(free_masters): UNet eps vs reference", eps.cpu(), eg["g7_eps"], 2e-2, 8e-2)
+    sampler = pipeline.init_sampling(10, 5.0, cuda)
+    cfgs = C.default_runtime_config(steps=10, batch_size=1, noise_iters=0)
+    torch.manual_seed(99)
+    x0 = sampler.get_init_noise(cfgs, fresh, cond=c, batch=b2, uc=uc)
+    z = sampler(fresh, x0.clone(), cond=c, batch=b2, uc=uc)
+    _check("ckpt -> prepare(free_masters): 10-step latent vs reference", z.cpu(), eg["g9_latent"], 6e-2)
+    del fresh
+    torch.cuda.empty_cache()

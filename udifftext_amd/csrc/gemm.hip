@@ -795,13 +795,10 @@ int lean_splitk_knob() {
   }
   return v;
 }
-std::atomic<int> g_lean_pf{1};        // look-ahead L2 touch of the two-stage configurations (lean.h PF)
-
 struct LeanPlan {
   int cfg;                 // 1, 2, 3 as above; 5 = 4 waves / 128x160 / 2 stages (N = 320, 960)
   int bm, bn, nw, smem;
   int tiles_m, tiles_n, tiles, nkt, splitk, kt_per, G, n_block;
-  bool pf;
 };
 
 int lean_mode() {
@@ -840,8 +837,6 @@ bool lean_plan(const udt_gemm_desc* d, LeanPlan& t) {
     case 5: t.nw = 4; t.bm = 128; t.bn = 160; t.smem = 128 * 160 * 4; break;          // the fp32 staging rows exceed the ring
     default: return false;
   }
-  t.pf = (t.cfg == 1 || t.cfg == 5) && g_lean_pf.load(std::memory_order_relaxed) != 0;
-  if (t.pf) t.smem += t.nw * 256;                           // scratch rows of the look-ahead touch, behind the ring
   {
     // the epilogue's fp32 staging rows re-use the ring (+ [BM][mean, rstd] behind them when two wave columns share rows)
     const int epi = t.bm * t.bn * 4 + ((ln && t.cfg != 5) ? t.bm * 8 : 0);
@@ -880,15 +875,15 @@ size_t lean_workspace(const LeanPlan& t) {
   return t.splitk > 1 ? G8_HEADER_BYTES + (size_t)t.tiles * t.splitk * t.bm * t.bn * sizeof(float) : 0;
 }
 
-template <int NW, int WGM, int WGN, int TM, int TN, int NST, bool PF>
+template <int NW, int WGM, int WGN, int TM, int TN, int NST>
 hipError_t launch_lean(const lg::LParams& lp, const LeanPlan& t, bool geglu, bool ln, hipStream_t s) {
   static AttrOnce once[4];
   const void* fn;
   if constexpr (TN == 2) {
-    fn = geglu ? (ln ? (const void*)lg::lgemm_kernel<NW, WGM, WGN, TM, TN, NST, true, true, PF> : (const void*)lg::lgemm_kernel<NW, WGM, WGN, TM, TN, NST, true, false, PF>)
-               : (ln ? (const void*)lg::lgemm_kernel<NW, WGM, WGN, TM, TN, NST, false, true, PF> : (const void*)lg::lgemm_kernel<NW, WGM, WGN, TM, TN, NST, false, false, PF>);
+    fn = geglu ? (ln ? (const void*)lg::lgemm_kernel<NW, WGM, WGN, TM, TN, NST, true, true> : (const void*)lg::lgemm_kernel<NW, WGM, WGN, TM, TN, NST, true, false>)
+               : (ln ? (const void*)lg::lgemm_kernel<NW, WGM, WGN, TM, TN, NST, false, true> : (const void*)lg::lgemm_kernel<NW, WGM, WGN, TM, TN, NST, false, false>);
   } else {
-    fn = ln ? (const void*)lg::lgemm_kernel<NW, WGM, WGN, TM, TN, NST, false, true, PF> : (const void*)lg::lgemm_kernel<NW, WGM, WGN, TM, TN, NST, false, false, PF>;
+    fn = ln ? (const void*)lg::lgemm_kernel<NW, WGM, WGN, TM, TN, NST, false, true> : (const void*)lg::lgemm_kernel<NW, WGM, WGN, TM, TN, NST, false, false>;
   }
   hipError_t e = once[(geglu ? 2 : 0) + (ln ? 1 : 0)].ensure(fn, t.smem);
   if (e != hipSuccess) return e;
@@ -984,7 +979,6 @@ extern "C" int udt_debug_set(const char* key, int32_t value) {
   if (!strcmp(key, "lean")) { g_lean.store(value < 0 ? -2 : value); return UDT_OK; }
   if (!strcmp(key, "lean_splitk")) { g_lean_splitk.store(value); return UDT_OK; }
   if (!strcmp(key, "lean_conv")) { g_lean_conv.store(value < 0 ? -1 : (value ? 1 : 0)); return UDT_OK; }
-  if (!strcmp(key, "lean_pf")) { g_lean_pf.store(value != 0 ? 1 : 0); return UDT_OK; }
 #ifdef UDT_MEASURE
   static const struct { const char* k; int bit; } bits[] = {{"no_xchg", 28}, {"no_epi", 27}, {"no_store", 26}, {"no_res", 25},
                                                             {"no_bias", 24}, {"no_fast", 22}};
@@ -1173,10 +1167,10 @@ extern "C" int udt_gemm(const udt_gemm_desc* d, void* workspace, size_t workspac
       const bool geglu = (d->flags & UDT_GEMM_GEGLU) != 0, ln = d->ln_colsum != nullptr;
       hipError_t el;
       switch (lt.cfg) {
-        case 1: el = lt.pf ? launch_lean<4, 2, 2, 2, 2, 2, true>(lp, lt, geglu, ln, s) : launch_lean<4, 2, 2, 2, 2, 2, false>(lp, lt, geglu, ln, s); break;
-        case 2: el = launch_lean<8, 4, 2, 2, 2, 3, false>(lp, lt, geglu, ln, s); break;
-        case 3: el = launch_lean<4, 2, 2, 2, 2, 3, false>(lp, lt, geglu, ln, s); break;
-        default: el = lt.pf ? launch_lean<4, 4, 1, 1, 5, 2, true>(lp, lt, false, ln, s) : launch_lean<4, 4, 1, 1, 5, 2, false>(lp, lt, false, ln, s); break;
+        case 1: el = launch_lean<4, 2, 2, 2, 2, 2>(lp, lt, geglu, ln, s); break;
+        case 2: el = launch_lean<8, 4, 2, 2, 2, 3>(lp, lt, geglu, ln, s); break;
+        case 3: el = launch_lean<4, 2, 2, 2, 2, 3>(lp, lt, geglu, ln, s); break;
+        default: el = launch_lean<4, 4, 1, 1, 5, 2>(lp, lt, false, ln, s); break;
       }
       if (el != hipSuccess) return udt_set_hip_error(el);
       return UDT_OK;

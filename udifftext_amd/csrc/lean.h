@@ -67,7 +67,7 @@ UDT_DEVINL float dot2_bf16(uint32_t a, uint32_t b, float c) {
 
 // NW waves as WGM x WGN, each TM x TN MFMA tiles of 32x32; NST ring stages; GEGLU: weight rows packed [32 x | 32 gate]
 // per 64-column wave block (TN == 2); LN: LayerNorm folded into the weights, row statistics from the A fragments
-template <int NW, int WGM, int WGN, int TM, int TN, int NST, bool GEGLU, bool LN, bool PF = false>
+template <int NW, int WGM, int WGN, int TM, int TN, int NST, bool GEGLU, bool LN>
 __global__ void __launch_bounds__(NW * 64, 2) lgemm_kernel(const LParams p) {
   static_assert(WGM * WGN == NW, "wave grid");
   static_assert(!GEGLU || TN == 2, "GEGLU pairs the two 32-column tiles of a wave");
@@ -79,7 +79,6 @@ __global__ void __launch_bounds__(NW * 64, 2) lgemm_kernel(const LParams p) {
   constexpr int WROWS = TM * 32, WCOLS = TN * 32;
   constexpr int EROW = WCOLS * 4;                       // bytes of one fp32 row of the wave block
   constexpr int EPI_WAVE = WROWS * EROW;                // (LN: + [BM][mean, rstd] behind the NW wave blocks)
-  constexpr int PF_OFF = NST * STAGE_BYTES;             // scratch rows of the look-ahead touch: behind the ring (K loop only)
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x;
@@ -148,41 +147,12 @@ __global__ void __launch_bounds__(NW * 64, 2) lgemm_kernel(const LParams p) {
     for (int i = 0; i < B_INSTR; ++i) buf_lds16(rsrc_w, bbuf + w_piece[i] * 1024, w_voff[i], kt * ROW_BYTES);
   };
 
-  // PF: one lane per tile row touches the row's 128-byte line of the K-tile AFTER the one being staged (a 4-byte load
-  // whose result is never used): the line is pulled into this XCD's L2 one more K-tile ahead than the two-stage ring
-  // can hold, so the LDS-DMA that follows finds it there (HBM-cold activations).  Loads return in order: the counted
-  // wait of the next iteration (vmcnt(1)) covers the LDS-DMA issued before the touch and leaves the touch in flight.
-  // (the touch is a 4-byte LDS-DMA into a 256-byte scratch row per wave behind the ring: no VGPR destination that a
-  //  late return could clobber)
-  unsigned pf_voff = OOB;
-  const bool pf_is_a = __builtin_amdgcn_readfirstlane(tid) < BM;       // wave-uniform: BM is a multiple of 64
-  char* const pf_lds = smem + PF_OFF + wave * 256;
-  if constexpr (PF) {
-    static_assert(NST == 2, "the look-ahead touch complements the two-stage ring");
-    if (pf_is_a) {
-      const int m = m0 + tid;
-      if (m < p.M) pf_voff = (unsigned)((long long)m * p.lda * 2);
-    } else if (tid < BM + BN) {
-      const int n = n0 + tid - BM;
-      if (n < p.N) pf_voff = (unsigned)((long long)n * p.ldw * 2);
-    }
-  }
-  auto touch = [&](int kt) {
-    if constexpr (PF) {
-      if (pf_is_a)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (__attribute__((address_space(3))) void*)pf_lds, 4, pf_voff, kt * ROW_BYTES, 0, 0);
-      else
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (__attribute__((address_space(3))) void*)pf_lds, 4, pf_voff, kt * ROW_BYTES, 0, 0);
-    }
-  };
-
+  // (measured and rejected, profiles/r03_trace_prefetch_wave.txt: touching the operand lines of later K-tiles to pull them
+  //  into L2 ahead of the two-stage ring — from the MFMA waves (vmcnt retires in order: the touch gates the next LDS-DMA
+  //  wait) or from a dedicated fifth wave — made the UNet's GEMMs 10-60 % SLOWER: a touch is 64 separate line requests)
 #pragma unroll
   for (int s = 0; s < NST - 1; ++s)
     if (kt0 + s < kt1) stage(s, kt0 + s);
-  bool touched = false;
-  if constexpr (PF) {
-    if (kt0 + 1 < kt1) { touch(kt0 + 1); touched = true; }
-  }
 
   f32x16 acc[TM][TN];
 #pragma unroll
@@ -200,17 +170,12 @@ __global__ void __launch_bounds__(NW * 64, 2) lgemm_kernel(const LParams p) {
   int st = 0;
   for (int kt = kt0; kt < kt1; ++kt) {
     if (NST > 2 && kt + NST - 2 < kt1) wait_vm<LPT*(NST > 2 ? NST - 2 : 0)>();
-    else if (PF && touched) wait_vm<1>();
     else wait_vm<0>();
     raw_barrier();                    // K-tile kt visible to all waves; the stage read in the previous iteration is free
     if (kt + NST - 1 < kt1) {
       int s2 = st + NST - 1;
       if (s2 >= NST) s2 -= NST;
       stage(s2, kt + NST - 1);
-    }
-    if constexpr (PF) {
-      touched = (kt + 2 < kt1);
-      if (touched) touch(kt + 2);
     }
     const char* abuf = smem + st * STAGE_BYTES;
     const char* bbuf = abuf + A_BYTES;
@@ -598,6 +563,12 @@ __global__ void __launch_bounds__(256, 2) lconv3_kernel(const C3Params p) {
 
   const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.a), 0, p.a_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.w), 0, p.w_bytes, 0x00020000);
+  // XOR swizzle of a patch row's 16-byte slots.  The rows one ds_read_b128 lane group touches are 16 consecutive pixels of
+  // one or two image rows; with the patch pitch of TW + 2 rows, (row >> 1) & 7 maps two of them onto the same slot (PMC:
+  // a third of the LDS cycles of the first version were bank conflicts).  Keying the swizzle on the row index with the
+  // halo pitch REMOVED (row - 2 * patch line: consecutive image rows then differ by the interior width, a multiple of
+  // 8) makes the lanes of a group hit 16 different (bank half, slot) pairs again.
+  auto patch_swz = [](int prow, int yy) { return ((prow - 2 * yy) >> 1) & 7; };
   unsigned w_voff[WP], p_voff[PP];
   int p_piece[PP];
 #pragma unroll
@@ -617,14 +588,15 @@ __global__ void __launch_bounds__(256, 2) lconv3_kernel(const C3Params p) {
     const int xx = prow - yy * C3_PW;
     const int gy = (UPS ? (y0 >> 1) : y0) + yy - 1, gx = (UPS ? (x0 >> 1) : x0) + xx - 1;
     const bool ok = (prow < C3_PROWS) && ((unsigned)gy < (unsigned)p.H) && ((unsigned)gx < (unsigned)p.W);
-    const int koff = (pslot ^ ((prow >> 1) & 7)) * 8;
+    const int koff = (pslot ^ patch_swz(prow, yy)) * 8;
     p_voff[i] = ok ? (unsigned)(((((long long)b * p.H + gy) * p.W + gx) * p.C + koff) * 2) : OOB;
   }
-  int a_prow[TM];
+  int a_prow[TM], a_py[TM];
 #pragma unroll
   for (int tm = 0; tm < TM; ++tm) {
     const int ml = row0 + tm * 32 + l31;
     const int py = ml / TW, px = ml - py * TW;
+    a_py[tm] = py;
     a_prow[tm] = UPS ? (py | (px << 16)) : (py * C3_PW + px);      // patch row of this lane's pixel at tap (0, 0)
   }
   auto issue_w = [&](int st, int c, int tap) {
@@ -667,14 +639,16 @@ __global__ void __launch_bounds__(256, 2) lconv3_kernel(const C3Params p) {
       bf16x8_t fx[4][TM], fw[4][TN];
 #pragma unroll
       for (int t = 0; t < TM; ++t) {
-        int prow;
+        int prow, yy;
         if constexpr (UPS) {
           const int py = a_prow[t] & 0xffff, px = a_prow[t] >> 16;
-          prow = (((py + dy - 1) >> 1) + 1) * C3_PW + (((px + dx - 1) >> 1) + 1);
+          yy = ((py + dy - 1) >> 1) + 1;
+          prow = yy * C3_PW + (((px + dx - 1) >> 1) + 1);
         } else {
+          yy = a_py[t] + dy;
           prow = a_prow[t] + dy * C3_PW + dx;
         }
-        const int arow = prow * ROW_BYTES, aswz = (prow >> 1) & 7;
+        const int arow = prow * ROW_BYTES, aswz = patch_swz(prow, yy);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) fx[ks][t] = lds_read_frag(pbuf + arow + (((ks * 2 + hi) ^ aswz) << 4));
       }

@@ -10,6 +10,7 @@ ROCm; "gloo" in the CPU tests).
 """
 from __future__ import annotations
 
+import copy
 from typing import Callable, List, Optional, Sequence, Tuple
 
 import torch
@@ -95,7 +96,7 @@ def predict_sharded(cfgs, model, sampler, global_batches: Sequence[dict], global
     sizes = sorted({len(s) for s in seeds}, reverse=True)
     for sz in sizes:
         idx = [i for i, s in enumerate(seeds) if len(s) == sz]
-        cfg = type(cfgs)(cfgs) if isinstance(cfgs, dict) else cfgs
+        cfg = type(cfgs)(cfgs) if isinstance(cfgs, dict) else copy.copy(cfgs)      # never mutate the caller's config
         cfg.batch_size = sz
         outs = predict_many(cfg, model, sampler, [micro[i] for i in idx], device, in_flight=in_flight, fuse=fuse,
                             image_seeds=[seeds[i] for i in idx])
@@ -107,9 +108,15 @@ def predict_sharded(cfgs, model, sampler, global_batches: Sequence[dict], global
         counts = counts_all[gi]
         if mine:
             local = torch.cat(mine, 0)
-        else:                                   # more ranks than images: an empty shard still joins the collective
-            ref = next(r for r in results if r is not None)
-            local = ref.new_zeros((0,) + tuple(ref.shape[1:]))
+        else:
+            # more ranks than images: an empty shard still joins the collective.  Its placeholder is built from the
+            # batch's own metadata (this rank may not have sampled ANY image, e.g. a global batch of 4 on 8 GPUs)
+            gb = global_batches[gi]
+            Hh, Ww = (int(v) for v in gb["target_size_as_tuple"][0]) if "target_size_as_tuple" in gb else gb["image"].shape[-2:]
+            ref = next((r for r in results if r is not None), None)
+            dt = ref.dtype if ref is not None else torch.float32
+            dv = ref.device if ref is not None else (torch.device(device) if device is not None else gb["image"].device)
+            local = torch.zeros((0, 3, Hh, Ww), dtype=dt, device=dv)
         if not on:
             frames.append(local)
         elif len(set(counts)) == 1:

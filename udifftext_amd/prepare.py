@@ -40,6 +40,7 @@ def prepare(engine, free_masters: bool = False, dedup_vae: bool = True) -> Dict[
                         and _same_weights(emb.model, engine.first_stage_model):
                     emb.model = engine.first_stage_model
                     report["vae_deduplicated"] += 1
+                    engine._vae_alias_prefixes = ("first_stage_model.", "conditioner.embedders.%d.model." % list(engine.conditioner.embedders).index(emb))
         # ---- pack roots (a fused child is packed through its parent only)
         fused = set()
         for m in engine.modules():
@@ -66,6 +67,19 @@ def prepare(engine, free_masters: bool = False, dedup_vae: bool = True) -> Dict[
             for m in unet.modules():
                 if isinstance(m, BasicTransformerBlock):
                     report["packed_bytes"] += m.prepare_ln(freeze=free_masters)
+        # ---- e4m3 layouts (UDT_FP8=1): built and frozen here, ahead of the release of the masters
+        if H.FP8_LINEARS:
+            for m in engine.modules():
+                if isinstance(m, H._Packed) and (id(m) in seen):
+                    try:
+                        pk8 = m.packed_fp8()
+                    except NotImplementedError:
+                        continue
+                    m._pk8_frozen = bool(free_masters)
+                    for t in (pk8 if isinstance(pk8, (tuple, list)) else (pk8,)):
+                        for u in (t if isinstance(t, (tuple, list)) else (t,)):
+                            if isinstance(u, torch.Tensor):
+                                report["packed_bytes"] += u.numel() * u.element_size()
         # ---- release the masters
         if free_masters:
             victims = []

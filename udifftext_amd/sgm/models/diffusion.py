@@ -55,6 +55,27 @@ class DiffusionEngine(nn.Module):
             print(f"Unexpected Keys: {unexpected}")
         return missing, unexpected
 
+    def _check_vae_alias(self, sd) -> None:
+        """prepare(dedup_vae=True) pointed the LatentEncoder at first_stage_model because their weights were equal; a later
+        checkpoint whose two prefixes DIFFER needs two modules again: split them before loading (and say so)"""
+        alias = getattr(self, "_vae_alias_prefixes", None)
+        if not alias:
+            return
+        a, b = alias
+        differ = any(k.startswith(a) and (b + k[len(a):]) in sd and not torch.equal(sd[k].cpu(), sd[b + k[len(a):]].cpu()) for k in sd)
+        if differ:
+            import copy
+            import warnings
+            warnings.warn("the checkpoint holds DIFFERENT weights under %s and %s: undoing the VAE dedup of prepare()" % (a, b))
+            for emb in self.conditioner.embedders:
+                if getattr(emb, "model", None) is self.first_stage_model:
+                    emb.model = copy.deepcopy(self.first_stage_model)
+            self._vae_alias_prefixes = None
+
+    def load_state_dict(self, state_dict, strict: bool = True, **kw):
+        self._check_vae_alias(state_dict)
+        return super().load_state_dict(state_dict, strict=strict, **kw)
+
     def prepare(self, free_masters: bool = False, dedup_vae: bool = True):
         """load-time packing of the device weight layouts, VAE dedup, optional release of the fp32 masters
         (udifftext_amd.prepare)"""

@@ -126,8 +126,8 @@ class CrossAttention(H._Packed):
         """fold the (step-invariant) context k|v, to_q, to_out and the LayerNorm in front of this module into the
         per-sample tables of udt_tattn_fused (None for a single-token context: the reference then applies a sigmoid
         instead of the softmax, attention.py:159-162 — that case stays on the unfused path)"""
-        if kv.shape[1] < 2:
-            return None
+        if kv.shape[1] < 2 or kv.shape[1] > 12 or self.dim_head != 64 or not TATTN_FUSED:
+            return None              # (udt_tattn_prepare takes 2..12 context tokens of head_dim 64: anything else -> xattn chain)
         wq, _ = self.to_q.packed()
         wo, _ = self.to_out[0].packed()
         return ops.tattn_prepare(kv.contiguous(), wq, wo, t_norm.weight, t_norm.bias, self.heads, self.scale, out=out)

@@ -137,7 +137,9 @@ class _Stepper:
         # graphs captured from it, freed with it
         self.ws = ops.Workspace(dev)
         self.ws_side = ops.Workspace(dev) if self.dual else None
-        self.cu_share = 1               # launch streams of OTHER runners sharing the device (set by _GraphedSteps)
+        # launch streams of OTHER runners sharing the device: the caller's ambient share (a lane of predict_many runs its
+        # conditioning AND its noise search under launch_context(cu_share=n)); _GraphedSteps overrides it for its runner
+        self.cu_share = max(1, int(ops._ctx.cu_share))
 
     def quantise(self, sigma: float):
         idx = int((self.table - sigma).abs().argmin())

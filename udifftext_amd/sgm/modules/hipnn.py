@@ -92,6 +92,12 @@ class _Packed(nn.Module):
 
     def packed_fp8(self):
         """the fp8 (e4m3 + per-channel scale) layout of the same weights, cached like ``packed()``"""
+        if getattr(self, "_pk8_frozen", False):
+            return self._pk8
+        if getattr(self, "_pk_frozen", False):
+            raise L.UdtError(f"{type(self).__name__}: the fp32 masters were released by prepare(free_masters=True) before the "
+                             "fp8 layout was built — call prepare() with UDT_FP8=1 set (it then packs and freezes the e4m3 "
+                             "layouts too), or reload the checkpoint")
         key = self._key()
         if getattr(self, "_pk8_key", None) != key:
             with torch.no_grad():
@@ -175,8 +181,10 @@ class Conv2d(_Packed):
         the reference's ``GroupNorm32 -> SiLU -> conv`` chains (openaimodel.py:183-187,218-231; model.py:128-148).  Fused
         into the convolution (statistics from the producers' epilogues, scale/shift applied on the staged patch) when
         possible, otherwise the separate GroupNorm kernels run first.  colstats: emit the output's statistics."""
-        if x2 is not None and self.segments is None and not getattr(self, "_pk_frozen", False):
-            # (channel counts of concatenated sources; only matters when one is not a multiple of 64 — never on this path)
+        if (x2 is not None and self.segments is None and not getattr(self, "_pk_frozen", False)
+                and (x.shape[-1] % 64 != 0 or x2.shape[-1] % 64 != 0)):
+            # channel counts of concatenated sources: each is padded to 64 separately, so the layout only differs from the
+            # load-time pack (and a repack is only needed) when one of them is not a multiple of 64 — never on this path
             self.segments = [x.shape[-1], x2.shape[-1]]
             self._pk_key = None
         w, b = self.packed()
