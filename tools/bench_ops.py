@@ -43,6 +43,8 @@ def attn_case(B, H, N):
     out = torch.empty((B, N, C), dtype=torch.bfloat16, device=dev)
     ms = timeit(lambda: ops.attention(qkv[..., :C], qkv[..., C:2*C], vt, H, 0.125, out=out))
     print(f"attn B{B} H{H} N{N}: {ms*1e3:8.1f} us  {4.0*B*H*N*N*64/ms/1e9:8.1f} TF/s")
+    ms = timeit(lambda: ops.attention_rowv(qkv[..., :C], qkv[..., C:2*C], qkv[..., 2*C:], H, 0.125, out=out))
+    print(f"attn (row-major V) B{B} H{H} N{N}: {ms*1e3:8.1f} us  {4.0*B*H*N*N*64/ms/1e9:8.1f} TF/s")
 
 B = 8
 conv_case(B, 64, 320, 0, 320)

@@ -20,6 +20,8 @@
 //   GEMM -> softmax -> GEMM because head_dim = 512 does not fit a register-resident flash tile).
 #include "common.h"
 #include <stdio.h>
+#include <stdlib.h>
+#include <atomic>
 
 namespace {
 
@@ -237,6 +239,203 @@ __global__ void __launch_bounds__(256, 4) attn_d64_kernel(const AttnParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------------
+// attn_d64_v2_kernel (round 3): the row-major-V flash kernel with the loop overheads removed.  Same arithmetic and the same
+// fragment orders as attn_d64_kernel<true> (128 queries per workgroup, 4 waves x 32 queries, swapped S^T = K Q^T, V^T
+// fragments by LDS transpose reads), but
+//   * a THREE-stage K|V ring filled two tiles ahead, counted `s_waitcnt vmcnt` + a raw barrier per 64-key tile (the
+//     first kernel drained vmcnt(0) and had one tile in flight: every tile paid the L2 latency of its successor);
+//   * every LDS address is a per-lane base computed once + an immediate (the transpose reads cost 3 VALU ops each before);
+//   * the online-softmax rescale of O is skipped while the running maximum grows by less than 2^8 (wave-uniform test;
+//     P then stays <= 256, exact in fp32 and harmless for the bf16 P fragments — the normaliser l sees the same P);
+//   * MFMA groups run at raised wave priority (the other waves of the SIMD are in their softmax / read phases).
+// 48 KiB of LDS -> three workgroups per CU.
+constexpr int A2_STAGE = 2 * TILE_BYTES;     // K tile + V tile
+constexpr int A2_NST = 3;
+constexpr float A2_DEFER = 8.0f;
+
+__global__ void __launch_bounds__(256, 3) attn_d64_v2_kernel(const AttnParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem2[];
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = tid & 63;
+  const int l31 = lane & 31;
+  const int hi = lane >> 5;
+  const int bh = blockIdx.y;
+  const int b = bh / p.heads;
+  const int h = bh - b * p.heads;
+  const uint16_t* __restrict__ Q = p.q + (long long)b * p.sq + h * 64;
+  const uint16_t* __restrict__ K = p.k + (long long)b * p.sk + h * 64;
+  const uint16_t* __restrict__ V = p.vt + (long long)b * p.svt + h * 64;
+  uint16_t* __restrict__ O = p.o + (long long)b * p.so + h * 64;
+  const int qi = blockIdx.x * 128 + wave * 32 + l31;
+  const bool qok = qi < p.nq;
+  bf16x8_t qf[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    const uint16_t* g = qok ? (Q + (long long)qi * p.ldq + ks * 16 + hi * 8) : p.zero;
+    qf[ks] = *reinterpret_cast<const bf16x8_t*>(g);
+  }
+  // staging: 2 K pieces + 2 V pieces (1 KiB each) per wave and tile, through buffer descriptors (keys past nk read zeros)
+  const int l3 = lane >> 3, pslot = lane & 7;
+  const unsigned kbytes = (unsigned)(((long long)(p.nk - 1) * p.ldk + 64) * 2);
+  const unsigned vbytes = (unsigned)(((long long)(p.nk - 1) * p.ldvt + 64) * 2);
+  const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(K), 0, kbytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(V), 0, vbytes, 0x00020000);
+  unsigned kvo[2], vvo[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = (wave * 2 + i) * 8 + l3;
+    const int koff = (pslot ^ ((row >> 1) & 7)) * 8;
+    kvo[i] = (unsigned)(((long long)row * p.ldk + koff) * 2);
+    vvo[i] = (unsigned)(((long long)row * p.ldvt + koff) * 2);
+  }
+  const int kstep = KV_TILE * p.ldk * 2, vstep = KV_TILE * p.ldvt * 2;        // bytes per 64-key tile
+  auto stage = [&](int st, int kt) {
+    char* kbuf = smem2 + st * A2_STAGE;
+    char* vbuf = kbuf + TILE_BYTES;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, (__attribute__((address_space(3))) void*)(kbuf + (wave * 2 + i) * 1024), 16, kvo[i], kt * kstep, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (__attribute__((address_space(3))) void*)(vbuf + (wave * 2 + i) * 1024), 16, vvo[i], kt * vstep, 0, 0);
+  };
+  // per-lane LDS offsets, fixed for the whole kernel
+  const int swz = (l31 >> 1) & 7;
+  int koff_l[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) koff_l[ks] = l31 * 128 + (((ks * 2 + hi) ^ swz) << 4);
+  const int tr_i = lane & 15, tr_g1 = (lane >> 4) & 1;
+  const int tr_row = 4 * hi + (tr_i >> 2);
+  const int tr_swz = (tr_row >> 1) & 7;
+  const int tr_chunk = 2 * tr_g1 + ((tr_i & 3) >> 1);
+  const int tr_base = tr_row * 128 + (tr_i & 1) * 8;
+  int voff_a[2], voff_b[2];
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt) {
+    const int c = dt * 4 + tr_chunk;
+    voff_a[dt] = TILE_BYTES + tr_base + ((c ^ tr_swz) << 4);
+    voff_b[dt] = TILE_BYTES + tr_base + 1024 + ((c ^ tr_swz ^ 4) << 4);
+  }
+
+  f32x16 o_acc[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o_acc[i][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+  const int ntiles = (p.nk + KV_TILE - 1) / KV_TILE;
+  const float c = p.scale_log2e;
+  stage(0, 0);
+  if (ntiles > 1) stage(1, 1);
+  int st = 0;
+  for (int kt = 0; kt < ntiles; ++kt) {
+    if (kt + 1 < ntiles) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");       // the tile after this one stays in flight
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (kt + 2 < ntiles) {
+      int s2 = st + 2;
+      if (s2 >= A2_NST) s2 -= A2_NST;
+      stage(s2, kt + 2);
+    }
+    const char* buf = smem2 + st * A2_STAGE;
+    f32x16 s[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[t][r] = 0.f;
+    bf16x8_t kf[4][2];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+      for (int t = 0; t < 2; ++t) kf[ks][t] = lds_read_frag(buf + koff_l[ks] + t * 32 * 128);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+      for (int t = 0; t < 2; ++t) s[t] = mfma32(kf[ks][t], qf[ks], s[t]);
+    __builtin_amdgcn_s_setprio(0);
+    if (kt * KV_TILE + KV_TILE > p.nk) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = kt * KV_TILE + t * 32 + 8 * (r >> 2) + 4 * hi + (r & 3);
+          if (key >= p.nk) s[t][r] = -INFINITY;
+        }
+    }
+    float mx = s[0][0];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[t][r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float mxs = mx * c;
+    if (!__all(mxs - m_run <= A2_DEFER)) {                  // wave-uniform: some query's maximum grew by more than 2^8
+      const float m_new = fmaxf(m_run, mxs);
+      const float alpha = fast_exp2(m_run - m_new);
+      m_run = m_new;
+      l_run *= alpha;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o_acc[i][r] *= alpha;
+    }
+    float psum = 0.f;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float pv = fast_exp2(s[t][r] * c - m_run);
+        s[t][r] = pv;
+        psum += pv;
+      }
+    l_run += psum;
+    typedef short v4s __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(3))) v4s* lds_v4s;
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+      const int t = s4 >> 1, half = s4 & 1;
+      u32x4 pk;
+      pk[0] = pack_bf16x2(s[t][half * 8 + 0], s[t][half * 8 + 1]);
+      pk[1] = pack_bf16x2(s[t][half * 8 + 2], s[t][half * 8 + 3]);
+      pk[2] = pack_bf16x2(s[t][half * 8 + 4], s[t][half * 8 + 5]);
+      pk[3] = pack_bf16x2(s[t][half * 8 + 6], s[t][half * 8 + 7]);
+      const bf16x8_t pf = __builtin_bit_cast(bf16x8_t, pk);
+      u32x4 vv[2];
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        const v4s a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s)(buf + s4 * 2048 + voff_a[dt]));
+        const v4s b8 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s)(buf + s4 * 2048 + voff_b[dt]));
+        const u32x2 lo = __builtin_bit_cast(u32x2, a), hh = __builtin_bit_cast(u32x2, b8);
+        u32x4 w = {lo[0], lo[1], hh[0], hh[1]};
+        vv[dt] = w;
+      }
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) o_acc[dt] = mfma32(__builtin_bit_cast(bf16x8_t, vv[dt]), pf, o_acc[dt]);
+      __builtin_amdgcn_s_setprio(0);
+    }
+    st = st + 1 == A2_NST ? 0 : st + 1;
+  }
+  const float l_tot = l_run + __shfl_xor(l_run, 32);
+  const float inv = 1.0f / l_tot;
+  if (qok) {
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) {
+        const int d = dt * 32 + qd * 8 + hi * 4;
+        u32x2 pk = {pack_bf16x2(o_acc[dt][qd * 4 + 0] * inv, o_acc[dt][qd * 4 + 1] * inv),
+                    pack_bf16x2(o_acc[dt][qd * 4 + 2] * inv, o_acc[dt][qd * 4 + 3] * inv)};
+        *reinterpret_cast<u32x2*>(O + (long long)qi * p.ldo + d) = pk;
+      }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // short-context attention: L <= 16 keys, head_dim a multiple of 64
 struct XattnParams {
   const uint16_t* q;
@@ -399,7 +598,18 @@ static int attn_fwd_impl(bool vrow, const void* q, const void* k, const void* vt
     udt_prof_tag(prof.rec, tag);
   }
   dim3 grid((nq + 127) / 128, batch * heads);
-  if (vrow) hipLaunchKernelGGL(attn_d64_kernel<true>, grid, dim3(256), 0, s, p);
+  // UDT_ATTN_V2=0: the first-generation loop (A/B measurements).  The v2 kernel addresses K / V through 31-bit buffer offsets
+  static const int v2 = [] { const char* e = getenv("UDT_ATTN_V2"); return (e && e[0] == '0') ? 0 : 1; }();
+  if (vrow && v2 && (long long)nk * ldk * 2 < (1LL << 31) && (long long)nk * ldvt * 2 < (1LL << 31)) {
+    static std::atomic<int> attr_done{0};
+    constexpr int smem = A2_NST * A2_STAGE;
+    if (!attr_done.load()) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_d64_v2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+      if (e != hipSuccess) return udt_set_hip_error(e);
+      attr_done.store(1);
+    }
+    hipLaunchKernelGGL(attn_d64_v2_kernel, grid, dim3(256), smem, s, p);
+  } else if (vrow) hipLaunchKernelGGL(attn_d64_kernel<true>, grid, dim3(256), 0, s, p);
   else hipLaunchKernelGGL(attn_d64_kernel<false>, grid, dim3(256), 0, s, p);
   UDT_CHECK_LAUNCH();
   return UDT_OK;
