@@ -65,6 +65,23 @@ for M, N, K, fl, res, rpb in CASES:
     dbg("lean_splitk", -1)
     print(line, flush=True)
 
+# two-source 1x1 convolutions (skip concat in front of a ResBlock's skip_connection) on the lean GEMM family
+import torch.nn.functional as F
+for B, H, C1, C2, N in [(8, 64, 320, 320, 320), (8, 32, 640, 320, 640), (8, 16, 1280, 1280, 1280), (8, 8, 1280, 1280, 1280), (2, 16, 128, 64, 192)]:
+    x1 = torch.randn((B, H, H, C1), device=dev).bfloat16(); x2 = torch.randn((B, H, H, C2), device=dev).bfloat16()
+    w4 = torch.randn((N, C1 + C2, 1, 1), device=dev) / math.sqrt(C1 + C2)
+    w = packing.pack_conv(w4, [C1, C2]); b = torch.randn((N,), device=dev)
+    y = F.conv2d(torch.cat([x1, x2], -1).float().permute(0, 3, 1, 2), w4.bfloat16().float(), b).permute(0, 2, 3, 1)
+    line = f"conv1x1 B{B} {H}x{H} {C1}+{C2}->{N}:"
+    for c in [0] + cfgs[:1]:
+        dbg("lean", c)
+        o = ops.conv2d(x1, w, b, ksize=1, x2=x2)
+        torch.cuda.synchronize()
+        e = rel(o, y)
+        ok = e[0] < 6e-3 and math.isfinite(e[0]); bad += 0 if ok else 1
+        line += f"  lean={c} {e[0]:.2e}{'' if ok else ' BAD'}"
+    print(line, flush=True)
+
 # LayerNorm-folded form against layer_norm + linear and a torch fp32 reference
 for M, N, K, fl in [(32768, 960, 320, 0), (8192, 5120, 640, GEGLU), (2048, 3840, 1280, 0), (777, 2560, 320, GEGLU), (512, 1280, 1280, 0)]:
     x = (torch.randn((M, K), device=dev) * 1.5 + 0.3).bfloat16()

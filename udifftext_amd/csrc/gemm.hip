@@ -814,17 +814,23 @@ int lean_mode() {
 bool lean_plan(const udt_gemm_desc* d, LeanPlan& t) {
   const int mode = lean_mode();
   if (mode == 0 || gemm_impl() == 4) return false;
-  constexpr int unsupported = UDT_GEMM_OUT_F32 | UDT_GEMM_RELU | UDT_GEMM_TRANSPOSED | UDT_GEMM_CONV | UDT_GEMM_SILU_OUT |
-                              UDT_GEMM_FP8;
+  constexpr int unsupported = UDT_GEMM_OUT_F32 | UDT_GEMM_RELU | UDT_GEMM_TRANSPOSED | UDT_GEMM_SILU_OUT | UDT_GEMM_FP8;
   if (d->flags & unsupported) return false;
+  // 1x1 / stride-1 convolutions are plain GEMMs over the pixels; two NHWC sources (the UNet's skip concat in front of a
+  // ResBlock's skip_connection, reference openaimodel.py:218-231,620) = two A sources along K
+  const bool conv1 = (d->flags & UDT_GEMM_CONV) != 0;
+  if (conv1 && (d->ksize != 1 || d->stride != 1 || d->upsample || d->pad_t != 0 || d->pad_l != 0 || d->Hout != d->Hin ||
+                d->Wout != d->Win || d->C1 % BK != 0 || d->C2 % BK != 0 || d->ln_colsum || (d->flags & UDT_GEMM_GEGLU)))
+    return false;
   if (d->batch > 1 || d->colstats || d->in_scsh || d->colscale) return false;
   const bool geglu = (d->flags & UDT_GEMM_GEGLU) != 0;
   const bool ln = d->ln_colsum != nullptr;
-  if (d->N <= 64 || d->N % 8 != 0 || d->K % BK != 0 || d->lda % 8 != 0 || d->ldo % 8 != 0) return false;
+  if (d->N <= 64 || d->N % 8 != 0 || d->K % BK != 0 || (!conv1 && d->lda % 8 != 0) || d->ldo % 8 != 0) return false;
   if (d->residual && d->ldr % 8 != 0) return false;
   if (geglu && (d->N % 64 != 0 || d->residual || d->rowvec)) return false;
   const long long ldw = d->ldw > 0 ? d->ldw : d->K;
-  if ((long long)d->M * d->lda * 2 >= (1LL << 31) || (long long)d->N * ldw * 2 >= (1LL << 31)) return false;
+  const long long lda_eff = conv1 ? (d->C1 > d->C2 ? d->C1 : d->C2) : d->lda;
+  if ((long long)d->M * lda_eff * 2 >= (1LL << 31) || (long long)d->N * ldw * 2 >= (1LL << 31)) return false;
   if ((reinterpret_cast<uintptr_t>(d->out) | reinterpret_cast<uintptr_t>(d->residual) | reinterpret_cast<uintptr_t>(d->bias) |
        reinterpret_cast<uintptr_t>(d->rowvec) | reinterpret_cast<uintptr_t>(d->ln_colsum)) & 15) return false;
   if (d->rowvec && ((d->ld_rowvec > 0 ? d->ld_rowvec : d->N) % 4 != 0)) return false;
@@ -1141,14 +1147,19 @@ extern "C" int udt_gemm(const udt_gemm_desc* d, void* workspace, size_t workspac
     LeanPlan lt;
     if (lean_plan(d, lt)) {
       lg::LParams lp;
-      lp.a = p.a; lp.w = p.w; lp.bias = p.bias; lp.res = p.res; lp.rowvec = p.rowvec; lp.ln_s = d->ln_colsum;
+      const bool conv1 = (d->flags & UDT_GEMM_CONV) != 0;
+      lp.a = p.a; lp.a2 = (conv1 && d->C2 > 0) ? p.a2 : nullptr; lp.w = p.w; lp.bias = p.bias; lp.res = p.res; lp.rowvec = p.rowvec;
+      lp.ln_s = d->ln_colsum;
       lp.out = reinterpret_cast<uint16_t*>(d->out);
       lp.M = d->M; lp.N = d->N; lp.K = d->K;
-      lp.lda = p.lda; lp.ldw = p.ldw; lp.ldo = p.ldo; lp.ldr = p.ldr; lp.ldrv = p.ldrv; lp.rows_per_batch = p.rows_per_batch;
+      lp.lda = conv1 ? d->C1 : p.lda; lp.ldw = p.ldw; lp.ldo = p.ldo; lp.ldr = p.ldr; lp.ldrv = p.ldrv; lp.rows_per_batch = p.rows_per_batch;
+      lp.lda2 = conv1 ? d->C2 : 0;
+      lp.kt_split = (conv1 && d->C2 > 0) ? d->C1 / BK : lt.nkt;
+      lp.a2_bytes = (unsigned)((long long)d->M * (conv1 ? d->C2 : 0) * 2);
       lp.alpha = d->alpha; lp.ln_eps = d->ln_eps;
       lp.tiles_m = lt.tiles_m; lp.tiles_n = lt.tiles_n; lp.n_block = lt.n_block; lp.tiles = lt.tiles;
       lp.nkt = lt.nkt; lp.splitk = lt.splitk; lp.kt_per = lt.kt_per;
-      lp.a_bytes = (unsigned)((long long)d->M * d->lda * 2);
+      lp.a_bytes = (unsigned)((long long)d->M * lp.lda * 2);
       lp.w_bytes = (unsigned)((long long)d->N * p.ldw * 2);
       lp.G = lt.G;
       lp.counters = nullptr; lp.slabs = nullptr;

@@ -42,6 +42,7 @@ using g8::OOB;
 
 struct LParams {
   const uint16_t* a;
+  const uint16_t* a2;      // second A source (channel concat along K: the UNet's 1x1 skip convolutions), or nullptr
   const uint16_t* w;
   const float* bias;       // [N] fp32 or nullptr (LN: c_n)
   const uint16_t* res;     // bf16 [M, ldr] or nullptr
@@ -55,6 +56,8 @@ struct LParams {
   int nkt;                 // K tiles of the problem
   int splitk, kt_per;      // K slices per tile, K tiles per slice
   unsigned a_bytes, w_bytes;
+  int kt_split, lda2;      // K tiles [0, kt_split) come from `a`, the rest from `a2` (row stride lda2); kt_split = nkt: one source
+  unsigned a2_bytes;
   int G;                   // launched workgroups (a multiple of 8 when > 8)
   int* counters;           // split-K: [tiles] arrival tickets, zero between launches
   float* slabs;            // split-K: [tiles * splitk][BM * BN] fp32
@@ -116,7 +119,9 @@ __global__ void __launch_bounds__(NW * 64, 2) lgemm_kernel(const LParams p) {
 
   const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.a), 0, p.a_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.w), 0, p.w_bytes, 0x00020000);
-  unsigned a_voff[A_INSTR], w_voff[B_INSTR];
+  const __amdgpu_buffer_rsrc_t rsrc_a2 =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.a2 ? p.a2 : p.a), 0, p.a2 ? p.a2_bytes : 0u, 0x00020000);
+  unsigned a_voff[A_INSTR], a2_voff[A_INSTR], w_voff[B_INSTR];
   int a_piece[A_INSTR], w_piece[B_INSTR];
 #pragma unroll
   for (int i = 0; i < A_INSTR; ++i) {
@@ -127,6 +132,7 @@ __global__ void __launch_bounds__(NW * 64, 2) lgemm_kernel(const LParams p) {
     const int koff = (pslot ^ ((row >> 1) & 7)) * 8;
     const int m = m0 + row;
     a_voff[i] = (m < p.M) ? (unsigned)(((long long)m * p.lda + koff) * 2) : OOB;
+    a2_voff[i] = (m < p.M) ? (unsigned)(((long long)m * p.lda2 + koff) * 2) : OOB;
   }
 #pragma unroll
   for (int i = 0; i < B_INSTR; ++i) {
@@ -141,8 +147,13 @@ __global__ void __launch_bounds__(NW * 64, 2) lgemm_kernel(const LParams p) {
   auto stage = [&](int st, int kt) {
     char* abuf = smem + st * STAGE_BYTES;
     char* bbuf = abuf + A_BYTES;
+    if (kt < p.kt_split) {                               // (wave-uniform: a K tile lies in exactly one source)
 #pragma unroll
-    for (int i = 0; i < A_INSTR; ++i) buf_lds16(rsrc_a, abuf + a_piece[i] * 1024, a_voff[i], kt * ROW_BYTES);
+      for (int i = 0; i < A_INSTR; ++i) buf_lds16(rsrc_a, abuf + a_piece[i] * 1024, a_voff[i], kt * ROW_BYTES);
+    } else {
+#pragma unroll
+      for (int i = 0; i < A_INSTR; ++i) buf_lds16(rsrc_a2, abuf + a_piece[i] * 1024, a2_voff[i], (kt - p.kt_split) * ROW_BYTES);
+    }
 #pragma unroll
     for (int i = 0; i < B_INSTR; ++i) buf_lds16(rsrc_w, bbuf + w_piece[i] * 1024, w_voff[i], kt * ROW_BYTES);
   };

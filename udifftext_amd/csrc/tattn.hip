@@ -20,6 +20,7 @@
 // FLOPs drop 5x against the unfused chain (K = 12 per head instead of 64); the kernel is bound by reading x once.
 #include "common.h"
 #include <stdio.h>
+#include <stdlib.h>
 
 namespace {
 
@@ -348,8 +349,11 @@ extern "C" int udt_tattn_fused(const void* x, void* out, const void* A, const fl
   const unsigned grid = (unsigned)(p.M / TT);
   // few token tiles (the 16x16 / 8x8 levels): split the output channels over up to 4 workgroups per tile so that the
   // launch covers >= ~128 CUs; every split recomputes the statistics and scores of its tile (a third of the work)
+  // (round 3: up to 8 splits and a full chip of workgroups — the launch is a chain of L2-latency-bound steps, so idle CUs
+  //  are the one thing that is free; UDT_TATTN_SPLIT_WGS overrides the workgroup target for A/B measurements)
+  static const unsigned target = [] { const char* e = getenv("UDT_TATTN_SPLIT_WGS"); return e ? (unsigned)atoi(e) : 256u; }();
   p.nsplit = 1;
-  while (p.nsplit < 4 && grid * p.nsplit < 128) p.nsplit *= 2;
+  while (p.nsplit < 8 && grid * p.nsplit < target) p.nsplit *= 2;
   if (TT == 64) {
     if (!attr64) {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(tattn_fused_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024);

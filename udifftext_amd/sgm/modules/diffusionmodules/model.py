@@ -99,9 +99,16 @@ class MemoryEfficientAttnBlock(H._Packed):
         hn = self.norm(x).reshape(B * N, C)
         qk = ops.linear(hn, wqk, bqk).reshape(B, N, 2 * C)
         vt = ops.linear(hn, wv, bv, flags=H.GEMM_TRANSPOSED, rows_per_batch=N)       # [B, C, N]
-        s = ops.bmm_nt(qk[..., :C], qk[..., C:], alpha=C ** -0.5)                    # [B, N, N]
-        ops.softmax_rows_(s)
-        o = ops.bmm_nt(s, vt)                                                        # [B, N, C]
+        # head_dim = 512 does not fit the register-resident flash tile of udt_attn_rowv_fwd; the scores are materialised in
+        # QUERY BLOCKS of <= 1024 rows (GEMM -> row softmax -> GEMM per block): [B, 1024, N] bf16 stays cache-resident (19 MB
+        # per image at 768x768) instead of a [B, N, N] tensor (170 MB per image there); the results are identical row for row
+        o = torch.empty((B, N, C), dtype=torch.bfloat16, device=x.device)
+        QB = 1024
+        for q0 in range(0, N, QB):
+            q1 = min(N, q0 + QB)
+            s = ops.bmm_nt(qk[:, q0:q1, :C], qk[..., C:], alpha=C ** -0.5)           # [B, q1 - q0, N]
+            ops.softmax_rows_(s)
+            ops.bmm_nt(s, vt, out=o[:, q0:q1])
         out = ops.linear(o.reshape(B * N, C), wo, bo, residual=x.reshape(B * N, C), rows_per_batch=N, colstats=H.FUSE_GN)
         return H.carry_stats(out.reshape(B, Hh, Ww, C), out)
 
