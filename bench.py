@@ -87,7 +87,8 @@ def measured_traffic():
     cannot run inside the timed region, hence the file; None if absent."""
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")), reverse=True):
         try:
-            return float(json.load(open(path))["conv3p"]["hbm_bytes_per_launch"]), os.path.basename(path)
+            d = json.load(open(path))
+            return float((d.get("conv3") or d["conv3p"])["hbm_bytes_per_launch"]), os.path.basename(path)
         except Exception:
             continue
     return None, None
@@ -421,7 +422,7 @@ def main():
         conv.update({"traffic": traffic, "traffic_source": traffic_file,
                      "traffic_hbm_gbps": (traffic / (conv["avg_launch_us"] * 1e-6) / 1e9) if traffic else None,
                      "traffic_frac_of_hbm_peak": (traffic / (conv["avg_launch_us"] * 1e-6) / PEAK_HBM) if traffic else None,
-                     "traffic_scope": "c3p::conv3p_kernel launches only (%d of the %d launches of the class): algorithmic "
+                     "traffic_scope": "patch-staged 3x3 launches (lg::lconv3_kernel + c3p::conv3p_kernel: %d of the %d launches of the class): algorithmic "
                                       "%.1f MB per launch" % (int(c3p_launches), conv_launches, c3p_bytes / max(c3p_launches, 1) / 1e6),
                      "measured_on": "one eager single-stream pass of one local batch right after the timed region: HIP "
                                     "events around every launch, each kernel alone on the chip (the timed region replays "

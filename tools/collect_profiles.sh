@@ -2,7 +2,7 @@
 # run on the GPU box: bench line + rocprofv3 kernel stats (timed regime and single-stream regime) + PMC traffic + MFMA util
 # usage: tools/collect_profiles.sh [round-tag]   -> gpurun_out/<tag>/ (copy what should be judged into profiles/)
 R=$GRAFT_REPO_ROOT; [ -z "$R" ] && R=/root/repo
-TAG=${1:-r02}
+TAG=${1:-r03}
 O=$R/gpurun_out/$TAG; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 # 1. the bench line (default flags = what the driver runs)
@@ -33,4 +33,9 @@ python $R/tools/pmc_mfma.py /tmp/pmc_mfma/p_counter_collection.csv > $O/mfma_uti
 (cd $R && python tools/bench_cu_share.py 2>/dev/null > $O/cu_share_sweep.txt)
 (cd $R && python tools/probes/stream_queues.py 12 2>/dev/null > $O/stream_queue_probe.txt)
 (cd $R && python tools/phase_times.py 2>/dev/null | grep -E "alone|predict_many|sampling only" > $O/phase_times.txt)
+# 8. round 3: GEMM shapes (lean family vs the 8-wave kernels), lean convolution vs conv3p (independent / dependent chains), trace of one step
+(cd $R && python tools/bench_gemm_shapes.py lean=0 lean=-1 2>/dev/null > $O/gemm_shapes.txt)
+(cd $R && python tools/check_lean_conv.py 2>/dev/null > $O/lean_conv.txt)
+(cd $R && UDT_DUAL_STREAM=0 python tools/trace_step.py 2>/dev/null > $O/trace_step.txt)
+(cd $R && python tools/bench_ops.py 2>/dev/null > $O/bench_ops.txt)
 ls -la $O; cut -c1-400 $O/bench.json; cat $O/traffic.json | head -30; head -30 $O/mfma_util.json

@@ -15,8 +15,16 @@ def totals(path, counter):
         if r["Counter_Name"] != counter:
             continue
         k = r["Kernel_Name"]
-        key = "conv3p" if "conv3p_kernel" in k else ("gemm8_conv" if ("gemm8_kernel" in k and "true, false" in k) else None)
-        if key:
+        keys = []
+        if "lconv3_kernel" in k:
+            keys = ["lconv3", "conv3"]               # lean patch-staged kernel (round 3); "conv3" = every patch-staged 3x3 launch
+        elif "conv3p_kernel" in k:
+            keys = ["conv3p", "conv3"]
+        elif "gemm8_kernel" in k and "true, false" in k:
+            keys = ["gemm8_conv"]
+        elif "lgemm_kernel" in k:
+            keys = ["lgemm"]
+        for key in keys:
             tot[key] += float(r["Counter_Value"]); n[key] += 1
     return tot, n
 
@@ -24,6 +32,8 @@ f2, nf2 = totals(sys.argv[1], "FETCH_SIZE"); w2, nw2 = totals(sys.argv[2], "WRIT
 f10, nf10 = totals(sys.argv[3], "FETCH_SIZE"); w10, nw10 = totals(sys.argv[4], "WRITE_SIZE")
 out = {}
 for k in f10:
+    if nf10[k] <= nf2[k] and k != "conv3":
+        pass
     def ext(t2, t10):
         u = (t10 - t2) / 8.0
         return 50 * u + (t2 - 2 * u)

@@ -836,16 +836,21 @@ bool lean_plan(const udt_gemm_desc* d, LeanPlan& t) {
   if (d->rowvec && ((d->ld_rowvec > 0 ? d->ld_rowvec : d->N) % 4 != 0)) return false;
   t.cfg = (mode > 0) ? mode : 1;
   if (!geglu && d->N % 160 == 0 && d->N % 128 != 0 && t.cfg == 1) t.cfg = 5;
+  // many tiles and a wide output: the 256 x 256 tile (8 waves, one workgroup per CU) halves the LDS-DMA instructions per MFMA.
+  // Measured (profiles/r03_gemm_shapes_256.txt): faster from ~2 tiles per CU up (32768x2560x320 GEGLU 93 -> 81 us,
+  // 32768x960x320 33 -> 32 us), slower below (every M <= 2048 shape)
+  if (mode <= 0 && d->N >= 768 && (long long)((d->M + 255) / 256) * ((d->N + 255) / 256) >= 2LL * device_cus()) t.cfg = 6;
   switch (t.cfg) {
     case 1: t.nw = 4; t.bm = 128; t.bn = 128; t.smem = 2 * (128 + 128) * ROW_BYTES; break;
     case 2: t.nw = 8; t.bm = 256; t.bn = 128; t.smem = 3 * (256 + 128) * ROW_BYTES; break;
     case 3: t.nw = 4; t.bm = 128; t.bn = 128; t.smem = 3 * (128 + 128) * ROW_BYTES; break;
     case 5: t.nw = 4; t.bm = 128; t.bn = 160; t.smem = 128 * 160 * 4; break;          // the fp32 staging rows exceed the ring
+    case 6: t.nw = 8; t.bm = 256; t.bn = 256; t.smem = 2 * (256 + 256) * ROW_BYTES; break;   // one per CU: 128x64 per wave
     default: return false;
   }
   {
     // the epilogue's fp32 staging rows re-use the ring (+ [BM][mean, rstd] behind them when two wave columns share rows)
-    const int epi = t.bm * t.bn * 4 + ((ln && t.cfg != 5) ? t.bm * 8 : 0);
+    const int epi = (t.cfg == 6 ? t.bm * t.bn : t.bm * t.bn * 4) + ((ln && t.cfg != 5) ? t.bm * 8 : 0);   // (cfg 6: passes of 32 rows per wave)
     if (t.smem < epi) t.smem = epi;
   }
   t.tiles_m = (d->M + t.bm - 1) / t.bm;
@@ -881,15 +886,15 @@ size_t lean_workspace(const LeanPlan& t) {
   return t.splitk > 1 ? G8_HEADER_BYTES + (size_t)t.tiles * t.splitk * t.bm * t.bn * sizeof(float) : 0;
 }
 
-template <int NW, int WGM, int WGN, int TM, int TN, int NST>
+template <int NW, int WGM, int WGN, int TM, int TN, int NST, int TMB = TM>
 hipError_t launch_lean(const lg::LParams& lp, const LeanPlan& t, bool geglu, bool ln, hipStream_t s) {
   static AttrOnce once[4];
   const void* fn;
   if constexpr (TN == 2) {
-    fn = geglu ? (ln ? (const void*)lg::lgemm_kernel<NW, WGM, WGN, TM, TN, NST, true, true> : (const void*)lg::lgemm_kernel<NW, WGM, WGN, TM, TN, NST, true, false>)
-               : (ln ? (const void*)lg::lgemm_kernel<NW, WGM, WGN, TM, TN, NST, false, true> : (const void*)lg::lgemm_kernel<NW, WGM, WGN, TM, TN, NST, false, false>);
+    fn = geglu ? (ln ? (const void*)lg::lgemm_kernel<NW, WGM, WGN, TM, TN, NST, true, true, TMB> : (const void*)lg::lgemm_kernel<NW, WGM, WGN, TM, TN, NST, true, false, TMB>)
+               : (ln ? (const void*)lg::lgemm_kernel<NW, WGM, WGN, TM, TN, NST, false, true, TMB> : (const void*)lg::lgemm_kernel<NW, WGM, WGN, TM, TN, NST, false, false, TMB>);
   } else {
-    fn = ln ? (const void*)lg::lgemm_kernel<NW, WGM, WGN, TM, TN, NST, false, true> : (const void*)lg::lgemm_kernel<NW, WGM, WGN, TM, TN, NST, false, false>;
+    fn = ln ? (const void*)lg::lgemm_kernel<NW, WGM, WGN, TM, TN, NST, false, true, TMB> : (const void*)lg::lgemm_kernel<NW, WGM, WGN, TM, TN, NST, false, false, TMB>;
   }
   hipError_t e = once[(geglu ? 2 : 0) + (ln ? 1 : 0)].ensure(fn, t.smem);
   if (e != hipSuccess) return e;
@@ -1181,6 +1186,7 @@ extern "C" int udt_gemm(const udt_gemm_desc* d, void* workspace, size_t workspac
         case 1: el = launch_lean<4, 2, 2, 2, 2, 2>(lp, lt, geglu, ln, s); break;
         case 2: el = launch_lean<8, 4, 2, 2, 2, 3>(lp, lt, geglu, ln, s); break;
         case 3: el = launch_lean<4, 2, 2, 2, 2, 3>(lp, lt, geglu, ln, s); break;
+        case 6: el = launch_lean<8, 2, 4, 4, 2, 2, 1>(lp, lt, geglu, ln, s); break;
         default: el = launch_lean<4, 4, 1, 1, 5, 2>(lp, lt, false, ln, s); break;
       }
       if (el != hipSuccess) return udt_set_hip_error(el);

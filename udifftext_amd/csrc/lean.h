@@ -70,8 +70,9 @@ UDT_DEVINL float dot2_bf16(uint32_t a, uint32_t b, float c) {
 
 // NW waves as WGM x WGN, each TM x TN MFMA tiles of 32x32; NST ring stages; GEGLU: weight rows packed [32 x | 32 gate]
 // per 64-column wave block (TN == 2); LN: LayerNorm folded into the weights, row statistics from the A fragments
-template <int NW, int WGM, int WGN, int TM, int TN, int NST, bool GEGLU, bool LN>
+template <int NW, int WGM, int WGN, int TM, int TN, int NST, bool GEGLU, bool LN, int TMB = TM>
 __global__ void __launch_bounds__(NW * 64, 2) lgemm_kernel(const LParams p) {
+  static_assert(TM % TMB == 0, "epilogue passes of TMB row tiles");
   static_assert(WGM * WGN == NW, "wave grid");
   static_assert(!GEGLU || TN == 2, "GEGLU pairs the two 32-column tiles of a wave");
   constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
@@ -81,7 +82,8 @@ __global__ void __launch_bounds__(NW * 64, 2) lgemm_kernel(const LParams p) {
   constexpr int LPT = A_INSTR + B_INSTR;
   constexpr int WROWS = TM * 32, WCOLS = TN * 32;
   constexpr int EROW = WCOLS * 4;                       // bytes of one fp32 row of the wave block
-  constexpr int EPI_WAVE = WROWS * EROW;                // (LN: + [BM][mean, rstd] behind the NW wave blocks)
+  constexpr int EPI_WAVE = TMB * 32 * EROW;             // fp32 staging rows of ONE epilogue pass (TMB of the wave's TM row tiles);
+                                                        // LN: + [BM][mean, rstd] behind the NW wave blocks
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x;
@@ -219,8 +221,10 @@ __global__ void __launch_bounds__(NW * 64, 2) lgemm_kernel(const LParams p) {
         }
       }
     }
-    __builtin_amdgcn_sched_group_barrier(0x100, 4 * (TM + TN), 0);    // all fragment reads of the K-tile ...
-    __builtin_amdgcn_sched_group_barrier(0x008, 4 * TM * TN, 0);      // ... ahead of its MFMAs (gemm8.h)
+    if constexpr (TM * TN <= 5) {
+      __builtin_amdgcn_sched_group_barrier(0x100, 4 * (TM + TN), 0);    // all fragment reads of the K-tile ...
+      __builtin_amdgcn_sched_group_barrier(0x008, 4 * TM * TN, 0);      // ... ahead of its MFMAs (gemm8.h)
+    }                                                                   // (128 x 64 wave tiles: the scheduler's own interleave)
     st = st + 1;
     if (st >= NST) st = 0;
   }
@@ -374,23 +378,14 @@ __global__ void __launch_bounds__(NW * 64, 2) lgemm_kernel(const LParams p) {
       if (m < p.M && col_ok) *reinterpret_cast<u32x4*>(p.out + (long long)m * p.ldo + n_out) = v;
     }
   } else {
-    // ---- epilogue: accumulators -> this wave's fp32 rows in LDS (16-byte chunks XOR-swizzled by row & 7) ----------------
+    // ---- epilogue: accumulators -> this wave's fp32 rows in LDS (16-byte chunks XOR-swizzled by row & 7), in TM / TMB
+    // passes of TMB * 32 rows (the 256 x 256 tile's accumulators exceed the LDS in one piece); a wave only ever touches
+    // its own staging block, and its LDS operations execute in order, so the passes need no barrier
     char* const wl = smem + wave * EPI_WAVE;
-#pragma unroll
-    for (int tm = 0; tm < TM; ++tm) {
-      const int row = tm * 32 + l31;
-#pragma unroll
-      for (int tn = 0; tn < TN; ++tn)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int chunk = (tn * 8 + q * 2 + hi) ^ (row & 7);
-          f32x4 v = {acc[tm][tn][q * 4 + 0], acc[tm][tn][q * 4 + 1], acc[tm][tn][q * 4 + 2], acc[tm][tn][q * 4 + 3]};
-          *reinterpret_cast<f32x4*>(wl + row * EROW + chunk * 16) = v;
-        }
-    }
+    constexpr int PROWS = TMB * 32;                      // rows per pass
     constexpr int CPR = TN * 4;                          // 8-column groups per wave row
     constexpr int RPI = 64 / CPR;                        // rows per instruction (8, or 3 with 4 idle lanes)
-    constexpr int NIT = (WROWS + RPI - 1) / RPI;
+    constexpr int NIT = (PROWS + RPI - 1) / RPI;
     const int rl = lane / CPR;
     const int c8 = lane - rl * CPR;
     const int n = n0 + col0 + c8 * 8;
@@ -406,68 +401,85 @@ __global__ void __launch_bounds__(NW * 64, 2) lgemm_kernel(const LParams p) {
         s1 = *reinterpret_cast<const f32x4*>(p.ln_s + n + 4);
       }
     }
-    // residual rows first (whole lines, all loads in flight together)
-    u32x4 rv[NIT];
-    if (p.res) {
+#pragma unroll
+    for (int pass = 0; pass < TM / TMB; ++pass) {
+      const int prow0 = pass * PROWS;                    // first wave row of this pass
+      // residual rows first (whole lines, all loads in flight together)
+      u32x4 rv[NIT];
+      if (p.res) {
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) {
+          const int row = i * RPI + rl;
+          const int m = m0 + row0 + prow0 + row;
+          u32x4 z = {0u, 0u, 0u, 0u};
+          rv[i] = z;
+          if (col_ok && row < PROWS && m < p.M) rv[i] = *reinterpret_cast<const u32x4*>(p.res + (long long)m * p.ldr + n);
+        }
+      }
+#pragma unroll
+      for (int tb = 0; tb < TMB; ++tb) {
+        const int row = tb * 32 + l31;
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int chunk = (tn * 8 + q * 2 + hi) ^ (row & 7);
+            const f32x16& a16 = acc[pass * TMB + tb][tn];
+            f32x4 v = {a16[q * 4 + 0], a16[q * 4 + 1], a16[q * 4 + 2], a16[q * 4 + 3]};
+            *reinterpret_cast<f32x4*>(wl + row * EROW + chunk * 16) = v;
+          }
+      }
 #pragma unroll
       for (int i = 0; i < NIT; ++i) {
         const int row = i * RPI + rl;
-        const int m = m0 + row0 + row;
-        u32x4 z = {0u, 0u, 0u, 0u};
-        rv[i] = z;
-        if (col_ok && row < WROWS && m < p.M) rv[i] = *reinterpret_cast<const u32x4*>(p.res + (long long)m * p.ldr + n);
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < NIT; ++i) {
-      const int row = i * RPI + rl;
-      const int m = m0 + row0 + row;
-      const bool ok = col_ok && row < WROWS && m < p.M;
-      const int rr = row < WROWS ? row : 0;
-      const char* rp = wl + rr * EROW;
-      const int sw = rr & 7;
-      const f32x4 v0 = *reinterpret_cast<const f32x4*>(rp + (((2 * c8) ^ sw) << 4));
-      const f32x4 v1 = *reinterpret_cast<const f32x4*>(rp + (((2 * c8 + 1) ^ sw) << 4));
-      float o[8];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        o[j] = v0[j];
-        o[4 + j] = v1[j];
-      }
-      if constexpr (LN) {
-        float mean, rstd;
-        row_stats(rr, mean, rstd);
+        const int m = m0 + row0 + prow0 + row;
+        const bool ok = col_ok && row < PROWS && m < p.M;
+        const int rr = row < PROWS ? row : 0;
+        const char* rp = wl + rr * EROW;
+        const int sw = rr & 7;
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(rp + (((2 * c8) ^ sw) << 4));
+        const f32x4 v1 = *reinterpret_cast<const f32x4*>(rp + (((2 * c8 + 1) ^ sw) << 4));
+        float o[8];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          o[j] = rstd * (o[j] - mean * s0[j]);
-          o[4 + j] = rstd * (o[4 + j] - mean * s1[j]);
+          o[j] = v0[j];
+          o[4 + j] = v1[j];
         }
-      }
+        if constexpr (LN) {
+          float mean, rstd;
+          row_stats(prow0 + rr, mean, rstd);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        o[j] = o[j] * p.alpha + b0[j];
-        o[4 + j] = o[4 + j] * p.alpha + b1[j];
-      }
-      if (p.rowvec && ok) {
-        const float* rvp = p.rowvec + (long long)(m / p.rows_per_batch) * p.ldrv + n;
-        const f32x4 r0 = *reinterpret_cast<const f32x4*>(rvp);
-        const f32x4 r1 = *reinterpret_cast<const f32x4*>(rvp + 4);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          o[j] += r0[j];
-          o[4 + j] += r1[j];
+          for (int j = 0; j < 4; ++j) {
+            o[j] = rstd * (o[j] - mean * s0[j]);
+            o[4 + j] = rstd * (o[4 + j] - mean * s1[j]);
+          }
         }
-      }
-      if (p.res) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          o[2 * j] += bf16_lo(rv[i][j]);
-          o[2 * j + 1] += bf16_hi(rv[i][j]);
+          o[j] = o[j] * p.alpha + b0[j];
+          o[4 + j] = o[4 + j] * p.alpha + b1[j];
         }
-      }
-      if (ok) {
-        u32x4 pk = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7])};
-        *reinterpret_cast<u32x4*>(p.out + (long long)m * p.ldo + n) = pk;
+        if (p.rowvec && ok) {
+          const float* rvp = p.rowvec + (long long)(m / p.rows_per_batch) * p.ldrv + n;
+          const f32x4 r0 = *reinterpret_cast<const f32x4*>(rvp);
+          const f32x4 r1 = *reinterpret_cast<const f32x4*>(rvp + 4);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            o[j] += r0[j];
+            o[4 + j] += r1[j];
+          }
+        }
+        if (p.res) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            o[2 * j] += bf16_lo(rv[i][j]);
+            o[2 * j + 1] += bf16_hi(rv[i][j]);
+          }
+        }
+        if (ok) {
+          u32x4 pk = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7])};
+          *reinterpret_cast<u32x4*>(p.out + (long long)m * p.ldo + n) = pk;
+        }
       }
     }
   }
