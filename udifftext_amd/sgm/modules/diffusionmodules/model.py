@@ -88,9 +88,11 @@ class MemoryEfficientAttnBlock(H._Packed):
     def _pack(self):
         c = self.in_channels
         f = lambda m: m.weight.reshape(c, c)
+        # (the biases are COPIED: `.float()` of an fp32 parameter is the parameter itself, and prepare(free_masters=True)
+        #  empties the parameters — an aliased bias silently became an empty tensor; found by the GPU checkpoint test)
         return (H.fuse_rows(f(self.q), f(self.k)), torch.cat([self.q.bias, self.k.bias]).float().contiguous(),
-                packing.pack_linear(f(self.v)), self.v.bias.float().contiguous(),
-                packing.pack_linear(f(self.proj_out)), self.proj_out.bias.float().contiguous())
+                packing.pack_linear(f(self.v)), packing.pad_bias(self.v.bias),
+                packing.pack_linear(f(self.proj_out)), packing.pad_bias(self.proj_out.bias))
 
     def forward(self, x, **kwargs):
         B, Hh, Ww, C = x.shape

@@ -221,7 +221,7 @@ class _EncoderLayer(H._Packed):
 
     def _pack(self):
         from udifftext_amd import packing
-        return packing.pack_linear(self.self_attn.in_proj_weight), self.self_attn.in_proj_bias.float().contiguous()
+        return packing.pack_linear(self.self_attn.in_proj_weight), packing.pad_bias(self.self_attn.in_proj_bias)   # (a COPY: own_masters() are released)
 
     def forward(self, x, B, Lc):
         d, Hh = self.d, self.heads

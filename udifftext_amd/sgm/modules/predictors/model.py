@@ -91,8 +91,8 @@ class _MHA(H._Packed):
     def _pack(self):
         C = self.dim
         w, b = self.in_proj_weight, self.in_proj_bias
-        return (packing.pack_linear(w[:C]), b[:C].float().contiguous(),
-                packing.pack_linear(w[C:]), b[C:].float().contiguous())
+        return (packing.pack_linear(w[:C]), b[:C].float().clone(),
+                packing.pack_linear(w[C:]), b[C:].float().clone())
 
     def project_kv(self, kv):
         """k|v rows of a key/value source [B, L, C] -> [B, L, 2C] (constant for the memory during decoding)"""
@@ -124,7 +124,7 @@ class _PatchEmbed(H._Packed):
 
     def _pack(self):
         w = self.proj.weight
-        return packing.pack_linear(w.reshape(w.shape[0], -1)), self.proj.bias.float().contiguous()
+        return packing.pack_linear(w.reshape(w.shape[0], -1)), packing.pad_bias(self.proj.bias)   # (a copy: never alias a master)
 
     def forward(self, img):
         """img fp32 [B, 3, H, W] -> tokens bf16 [B, (H/ph)*(W/pw), E]; token order y*W' + x as Conv2d + flatten(2)"""
