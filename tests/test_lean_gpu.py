@@ -1,0 +1,292 @@
+"""The lean co-resident kernel family of csrc/lean.h (every plain / GEGLU / LayerNorm-fed linear, the 1x1 and the 3x3
+stride-1 convolutions of the UNet run on it by default) against a plain PyTorch fp32 reference of the same op on the same
+bf16-rounded inputs, per tile configuration (forced through ``udt_debug_set``), with and without the ticket split-K, plus
+run-to-run bit-reproducibility (the split-K sums its slabs in slice order, not in arrival order).  ``pytest -m gpu``.
+
+Reference ops: nn.Linear / GEGLU / LayerNorm→Linear of sgm/modules/attention.py:83-99,310-339, nn.Conv2d 1x1 / 3x3 and
+Upsample→Conv2d of sgm/modules/diffusionmodules/openaimodel.py:96-133,262-282.
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+# stated tolerance: fp32-accumulated bf16 products + one bf16 rounding of the output (rel 2^-8); the LayerNorm-folded
+# form additionally rounds gamma*W to bf16 and subtracts mean*colsum in fp32 (cancellation), hence the wider bound
+REL_RMS = 6e-3
+REL_RMS_LN = 1e-2
+
+
+def _rel(a, b):
+    a, b = a.float(), b.float()
+    return ((a - b).pow(2).mean().sqrt() / b.pow(2).mean().sqrt().clamp_min(1e-30)).item()
+
+
+@pytest.fixture(scope="module")
+def env(cuda):
+    import udifftext_amd  # noqa: F401
+    from udifftext_amd import lib as L, ops as O, packing as P
+    lib = L.load()
+    assert lib.udt_device_arch_ok() == 1, "tests expect a gfx950 device"
+
+    class Env:
+        ops, packing, GEGLU = O, P, L.GEMM_GEGLU
+
+        @staticmethod
+        def dbg(key, val):
+            L.check(lib.udt_debug_set(key.encode(), int(val)), "udt_debug_set " + key)
+
+        @staticmethod
+        def reset():
+            for k in ("lean", "lean_splitk", "lean_conv"):
+                L.check(lib.udt_debug_set(k.encode(), -1), "udt_debug_set " + k)
+    yield Env
+    Env.reset()
+
+
+def _linear_case(env, dev, M, N, K, flags, res, rpb, seed=0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    x = torch.randn((M, K), generator=g).to(dev).bfloat16()
+    w = (torch.randn((N, K), generator=g) / math.sqrt(K)).to(dev) * (1.0 + torch.arange(N, device=dev)[:, None] / N)
+    b = torch.randn((N,), generator=g).to(dev)
+    wp, bp = env.packing.pack_geglu(w, b) if flags & env.GEGLU else (env.packing.pack_linear(w), b)
+    r = torch.randn((M, N // 2 if flags & env.GEGLU else N), generator=g).to(dev).bfloat16() if res else None
+    rv = torch.randn((M // rpb, N), generator=g).to(dev) if rpb else None
+    y = x.float() @ w.bfloat16().float().t() + b
+    if flags & env.GEGLU:
+        y = y[:, :N // 2] * F.gelu(y[:, N // 2:])
+    if rv is not None:
+        y = y + rv.repeat_interleave(rpb, 0)
+    if r is not None:
+        y = y + r.float()
+    return x, wp, bp, dict(residual=r, rowvec=rv, rows_per_batch=rpb, flags=flags), y
+
+
+LINEAR_CASES = [  # M, N, K, geglu, residual, rows_per_batch (time-embedding row vector)
+    (4096, 320, 320, False, True, 0),        # L0 proj_out + residual (128x160 tiles when automatic)
+    (4096, 960, 320, False, False, 0),       # fused q|k|v
+    (2048, 2560, 320, True, False, 0),       # GEGLU, N=2*1280
+    (2048, 640, 2560, False, True, 0),       # ff.net[2] + residual
+    (512, 1280, 5120, False, True, 0),       # deep K: ticket split-K candidates
+    (512, 10240, 1280, True, False, 0),      # L2/L3 GEGLU (256x256 tiles when automatic)
+    (1000, 328, 192, False, True, 0),        # ragged M, N not a tile multiple
+    (130, 136, 64, False, False, 0),         # one K tile, partial tiles both ways
+    (4096, 640, 640, False, True, 1024),     # rowvec per batch (emb_layers output added per sample)
+    (300, 1280, 1280, False, False, 100),
+]
+
+
+@pytest.mark.parametrize("cfg", [-1, 1, 2, 3])
+@pytest.mark.parametrize("case", LINEAR_CASES, ids=lambda c: "x".join(str(int(v)) for v in c))
+def test_lean_linear_vs_torch(env, cuda, cfg, case):
+    """cfg -1 = the library's own choice (incl. the 128x160 and 256x256 tiles), 1 / 2 / 3 = forced 4-wave 128x128
+    2-stage, 8-wave 256x128 3-stage, 4-wave 128x128 3-stage; each without and with forced split-K"""
+    M, N, K, geglu, res, rpb = case
+    x, wp, bp, kw, y = _linear_case(env, cuda, M, N, K, env.GEGLU if geglu else 0, res, rpb)
+    try:
+        env.dbg("lean", cfg)
+        for sk in (-1, 3):
+            env.dbg("lean_splitk", sk)
+            out = env.ops.linear(x, wp, bp, **kw)
+            torch.cuda.synchronize()
+            e = _rel(out, y)
+            assert math.isfinite(e) and e < REL_RMS, f"lean cfg {cfg} splitk {sk} {case}: rel rms {e:.3e}"
+    finally:
+        env.reset()
+
+
+def test_lean_matches_stream_k_kernels(env, cuda):
+    """same products through the 8-wave stream-K kernels (UDT_LEAN=0 path) and the lean family: both round an fp32
+    accumulator once, so they agree to one bf16 ulp of the output"""
+    for case in [(4096, 320, 320, False, True, 0), (512, 1280, 5120, False, True, 0), (2048, 2560, 320, True, False, 0)]:
+        M, N, K, geglu, res, rpb = case
+        x, wp, bp, kw, y = _linear_case(env, cuda, M, N, K, env.GEGLU if geglu else 0, res, rpb, seed=3)
+        try:
+            env.dbg("lean", 0)
+            old = env.ops.linear(x, wp, bp, **kw)
+            env.dbg("lean", -1)
+            new = env.ops.linear(x, wp, bp, **kw)
+        finally:
+            env.reset()
+        torch.cuda.synchronize()
+        d = (old.float() - new.float()).abs()
+        ulp = y.abs().clamp_min(1e-3) * 2.0 ** -7
+        assert (d <= ulp).all(), f"{case}: {(d > ulp).sum().item()} outputs differ by more than one bf16 ulp, max {d.max().item():.3e}"
+
+
+@pytest.mark.parametrize("M,N,K,geglu", [(4096, 960, 320, False), (2048, 5120, 640, True), (1024, 3840, 1280, False),
+                                         (777, 2560, 320, True), (512, 1280, 1280, False), (512, 10240, 1280, True)])
+def test_ln_gemm_fwd_vs_torch(env, cuda, M, N, K, geglu):
+    """udt_ln_gemm_fwd: LayerNorm folded into the GEMM — LN(x) W^T = rstd (x W'^T - mean s) + c on W' = gamma∘W — against
+    torch layer_norm → linear (→ GEGLU) in fp32, and against the unfused two-launch form"""
+    g = torch.Generator(device="cpu").manual_seed(5)
+    x = (torch.randn((M, K), generator=g) * 1.5 + 0.3).to(cuda).bfloat16()
+    w = (torch.randn((N, K), generator=g) / math.sqrt(K)).to(cuda)
+    b = torch.randn((N,), generator=g).to(cuda)
+    gamma = (1 + 0.1 * torch.randn((K,), generator=g)).to(cuda)
+    beta = (0.05 * torch.randn((K,), generator=g)).to(cuda)
+    y = F.layer_norm(x.float(), (K,), gamma, beta, 1e-5) @ w.t() + b
+    if geglu:
+        y = y[:, :N // 2] * F.gelu(y[:, N // 2:])
+    fl = env.GEGLU if geglu else 0
+    wf, cf, sf = env.packing.pack_ln_linear(w, b, gamma, beta, geglu=geglu)
+    try:
+        for cfg in (-1, 1, 2):
+            env.dbg("lean", cfg)
+            out = env.ops.ln_linear(x, wf, cf, sf, flags=fl)
+            torch.cuda.synchronize()
+            e = _rel(out, y)
+            assert math.isfinite(e) and e < REL_RMS_LN, f"ln_gemm cfg {cfg}: rel rms {e:.3e}"
+    finally:
+        env.reset()
+    wp, bp = env.packing.pack_geglu(w, b) if geglu else (env.packing.pack_linear(w), b)
+    two = env.ops.linear(env.ops.layer_norm(x, gamma, beta), wp, bp, flags=fl)
+    assert _rel(out, two) < REL_RMS_LN
+
+
+def test_ln_gemm_constant_rows_and_large_mean(env, cuda):
+    """edge cases of the folded form: a constant row (variance 0 -> rstd = 1/sqrt(eps), output = c exactly as torch gives
+    beta W^T + b) and rows with a mean far from 0 (the x W'^T - mean s cancellation)"""
+    M, N, K = 256, 640, 640
+    g = torch.Generator(device="cpu").manual_seed(6)
+    x = torch.randn((M, K), generator=g)
+    x[0] = 2.0
+    x[1] = 0.0
+    x[2:66] += 12.0
+    x = x.to(cuda).bfloat16()
+    w = (torch.randn((N, K), generator=g) / math.sqrt(K)).to(cuda)
+    b = torch.randn((N,), generator=g).to(cuda)
+    gamma = (1 + 0.1 * torch.randn((K,), generator=g)).to(cuda)
+    beta = (0.05 * torch.randn((K,), generator=g)).to(cuda)
+    y = F.layer_norm(x.float(), (K,), gamma, beta, 1e-5) @ w.t() + b
+    wf, cf, sf = env.packing.pack_ln_linear(w, b, gamma, beta)
+    out = env.ops.ln_linear(x, wf, cf, sf)
+    torch.cuda.synchronize()
+    assert torch.isfinite(out.float()).all()
+    # constant rows: |out - c| only carries the bf16 rounding of the output
+    assert (out[:2].float() - y[:2]).abs().max().item() < 2e-2
+    # shifted rows: tolerance scaled by the cancellation (|mean| / std = 12)
+    assert _rel(out[2:66], y[2:66]) < 3e-2
+    assert _rel(out[66:], y[66:]) < REL_RMS_LN
+
+
+@pytest.mark.parametrize("B,H,C1,C2,N", [(2, 64, 320, 320, 320), (2, 32, 640, 320, 640), (3, 16, 1280, 1280, 1280),
+                                          (4, 8, 1280, 1280, 1280), (2, 16, 128, 64, 192), (2, 32, 320, 0, 640)])
+def test_lean_conv1x1_two_sources(env, cuda, B, H, C1, C2, N):
+    """skip_connection of a decoder ResBlock: Conv2d 1x1 over cat([h, skip], C) without materialising the concat
+    (openaimodel.py:262-282 / th.cat at :1060)"""
+    g = torch.Generator(device="cpu").manual_seed(7)
+    x1 = torch.randn((B, H, H, C1), generator=g).to(cuda).bfloat16()
+    x2 = torch.randn((B, H, H, C2), generator=g).to(cuda).bfloat16() if C2 else None
+    w4 = (torch.randn((N, C1 + C2, 1, 1), generator=g) / math.sqrt(C1 + C2)).to(cuda)
+    b = torch.randn((N,), generator=g).to(cuda)
+    w = env.packing.pack_conv(w4, [C1, C2] if C2 else None)
+    xin = torch.cat([x1, x2], -1) if C2 else x1
+    y = F.conv2d(xin.float().permute(0, 3, 1, 2), w4.bfloat16().float(), b).permute(0, 2, 3, 1)
+    try:
+        for cfg in (-1, 1):
+            env.dbg("lean", cfg)
+            out = env.ops.conv2d(x1, w, b, ksize=1, x2=x2)
+            torch.cuda.synchronize()
+            e = _rel(out, y)
+            assert math.isfinite(e) and e < REL_RMS, f"conv1x1 cfg {cfg}: rel rms {e:.3e}"
+    finally:
+        env.reset()
+
+
+CONV3_CASES = [  # B, H, W, C, N, upsample, residual, rowvec
+    (2, 64, 64, 320, 320, False, True, True),      # L0 ResBlock convolutions (16x8 patches, N=320: ragged N tile)
+    (2, 32, 32, 640, 640, False, False, True),
+    (3, 16, 16, 1280, 1280, False, True, False),
+    (4, 8, 8, 1280, 1280, False, False, True),     # 8x8 maps: the 8x8-patch geometry
+    (2, 24, 40, 128, 256, False, True, False),     # non-square map, partial patches on both axes
+    (1, 20, 12, 64, 136, False, False, False),     # single input chunk, N not a multiple of the tile
+    (2, 16, 16, 1280, 1280, True, False, False),   # Upsample (nearest x2) folded into the patch staging
+    (2, 32, 32, 640, 640, True, False, False),
+    (1, 12, 20, 192, 128, True, False, False),
+    (2, 96, 96, 320, 320, False, True, True),      # config #4 (768 px) map size
+]
+
+
+@pytest.mark.parametrize("case", CONV3_CASES, ids=lambda c: "x".join(str(int(v)) for v in c))
+def test_lean_conv3x3_vs_torch(env, cuda, case):
+    B, H, W, C, N, ups, res, rowvec = case
+    g = torch.Generator(device="cpu").manual_seed(8)
+    x = torch.randn((B, H, W, C), generator=g).to(cuda).bfloat16()
+    w4 = (torch.randn((N, C, 3, 3), generator=g) / math.sqrt(9 * C)).to(cuda)
+    b = torch.randn((N,), generator=g).to(cuda)
+    Ho, Wo = (2 * H, 2 * W) if ups else (H, W)
+    r = torch.randn((B, Ho, Wo, N), generator=g).to(cuda).bfloat16() if res else None
+    rv = torch.randn((B, N), generator=g).to(cuda) if rowvec else None
+    xin = x.float().permute(0, 3, 1, 2)
+    if ups:
+        xin = F.interpolate(xin, scale_factor=2.0, mode="nearest")
+    y = F.conv2d(xin, w4.bfloat16().float(), b, padding=1).permute(0, 2, 3, 1)
+    if rv is not None:
+        y = y + rv[:, None, None, :]
+    if r is not None:
+        y = y + r.float()
+    w = env.packing.pack_conv(w4)
+    kw = dict(ksize=3, upsample=ups, residual=r, rowvec=rv)
+    try:
+        outs = {}
+        for lean_conv in (1, 0):                       # the lean patch kernel, then the 8-wave stream-K one
+            env.dbg("lean_conv", lean_conv)
+            out = env.ops.conv2d(x, w, b, **kw)
+            torch.cuda.synchronize()
+            e = _rel(out, y)
+            assert math.isfinite(e) and e < REL_RMS, f"conv3x3 lean_conv={lean_conv} {case}: rel rms {e:.3e}"
+            outs[lean_conv] = out
+        assert _rel(outs[1], outs[0]) < REL_RMS
+    finally:
+        env.reset()
+
+
+def test_lean_bit_reproducible_across_launches_and_streams(env, cuda):
+    """the ticket split-K adds its slabs in slice order whatever the arrival order, and the raw s_barrier is fenced by
+    s_waitcnt lgkmcnt(0): the same launch gives the same bits alone, repeated, and while a second stream keeps the device
+    busy with other lean launches (the race this guards against showed up only under dual-stream load)"""
+    M, N, K = 512, 1280, 5120
+    x, wp, bp, kw, _ = _linear_case(env, cuda, M, N, K, 0, True, 0, seed=11)
+    g = torch.Generator(device="cpu").manual_seed(12)
+    cx = torch.randn((2, 32, 32, 640), generator=g).to(cuda).bfloat16()
+    cw = env.packing.pack_conv((torch.randn((640, 640, 3, 3), generator=g) / math.sqrt(9 * 640)).to(cuda))
+    side = torch.cuda.Stream()
+    side_ws = env.ops.Workspace(cuda)
+    try:
+        env.dbg("lean_splitk", 4)
+        first = env.ops.linear(x, wp, bp, **kw).clone()
+        cfirst = env.ops.conv2d(cx, cw, None, ksize=3).clone()
+        torch.cuda.synchronize()
+        for it in range(6):
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side), env.ops.launch_context(cu_share=2, workspace=side_ws):
+                for _ in range(4):
+                    env.ops.conv2d(cx, cw, None, ksize=3)
+            out = env.ops.linear(x, wp, bp, **kw)
+            cout = env.ops.conv2d(cx, cw, None, ksize=3)
+            torch.cuda.synchronize()
+            assert torch.equal(out, first), f"split-K linear changed bits on repeat {it}"
+            assert torch.equal(cout, cfirst), f"3x3 convolution changed bits on repeat {it}"
+    finally:
+        env.reset()
+
+
+def test_lean_conv_plan_declines_what_it_does_not_cover(env, cuda):
+    """with the lean convolution forced on, problems outside its plan (fewer than 128 output channels; the stride-2
+    Downsample) still give the right product: the plan, not the caller, decides which kernel runs"""
+    g = torch.Generator(device="cpu").manual_seed(13)
+    for C, N, stride in [(128, 64, 1), (320, 320, 2)]:
+        x = torch.randn((2, 16, 16, C), generator=g).to(cuda).bfloat16()
+        w4 = (torch.randn((N, C, 3, 3), generator=g) / math.sqrt(9 * C)).to(cuda)
+        y = F.conv2d(x.float().permute(0, 3, 1, 2), w4.bfloat16().float(), None, stride=stride, padding=1).permute(0, 2, 3, 1)
+        try:
+            env.dbg("lean_conv", 1)
+            out = env.ops.conv2d(x, env.packing.pack_conv(w4), None, ksize=3, stride=stride)
+            torch.cuda.synchronize()
+        finally:
+            env.reset()
+        assert _rel(out, y) < REL_RMS
