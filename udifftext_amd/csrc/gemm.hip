@@ -905,7 +905,9 @@ hipError_t launch_lean(const lg::LParams& lp, const LeanPlan& t, bool geglu, boo
 // ---- lean 3x3 convolution (lean.h lconv3_kernel): host side ------------------------------------------------------------
 // udt_debug_set("lean_conv", v): -1 automatic (default: on), 0 off, 1 on
 std::atomic<int> g_lean_conv{-1};
-struct LeanConvPlan { lg::C3Params cp; };
+#ifdef UDT_MEASURE
+std::atomic<int> g_lconv_dbg{0};   // cost attribution of the lean convolution's loop (C3Params.dbg): wrong results
+#endif
 
 bool lean_conv_plan(const udt_gemm_desc* d, lg::C3Params& c) {
   int on = g_lean_conv.load(std::memory_order_relaxed);
@@ -930,6 +932,10 @@ bool lean_conv_plan(const udt_gemm_desc* d, lg::C3Params& c) {
   if ((reinterpret_cast<uintptr_t>(d->out) | reinterpret_cast<uintptr_t>(d->residual) | reinterpret_cast<uintptr_t>(d->bias) |
        reinterpret_cast<uintptr_t>(d->rowvec)) & 15) return false;
   if (d->rowvec && ((d->ld_rowvec > 0 ? d->ld_rowvec : d->N) % 4 != 0)) return false;
+  c.dbg = 0;
+#ifdef UDT_MEASURE
+  c.dbg = g_lconv_dbg.load(std::memory_order_relaxed);
+#endif
   c.N = d->N; c.C = d->C1; c.H = d->Hin; c.W = d->Win; c.B = d->M / (d->Hout * d->Wout);
   c.ldw = (int)ldw; c.ldo = d->ldo; c.ldr = d->ldr; c.ldrv = d->ld_rowvec > 0 ? d->ld_rowvec : d->N;
   c.alpha = d->alpha;
@@ -991,6 +997,7 @@ extern "C" int udt_debug_set(const char* key, int32_t value) {
   if (!strcmp(key, "lean_splitk")) { g_lean_splitk.store(value); return UDT_OK; }
   if (!strcmp(key, "lean_conv")) { g_lean_conv.store(value < 0 ? -1 : (value ? 1 : 0)); return UDT_OK; }
 #ifdef UDT_MEASURE
+  if (!strcmp(key, "lconv_dbg")) { g_lconv_dbg.store(value); return UDT_OK; }
   static const struct { const char* k; int bit; } bits[] = {{"no_xchg", 28}, {"no_epi", 27}, {"no_store", 26}, {"no_res", 25},
                                                             {"no_bias", 24}, {"no_fast", 22}};
   for (const auto& b : bits)

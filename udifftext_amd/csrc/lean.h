@@ -513,6 +513,7 @@ struct C3Params {
   int* counters;
   float* slabs;
   int geo, tw, th;         // host side: kernel instance (0: 16x8, 1: 8x8, 2: 16x8 upsampling) and its pixel tile
+  int dbg;                 // measurement builds only (UDT_DBG): bit 0 no weight DMA, 1 no patch DMA, 2 no MFMA, 3 no LDS fragment reads
 };
 
 // tile geometry: TW x TH output pixels (128 = 16 x 8: two 32-pixel MFMA tiles per wave; 64 = 8 x 8 for the 8 x 8 maps: one),
@@ -654,39 +655,53 @@ __global__ void __launch_bounds__(256, 2) lconv3_kernel(const C3Params p) {
       // weight tile of this tap is the youngest load
       if (tap == 1 && nxt) wait_vm<PP>(); else wait_vm<0>();
       raw_barrier();
-      if (tap < 8) issue_w(st ^ 1, c, tap + 1);
-      else if (nxt) issue_w(st ^ 1, c + 1, 0);
-      if (tap == 0 && nxt) issue_patch(c + 1);
+      if (!UDT_DBG(p.dbg, 0)) {
+        if (tap < 8) issue_w(st ^ 1, c, tap + 1);
+        else if (nxt) issue_w(st ^ 1, c + 1, 0);
+      }
+      if (tap == 0 && nxt && !UDT_DBG(p.dbg, 1)) issue_patch(c + 1);
       const int dy = tap / 3, dx = tap - dy * 3;
       const char* wbuf = wring + st * C3_W_BYTES;
       bf16x8_t fx[4][TM], fw[4][TN];
+      if (!UDT_DBG(p.dbg, 3)) {
 #pragma unroll
-      for (int t = 0; t < TM; ++t) {
-        int prow, yy;
-        if constexpr (UPS) {
-          const int py = a_prow[t] & 0xffff, px = a_prow[t] >> 16;
-          yy = ((py + dy - 1) >> 1) + 1;
-          prow = yy * C3_PW + (((px + dx - 1) >> 1) + 1);
-        } else {
-          yy = a_py[t] + dy;
-          prow = a_prow[t] + dy * C3_PW + dx;
+        for (int t = 0; t < TM; ++t) {
+          int prow, yy;
+          if constexpr (UPS) {
+            const int py = a_prow[t] & 0xffff, px = a_prow[t] >> 16;
+            yy = ((py + dy - 1) >> 1) + 1;
+            prow = yy * C3_PW + (((px + dx - 1) >> 1) + 1);
+          } else {
+            yy = a_py[t] + dy;
+            prow = a_prow[t] + dy * C3_PW + dx;
+          }
+          const int arow = prow * ROW_BYTES, aswz = patch_swz(prow, yy);
+#pragma unroll
+          for (int ks = 0; ks < 4; ++ks) fx[ks][t] = lds_read_frag(pbuf + arow + (((ks * 2 + hi) ^ aswz) << 4));
         }
-        const int arow = prow * ROW_BYTES, aswz = patch_swz(prow, yy);
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) fx[ks][t] = lds_read_frag(pbuf + arow + (((ks * 2 + hi) ^ aswz) << 4));
+        for (int ks = 0; ks < 4; ++ks) {
+          const int slot = ((ks * 2 + hi) ^ swz_w) << 4;
+#pragma unroll
+          for (int t = 0; t < TN; ++t) fw[ks][t] = lds_read_frag(wbuf + w_frag_row + t * 32 * ROW_BYTES + slot);
+        }
       }
+      if (UDT_DBG(p.dbg, 2)) {                           // measurement builds: keep the fragment reads, drop the MFMAs
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        const int slot = ((ks * 2 + hi) ^ swz_w) << 4;
+        for (int ks = 0; ks < 4; ++ks) {
 #pragma unroll
-        for (int t = 0; t < TN; ++t) fw[ks][t] = lds_read_frag(wbuf + w_frag_row + t * 32 * ROW_BYTES + slot);
+          for (int tm = 0; tm < TM; ++tm) asm volatile("" ::"v"(fx[ks][tm]));
+#pragma unroll
+          for (int tn = 0; tn < TN; ++tn) asm volatile("" ::"v"(fw[ks][tn]));
+        }
+      } else {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+          for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = mfma32(fw[ks][tn], fx[ks][tm], acc[tm][tn]);
       }
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-        for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-          for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = mfma32(fw[ks][tn], fx[ks][tm], acc[tm][tn]);
       st ^= 1;
     }
   }
