@@ -495,6 +495,16 @@ __global__ void __launch_bounds__(NW * 64, 2) lgemm_kernel(const LParams p) {
 // epilogue of lgemm_kernel (bias + time-embedding row vector + residual before the single bf16 rounding, 16-byte stores of
 // whole 128-byte lines).  ~190 VGPRs, no scratch, no stream-K residency contract.
 // Replaces nn.Conv2d(k=3, pad=1) of ResBlock / ResnetBlock (reference openaimodel.py:183-187,218-231; model.py:128-148).
+// s_waitcnt vmcnt(n) for a run-time n in 0 .. MAXN that the unrolled caller makes a constant
+template <int MAXN>
+UDT_DEVINL void wait_vm_upto(int n) {
+  if constexpr (MAXN == 0) wait_vm<0>();
+  else {
+    if (n >= MAXN) wait_vm<MAXN>();
+    else wait_vm_upto<MAXN - 1>(n);
+  }
+}
+
 struct C3Params {
   const uint16_t* a;
   const uint16_t* w;
@@ -529,7 +539,11 @@ struct C3Geo {
   static constexpr int PIECES = (PROWS + 7) / 8;
   static constexpr int PATCH_BYTES = PIECES * 1024;
   static constexpr int W_BYTES = 128 * ROW_BYTES;
-  static constexpr int RING = 2 * W_BYTES + 2 * PATCH_BYTES;
+  // weight ring: two stages (one tile in flight while one is consumed); THREE where the smaller patch of the 8 x 8 geometry
+  // leaves room inside 80 KiB — those are the deep layers whose weights stream from HBM once per launch (M = 512, K = 11520:
+  // 29 MB of weights for 15 GFLOP), i.e. the launches that wait on tile arrival
+  static constexpr int NRING = (3 * W_BYTES + 2 * PATCH_BYTES <= 80 * 1024) ? 3 : 2;
+  static constexpr int RING = NRING * W_BYTES + 2 * PATCH_BYTES;
   static constexpr int STAGING = 4 * TM * 32 * 256;        // fp32 rows of the epilogue
   static constexpr int SMEM = RING > STAGING ? RING : STAGING;
   static_assert(PX == 128 || PX == 64, "128 or 64 output pixels per workgroup");
@@ -548,7 +562,8 @@ __global__ void __launch_bounds__(256, 2) lconv3_kernel(const C3Params p) {
   constexpr int EROW = 64 * 4;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const wring = smem;
-  char* const patches = smem + 2 * C3_W_BYTES;
+  constexpr int NR = Geo::NRING;
+  char* const patches = smem + NR * C3_W_BYTES;
 
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -644,20 +659,29 @@ __global__ void __launch_bounds__(256, 2) lconv3_kernel(const C3Params p) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   issue_patch(c0);
-  issue_w(0, c0, 0);
+#pragma unroll
+  for (int j = 0; j < NR - 1; ++j) issue_w(j, c0, j);     // (a chunk has nine taps >= NR - 1)
   int st = 0;
   for (int c = c0; c < c1; ++c) {
     const bool nxt = (c + 1 < c1);
     const char* pbuf = patches + (c & 1) * C3_PATCH_BYTES;
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
-      // queue ahead of this wait (in order): tap 1: [W(c,1), patch(c+1)] -> leave the patch in flight; otherwise the
-      // weight tile of this tap is the youngest load
-      if (tap == 1 && nxt) wait_vm<PP>(); else wait_vm<0>();
+      // loads younger than this tap's weight tile, in issue order: the NR - 2 tiles after it (fewer at the very end) and,
+      // for taps 1 .. NR - 1 of a chunk that has a successor, the next patch (issued at tap 0 behind that tap's tile): they
+      // stay in flight, everything older has landed
+      {
+        const int w_ahead = nxt ? NR - 2 : ((8 - tap) < NR - 2 ? (8 - tap) : NR - 2);
+        const bool patch_ahead = nxt && tap >= 1 && tap <= NR - 1;
+        wait_vm_upto<(NR - 2) * WP + PP>(w_ahead * WP + (patch_ahead ? PP : 0));   // (folds to one s_waitcnt per tap)
+      }
       raw_barrier();
       if (!UDT_DBG(p.dbg, 0)) {
-        if (tap < 8) issue_w(st ^ 1, c, tap + 1);
-        else if (nxt) issue_w(st ^ 1, c + 1, 0);
+        const int ahead = tap + NR - 1;
+        int s2 = st + NR - 1;
+        if (s2 >= NR) s2 -= NR;
+        if (ahead < 9) issue_w(s2, c, ahead);
+        else if (nxt) issue_w(s2, c + 1, ahead - 9);
       }
       if (tap == 0 && nxt && !UDT_DBG(p.dbg, 1)) issue_patch(c + 1);
       const int dy = tap / 3, dx = tap - dy * 3;
@@ -702,7 +726,7 @@ __global__ void __launch_bounds__(256, 2) lconv3_kernel(const C3Params p) {
 #pragma unroll
             for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = mfma32(fw[ks][tn], fx[ks][tm], acc[tm][tn]);
       }
-      st ^= 1;
+      st = (st + 1 == NR) ? 0 : st + 1;
     }
   }
   raw_barrier();
