@@ -190,6 +190,18 @@ int udt_attn_rowv_fwd(const void* q, const void* k, const void* v, void* o,
                       int64_t q_bstride, int64_t k_bstride, int64_t v_bstride, int64_t o_bstride,
                       float scale, void* stream);
 
+/* Flash attention forward for ONE head of 512 dims: the AutoencoderKL mid-block attention (reference
+ * sgm/modules/diffusionmodules/model.py:236-260, MemoryEfficientAttnBlock.attention: xformers.ops.memory_efficient_attention on
+ * [B, H*W, 512]; AttnBlock.attention, model.py:169-190, is the same product through softmax(q k^T / sqrt(C)) v).
+ *   q, k, v : bf16 rows (b, tok) at x + b*x_bstride + tok*ldx, 512 dims each — they may be column ranges of ONE q|k|v projection
+ *   o       : bf16 rows of 512 dims (ldo); nq / nk arbitrary (keys past nk are masked), 16-byte aligned q / k / v, ld % 8 == 0.
+ * No [nq, nk] score tensor is materialised (the score tile of 32 queries x 32 keys lives in registers / LDS). */
+int udt_attn512_fwd(const void* q, const void* k, const void* v, void* o,
+                    int32_t batch, int32_t nq, int32_t nk,
+                    int32_t ldq, int32_t ldk, int32_t ldv, int32_t ldo,
+                    int64_t q_bstride, int64_t k_bstride, int64_t v_bstride, int64_t o_bstride,
+                    float scale, void* stream);
+
 /* Masked small attention (the OCR scorer's decoder: nn.MultiheadAttention of PARSeq's DecoderLayer, reference
  * src/parseq/strhub/models/parseq/modules.py:35-36,57-70 -> torch's scaled-dot-product with attn_mask and
  * key_padding_mask).  Few queries against a short key set, any head_dim that is a multiple of 8 up to 64:

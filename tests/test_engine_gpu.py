@@ -386,6 +386,28 @@ def test_vae_at_512_vs_oracle(engine, cuda):
     _check("VAE decoder 64x64 -> 512x512 vs oracle", dec.cpu(), ref_d, 2e-2, 8e-2)
 
 
+def test_vae_decode_flash_attention_d512_vs_oracle_and_block_form(engine, cuda, monkeypatch):
+    """the VAE mid-block attention through udt_attn512_fwd (forced: a single 64x64 latent has too few query blocks for the
+    automatic rule to pick it) against the oracle, and against the GEMM -> softmax -> GEMM block form on the same latent"""
+    from oracle import nets, spec
+    from sgm.modules.diffusionmodules import model as vmodel
+    cfg = spec.EngineConfig()
+    fs = engine.first_stage_model
+    sd = {k: v.detach().float().cpu() for k, v in engine.state_dict().items() if k.startswith("first_stage_model.")}
+    g = torch.Generator().manual_seed(19)
+    z = torch.randn((1, 4, 64, 64), generator=g) * 3.0
+    with torch.no_grad():
+        ref_d = nets.vae_decode(sd, z, cfg.vae)
+    monkeypatch.setattr(vmodel, "ATTN_FLASH_512", "1")
+    assert vmodel._flash512(4, 4096) and not vmodel._flash512(1, 4096)        # batch of 4: flash; one image: block form
+    monkeypatch.setattr(vmodel, "ATTN_FLASH_512", "2")
+    dec_flash = fs.decode(z.to(cuda))
+    monkeypatch.setattr(vmodel, "ATTN_FLASH_512", "0")
+    dec_block = fs.decode(z.to(cuda))
+    _check("VAE decoder 64x64 -> 512x512, flash attention (head_dim 512) vs oracle", dec_flash.cpu(), ref_d, 2e-2, 8e-2)
+    _check("VAE decoder: flash attention vs block form", dec_flash.cpu(), dec_block.cpu(), 1e-2, 4e-2)
+
+
 def test_graph_replay_matches_eager_launches(engine, cond256, cuda):
     """the sampler's hipGraph path (capture once per step index, replay; static conditioning buffers refreshed by
     rebind for the next batch) must give exactly the eager launch sequence's latent"""

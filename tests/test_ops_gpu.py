@@ -464,6 +464,37 @@ def test_flash_attention_spike(ops, cuda):
     _close(ops.attention_rowv(q, k2.contiguous(), v, H, 0.125), ref2, what="attn rowv slowly growing maximum")
 
 
+@pytest.mark.parametrize("B,N,Nk", [(2, 1024, 1024), (1, 4096, 4096), (3, 100, 77), (1, 33, 2050), (1, 9216, 9216), (4, 64, 64)])
+def test_flash_attention_d512(ops, cuda, B, N, Nk):
+    """udt_attn512_fwd (the VAE mid-block attention: one head of 512 dims, reference model.py:236-260) on the column ranges of
+    one q|k|v projection vs torch scaled_dot_product_attention in fp32; N = 9216 is the 768 x 768 decode (96 x 96 latents),
+    the ragged cases end inside a 32-query block / a 32-key tile"""
+    qkv = _rand((B, max(N, Nk), 3 * 512), cuda, seed=1).bfloat16()
+    q, k, v = qkv[:, :N, :512], qkv[:, :Nk, 512:1024], qkv[:, :Nk, 1024:]
+    out = ops.attention_d512(q, k, v, 512 ** -0.5)
+    ref = F.scaled_dot_product_attention(q.float(), k.float(), v.float())
+    _close(out, ref, what=f"attn512 {B,N,Nk}")
+    # the same launch twice: bit-identical (the four waves sum the partial score tiles in a fixed order)
+    assert torch.equal(out, ops.attention_d512(q, k, v, 512 ** -0.5))
+
+
+def test_flash_attention_d512_spike_and_block_form(ops, cuda):
+    """a late key that dominates one query (large online-softmax rescale), and agreement with the query-block
+    GEMM -> softmax -> GEMM form the VAE block used before (UDT_ATTN512=0)"""
+    B, N = 1, 640
+    q = _rand((B, N, 512), cuda, seed=1).bfloat16()
+    k = _rand((B, N, 512), cuda, seed=2).bfloat16()
+    v = _rand((B, N, 512), cuda, seed=3).bfloat16()
+    k[0, 500] = (q[0, 17].float() * 3).bfloat16()
+    out = ops.attention_d512(q, k, v, 512 ** -0.5)
+    ref = F.scaled_dot_product_attention(q.float(), k.float(), v.float())
+    _close(out, ref, what="attn512 spike")
+    s = ops.bmm_nt(q, k, alpha=512 ** -0.5)
+    ops.softmax_rows_(s)
+    blk = ops.bmm_nt(s, v.permute(0, 2, 1).contiguous())
+    _close(out, blk.float(), what="attn512 vs block form")
+
+
 @pytest.mark.parametrize("B,H,D,N,Lc", [(2, 5, 64, 1024, 12), (4, 20, 64, 64, 12), (3, 8, 256, 12, 12), (1, 10, 64, 300, 1)])
 def test_xattention(ops, cuda, B, H, D, N, Lc):
     Cc = H * D

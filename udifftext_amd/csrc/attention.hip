@@ -16,8 +16,10 @@
 //   self-attention).  VALU kernel: one lane per (query, head), K/V of the (batch, head) broadcast from LDS,
 //   optional write-out of the softmax probabilities ("attn_map_cache", attention.py:165-169).
 //
-// udt_softmax_rows: in-place row softmax (VAE single-head attention, model.py:246, computed as
-//   GEMM -> softmax -> GEMM because head_dim = 512 does not fit a register-resident flash tile).
+// udt_attn512_fwd: flash attention forward for ONE head of 512 dims (the AutoencoderKL mid-block attention, model.py:236-260):
+//   the head dimension is split over the four waves of a workgroup (attn_d512_body).
+//
+// udt_softmax_rows: in-place row softmax (the VAE attention's earlier GEMM -> softmax -> GEMM form, kept for A/B).
 #include "common.h"
 #include <stdio.h>
 #include <stdlib.h>
@@ -436,6 +438,258 @@ __global__ void __launch_bounds__(256, 3) attn_d64_v2_kernel(const AttnParams p)
 }
 
 // ---------------------------------------------------------------------------------------------------
+// head_dim 512, one head (the AutoencoderKL mid-block attention, reference sgm/modules/diffusionmodules/model.py:236-260:
+// xformers.ops.memory_efficient_attention on [B, H*W, 512]).  512 dims do not fit one wave's registers (O alone would be
+// 256 accumulator registers per 32 queries), so the head dimension is SPLIT OVER THE FOUR WAVES of a workgroup:
+//   * one workgroup = 32 queries; a K|V stage = 32 keys x 512 dims of each, kept as 8 + 8 sub-tiles of [32 keys][64 dims]
+//     in the 128-byte-row swizzled image of the head_dim-64 kernel (so its fragment / transpose-read addressing carries over);
+//   * wave w owns dims 128w .. 128w+127: it accumulates the PARTIAL scores S^T_w = K[:, dims_w] Q^T[dims_w, :] (8 MFMAs), the
+//     four partial tiles are exchanged through LDS (fp32, 4 KiB per wave) and summed by every wave in the same order (so all
+//     waves hold bit-identical scores, maxima and sums), each wave runs the online softmax redundantly (16 exponentials per
+//     lane and tile) and then accumulates ITS 128 output dims O^T_w += V^T[dims_w, :] P^T (8 MFMAs);
+//   * two stages of 64 KiB (the next K|V tile is in flight while one is consumed) + 16 KiB of exchange = 144 KiB, one
+//     workgroup per CU.  No [N, N] score tensor exists anywhere.
+template <int N> UDT_DEVINL void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+struct Attn512Params {
+  const uint16_t* q;
+  const uint16_t* k;
+  const uint16_t* v;
+  uint16_t* o;
+  const uint16_t* zero;
+  int nq, nk;
+  int ldq, ldk, ldv, ldo;
+  long long sq, sk, sv, so;
+  float scale_log2e;
+};
+constexpr int A5_KEYS = 32;
+constexpr int A5_SUB = A5_KEYS * 128;              // one [32 keys][64 dims] sub-tile
+constexpr int A5_HALF = 8 * A5_SUB;                // K (or V) part of a stage: 32 KiB
+constexpr int A5_STAGE = 2 * A5_HALF;
+template <int QT> constexpr int a5_smem() { return 2 * A5_STAGE + 4 * QT * 4096; }
+
+// QT: 32-query tiles per workgroup = groups of four waves (QT = 2: eight waves, two per SIMD — the second group halves the
+// K|V bytes staged per FLOP and gives every SIMD a second wave to issue while the first waits on LDS / MFMA results; one
+// wave per SIMD, which is all a 144 KiB workgroup of four waves allows, left every latency exposed: 274 -> 365 TFLOP/s with
+// two query tiles per WAVE, see profiles/r03_attn512.txt).
+// Staging order: K and V halves of a stage are refilled SEPARATELY as soon as they are free — K(t + 2) right after the score
+// exchange barrier of tile t (every wave is past its K reads), V(t + 1) right after the top barrier of tile t (every wave is
+// past P V of tile t - 1).
+template <int QT>
+UDT_DEVINL void attn_d512_body(const Attn512Params& p) {
+  constexpr int NWV = 4 * QT;                              // waves per workgroup
+  constexpr int PCS = 32 / NWV;                            // K (and V) pieces per wave and tile
+  extern __shared__ __attribute__((aligned(16))) char smem5[];
+  char* const xch = smem5 + 2 * A5_STAGE;
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = tid & 63;
+  const int l31 = lane & 31;
+  const int hi = lane >> 5;
+  const int qt = wave >> 2, dw = wave & 3;                 // query tile, dims quarter
+  const int b = blockIdx.y;
+  const uint16_t* __restrict__ Q = p.q + (long long)b * p.sq;
+  const uint16_t* __restrict__ K = p.k + (long long)b * p.sk;
+  const uint16_t* __restrict__ V = p.v + (long long)b * p.sv;
+  uint16_t* __restrict__ O = p.o + (long long)b * p.so;
+  const int qi = blockIdx.x * (32 * QT) + qt * 32 + l31;
+  const bool qok = qi < p.nq;
+  const int d0 = dw * 128;                                 // this wave's dims
+  bf16x8_t qf[8];
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) {
+    const uint16_t* g = qok ? (Q + (long long)qi * p.ldq + d0 + ks * 16 + hi * 8) : p.zero;
+    qf[ks] = *reinterpret_cast<const bf16x8_t*>(g);
+  }
+  // staging: 32 K pieces + 32 V pieces of 1 KiB (8 keys x 128 B of one sub-tile) per tile, PCS + PCS per wave
+  const int l3 = lane >> 3, pslot = lane & 7;
+  const unsigned kbytes = (unsigned)(((long long)(p.nk - 1) * p.ldk + 512) * 2);
+  const unsigned vbytes = (unsigned)(((long long)(p.nk - 1) * p.ldv + 512) * 2);
+  const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(K), 0, kbytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(V), 0, vbytes, 0x00020000);
+  unsigned kvo[PCS], vvo[PCS];
+#pragma unroll
+  for (int i = 0; i < PCS; ++i) {
+    const int piece = wave + NWV * i;                      // sub-tile piece >> 2, key rows (piece & 3) * 8 ..
+    const int sub = piece >> 2, row = (piece & 3) * 8 + l3;
+    const int doff = sub * 64 + (pslot ^ ((row >> 1) & 7)) * 8;
+    kvo[i] = (unsigned)(((long long)row * p.ldk + doff) * 2);
+    vvo[i] = (unsigned)(((long long)row * p.ldv + doff) * 2);
+  }
+  const int kstep = A5_KEYS * p.ldk * 2, vstep = A5_KEYS * p.ldv * 2;          // bytes per 32-key tile
+  auto stage_k = [&](int kt) {
+    char* kbuf = smem5 + (kt & 1) * A5_STAGE;
+#pragma unroll
+    for (int i = 0; i < PCS; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, (__attribute__((address_space(3))) void*)(kbuf + (wave + NWV * i) * 1024), 16, kvo[i], kt * kstep, 0, 0);
+  };
+  auto stage_v = [&](int kt) {
+    char* vbuf = smem5 + (kt & 1) * A5_STAGE + A5_HALF;
+#pragma unroll
+    for (int i = 0; i < PCS; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (__attribute__((address_space(3))) void*)(vbuf + (wave + NWV * i) * 1024), 16, vvo[i], kt * vstep, 0, 0);
+  };
+  // per-lane LDS offsets inside a sub-tile (as attn_d64_v2_kernel)
+  const int swz = (l31 >> 1) & 7;
+  int koff_l[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) koff_l[ks] = l31 * 128 + (((ks * 2 + hi) ^ swz) << 4);
+  const int tr_i = lane & 15, tr_g1 = (lane >> 4) & 1;
+  const int tr_row = 4 * hi + (tr_i >> 2);
+  const int tr_swz = (tr_row >> 1) & 7;
+  const int tr_chunk = 2 * tr_g1 + ((tr_i & 3) >> 1);
+  const int tr_base = tr_row * 128 + (tr_i & 1) * 8;
+  int voff_a[2], voff_b[2];
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt) {
+    const int c = dt * 4 + tr_chunk;
+    voff_a[dt] = tr_base + ((c ^ tr_swz) << 4);
+    voff_b[dt] = tr_base + 1024 + ((c ^ tr_swz ^ 4) << 4);
+  }
+  const int sub0 = dw * 2;                                 // this wave's two sub-tiles (128 dims)
+  char* const xq = xch + qt * (4 * 4096);                  // exchange area of this query tile's four waves
+
+  f32x16 o_acc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o_acc[i][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+  const int ntiles = (p.nk + A5_KEYS - 1) / A5_KEYS;
+  const float c = p.scale_log2e;
+  // issue order: K(0) V(0) K(1) | tile t: [top barrier] V(t+1) ... [exchange barrier] K(t+2)
+  stage_k(0);
+  stage_v(0);
+  if (ntiles > 1) stage_k(1);
+  for (int kt = 0; kt < ntiles; ++kt) {
+    const int st = kt & 1;
+    // K(kt) landed: the loads behind it are V(kt) and K(kt+1) (PCS + PCS per wave) while both exist
+    if (kt + 2 < ntiles) wait_vm<2 * PCS>(); else wait_vm<0>();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                          // every wave is past P V of tile kt - 1: V slot (kt+1)&1 and xch are free
+    asm volatile("" ::: "memory");
+    if (kt + 1 < ntiles) stage_v(kt + 1);
+    const char* kbuf = smem5 + st * A5_STAGE;
+    const char* vbuf = kbuf + A5_HALF;
+    // partial scores over this wave's 128 dims: two accumulators (one per sub-tile) keep the MFMA chain from serialising
+    f32x16 sp0, sp1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sp0[r] = 0.f, sp1[r] = 0.f;
+    {
+      bf16x8_t kf0[4], kf1[4];
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        kf0[ks] = lds_read_frag(kbuf + sub0 * A5_SUB + koff_l[ks]);
+        kf1[ks] = lds_read_frag(kbuf + (sub0 + 1) * A5_SUB + koff_l[ks]);
+      }
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        sp0 = mfma32(kf0[ks], qf[ks], sp0);
+        sp1 = mfma32(kf1[ks], qf[4 + ks], sp1);
+      }
+    }
+    // exchange: xq[dw][q4][lane] (16 B), then every wave of the query tile sums the four partial tiles in the same order
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4) {
+      f32x4 v = {sp0[q4 * 4 + 0] + sp1[q4 * 4 + 0], sp0[q4 * 4 + 1] + sp1[q4 * 4 + 1], sp0[q4 * 4 + 2] + sp1[q4 * 4 + 2],
+                 sp0[q4 * 4 + 3] + sp1[q4 * 4 + 3]};
+      *reinterpret_cast<f32x4*>(xq + dw * 4096 + q4 * 1024 + lane * 16) = v;
+    }
+    // V(kt) landed too (behind it: K(kt+1), V(kt+1))
+    if (kt + 2 < ntiles) wait_vm<2 * PCS>(); else wait_vm<0>();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                          // every wave is past its K reads of tile kt: K slot kt&1 is free
+    asm volatile("" ::: "memory");
+    if (kt + 2 < ntiles) stage_k(kt + 2);
+    f32x16 s;
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4) {
+      f32x4 a = *reinterpret_cast<const f32x4*>(xq + q4 * 1024 + lane * 16);
+#pragma unroll
+      for (int w = 1; w < 4; ++w) {
+        const f32x4 t = *reinterpret_cast<const f32x4*>(xq + w * 4096 + q4 * 1024 + lane * 16);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) a[e] += t[e];
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) s[q4 * 4 + e] = a[e];
+    }
+    if (kt * A5_KEYS + A5_KEYS > p.nk) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = kt * A5_KEYS + 8 * (r >> 2) + 4 * hi + (r & 3);
+        if (key >= p.nk) s[r] = -INFINITY;
+      }
+    }
+    float mx = s[0];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float m_new = fmaxf(m_run, mx * c);
+    if (!__all(m_new == m_run)) {                          // (wave-uniform: skip the 64 multiplies when no maximum moved)
+      const float alpha = fast_exp2(m_run - m_new);
+      m_run = m_new;
+      l_run *= alpha;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o_acc[i][r] *= alpha;
+    }
+    float psum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float pv = fast_exp2(s[r] * c - m_run);
+      s[r] = pv;
+      psum += pv;
+    }
+    l_run += psum;
+    typedef short v4s __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(3))) v4s* lds_v4s;
+#pragma unroll
+    for (int s4 = 0; s4 < 2; ++s4) {                       // two 16-key steps
+      u32x4 pk;
+      pk[0] = pack_bf16x2(s[s4 * 8 + 0], s[s4 * 8 + 1]);
+      pk[1] = pack_bf16x2(s[s4 * 8 + 2], s[s4 * 8 + 3]);
+      pk[2] = pack_bf16x2(s[s4 * 8 + 4], s[s4 * 8 + 5]);
+      pk[3] = pack_bf16x2(s[s4 * 8 + 6], s[s4 * 8 + 7]);
+      const bf16x8_t pf = __builtin_bit_cast(bf16x8_t, pk);
+      u32x4 vv[4];
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          const char* sb = vbuf + (sub0 + j) * A5_SUB + s4 * 2048;
+          const v4s a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s)(sb + voff_a[dt]));
+          const v4s b8 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s)(sb + voff_b[dt]));
+          const u32x2 lo = __builtin_bit_cast(u32x2, a), hh = __builtin_bit_cast(u32x2, b8);
+          const u32x4 w = {lo[0], lo[1], hh[0], hh[1]};
+          vv[j * 2 + dt] = w;
+        }
+#pragma unroll
+      for (int t = 0; t < 4; ++t) o_acc[t] = mfma32(__builtin_bit_cast(bf16x8_t, vv[t]), pf, o_acc[t]);
+    }
+  }
+  const float l_tot = l_run + __shfl_xor(l_run, 32);
+  const float inv = 1.0f / l_tot;
+  if (qok) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) {
+        const int d = d0 + t * 32 + qd * 8 + hi * 4;
+        u32x2 pk = {pack_bf16x2(o_acc[t][qd * 4 + 0] * inv, o_acc[t][qd * 4 + 1] * inv),
+                    pack_bf16x2(o_acc[t][qd * 4 + 2] * inv, o_acc[t][qd * 4 + 3] * inv)};
+        *reinterpret_cast<u32x2*>(O + (long long)qi * p.ldo + d) = pk;
+      }
+  }
+}
+
+// (two plain kernels around the template body: a launch bound that depends on a template parameter left the host stub of an
+//  anonymous-namespace kernel template undefined at link time)
+__global__ void __launch_bounds__(256, 1) attn_d512_q32_kernel(const Attn512Params p) { attn_d512_body<1>(p); }
+__global__ void __launch_bounds__(512, 1) attn_d512_q64_kernel(const Attn512Params p) { attn_d512_body<2>(p); }
+
+// ---------------------------------------------------------------------------------------------------
 // short-context attention: L <= 16 keys, head_dim a multiple of 64
 struct XattnParams {
   const uint16_t* q;
@@ -629,6 +883,51 @@ extern "C" int udt_attn_rowv_fwd(const void* q, const void* k, const void* v, vo
                                  float scale, void* stream) {
   return attn_fwd_impl(true, q, k, v, o, batch, heads, nq, nk, ldq, ldk, ldv, ldo, q_bstride, k_bstride, v_bstride,
                        o_bstride, scale, stream);
+}
+
+extern "C" int udt_attn512_fwd(const void* q, const void* k, const void* v, void* o, int32_t batch, int32_t nq, int32_t nk,
+                               int32_t ldq, int32_t ldk, int32_t ldv, int32_t ldo,
+                               int64_t q_bstride, int64_t k_bstride, int64_t v_bstride, int64_t o_bstride,
+                               float scale, void* stream) {
+  if (!q || !k || !v || !o) return UDT_ERR_BAD_ARG;
+  if (batch <= 0 || nq <= 0 || nk <= 0) return UDT_ERR_BAD_SHAPE;
+  if (ldq % 8 != 0 || ldk % 8 != 0 || ldv % 8 != 0 || ldo % 4 != 0 || ldq < 512 || ldk < 512 || ldv < 512 || ldo < 512) return UDT_ERR_BAD_SHAPE;
+  if ((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(k) | reinterpret_cast<uintptr_t>(v)) & 15) return UDT_ERR_BAD_SHAPE;
+  if (reinterpret_cast<uintptr_t>(o) & 7) return UDT_ERR_BAD_SHAPE;
+  if ((long long)nk * ldk * 2 >= (1LL << 31) || (long long)nk * ldv * 2 >= (1LL << 31)) return UDT_ERR_BAD_SHAPE;
+  if (batch > 65535) return UDT_ERR_BAD_SHAPE;
+  Attn512Params p;
+  p.q = reinterpret_cast<const uint16_t*>(q);
+  p.k = reinterpret_cast<const uint16_t*>(k);
+  p.v = reinterpret_cast<const uint16_t*>(v);
+  p.o = reinterpret_cast<uint16_t*>(o);
+  p.zero = udt_zero_page();
+  if (!p.zero) return UDT_ERR_HIP;
+  p.nq = nq; p.nk = nk;
+  p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo;
+  p.sq = q_bstride; p.sk = k_bstride; p.sv = v_bstride; p.so = o_bstride;
+  p.scale_log2e = scale * 1.4426950408889634f;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  UdtProfScope prof(2, s);
+  if (prof.rec) {
+    char tag[96];
+    snprintf(tag, sizeof(tag), "attn512 B=%d nq=%d nk=%d", batch, nq, nk);
+    udt_prof_tag(prof.rec, tag);
+  }
+  // 64 queries (eight waves) per workgroup when that still gives every CU work; 32 otherwise (UDT_ATTN512_TQ=1|2 forces one: A/B)
+  static const int tq_force = [] { const char* e = getenv("UDT_ATTN512_TQ"); return e ? atoi(e) : 0; }();
+  const bool two = tq_force ? tq_force == 2 : ((long long)((nq + 63) / 64) * batch >= 224);
+  static std::atomic<int> attr_done{0};
+  if (!attr_done.load()) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_d512_q32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, a5_smem<1>());
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_d512_q64_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, a5_smem<2>());
+    if (e != hipSuccess) return udt_set_hip_error(e);
+    attr_done.store(1);
+  }
+  if (two) hipLaunchKernelGGL(attn_d512_q64_kernel, dim3((nq + 63) / 64, batch), dim3(512), a5_smem<2>(), s, p);
+  else hipLaunchKernelGGL(attn_d512_q32_kernel, dim3((nq + 31) / 32, batch), dim3(256), a5_smem<1>(), s, p);
+  UDT_CHECK_LAUNCH();
+  return UDT_OK;
 }
 
 extern "C" int udt_xattn_fwd(const void* q, const void* k, const void* v, void* o, float* probs, int32_t batch,

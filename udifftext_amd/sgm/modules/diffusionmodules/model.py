@@ -5,11 +5,13 @@ Module tree and state-dict names follow reference sgm/modules/diffusionmodules/m
                             add fused in the second conv's epilogue (temb_channels = 0 on this path)
   Downsample  :71-88        zero pad right/bottom then conv3x3 stride 2 pad 0 == gather with pad_t = pad_l = 0
   Upsample    :55-68        nearest x2 folded into the conv gather
-  MemoryEfficientAttnBlock :201-262   single head, head_dim = C = 512: q|k GEMM, V^T GEMM, batched QK^T GEMM
-                            (scale folded in), row softmax, batched P·V GEMM, proj_out with fused residual
+  MemoryEfficientAttnBlock :201-262   single head, head_dim = C = 512: one q|k|v GEMM, the head_dim-512 flash kernel
+                            (udt_attn512_fwd), proj_out with fused residual
   Encoder :482-596 / Decoder :599-743
 """
 from __future__ import annotations
+
+import os
 
 import torch
 import torch.nn as nn
@@ -69,6 +71,19 @@ class ResnetBlock(nn.Module):
         return self.conv2(h, residual=skip, norm=self.norm2, norm_silu=True, colstats=True)
 
 
+# The VAE mid-block attention (one head of 512 dims) runs on the flash kernel udt_attn512_fwd when its grid of 64-query
+# workgroups covers at least half of the CUs (a batch of 4 at 512 x 512: 256 workgroups, 283 us vs 326 us for the block form);
+# a single image (64 workgroups, each walking all 4096 keys alone) is faster as GEMM -> softmax -> GEMM in query blocks
+# (159 us vs 222 us, profiles/r03_attn512.txt).  UDT_ATTN512=0 never / 2 always uses the flash kernel (A/B).
+ATTN_FLASH_512 = os.environ.get("UDT_ATTN512", "1")
+
+
+def _flash512(batch: int, n: int) -> bool:
+    if ATTN_FLASH_512 == "0":
+        return False
+    return ATTN_FLASH_512 == "2" or ((n + 63) // 64) * batch >= 128
+
+
 class MemoryEfficientAttnBlock(H._Packed):
     def __init__(self, in_channels):
         super().__init__()
@@ -90,27 +105,32 @@ class MemoryEfficientAttnBlock(H._Packed):
         f = lambda m: m.weight.reshape(c, c)
         # (the biases are COPIED: `.float()` of an fp32 parameter is the parameter itself, and prepare(free_masters=True)
         #  empties the parameters — an aliased bias silently became an empty tensor; found by the GPU checkpoint test)
-        return (H.fuse_rows(f(self.q), f(self.k)), torch.cat([self.q.bias, self.k.bias]).float().contiguous(),
+        # one q|k|v projection (V row-major) for the flash kernel AND the separate V^T projection of the block form
+        return (H.fuse_rows(f(self.q), f(self.k), f(self.v)), torch.cat([self.q.bias, self.k.bias, self.v.bias]).float().contiguous(),
                 packing.pack_linear(f(self.v)), packing.pad_bias(self.v.bias),
                 packing.pack_linear(f(self.proj_out)), packing.pad_bias(self.proj_out.bias))
 
     def forward(self, x, **kwargs):
         B, Hh, Ww, C = x.shape
         N = Hh * Ww
-        wqk, bqk, wv, bv, wo, bo = self.packed()
         hn = self.norm(x).reshape(B * N, C)
-        qk = ops.linear(hn, wqk, bqk).reshape(B, N, 2 * C)
-        vt = ops.linear(hn, wv, bv, flags=H.GEMM_TRANSPOSED, rows_per_batch=N)       # [B, C, N]
-        # head_dim = 512 does not fit the register-resident flash tile of udt_attn_rowv_fwd; the scores are materialised in
-        # QUERY BLOCKS of <= 1024 rows (GEMM -> row softmax -> GEMM per block): [B, 1024, N] bf16 stays cache-resident (19 MB
-        # per image at 768x768) instead of a [B, N, N] tensor (170 MB per image there); the results are identical row for row
-        o = torch.empty((B, N, C), dtype=torch.bfloat16, device=x.device)
-        QB = 1024
-        for q0 in range(0, N, QB):
-            q1 = min(N, q0 + QB)
-            s = ops.bmm_nt(qk[:, q0:q1, :C], qk[..., C:], alpha=C ** -0.5)           # [B, q1 - q0, N]
-            ops.softmax_rows_(s)
-            ops.bmm_nt(s, vt, out=o[:, q0:q1])
+        wqkv, bqkv, wv, bv, wo, bo = self.packed()
+        if C == 512 and _flash512(B, N):
+            # one q|k|v projection, then the head_dim-512 flash kernel (udt_attn512_fwd): the score tile never leaves the CU
+            qkv = ops.linear(hn, wqkv, bqkv).reshape(B, N, 3 * C)
+            o = ops.attention_d512(qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:], C ** -0.5)
+        else:
+            qk = ops.linear(hn, wqkv[:2 * C], bqkv[:2 * C]).reshape(B, N, 2 * C)
+            vt = ops.linear(hn, wv, bv, flags=H.GEMM_TRANSPOSED, rows_per_batch=N)       # [B, C, N]
+            # small grids / other widths: the scores are materialised in QUERY BLOCKS of <= 1024 rows (GEMM -> row softmax ->
+            # GEMM per block): [B, 1024, N] bf16 instead of a [B, N, N] tensor
+            o = torch.empty((B, N, C), dtype=torch.bfloat16, device=x.device)
+            QB = 1024
+            for q0 in range(0, N, QB):
+                q1 = min(N, q0 + QB)
+                s = ops.bmm_nt(qk[:, q0:q1, :C], qk[..., C:], alpha=C ** -0.5)           # [B, q1 - q0, N]
+                ops.softmax_rows_(s)
+                ops.bmm_nt(s, vt, out=o[:, q0:q1])
         out = ops.linear(o.reshape(B * N, C), wo, bo, residual=x.reshape(B * N, C), rows_per_batch=N, colstats=H.FUSE_GN)
         return H.carry_stats(out.reshape(B, Hh, Ww, C), out)
 
