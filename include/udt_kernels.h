@@ -266,6 +266,14 @@ int udt_gn_finalize(const float* stats1, int32_t slots1, int32_t C1, const float
                     const float* gamma, const float* beta, float* scsh, int32_t B, int64_t HW, int32_t G, float eps,
                     void* stream);
 
+/* GroupNorm (+ SiLU) from a finished scale / shift table: y = act(x * scale[b, c] + shift[b, c]) with `scsh` as written by
+ * udt_gn_finalize from the column statistics the PRODUCERS of x (and x2) emitted in their epilogues (udt_gemm_desc.colstats) —
+ * the statistics pass over the tensor is gone, this is the one remaining read + write of reference GroupNorm32 -> SiLU
+ * (sgm/modules/diffusionmodules/util.py:214-216, openaimodel.py:183-187).  Two sources = the channel concat of a decoder
+ * ResBlock's input; C1 + C2 a multiple of 64. */
+int udt_gn_apply_scsh(const void* x, const void* x2, void* y, const float* scsh, int32_t B, int64_t HW, int32_t C1,
+                      int32_t C2, int32_t act, void* stream);
+
 /* LayerNorm over the last dim of bf16 [rows, C] (C % 8 == 0, C <= 4096). */
 int udt_layernorm(const void* x, void* y, const float* gamma, const float* beta,
                   int64_t rows, int32_t C, float eps, void* stream);

@@ -290,3 +290,84 @@ def test_lean_conv_plan_declines_what_it_does_not_cover(env, cuda):
         finally:
             env.reset()
         assert _rel(out, y) < REL_RMS
+
+
+def _stats_ref(out, rows):
+    """[slots, C, 2] (sum, sum of squares) over consecutive blocks of ``rows`` output rows"""
+    o = out.float().reshape(-1, rows, out.shape[-1])
+    return torch.stack([o.sum(1), (o * o).sum(1)], dim=-1)
+
+
+@pytest.mark.parametrize("M,N,K,rpb,res", [(8192, 640, 640, 1024, True), (4096, 320, 320, 4096, True), (2048, 1280, 1280, 256, True),
+                                           (1024, 640, 2560, 1024, False), (4096, 960, 320, 1024, False)])
+def test_lean_linear_epilogue_statistics(env, cuda, M, N, K, rpb, res):
+    """udt_gemm_desc.colstats on the lean GEMM kernels (128x128 and 128x160 tiles): per-(row slot, column) sum and sum of
+    squares of the STORED bf16 values, the input of udt_gn_finalize — against torch sums of the returned output; the output
+    itself must not change when statistics are requested"""
+    x, wp, bp, kw, y = _linear_case(env, cuda, M, N, K, 0, res, 0, seed=21)
+    kw["rows_per_batch"] = rpb
+    plain = env.ops.linear(x, wp, bp, **kw)
+    out = env.ops.linear(x, wp, bp, colstats=True, **kw)
+    torch.cuda.synchronize()
+    st = env.ops.gn_stats_of(out)
+    assert st is not None, "the library declined statistics for a lean-kernel shape"
+    assert torch.equal(out, plain)
+    rows = rpb // st.slots_per_sample
+    assert rows in (32, 64) and st.data.shape == (M // rows, N, 2)
+    ref = _stats_ref(out, rows)
+    err = (st.data - ref).abs()
+    tol = 1e-4 * ref.abs() + 1e-3 * math.sqrt(rows)
+    assert (err <= tol).all(), f"max err {err.max().item():.3e}"
+    assert _rel(out, y) < REL_RMS
+
+
+@pytest.mark.parametrize("B,H,W,C,N,ups,res", [(2, 64, 64, 320, 320, False, True), (3, 32, 32, 640, 640, False, False),
+                                                (2, 8, 8, 1280, 1280, False, True), (2, 16, 16, 640, 640, True, False),
+                                                (1, 24, 40, 128, 136, False, False)])
+def test_lean_conv_epilogue_statistics_and_groupnorm_from_them(env, cuda, B, H, W, C, N, ups, res):
+    """statistics out of the lean 3x3 convolution's epilogue (all three geometries), then GroupNorm(32)+SiLU built from them
+    (udt_gn_finalize + udt_gn_apply_scsh) against torch group_norm of the convolution's output in fp32 and against the
+    two-kernel GroupNorm (udt_gn_stats + udt_gn_apply)"""
+    g = torch.Generator(device="cpu").manual_seed(22)
+    x = torch.randn((B, H, W, C), generator=g).to(cuda).bfloat16()
+    w = env.packing.pack_conv((torch.randn((N, C, 3, 3), generator=g) / math.sqrt(9 * C)).to(cuda))
+    b = torch.randn((N,), generator=g).to(cuda)
+    Ho, Wo = (2 * H, 2 * W) if ups else (H, W)
+    r = torch.randn((B, Ho, Wo, N), generator=g).to(cuda).bfloat16() if res else None
+    plain = env.ops.conv2d(x, w, b, ksize=3, upsample=ups, residual=r)
+    out = env.ops.conv2d(x, w, b, ksize=3, upsample=ups, residual=r, colstats=True)
+    torch.cuda.synchronize()
+    st = env.ops.gn_stats_of(out)
+    assert st is not None and torch.equal(out, plain)
+    tot = st.data.reshape(B, st.slots_per_sample, N, 2).sum(1)
+    o = out.float().reshape(B, Ho * Wo, N)
+    ref = torch.stack([o.sum(1), (o * o).sum(1)], dim=-1)
+    assert ((tot - ref).abs() <= 2e-4 * ref.abs() + 2e-2 * math.sqrt(Ho * Wo)).all()
+    if N % 64 == 0:
+        gamma = (1 + 0.1 * torch.randn((N,), generator=g)).to(cuda)
+        beta = (0.1 * torch.randn((N,), generator=g)).to(cuda)
+        got = env.ops.group_norm_from_stats(out, st, gamma, beta, 32, 1e-5, True)
+        want = F.silu(F.group_norm(out.float().permute(0, 3, 1, 2), 32, gamma, beta, 1e-5)).permute(0, 2, 3, 1)
+        two = env.ops.group_norm(out, gamma, beta, 32, 1e-5, True)
+        torch.cuda.synchronize()
+        assert _rel(got, want) < 6e-3, f"GroupNorm from epilogue statistics vs torch: {_rel(got, want):.3e}"
+        assert (got.float() - two.float()).abs().max().item() <= 4e-2      # same statistics up to fp32 summation order
+
+
+def test_groupnorm_from_statistics_two_sources(env, cuda):
+    """decoder ResBlock input: GroupNorm over the channel concat of two tensors, each with its own producer statistics"""
+    g = torch.Generator(device="cpu").manual_seed(23)
+    B, H, C1, C2 = 2, 32, 640, 320
+    mk = lambda c_in, c_out, seed: env.ops.conv2d(
+        torch.randn((B, H, H, c_in), generator=g).to(cuda).bfloat16(),
+        env.packing.pack_conv((torch.randn((c_out, c_in, 3, 3), generator=g) / math.sqrt(9 * c_in)).to(cuda)), None, ksize=3, colstats=True)
+    a, b2 = mk(320, C1, 1), mk(320, C2, 2)
+    sa, sb = env.ops.gn_stats_of(a), env.ops.gn_stats_of(b2)
+    assert sa is not None and sb is not None
+    gamma = (1 + 0.1 * torch.randn((C1 + C2,), generator=g)).to(cuda)
+    beta = (0.1 * torch.randn((C1 + C2,), generator=g)).to(cuda)
+    got = env.ops.group_norm_from_stats(a, sa, gamma, beta, 32, 1e-5, True, x2=b2, st2=sb)
+    cat = torch.cat([a, b2], -1).float()
+    want = F.silu(F.group_norm(cat.permute(0, 3, 1, 2), 32, gamma, beta, 1e-5)).permute(0, 2, 3, 1)
+    torch.cuda.synchronize()
+    assert _rel(got, want) < 6e-3

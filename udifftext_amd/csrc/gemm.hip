@@ -754,10 +754,13 @@ hipError_t launch3p(const c3p::CParams& cp, const TilePlan& t, hipStream_t s) {
 }
 
 // rows of the output one colstats slot covers for this problem, 0 = statistics not available
+struct LeanPlan;
+bool lean_stats_probe(const udt_gemm_desc* d, int& rows, int& slots);
 int colstats_rows(const udt_gemm_desc* d) {
   if (d->flags & (UDT_GEMM_OUT_F32 | UDT_GEMM_GEGLU | UDT_GEMM_TRANSPOSED)) return 0;
   if ((d->batch > 1) || d->M <= 0 || d->N <= 0 || d->K <= 0 || d->K % BK != 0) return 0;
-  int rows = 0;
+  int rows = 0, slots = 0;
+  if (lean_stats_probe(d, rows, slots)) return rows;             // the launch would take a lean kernel with a STATS epilogue
   c3p::Geo ge;
   if (conv3p_geometry(d, ge, d->in_scsh != nullptr)) {
     rows = (d->N % 160 == 0 && d->N % 128 != 0) ? 32 : 64;
@@ -774,6 +777,8 @@ int colstats_rows(const udt_gemm_desc* d) {
 int colstats_slots(const udt_gemm_desc* d) {
   const int rows = colstats_rows(d);
   if (rows == 0) return 0;
+  int lrows = 0, lslots = 0;
+  if (lean_stats_probe(d, lrows, lslots)) return lslots;
   c3p::Geo ge;
   if (conv3p_geometry(d, ge, d->in_scsh != nullptr)) return ge.img_groups * ge.tiles_y * ge.tiles_x * (256 / rows);
   return ((d->M + 255) / 256) * (256 / rows);
@@ -795,7 +800,14 @@ int lean_splitk_knob() {
   }
   return v;
 }
+// UDT_LEAN_STATS=0: statistics-emitting launches stay on the 8-wave kernels (A/B)
+bool lean_stats_enabled() {
+  static const int on = [] { const char* e = getenv("UDT_LEAN_STATS"); return (e && e[0] == '0') ? 0 : 1; }();
+  return on != 0;
+}
+
 struct LeanPlan {
+  int stats_rows = 0;      // rows per colstats slot when the launch emits statistics (lean.h wave_colstats), else 0
   int cfg;                 // 1, 2, 3 as above; 5 = 4 waves / 128x160 / 2 stages (N = 320, 960)
   int bm, bn, nw, smem;
   int tiles_m, tiles_n, tiles, nkt, splitk, kt_per, G, n_block;
@@ -811,7 +823,7 @@ int lean_mode() {
   return v;
 }
 
-bool lean_plan(const udt_gemm_desc* d, LeanPlan& t) {
+bool lean_plan(const udt_gemm_desc* d, LeanPlan& t, bool want_stats) {
   const int mode = lean_mode();
   if (mode == 0 || gemm_impl() == 4) return false;
   constexpr int unsupported = UDT_GEMM_OUT_F32 | UDT_GEMM_RELU | UDT_GEMM_TRANSPOSED | UDT_GEMM_SILU_OUT | UDT_GEMM_FP8;
@@ -822,9 +834,10 @@ bool lean_plan(const udt_gemm_desc* d, LeanPlan& t) {
   if (conv1 && (d->ksize != 1 || d->stride != 1 || d->upsample || d->pad_t != 0 || d->pad_l != 0 || d->Hout != d->Hin ||
                 d->Wout != d->Win || d->C1 % BK != 0 || d->C2 % BK != 0 || d->ln_colsum || (d->flags & UDT_GEMM_GEGLU)))
     return false;
-  if (d->batch > 1 || d->colstats || d->in_scsh || d->colscale) return false;
+  if (d->batch > 1 || d->in_scsh || d->colscale) return false;
   const bool geglu = (d->flags & UDT_GEMM_GEGLU) != 0;
   const bool ln = d->ln_colsum != nullptr;
+  if (want_stats && (geglu || ln || !lean_stats_enabled())) return false;
   if (d->N <= 64 || d->N % 8 != 0 || d->K % BK != 0 || (!conv1 && d->lda % 8 != 0) || d->ldo % 8 != 0) return false;
   if (d->residual && d->ldr % 8 != 0) return false;
   if (geglu && (d->N % 64 != 0 || d->residual || d->rowvec)) return false;
@@ -840,6 +853,17 @@ bool lean_plan(const udt_gemm_desc* d, LeanPlan& t) {
   // Measured (profiles/r03_gemm_shapes_256.txt): faster from ~2 tiles per CU up (32768x2560x320 GEGLU 93 -> 81 us,
   // 32768x960x320 33 -> 32 us), slower below (every M <= 2048 shape)
   if (mode <= 0 && d->N >= 768 && (long long)((d->M + 255) / 256) * ((d->N + 255) / 256) >= 2LL * device_cus()) t.cfg = 6;
+  t.stats_rows = 0;
+  if (want_stats) {
+    // statistics-emitting epilogues exist for the two 4-wave plain kernels; a slot = one wave row block, inside one sample
+    if (t.cfg != 1 && t.cfg != 5) {
+      if (mode > 0) return false;
+      t.cfg = (d->N % 160 == 0 && d->N % 128 != 0) ? 5 : 1;
+    }
+    t.stats_rows = t.cfg == 1 ? 64 : 32;
+    const int rpb = d->rows_per_batch > 0 ? d->rows_per_batch : d->M;
+    if (rpb % t.stats_rows != 0) return false;
+  }
   switch (t.cfg) {
     case 1: t.nw = 4; t.bm = 128; t.bn = 128; t.smem = 2 * (128 + 128) * ROW_BYTES; break;
     case 2: t.nw = 8; t.bm = 256; t.bn = 128; t.smem = 3 * (256 + 128) * ROW_BYTES; break;
@@ -888,8 +912,19 @@ size_t lean_workspace(const LeanPlan& t) {
 
 template <int NW, int WGM, int WGN, int TM, int TN, int NST, int TMB = TM>
 hipError_t launch_lean(const lg::LParams& lp, const LeanPlan& t, bool geglu, bool ln, hipStream_t s) {
-  static AttrOnce once[4];
+  static AttrOnce once[5];
   const void* fn;
+  const bool stats = lp.colstats != nullptr;
+  if constexpr (NW == 4 && NST == 2) {                    // (the two kernels with a statistics-emitting epilogue)
+    if (stats) {
+      fn = (const void*)lg::lgemm_kernel<NW, WGM, WGN, TM, TN, NST, false, false, TMB, true>;
+      hipError_t e = once[4].ensure(fn, t.smem);
+      if (e != hipSuccess) return e;
+      void* args[] = {const_cast<lg::LParams*>(&lp)};
+      return hipLaunchKernel(fn, dim3(t.G), dim3(NW * 64), args, t.smem, s);
+    }
+  }
+  if (stats) return hipErrorInvalidValue;
   if constexpr (TN == 2) {
     fn = geglu ? (ln ? (const void*)lg::lgemm_kernel<NW, WGM, WGN, TM, TN, NST, true, true, TMB> : (const void*)lg::lgemm_kernel<NW, WGM, WGN, TM, TN, NST, true, false, TMB>)
                : (ln ? (const void*)lg::lgemm_kernel<NW, WGM, WGN, TM, TN, NST, false, true, TMB> : (const void*)lg::lgemm_kernel<NW, WGM, WGN, TM, TN, NST, false, false, TMB>);
@@ -909,7 +944,7 @@ std::atomic<int> g_lean_conv{-1};
 std::atomic<int> g_lconv_dbg{0};   // cost attribution of the lean convolution's loop (C3Params.dbg): wrong results
 #endif
 
-bool lean_conv_plan(const udt_gemm_desc* d, lg::C3Params& c) {
+bool lean_conv_plan(const udt_gemm_desc* d, lg::C3Params& c, bool want_stats) {
   int on = g_lean_conv.load(std::memory_order_relaxed);
   if (on < 0) {
     const char* e = getenv("UDT_LEAN_CONV");
@@ -918,7 +953,8 @@ bool lean_conv_plan(const udt_gemm_desc* d, lg::C3Params& c) {
   }
   if (!on || gemm_impl() == 4 || lean_mode() == 0) return false;
   if (d->flags != UDT_GEMM_CONV || d->ksize != 3 || d->stride != 1 || d->pad_t != 1 || d->pad_l != 1) return false;
-  if (d->C2 != 0 || d->in_scsh || d->colstats || d->colscale || d->batch > 1) return false;
+  if (d->C2 != 0 || d->in_scsh || d->colscale || d->batch > 1) return false;
+  if (want_stats && !lean_stats_enabled()) return false;
   if (d->N < 128 || d->N % 8 != 0 || d->C1 <= 0 || d->C1 % 64 != 0) return false;
   const bool ups = d->upsample != 0;
   if (d->Hout != (d->Hin << (ups ? 1 : 0)) || d->Wout != (d->Win << (ups ? 1 : 0))) return false;
@@ -976,14 +1012,40 @@ size_t lean_conv_workspace(const lg::C3Params& c) {
   return c.splitk > 1 ? G8_HEADER_BYTES + (size_t)c.tiles * c.splitk * c.tw * c.th * 128 * sizeof(float) : 0;
 }
 
-template <int TW, int TH, bool UPS>
-hipError_t launch_lconv3(const lg::C3Params& c3, hipStream_t s) {
+template <int TW, int TH, bool UPS, bool STATS>
+hipError_t launch_lconv3s(const lg::C3Params& c3, hipStream_t s) {
   static AttrOnce once;
   constexpr int smem = lg::C3Geo<TW, TH, UPS>::SMEM;
-  hipError_t e = once.ensure(reinterpret_cast<const void*>(lg::lconv3_kernel<TW, TH, UPS>), smem);
+  hipError_t e = once.ensure(reinterpret_cast<const void*>(lg::lconv3_kernel<TW, TH, UPS, STATS>), smem);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL((lg::lconv3_kernel<TW, TH, UPS>), dim3(c3.G), dim3(256), smem, s, c3);
+  hipLaunchKernelGGL((lg::lconv3_kernel<TW, TH, UPS, STATS>), dim3(c3.G), dim3(256), smem, s, c3);
   return hipGetLastError();
+}
+template <int TW, int TH, bool UPS>
+hipError_t launch_lconv3(const lg::C3Params& c3, hipStream_t s) {
+  return c3.colstats ? launch_lconv3s<TW, TH, UPS, true>(c3, s) : launch_lconv3s<TW, TH, UPS, false>(c3, s);
+}
+
+// would this problem run on a lean kernel WITH a statistics-emitting epilogue?  (udt_gemm_colstats_rows / _slots, asked by
+// the caller before it allocates the statistics and sets udt_gemm_desc.colstats)
+bool lean_stats_probe(const udt_gemm_desc* d, int& rows, int& slots) {
+  if (d->in_scsh) return false;
+  {
+    lg::C3Params c3;
+    if (lean_conv_plan(d, c3, true)) {
+      rows = c3.tw * c3.th / 2;                                   // two wave pixel blocks per tile
+      slots = c3.tiles_m * 2;
+      return true;
+    }
+  }
+  if ((d->flags & UDT_GEMM_CONV) && d->ksize == 3) return false;
+  LeanPlan lt;
+  if (lean_plan(d, lt, true)) {
+    rows = lt.stats_rows;
+    slots = lt.tiles_m * (lt.bm / lt.stats_rows);
+    return true;
+  }
+  return false;
 }
 }  // namespace
 
@@ -1045,7 +1107,7 @@ extern "C" int udt_gn_silu_conv3x3_fwd(const udt_gemm_desc* d, void* workspace, 
 extern "C" int udt_ln_gemm_fwd(const udt_gemm_desc* d, void* workspace, size_t workspace_bytes, void* stream) {
   if (!d || !d->ln_colsum || !d->bias || !(d->ln_eps > 0.f)) return UDT_ERR_BAD_ARG;
   LeanPlan lt;
-  if (!lean_plan(d, lt)) return UDT_ERR_BAD_SHAPE;
+  if (!lean_plan(d, lt, false)) return UDT_ERR_BAD_SHAPE;
   return udt_gemm(d, workspace, workspace_bytes, stream);
 }
 
@@ -1053,9 +1115,9 @@ extern "C" size_t udt_gemm_workspace_bytes(const udt_gemm_desc* d) {
   if (!d || d->K <= 0 || d->M <= 0 || d->N <= 0 || d->K % k_tile(d) != 0) return 0;
   {
     LeanPlan lt;
-    if (lean_plan(d, lt)) return lean_workspace(lt);
+    if (lean_plan(d, lt, d->colstats != nullptr)) return lean_workspace(lt);
     lg::C3Params c3;
-    if (lean_conv_plan(d, c3)) return lean_conv_workspace(c3);
+    if (lean_conv_plan(d, c3, d->colstats != nullptr)) return lean_conv_workspace(c3);
   }
   {
     c3p::Geo ge;
@@ -1157,8 +1219,9 @@ extern "C" int udt_gemm(const udt_gemm_desc* d, void* workspace, size_t workspac
   const int cls = (conv && d->ksize == 3) ? 0 : 1;
   {
     LeanPlan lt;
-    if (lean_plan(d, lt)) {
+    if (lean_plan(d, lt, d->colstats != nullptr)) {
       lg::LParams lp;
+      lp.colstats = d->colstats;
       const bool conv1 = (d->flags & UDT_GEMM_CONV) != 0;
       lp.a = p.a; lp.a2 = (conv1 && d->C2 > 0) ? p.a2 : nullptr; lp.w = p.w; lp.bias = p.bias; lp.res = p.res; lp.rowvec = p.rowvec;
       lp.ln_s = d->ln_colsum;
@@ -1203,7 +1266,8 @@ extern "C" int udt_gemm(const udt_gemm_desc* d, void* workspace, size_t workspac
   if (d->ln_colsum) return UDT_ERR_BAD_ARG;            // the LayerNorm-folded form exists on the lean kernels only
   {
     lg::C3Params c3;
-    if (lean_conv_plan(d, c3)) {
+    if (lean_conv_plan(d, c3, d->colstats != nullptr)) {
+      c3.colstats = d->colstats;
       c3.a = p.a; c3.w = p.w; c3.bias = p.bias; c3.res = p.res; c3.rowvec = p.rowvec; c3.out = reinterpret_cast<uint16_t*>(d->out);
       if (c3.splitk > 1) {
         if (!workspace || workspace_bytes < lean_conv_workspace(c3)) return UDT_ERR_WORKSPACE;

@@ -61,6 +61,7 @@ struct LParams {
   int G;                   // launched workgroups (a multiple of 8 when > 8)
   int* counters;           // split-K: [tiles] arrival tickets, zero between launches
   float* slabs;            // split-K: [tiles * splitk][BM * BN] fp32
+  float* colstats;         // STATS kernels: fp32 [row slots][N][2] (sum, sum of squares) of the stored values, one slot per wave row block
 };
 
 typedef __attribute__((ext_vector_type(2))) __bf16 bf2_t;
@@ -68,10 +69,48 @@ UDT_DEVINL float dot2_bf16(uint32_t a, uint32_t b, float c) {
   return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2_t, a), __builtin_bit_cast(bf2_t, b), c, false);
 }
 
+// Column statistics of a wave's output rows for the consumer's GroupNorm (udt_gemm_desc.colstats; the 8-wave kernels' STATS
+// epilogues emit the same [slot][N][2] records): every lane has summed its 8 columns over the rows it stored; the lanes
+// that share a column group (rl = 0 .. RPI-1) are combined through the wave's own staging block (a wave's LDS operations
+// execute in order, no barrier) in a fixed order, and the rl = 0 lanes write 8 x (sum, sum of squares).
+template <int CPR, int RPI>
+UDT_DEVINL void wave_colstats(char* wl, int lane, const float (&cs)[8], const float (&cq)[8], float* dst, bool col_ok) {
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    f32x4 a = {cs[4 * h + 0], cs[4 * h + 1], cs[4 * h + 2], cs[4 * h + 3]};
+    f32x4 b = {cq[4 * h + 0], cq[4 * h + 1], cq[4 * h + 2], cq[4 * h + 3]};
+    *reinterpret_cast<f32x4*>(wl + lane * 64 + h * 16) = a;
+    *reinterpret_cast<f32x4*>(wl + lane * 64 + 32 + h * 16) = b;
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  if (lane < CPR && col_ok) {
+    float ts[8], tq[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ts[j] = tq[j] = 0.f;
+#pragma unroll
+    for (int r = 0; r < RPI; ++r) {
+      const char* src = wl + (r * CPR + lane) * 64;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(src + h * 16);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(src + 32 + h * 16);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { ts[4 * h + e] += a[e]; tq[4 * h + e] += b[e]; }
+      }
+    }
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+      f32x4 v = {ts[2 * h], tq[2 * h], ts[2 * h + 1], tq[2 * h + 1]};
+      *reinterpret_cast<f32x4*>(dst + h * 4) = v;
+    }
+  }
+}
+
 // NW waves as WGM x WGN, each TM x TN MFMA tiles of 32x32; NST ring stages; GEGLU: weight rows packed [32 x | 32 gate]
 // per 64-column wave block (TN == 2); LN: LayerNorm folded into the weights, row statistics from the A fragments
-template <int NW, int WGM, int WGN, int TM, int TN, int NST, bool GEGLU, bool LN, int TMB = TM>
+template <int NW, int WGM, int WGN, int TM, int TN, int NST, bool GEGLU, bool LN, int TMB = TM, bool STATS = false>
 __global__ void __launch_bounds__(NW * 64, 2) lgemm_kernel(const LParams p) {
+  static_assert(!STATS || (!GEGLU && !LN), "statistics-emitting epilogue: plain linears / 1x1 convolutions");
   static_assert(TM % TMB == 0, "epilogue passes of TMB row tiles");
   static_assert(WGM * WGN == NW, "wave grid");
   static_assert(!GEGLU || TN == 2, "GEGLU pairs the two 32-column tiles of a wave");
@@ -401,6 +440,9 @@ __global__ void __launch_bounds__(NW * 64, 2) lgemm_kernel(const LParams p) {
         s1 = *reinterpret_cast<const f32x4*>(p.ln_s + n + 4);
       }
     }
+    float cs[8], cq[8];                                  // STATS: this lane's column sums over the rows it stores
+#pragma unroll
+    for (int j = 0; j < 8; ++j) cs[j] = cq[j] = 0.f;
 #pragma unroll
     for (int pass = 0; pass < TM / TMB; ++pass) {
       const int prow0 = pass * PROWS;                    // first wave row of this pass
@@ -479,8 +521,20 @@ __global__ void __launch_bounds__(NW * 64, 2) lgemm_kernel(const LParams p) {
         if (ok) {
           u32x4 pk = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7])};
           *reinterpret_cast<u32x4*>(p.out + (long long)m * p.ldo + n) = pk;
+          if constexpr (STATS) {                         // statistics of the values as stored (bf16-rounded)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const float a = bf16_lo(pk[j]), bb = bf16_hi(pk[j]);
+              cs[2 * j] += a; cq[2 * j] += a * a;
+              cs[2 * j + 1] += bb; cq[2 * j + 1] += bb * bb;
+            }
+          }
         }
       }
+    }
+    if constexpr (STATS) {
+      const int slot = (m0 + row0) / WROWS;
+      wave_colstats<CPR, RPI>(wl, lane, cs, cq, p.colstats + ((long long)slot * p.N + n) * 2, col_ok);
     }
   }
 }
@@ -522,6 +576,7 @@ struct C3Params {
   int G;
   int* counters;
   float* slabs;
+  float* colstats;         // STATS kernels: fp32 [tiles_m * 2][N][2] per-(wave pixel block, channel) (sum, sum of squares)
   int geo, tw, th;         // host side: kernel instance (0: 16x8, 1: 8x8, 2: 16x8 upsampling) and its pixel tile
   int dbg;                 // measurement builds only (UDT_DBG): bit 0 no weight DMA, 1 no patch DMA, 2 no MFMA, 3 no LDS fragment reads
 };
@@ -550,7 +605,7 @@ struct C3Geo {
   static_assert(SMEM <= 80 * 1024, "two workgroups per CU");
 };
 
-template <int TW, int TH, bool UPS>
+template <int TW, int TH, bool UPS, bool STATS = false>
 __global__ void __launch_bounds__(256, 2) lconv3_kernel(const C3Params p) {
   using Geo = C3Geo<TW, TH, UPS>;
   constexpr int NW = 4, TM = Geo::TM, TN = 2, BN = 128, BMPX = Geo::PX;
@@ -827,6 +882,9 @@ __global__ void __launch_bounds__(256, 2) lconv3_kernel(const C3Params p) {
       if (col_ok) rv[i] = *reinterpret_cast<const u32x4*>(p.res + mrow[i] * p.ldr + n);
     }
   }
+  float cs[8], cq[8];                                    // STATS: this lane's column sums over the pixels it stores
+#pragma unroll
+  for (int j = 0; j < 8; ++j) cs[j] = cq[j] = 0.f;
 #pragma unroll
   for (int i = 0; i < NIT; ++i) {
     const int row = i * 8 + rl;
@@ -850,7 +908,20 @@ __global__ void __launch_bounds__(256, 2) lconv3_kernel(const C3Params p) {
     if (col_ok) {
       u32x4 pk = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7])};
       *reinterpret_cast<u32x4*>(p.out + mrow[i] * p.ldo + n) = pk;
+      if constexpr (STATS) {                             // statistics of the values as stored (bf16-rounded)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float a = bf16_lo(pk[j]), bb = bf16_hi(pk[j]);
+          cs[2 * j] += a; cq[2 * j] += a * a;
+          cs[2 * j + 1] += bb; cq[2 * j + 1] += bb * bb;
+        }
+      }
     }
+  }
+  if constexpr (STATS) {
+    // one slot per wave pixel block (WROWS pixels of one image); the two waves that share the pixels cover different channels
+    const int slot = tile_m * 2 + wm;
+    wave_colstats<8, 8>(wl, lane, cs, cq, p.colstats + ((long long)slot * p.N + n) * 2, col_ok);
   }
 }
 

@@ -90,7 +90,7 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const uint16_t* __restric
                                                        const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, long long HW, int C1, int C2,
                                                        int G, int nchunks, float eps, int act,
-                                                       long long chunks_per_wg) {
+                                                       long long chunks_per_wg, const float* __restrict__ scsh) {
   const int C = C1 + C2;
   extern __shared__ __attribute__((aligned(16))) float asm_[];   // [C] scale, [C] shift, [G] mean, [G] rstd
   float* sc = asm_;
@@ -100,7 +100,15 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const uint16_t* __restric
   const int t = threadIdx.x;
   const int b = blockIdx.y;
   const int cpg = C / G;
-  {
+  if (scsh) {
+    // the per-(sample, channel) scale / shift table of udt_gn_finalize ([B][C/64][2][64]): statistics came from the
+    // producers' epilogues, nothing to reduce here
+    for (int c = t; c < C; c += 256) {
+      const float* src = scsh + (((long long)b * (C >> 6) + (c >> 6)) * 2) * 64 + (c & 63);
+      sc[c] = src[0];
+      sh[c] = src[64];
+    }
+  } else {
     // 256 threads = G groups x (256/G) lanes; each lane sums a strided subset of the chunk partials
     double* red = reinterpret_cast<double*>(gr + G);          // [2][256] doubles
     const int lanes = 256 / G;
@@ -125,13 +133,13 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const uint16_t* __restric
       gm[t] = (float)mean;
       gr[t] = (float)(1.0 / sqrt(var + (double)eps));
     }
-  }
-  __syncthreads();
-  for (int c = t; c < C; c += 256) {
-    const int g = c / cpg;
-    const float a = gr[g] * gamma[c];
-    sc[c] = a;
-    sh[c] = beta[c] - gm[g] * a;
+    __syncthreads();
+    for (int c = t; c < C; c += 256) {
+      const int g = c / cpg;
+      const float a = gr[g] * gamma[c];
+      sc[c] = a;
+      sh[c] = beta[c] - gm[g] * a;
+    }
   }
   __syncthreads();
   const int c8 = C >> 3;
@@ -668,7 +676,32 @@ extern "C" int udt_gn_apply(const void* x, const void* x2, void* y, const float*
   }
   hipLaunchKernelGGL(gn_apply_kernel, dim3(blocks, B), dim3(256), smem, s, reinterpret_cast<const uint16_t*>(x),
                      reinterpret_cast<const uint16_t*>(x2), reinterpret_cast<uint16_t*>(y), partials, gamma, beta,
-                     (long long)HW, C1, C2, G, nchunks, eps, act, chunks_per_wg);
+                     (long long)HW, C1, C2, G, nchunks, eps, act, chunks_per_wg, static_cast<const float*>(nullptr));
+  UDT_CHECK_LAUNCH();
+  return UDT_OK;
+}
+
+extern "C" int udt_gn_apply_scsh(const void* x, const void* x2, void* y, const float* scsh, int32_t B, int64_t HW, int32_t C1,
+                                 int32_t C2, int32_t act, void* stream) {
+  if (!x || !y || !scsh || (C2 > 0 && !x2)) return UDT_ERR_BAD_ARG;
+  if (C2 < 0 || C1 <= 0 || C1 % 8 != 0 || C2 % 8 != 0) return UDT_ERR_BAD_SHAPE;
+  const int C = C1 + C2;
+  if (B <= 0 || HW <= 0 || C % 64 != 0 || C > GN_MAX_C) return UDT_ERR_BAD_SHAPE;
+  const long long total = (long long)HW * (C / 8);
+  const long long chunks_per_wg = 2048;   // 32 KiB of bf16 per workgroup
+  const int blocks = (int)((total + chunks_per_wg - 1) / chunks_per_wg);
+  const size_t smem = (size_t)(2 * C) * sizeof(float);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  UdtProfScope prof(4, s);
+  if (prof.rec) {
+    char tag[96];
+    snprintf(tag, sizeof(tag), "gn_apply_scsh B=%d HW=%lld C=%d", B, (long long)HW, C);
+    udt_prof_tag(prof.rec, tag);
+  }
+  hipLaunchKernelGGL(gn_apply_kernel, dim3(blocks, B), dim3(256), smem, s, reinterpret_cast<const uint16_t*>(x),
+                     reinterpret_cast<const uint16_t*>(x2), reinterpret_cast<uint16_t*>(y), static_cast<const float*>(nullptr),
+                     static_cast<const float*>(nullptr), static_cast<const float*>(nullptr), (long long)HW, C1, C2, 1, 1, 0.f, act,
+                     chunks_per_wg, scsh);
   UDT_CHECK_LAUNCH();
   return UDT_OK;
 }

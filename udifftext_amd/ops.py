@@ -290,12 +290,13 @@ def conv2d(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
                   ld_rowvec=(rowvec.stride(0) if rowvec is not None else 0), flags=flags | L.GEMM_CONV)
     if probe_in_scsh:
         return bool(L.load().udt_gemm_in_scsh_ok(C.byref(d)))
-    if colstats:
-        _attach_colstats(d, out, N, Ho * Wo)
-    if in_scsh is not None:
+    if in_scsh is not None:                       # (before the statistics probe: the plan depends on it)
         assert in_scsh.dtype == torch.float32 and in_scsh.is_contiguous() and in_scsh.numel() == B * (C1 + C2) * 2
         d.in_scsh = in_scsh.data_ptr()
         d.in_act = int(in_act)
+    if colstats:
+        _attach_colstats(d, out, N, Ho * Wo)
+    if in_scsh is not None:
         run_gemm(d, x.device, fused_gn=True)
     else:
         run_gemm(d, x.device)
@@ -502,6 +503,33 @@ def gn_finalize(st1: GnStats, C1: int, st2: Optional[GnStats], C2: int, gamma: t
                                      st2.slots_per_sample if st2 is not None else 0, C2, _ptr(gamma), _ptr(beta), _ptr(scsh),
                                      B, HW, groups, eps, _stream()), "udt_gn_finalize")
     return scsh
+
+
+def gn_strip_ok(B: int, HW: int, C1: int, C2: int, groups: int) -> bool:
+    """would group_norm run this shape as ONE strip launch (statistics + apply)?"""
+    return bool(GN_STRIP and L.load().udt_gn_strip_ok(B, HW, C1, C2, groups))
+
+
+def group_norm_from_stats(x: torch.Tensor, st1: GnStats, gamma: torch.Tensor, beta: torch.Tensor, groups: int, eps: float,
+                          silu: bool, x2: Optional[torch.Tensor] = None, st2: Optional[GnStats] = None,
+                          out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """GroupNorm (+ SiLU) whose statistics came out of the producers' epilogues (``x.gn_stats``): udt_gn_finalize turns them
+    into a per-(sample, channel) scale / shift table, udt_gn_apply_scsh is the one read + write left of the norm"""
+    _bf16(x)
+    assert x.is_contiguous()
+    B, C1 = x.shape[0], x.shape[-1]
+    C2 = 0
+    if x2 is not None:
+        _bf16(x2)
+        assert x2.is_contiguous() and x2.shape[:-1] == x.shape[:-1] and st2 is not None
+        C2 = x2.shape[-1]
+    HW = x.numel() // (B * C1)
+    scsh = gn_finalize(st1, C1, st2, C2, gamma, beta, B, HW, groups, eps)
+    if out is None:
+        out = torch.empty(x.shape[:-1] + (C1 + C2,), dtype=torch.bfloat16, device=x.device)
+    L.check(L.load().udt_gn_apply_scsh(_ptr(x), _ptr(x2), _ptr(out), _ptr(scsh), B, HW, C1, C2, 1 if silu else 0, _stream()),
+            "udt_gn_apply_scsh")
+    return out
 
 
 class Fp8Act(NamedTuple):

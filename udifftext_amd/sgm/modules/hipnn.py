@@ -33,6 +33,22 @@ def count_flops(kind: str, flops: float) -> None:
 # (one pixel per lane: 32-lane reductions) cost more than the two HBM passes they replace.
 FUSE_GN = os.environ.get("UDT_FUSE_GN", "0") != "0"
 
+# UDT_GN_EPI (default 1): the GroupNorm STATISTICS come out of the producers' epilogues (the lean GEMM / convolution kernels'
+# STATS variants sum the stored values per column in the fp32-row epilogue: ~200 VALU instructions per wave and tile), a tiny
+# finalize launch turns them into a scale / shift table and the apply pass stays a separate streaming kernel — the gn_stats
+# read of every 64x64 / 32x32 activation is gone, the patch transform that made the fully fused chain slower is not involved.
+# The 16x16 / 8x8 levels keep their one-launch strip GroupNorm (no statistics emitted there).
+GN_EPI = os.environ.get("UDT_GN_EPI", "1") != "0" and os.environ.get("UDT_LEAN", "") != "0"
+EMIT_STATS = FUSE_GN or GN_EPI
+
+
+def want_stats(B: int, HW: int, C: int) -> bool:
+    """should a producer of a [B, HW, C] activation emit column statistics?  fused chain: always; GN_EPI: only where the
+    consumer will not be the strip GroupNorm (which computes its own in the same launch)"""
+    if FUSE_GN:
+        return True
+    return GN_EPI and C % 64 == 0 and not ops.gn_strip_ok(B, HW, C, 0, 32)
+
 
 # UDT_FP8=1 (BASELINE config #5): the LayerNorm-fed linears of every transformer block (q|k, v, t_attn.to_q, GEGLU — 60 % of
 # the linear FLOPs) run on the fp8 MFMA path: e4m3 weights with per-output-channel scales, e4m3 activations quantised
@@ -150,8 +166,11 @@ class Linear(_Packed):
             wq, cs, b = self.packed_fp8()
             return ops.linear_fp8(x, wq, cs, b, residual=residual, flags=flags, out=out, rows_per_batch=rows_per_batch)
         w, b = self.packed()
+        if colstats:
+            rpb = rows_per_batch if rows_per_batch > 0 else x.shape[0]
+            colstats = want_stats(x.shape[0] // rpb, rpb, w.shape[0])
         return ops.linear(x, w, b, residual=residual, flags=flags, out=out, rowvec=rowvec, rows_per_batch=rows_per_batch,
-                          colstats=colstats and FUSE_GN)
+                          colstats=bool(colstats))
 
 
 class Conv2d(_Packed):
@@ -192,7 +211,11 @@ class Conv2d(_Packed):
             pad = (self.padding, self.padding)
         if colstats is None:
             colstats = self.emit_colstats
-        colstats = bool(colstats) and FUSE_GN          # statistics are only worth emitting for the fused chain
+        if colstats:                                    # statistics are emitted where a consumer will use them
+            oh, ow = out_hw if out_hw is not None else ((x.shape[1] * (2 if upsample else 1) + 2 * pad[0] - self.kernel_size) // self.stride + 1,
+                                                        (x.shape[2] * (2 if upsample else 1) + 2 * pad[1] - self.kernel_size) // self.stride + 1)
+            colstats = want_stats(x.shape[0], oh * ow, w.shape[0])
+        colstats = bool(colstats)
         kw = dict(ksize=self.kernel_size, stride=self.stride, pad=pad, upsample=upsample, out_hw=out_hw, residual=residual,
                   rowvec=rowvec, flags=flags, n_out=w.shape[0], colstats=colstats)
         in_scsh = None
@@ -236,6 +259,14 @@ class GroupNorm(nn.Module):
         self.bias = nn.Parameter(torch.zeros(num_channels))
 
     def forward(self, x, x2=None, silu: bool = False):
+        if GN_EPI:
+            st1, st2 = ops.gn_stats_of(x), ops.gn_stats_of(x2)
+            C1, C2 = x.shape[-1], (x2.shape[-1] if x2 is not None else 0)
+            HW = x.numel() // (x.shape[0] * C1)
+            if (st1 is not None and (x2 is None or st2 is not None) and (C1 + C2) % 64 == 0
+                    and (C1 + C2) // self.num_groups <= 128 and not ops.gn_strip_ok(x.shape[0], HW, C1, C2, self.num_groups)):
+                count_flops("gn_from_epilogue_stats", 1)
+                return ops.group_norm_from_stats(x, st1, self.weight, self.bias, self.num_groups, self.eps, silu, x2=x2, st2=st2)
         return ops.group_norm(x, self.weight, self.bias, self.num_groups, self.eps, silu, x2=x2)
 
 
