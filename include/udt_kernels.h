@@ -274,6 +274,13 @@ int udt_gn_finalize(const float* stats1, int32_t slots1, int32_t C1, const float
 int udt_gn_apply_scsh(const void* x, const void* x2, void* y, const float* scsh, int32_t B, int64_t HW, int32_t C1,
                       int32_t C2, int32_t act, void* stream);
 
+/* The one-launch strip GroupNorm (udt_gn_strip) when the producers of x (and x2) emitted column statistics
+ * (udt_gemm_desc.colstats: fp32 [B * slots][C][2]): the statistics pass over the strip becomes a sum over `slots` records per
+ * channel, the launch is the normalise(+SiLU) pass alone.  Same shapes as udt_gn_strip (udt_gn_strip_ok). */
+int udt_gn_strip_stats(const void* x, const void* x2, void* y, const float* stats1, int32_t slots1, const float* stats2,
+                       int32_t slots2, const float* gamma, const float* beta, int32_t B, int64_t HW, int32_t C1, int32_t C2,
+                       int32_t G, float eps, int32_t act, void* stream);
+
 /* LayerNorm over the last dim of bf16 [rows, C] (C % 8 == 0, C <= 4096). */
 int udt_layernorm(const void* x, void* y, const float* gamma, const float* beta,
                   int64_t rows, int32_t C, float eps, void* stream);

@@ -371,3 +371,23 @@ def test_groupnorm_from_statistics_two_sources(env, cuda):
     want = F.silu(F.group_norm(cat.permute(0, 3, 1, 2), 32, gamma, beta, 1e-5)).permute(0, 2, 3, 1)
     torch.cuda.synchronize()
     assert _rel(got, want) < 6e-3
+
+
+@pytest.mark.parametrize("B,H,C,N", [(4, 16, 1280, 1280), (8, 8, 1280, 1280), (3, 16, 640, 1280)])
+def test_strip_groupnorm_from_epilogue_statistics(env, cuda, B, H, C, N):
+    """small levels: udt_gn_strip_stats (the strip GroupNorm without its statistics pass, fed by the lean convolution's
+    epilogue statistics, incl. the split-K launches of the 16x16 / 8x8 maps) vs torch group_norm and vs udt_gn_strip"""
+    g = torch.Generator(device="cpu").manual_seed(24)
+    x = torch.randn((B, H, H, C), generator=g).to(cuda).bfloat16()
+    w = env.packing.pack_conv((torch.randn((N, C, 3, 3), generator=g) / math.sqrt(9 * C)).to(cuda))
+    out = env.ops.conv2d(x, w, None, ksize=3, colstats=True)
+    st = env.ops.gn_stats_of(out)
+    assert st is not None and env.ops.gn_strip_ok(B, H * H, N, 0, 32)
+    gamma = (1 + 0.1 * torch.randn((N,), generator=g)).to(cuda)
+    beta = (0.1 * torch.randn((N,), generator=g)).to(cuda)
+    got = env.ops.group_norm_from_stats(out, st, gamma, beta, 32, 1e-5, True)
+    two = env.ops.group_norm(out, gamma, beta, 32, 1e-5, True)
+    want = F.silu(F.group_norm(out.float().permute(0, 3, 1, 2), 32, gamma, beta, 1e-5)).permute(0, 2, 3, 1)
+    torch.cuda.synchronize()
+    assert _rel(got, want) < 6e-3
+    assert (got.float() - two.float()).abs().max().item() <= 4e-2

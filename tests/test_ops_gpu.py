@@ -326,18 +326,27 @@ def test_fused_gn_matches_unfused_resblock(ops, cuda):
     wq = packing.pack_linear(_rand((640, 128), cuda, 0.1, seed=2))
     y = ops.linear(a, wq, None, rows_per_batch=1024, colstats=True)
     x = H.carry_stats(y.reshape(2, 32, 32, 640), y)
-    prev = H.FUSE_GN
+    prev = (H.FUSE_GN, H.GN_EPI)
     try:
-        H.FUSE_GN = True
+        H.FUSE_GN, H.GN_EPI = True, False
         fused = conv(x, norm=norm, norm_silu=True, colstats=True)
         assert ops.gn_stats_of(fused) is not None
-        H.FUSE_GN = False
+        H.FUSE_GN, H.GN_EPI = False, False
         plain = conv(x, norm=norm, norm_silu=True, colstats=True)
         assert ops.gn_stats_of(plain) is None
+        # the default since round 3: statistics from the producer's epilogue, finalize + streaming apply, unfused convolution
+        H.FUSE_GN, H.GN_EPI = False, True
+        ops.WORK_COUNTER = {}
+        epi = conv(x, norm=norm, norm_silu=True, colstats=True)
+        used = ops.WORK_COUNTER.get("gn_from_epilogue_stats", 0)
+        ops.WORK_COUNTER = None
+        assert used == 1 and ops.gn_stats_of(epi) is not None
     finally:
-        H.FUSE_GN = prev
+        H.FUSE_GN, H.GN_EPI = prev
     _close(fused, plain, atol=3e-2, what="fused vs unfused GN+SiLU+conv")
     assert (fused.float() - plain.float()).abs().mean().item() < 4e-3
+    _close(epi, plain, atol=3e-2, what="GroupNorm from epilogue statistics vs the gn_stats / gn_apply pair")
+    assert (epi.float() - plain.float()).abs().mean().item() < 4e-3
 
 
 def _deq(q_u8):

@@ -100,6 +100,32 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const uint16_t* __restric
   const int t = threadIdx.x;
   const int b = blockIdx.y;
   const int cpg = C / G;
+  const int c8 = C >> 3;
+  const long long total = HW * c8;                 // 16-byte chunks in this sample
+  const long long begin = (long long)blockIdx.x * chunks_per_wg;
+  long long end = begin + chunks_per_wg;
+  if (end > total) end = total;
+  const uint16_t* xb1 = x + (long long)b * HW * C1;
+  const uint16_t* xb2 = x2 ? (x2 + (long long)b * HW * C2) : nullptr;
+  uint16_t* yb = y + (long long)b * HW * C;
+  auto src_of = [&](long long i, int& cc) -> const uint16_t* {
+    const long long pix = i / c8;
+    cc = (int)(i - pix * c8);
+    return (cc * 8 < C1) ? (xb1 + pix * C1 + cc * 8) : (xb2 + pix * C2 + (cc * 8 - C1));
+  };
+  // the first round of loads goes out BEFORE the scale / shift table is built: a workgroup's latency is one memory round
+  // trip, not table + data (the kernel is a chain of dependent round trips per workgroup; 32 KiB spans of 8 rounds ran at
+  // 1.5 TB/s, profiles/r03_trace_step_gn_epilogue.txt)
+  long long i = begin + t;
+  u32x4 v0 = {0u, 0u, 0u, 0u}, v1 = v0, v2 = v0, v3 = v0;
+  int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+  const bool full = i + 768 < end;
+  if (full) {
+    v0 = *reinterpret_cast<const u32x4*>(src_of(i, c0));
+    v1 = *reinterpret_cast<const u32x4*>(src_of(i + 256, c1));
+    v2 = *reinterpret_cast<const u32x4*>(src_of(i + 512, c2));
+    v3 = *reinterpret_cast<const u32x4*>(src_of(i + 768, c3));
+  }
   if (scsh) {
     // the per-(sample, channel) scale / shift table of udt_gn_finalize ([B][C/64][2][64]): statistics came from the
     // producers' epilogues, nothing to reduce here
@@ -142,14 +168,6 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const uint16_t* __restric
     }
   }
   __syncthreads();
-  const int c8 = C >> 3;
-  const long long total = HW * c8;                 // 16-byte chunks in this sample
-  const long long begin = (long long)blockIdx.x * chunks_per_wg;
-  long long end = begin + chunks_per_wg;
-  if (end > total) end = total;
-  const uint16_t* xb1 = x + (long long)b * HW * C1;
-  const uint16_t* xb2 = x2 ? (x2 + (long long)b * HW * C2) : nullptr;
-  uint16_t* yb = y + (long long)b * HW * C;
   auto norm8 = [&](const u32x4 v, int cc) {
     u32x4 o;
 #pragma unroll
@@ -165,18 +183,18 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const uint16_t* __restric
     }
     return o;
   };
-  auto src_of = [&](long long i, int& cc) -> const uint16_t* {
-    const long long pix = i / c8;
-    cc = (int)(i - pix * c8);
-    return (cc * 8 < C1) ? (xb1 + pix * C1 + cc * 8) : (xb2 + pix * C2 + (cc * 8 - C1));
-  };
-  long long i = begin + t;
+  if (full) {
+    *reinterpret_cast<u32x4*>(yb + i * 8) = norm8(v0, c0);
+    *reinterpret_cast<u32x4*>(yb + (i + 256) * 8) = norm8(v1, c1);
+    *reinterpret_cast<u32x4*>(yb + (i + 512) * 8) = norm8(v2, c2);
+    *reinterpret_cast<u32x4*>(yb + (i + 768) * 8) = norm8(v3, c3);
+    i += 1024;
+  }
   for (; i + 768 < end; i += 1024) {                       // 4 independent 16-byte loads per lane
-    int c0, c1, c2, c3;
-    const u32x4 v0 = *reinterpret_cast<const u32x4*>(src_of(i, c0));
-    const u32x4 v1 = *reinterpret_cast<const u32x4*>(src_of(i + 256, c1));
-    const u32x4 v2 = *reinterpret_cast<const u32x4*>(src_of(i + 512, c2));
-    const u32x4 v3 = *reinterpret_cast<const u32x4*>(src_of(i + 768, c3));
+    v0 = *reinterpret_cast<const u32x4*>(src_of(i, c0));
+    v1 = *reinterpret_cast<const u32x4*>(src_of(i + 256, c1));
+    v2 = *reinterpret_cast<const u32x4*>(src_of(i + 512, c2));
+    v3 = *reinterpret_cast<const u32x4*>(src_of(i + 768, c3));
     *reinterpret_cast<u32x4*>(yb + i * 8) = norm8(v0, c0);
     *reinterpret_cast<u32x4*>(yb + (i + 256) * 8) = norm8(v1, c1);
     *reinterpret_cast<u32x4*>(yb + (i + 512) * 8) = norm8(v2, c2);
@@ -272,7 +290,8 @@ constexpr int GNS_THREADS = 512;
 __global__ void __launch_bounds__(GNS_THREADS) gn_strip_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ x2,
                                                                uint16_t* __restrict__ y, const float* __restrict__ gamma,
                                                                const float* __restrict__ beta, long long HW, int C1, int C2, int G,
-                                                               int gw, float eps, int act) {
+                                                               int gw, float eps, int act, const float* __restrict__ st1,
+                                                               int slots1, const float* __restrict__ st2, int slots2) {
   extern __shared__ __attribute__((aligned(16))) float gss[];
   const int C = C1 + C2;
   const int cpg = C / G;
@@ -294,6 +313,25 @@ __global__ void __launch_bounds__(GNS_THREADS) gn_strip_kernel(const uint16_t* _
   const bool second = c >= C1;
   const int cs = second ? C2 : C1;
   const uint16_t* src = (second ? x2 : x) + (long long)b * HW * cs + (second ? c - C1 : c);
+  if (st1) {
+    // the producers emitted this activation's column statistics from their epilogues (udt_gemm_desc.colstats, fp32
+    // [slots][C][2] per source): the statistics pass over the strip is a sum over a few slots per channel
+    if (t < cw) {
+      const int cc = c_base + t;
+      const bool sec = cc >= C1;
+      const float* sp = sec ? st2 + ((long long)b * slots2 * C2 + (cc - C1)) * 2 : st1 + ((long long)b * slots1 * C1 + cc) * 2;
+      const int n = sec ? slots2 : slots1;
+      const long long stride = (long long)(sec ? C2 : C1) * 2;
+      double a = 0.0, qq = 0.0;
+      for (int k = 0; k < n; ++k) {
+        const f32x2 v = *reinterpret_cast<const f32x2*>(sp + k * stride);
+        a += (double)v[0];
+        qq += (double)v[1];
+      }
+      csum[t] = a;
+      csq[t] = qq;
+    }
+  }
   float s[8], q[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) s[i] = q[i] = 0.f;
@@ -305,7 +343,7 @@ __global__ void __launch_bounds__(GNS_THREADS) gn_strip_kernel(const uint16_t* _
       s[2 * i + 1] += bb; q[2 * i + 1] += bb * bb;
     }
   };
-  if (active) {
+  if (active && !st1) {
     long long p = pl;
     for (; p + 3LL * pstep < HW; p += 4LL * pstep) {           // 4 loads in flight per lane
       const u32x4 v0 = *reinterpret_cast<const u32x4*>(src + p * cs);
@@ -322,7 +360,7 @@ __global__ void __launch_bounds__(GNS_THREADS) gn_strip_kernel(const uint16_t* _
     }
   }
   __syncthreads();
-  if (t < cw) {
+  if (t < cw && !st1) {
     double a = 0.0, qq = 0.0;
     for (int r = 0; r < pstep; ++r) { a += (double)psum[r * cw + t]; qq += (double)psq[r * cw + t]; }
     csum[t] = a;
@@ -593,10 +631,12 @@ extern "C" int32_t udt_gn_strip_ok(int32_t B, int64_t HW, int32_t C1, int32_t C2
   return (B > 0 && gn_strip_groups(HW, C1, C2, G) > 0) ? 1 : 0;
 }
 
-extern "C" int udt_gn_strip(const void* x, const void* x2, void* y, const float* gamma, const float* beta, int32_t B, int64_t HW,
-                            int32_t C1, int32_t C2, int32_t G, float eps, int32_t act, void* stream) {
+static int gn_strip_impl(const void* x, const void* x2, void* y, const float* st1, int slots1, const float* st2, int slots2,
+                         const float* gamma, const float* beta, int32_t B, int64_t HW, int32_t C1, int32_t C2, int32_t G, float eps,
+                         int32_t act, void* stream) {
   if (!x || !y || !gamma || !beta || (C2 > 0 && !x2)) return UDT_ERR_BAD_ARG;
   if (B <= 0 || HW <= 0 || C1 <= 0 || C2 < 0) return UDT_ERR_BAD_SHAPE;
+  if (st1 && (slots1 <= 0 || (C2 > 0 && (!st2 || slots2 <= 0)))) return UDT_ERR_BAD_ARG;
   const int gw = gn_strip_groups(HW, C1, C2, G);
   if (gw <= 0) return UDT_ERR_BAD_SHAPE;
   const int C = C1 + C2;
@@ -607,7 +647,7 @@ extern "C" int udt_gn_strip(const void* x, const void* x2, void* y, const float*
   UdtProfScope prof(4, s);
   if (prof.rec) {
     char tag[96];
-    snprintf(tag, sizeof(tag), "gn_strip B=%d HW=%lld C=%d+%d gw=%d", B, (long long)HW, C1, C2, gw);
+    snprintf(tag, sizeof(tag), "gn_strip%s B=%d HW=%lld C=%d+%d gw=%d", st1 ? "_stats" : "", B, (long long)HW, C1, C2, gw);
     udt_prof_tag(prof.rec, tag);
   }
   static bool attr_set = false;
@@ -618,9 +658,21 @@ extern "C" int udt_gn_strip(const void* x, const void* x2, void* y, const float*
   }
   hipLaunchKernelGGL(gn_strip_kernel, dim3(G / gw, B), dim3(GNS_THREADS), smem, s, reinterpret_cast<const uint16_t*>(x),
                      reinterpret_cast<const uint16_t*>(x2), reinterpret_cast<uint16_t*>(y), gamma, beta, (long long)HW, C1, C2, G, gw,
-                     eps, act);
+                     eps, act, st1, slots1, st2, slots2);
   UDT_CHECK_LAUNCH();
   return UDT_OK;
+}
+
+extern "C" int udt_gn_strip(const void* x, const void* x2, void* y, const float* gamma, const float* beta, int32_t B, int64_t HW,
+                            int32_t C1, int32_t C2, int32_t G, float eps, int32_t act, void* stream) {
+  return gn_strip_impl(x, x2, y, nullptr, 0, nullptr, 0, gamma, beta, B, HW, C1, C2, G, eps, act, stream);
+}
+
+extern "C" int udt_gn_strip_stats(const void* x, const void* x2, void* y, const float* stats1, int32_t slots1, const float* stats2,
+                                  int32_t slots2, const float* gamma, const float* beta, int32_t B, int64_t HW, int32_t C1,
+                                  int32_t C2, int32_t G, float eps, int32_t act, void* stream) {
+  if (!stats1) return UDT_ERR_BAD_ARG;
+  return gn_strip_impl(x, x2, y, stats1, slots1, stats2, slots2, gamma, beta, B, HW, C1, C2, G, eps, act, stream);
 }
 
 extern "C" int32_t udt_gn_nchunks(int64_t HW, int32_t C) {
@@ -663,7 +715,7 @@ extern "C" int udt_gn_apply(const void* x, const void* x2, void* y, const float*
   if (B <= 0 || HW <= 0 || G <= 0 || G > 256 || C % G != 0 || C > GN_MAX_C) return UDT_ERR_BAD_SHAPE;
   const int nchunks = udt_gn_nchunks(HW, C);
   const long long total = (long long)HW * (C / 8);
-  const long long chunks_per_wg = 2048;   // 32 KiB of bf16 per workgroup
+  const long long chunks_per_wg = 1024;   // 16 KiB of bf16 per workgroup: one round of four 16-byte loads per lane
   const int blocks = (int)((total + chunks_per_wg - 1) / chunks_per_wg);
   if (256 % G != 0) return UDT_ERR_BAD_SHAPE;
   const size_t smem = (size_t)(2 * C + 2 * G) * sizeof(float) + 8 + 512 * sizeof(double);
@@ -688,7 +740,7 @@ extern "C" int udt_gn_apply_scsh(const void* x, const void* x2, void* y, const f
   const int C = C1 + C2;
   if (B <= 0 || HW <= 0 || C % 64 != 0 || C > GN_MAX_C) return UDT_ERR_BAD_SHAPE;
   const long long total = (long long)HW * (C / 8);
-  const long long chunks_per_wg = 2048;   // 32 KiB of bf16 per workgroup
+  const long long chunks_per_wg = 1024;   // 16 KiB of bf16 per workgroup: one round of four 16-byte loads per lane
   const int blocks = (int)((total + chunks_per_wg - 1) / chunks_per_wg);
   const size_t smem = (size_t)(2 * C) * sizeof(float);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);

@@ -524,9 +524,15 @@ def group_norm_from_stats(x: torch.Tensor, st1: GnStats, gamma: torch.Tensor, be
         assert x2.is_contiguous() and x2.shape[:-1] == x.shape[:-1] and st2 is not None
         C2 = x2.shape[-1]
     HW = x.numel() // (B * C1)
-    scsh = gn_finalize(st1, C1, st2, C2, gamma, beta, B, HW, groups, eps)
     if out is None:
         out = torch.empty(x.shape[:-1] + (C1 + C2,), dtype=torch.bfloat16, device=x.device)
+    if gn_strip_ok(B, HW, C1, C2, groups):          # small levels: one launch, the strip kernel without its statistics pass
+        L.check(L.load().udt_gn_strip_stats(_ptr(x), _ptr(x2), _ptr(out), _ptr(st1.data), st1.slots_per_sample,
+                                            _ptr(st2.data) if st2 is not None else None,
+                                            st2.slots_per_sample if st2 is not None else 0, _ptr(gamma), _ptr(beta), B, HW, C1, C2,
+                                            groups, eps, 1 if silu else 0, _stream()), "udt_gn_strip_stats")
+        return out
+    scsh = gn_finalize(st1, C1, st2, C2, gamma, beta, B, HW, groups, eps)
     L.check(L.load().udt_gn_apply_scsh(_ptr(x), _ptr(x2), _ptr(out), _ptr(scsh), B, HW, C1, C2, 1 if silu else 0, _stream()),
             "udt_gn_apply_scsh")
     return out
