@@ -241,8 +241,9 @@ def test_linear_colstats(ops, cuda, M, N, K, hw):
     rows = hw // st.slots_per_sample
     assert rows in (32, 64)
     ref = _colstats_ref(out.reshape(1, 1, M, N), rows)
-    n = ref.shape[0]
-    torch.testing.assert_close(st.data[:n], ref, rtol=2e-4, atol=2e-3)
+    n = (M + rows - 1) // rows            # slots that hold rows (the 8-wave kernels pad to 256-row tiles, the lean ones to 128)
+    assert st.data.shape[0] >= n
+    torch.testing.assert_close(st.data[:n], ref[:n], rtol=2e-4, atol=2e-3)
     _close(out, x.float() @ wp.float().t() + b + res.float(), what="linear with colstats")
 
 
