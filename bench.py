@@ -469,7 +469,7 @@ def main():
                 "gemm": cls("linears + 1x1 convolutions: lg::lgemm_kernel (lean co-resident family; plain / GEGLU / LayerNorm-folded) "
                             "+ g8::gemm8_kernel (two-source 1x1, transposed, fp32 outputs)", gemm_flops,
                             gemm_bytes, gemm_ms, gemm_launches),
-                "attention": cls("flash self-attention: attn_d64_kernel", attn_flops, attn_bytes, attn_ms, attn_launches)},
+                "attention": cls("flash attention: attn_d64_v2_kernel (UNet self-attention, head_dim 64) + attn_d512_q64_kernel (VAE mid block, one head of 512)", attn_flops, attn_bytes, attn_ms, attn_launches)},
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(model, args.size, args.chars, args.sampler_steps)
