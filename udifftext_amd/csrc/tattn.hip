@@ -26,6 +26,7 @@ namespace {
 
 constexpr int TA_THREADS = 512;        // 8 waves: the MFMA phases are chains of L2-latency-bound steps, more waves hide more of it
 constexpr int TA_WAVES = TA_THREADS / 64;
+constexpr int TA_AHEAD = 5;          // A' K-tiles in flight per wave (the UNet's C / 64 = 5, 10, 20 are multiples)
 
 struct TattnParams {
   const uint16_t* x;       // [M, C] bf16
@@ -140,27 +141,32 @@ __global__ void __launch_bounds__(TA_THREADS) tattn_fused_kernel(const TattnPara
     const int swz = (l31 >> 1) & 7;                         // (row >> 1) & 7 with row = rt*32 + l31
     const uint16_t* arow = Ab + (long long)(ct * 32 + l31) * C + hi * 8;
     f32x16 acc = zero16();
-    // the A' fragments come straight from L2 (each is used once per workgroup): loads run TWO K-tiles ahead of the MFMAs
-    bf16x8_t a0[4], a1[4];
+    // the A' fragments come straight from L2 (each is used once per workgroup): loads run TA_AHEAD K-tiles ahead of the MFMAs
+    // (a register ring, the K loop unrolled by its length; two ahead left an L2 round trip exposed every other K-tile)
+    bf16x8_t ar[TA_AHEAD][4];
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      a0[ks] = *reinterpret_cast<const bf16x8_t*>(arow + ks * 16);
-      a1[ks] = *reinterpret_cast<const bf16x8_t*>(arow + (nkt > 1 ? 64 : 0) + ks * 16);
-    }
-    for (int kt = 0; kt < nkt; ++kt) {
-      const char* xrow = xs + ((size_t)kt * TT + row) * 128;
-      bf16x8_t af[4], xf[4];
+    for (int u = 0; u < TA_AHEAD; ++u)
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        af[ks] = a0[ks];
-        a0[ks] = a1[ks];
-        xf[ks] = lds_read_frag(xrow + (((ks * 2 + hi) ^ swz) << 4));
+      for (int ks = 0; ks < 4; ++ks) ar[u][ks] = *reinterpret_cast<const bf16x8_t*>(arow + (u < nkt ? u : 0) * 64 + ks * 16);
+    for (int kt0 = 0; kt0 < nkt; kt0 += TA_AHEAD) {
+#pragma unroll
+      for (int u = 0; u < TA_AHEAD; ++u) {
+        const int kt = kt0 + u;
+        if (kt < nkt) {
+          const char* xrow = xs + ((size_t)kt * TT + row) * 128;
+          bf16x8_t af[4], xf[4];
+#pragma unroll
+          for (int ks = 0; ks < 4; ++ks) {
+            af[ks] = ar[u][ks];
+            xf[ks] = lds_read_frag(xrow + (((ks * 2 + hi) ^ swz) << 4));
+          }
+          const int ktn = (kt + TA_AHEAD < nkt) ? kt + TA_AHEAD : kt;
+#pragma unroll
+          for (int ks = 0; ks < 4; ++ks) ar[u][ks] = *reinterpret_cast<const bf16x8_t*>(arow + ktn * 64 + ks * 16);
+#pragma unroll
+          for (int ks = 0; ks < 4; ++ks) acc = mfma32(af[ks], xf[ks], acc);
+        }
       }
-      const int ktn = (kt + 2 < nkt) ? kt + 2 : kt;
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) a1[ks] = *reinterpret_cast<const bf16x8_t*>(arow + ktn * 64 + ks * 16);
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) acc = mfma32(af[ks], xf[ks], acc);
     }
     const float mean = stats[row * 2], rstd = stats[row * 2 + 1];
     // reg r <-> column j = ct*32 + (r&3) + 8*(r>>2) + 4*hi; regs 0..7 lie in the tile's first head, 8..15 in the second
