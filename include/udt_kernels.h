@@ -69,6 +69,13 @@ typedef enum {
                                  tile is NaN-poisoned); reported by udt_check_async_error                */
 } udt_status;
 
+/* element types of packed weights (udt_pack_*) */
+typedef enum {
+  UDT_DTYPE_F32 = 0,
+  UDT_DTYPE_BF16 = 1,
+  UDT_DTYPE_FP8_E4M3 = 2      /* OCP e4m3 (not the fnuz format of MI300X) + one fp32 scale per output channel */
+} udt_dtype;
+
 /* ---- epilogue / mode flags for udt_gemm ------------------------------------------------------- */
 #define UDT_GEMM_OUT_F32     (1 << 0)  /* out is fp32 instead of bf16                              */
 #define UDT_GEMM_GEGLU       (1 << 1)  /* out[:, j] = x_j * gelu_erf(gate_j); weight rows packed
@@ -343,6 +350,37 @@ int udt_debug_set(const char* key, int32_t value);
 int udt_bias_add_bf16(const void* x, const float* bias, void* out, int64_t rows, int32_t C, void* stream);
 
 /* ---- library services -------------------------------------------------------------------------- */
+/* ---- packed-weight handles: the only memory the library allocates on a caller's behalf (SURVEY §8b "Ownership") ----------
+ * Checkpoint layouts in (the reference's): nn.Linear weight [N, K] fp32 (+ bias [N]), nn.Conv2d weight [N, Cin, kh, kw] fp32,
+ * DEVICE pointers; out: an immutable handle whose buffers have the layouts udt_gemm consumes.
+ *   udt_pack_linear: bf16 [Npad][Kpad] (K padded to 64, N to 4, zeros) or, dtype = UDT_DTYPE_FP8_E4M3, e4m3 bytes [Npad][Kpad128]
+ *     + colscale[n] = max_k |w[n, k]| / 448; geglu != 0: rows permuted into [32 value | 32 gate] blocks for UDT_GEMM_GEGLU
+ *     (GEGLU.proj, reference attention.py:83-99), bias permuted the same way.
+ *   udt_pack_conv: bf16 [Npad][kh*kw*Cpad], k = (ky*kw + kx)*Cpad + c; `segments` (may be NULL) = channel counts of the
+ *     concatenated sources (decoder skip concat), each padded to a multiple of 64 separately; N padded to n_pad_to.
+ * udt_packed_dim(h, which): 0 N, 1 Npad, 2 K, 3 Kpad (= the `ldw` / `K` to put into udt_gemm_desc), 4 dtype.
+ * The LayerNorm fold of udt_ln_gemm_fwd (W' = gamma * W, colsum, c) is done by the Python front end (packing.pack_ln_linear). */
+typedef struct udt_packed udt_packed;
+int udt_pack_linear(const float* w, const float* bias, int32_t N, int32_t K, int32_t dtype, int32_t geglu,
+                    udt_packed** out, void* stream);
+int udt_pack_conv(const float* w, const float* bias, int32_t N, int32_t Cin, int32_t kh, int32_t kw, const int32_t* segments,
+                  int32_t n_segments, int32_t n_pad_to, udt_packed** out, void* stream);
+const void* udt_packed_weight(const udt_packed* h);
+const float* udt_packed_bias(const udt_packed* h);
+const float* udt_packed_colscale(const udt_packed* h);
+int32_t udt_packed_dim(const udt_packed* h, int32_t which);
+int udt_free_packed(udt_packed* h);
+
+/* ---- the names SURVEY §8b lists for the generic entry points (same functions) -------------------------------------------------
+ * udt_gemm_fwd = udt_gemm; udt_conv1x1_fwd = udt_gemm restricted to UDT_GEMM_CONV with ksize 1 (nn.Conv2d 1x1: proj_in / proj_out of
+ * the VAE attention block, skip_connection); udt_workspace_bytes = udt_gemm_workspace_bytes; udt_sampler_step = udt_cfg_euler_step
+ * (VanillaCFG + DiscreteDenoiser scaling + the Euler update, reference sampling.py:68-80, guiders.py:17-22, denoiser.py:23-31). */
+int udt_gemm_fwd(const udt_gemm_desc* d, void* workspace, size_t workspace_bytes, void* stream);
+int udt_conv1x1_fwd(const udt_gemm_desc* d, void* workspace, size_t workspace_bytes, void* stream);
+size_t udt_workspace_bytes(const udt_gemm_desc* d);
+int udt_sampler_step(float* x, const float* eps, float* denoised_out, int32_t B, int32_t hw, int32_t ld_eps,
+                     float c_out, float sigma, float sigma_next, float cfg_scale, void* stream);
+
 const char* udt_version(void);
 const char* udt_status_string(int status);
 int udt_last_hip_error(void);            /* hipError_t of the last failing HIP call (0 if none)     */

@@ -765,3 +765,68 @@ def test_error_codes(ops, cuda):
         ops.attention(torch.zeros((1, 12, 64), dtype=torch.bfloat16, device=cuda),
                       torch.zeros((1, 12, 64), dtype=torch.bfloat16, device=cuda),
                       torch.zeros((1, 64, 12), dtype=torch.bfloat16, device=cuda), 1, 0.125)   # nk % 8
+
+
+def _packed_tensor(lib, h, which, shape, dtype):
+    """copy of a packed-weight handle's buffer as a torch tensor (the handle owns its memory: hipMemcpy device to device)"""
+    import ctypes as C
+    ptr = {"w": lib.udt_packed_weight, "b": lib.udt_packed_bias, "s": lib.udt_packed_colscale}[which](h)
+    assert ptr
+    out = torch.empty(shape, dtype=dtype, device="cuda")
+    torch.cuda.synchronize()
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    assert hip.hipMemcpy(out.data_ptr(), ptr, out.numel() * out.element_size(), 3) == 0      # 3 = hipMemcpyDeviceToDevice
+    return out
+
+
+def test_pack_handles_match_python_packing(ops, cuda):
+    """udt_pack_linear / udt_pack_conv (+ udt_free_packed): the C-ABI packers give bit-identical buffers to
+    udifftext_amd/packing.py (bf16 linear with ragged N / K, GEGLU row permutation + bias, e4m3 + per-channel scales, a 3x3
+    convolution over two concatenated sources padded to 64 separately), and a GEMM runs straight off a handle"""
+    import ctypes as C
+    from udifftext_amd import lib as L, packing
+    lib = L.load()
+    st = torch.cuda.current_stream().cuda_stream
+
+    def pack_linear(w, b, dtype, geglu):
+        h = C.c_void_p()
+        L.check(lib.udt_pack_linear(w.data_ptr(), b.data_ptr() if b is not None else None, w.shape[0], w.shape[1], dtype, geglu,
+                                    C.byref(h), st), "udt_pack_linear")
+        return h
+
+    w = _rand((322, 200), cuda, seed=1); b = _rand((322,), cuda, seed=2)
+    h = pack_linear(w, b, L.DTYPE_BF16, 0)
+    ref = packing.pack_linear(w)
+    assert (lib.udt_packed_dim(h, 1), lib.udt_packed_dim(h, 3)) == tuple(ref.shape) == (324, 256)
+    assert torch.equal(_packed_tensor(lib, h, "w", ref.shape, torch.bfloat16).view(torch.int16), ref.view(torch.int16))
+    assert torch.equal(_packed_tensor(lib, h, "b", (324,), torch.float32), packing.pad_bias(b))
+    # a GEMM straight off the handle's pointers
+    x = _rand((256, 200), cuda, seed=3).bfloat16()
+    xp = torch.zeros((256, 256), dtype=torch.bfloat16, device=cuda); xp[:, :200] = x
+    got = ops.linear(xp, _packed_tensor(lib, h, "w", ref.shape, torch.bfloat16), _packed_tensor(lib, h, "b", (324,), torch.float32))
+    _close(got[:, :322], x.float() @ w.bfloat16().float().t() + b, what="GEMM off a packed handle")
+    L.check(lib.udt_free_packed(h), "udt_free_packed")
+
+    wg = _rand((2 * 640, 320), cuda, seed=4); bg = _rand((2 * 640,), cuda, seed=5)
+    h = pack_linear(wg, bg, L.DTYPE_BF16, 1)
+    rw, rb = packing.pack_geglu(wg, bg)
+    assert torch.equal(_packed_tensor(lib, h, "w", rw.shape, torch.bfloat16).view(torch.int16), rw.view(torch.int16))
+    assert torch.equal(_packed_tensor(lib, h, "b", rb.shape, torch.float32), rb)
+    L.check(lib.udt_free_packed(h), "udt_free_packed")
+
+    h = pack_linear(w, None, L.DTYPE_FP8_E4M3, 0)
+    rq, rs = packing.pack_linear_fp8(w)
+    assert torch.equal(_packed_tensor(lib, h, "s", rs.shape, torch.float32), rs)
+    assert torch.equal(_packed_tensor(lib, h, "w", rq.shape, torch.uint8), rq)
+    L.check(lib.udt_free_packed(h), "udt_free_packed")
+
+    wc = _rand((130, 96 + 40, 3, 3), cuda, seed=6); bc = _rand((130,), cuda, seed=7)
+    segs = (C.c_int32 * 2)(96, 40)
+    h = C.c_void_p()
+    L.check(lib.udt_pack_conv(wc.data_ptr(), bc.data_ptr(), 130, 136, 3, 3, segs, 2, 4, C.byref(h), st), "udt_pack_conv")
+    rc = packing.pack_conv(wc, [96, 40])
+    assert lib.udt_packed_dim(h, 3) == rc.shape[1] == 9 * (128 + 64)
+    assert torch.equal(_packed_tensor(lib, h, "w", rc.shape, torch.bfloat16).view(torch.int16), rc.view(torch.int16))
+    L.check(lib.udt_free_packed(h), "udt_free_packed")
+    assert lib.udt_free_packed(None) == 0

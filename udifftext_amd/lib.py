@@ -13,6 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libudt_kernels.so")
 
 # flags (mirror include/udt_kernels.h)
 GEMM_OUT_F32 = 1 << 0
+DTYPE_F32, DTYPE_BF16, DTYPE_FP8_E4M3 = 0, 1, 2
 GEMM_GEGLU = 1 << 1
 GEMM_RELU = 1 << 2
 GEMM_TRANSPOSED = 1 << 3
@@ -45,6 +46,16 @@ _vp, _i32, _i64, _f32, _fp = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_vo
 SYMBOLS = {
     "udt_gemm_workspace_bytes": (C.c_size_t, [C.POINTER(GemmDesc)]),
     "udt_gemm": (C.c_int, [C.POINTER(GemmDesc), _vp, C.c_size_t, _vp]),
+    "udt_gemm_fwd": (C.c_int, [C.POINTER(GemmDesc), _vp, C.c_size_t, _vp]),
+    "udt_conv1x1_fwd": (C.c_int, [C.POINTER(GemmDesc), _vp, C.c_size_t, _vp]),
+    "udt_workspace_bytes": (C.c_size_t, [C.POINTER(GemmDesc)]),
+    "udt_pack_linear": (C.c_int, [_fp, _fp, _i32, _i32, _i32, _i32, C.POINTER(_vp), _vp]),
+    "udt_pack_conv": (C.c_int, [_fp, _fp, _i32, _i32, _i32, _i32, C.POINTER(_i32), _i32, _i32, C.POINTER(_vp), _vp]),
+    "udt_packed_weight": (_vp, [_vp]),
+    "udt_packed_bias": (_vp, [_vp]),
+    "udt_packed_colscale": (_vp, [_vp]),
+    "udt_packed_dim": (_i32, [_vp, _i32]),
+    "udt_free_packed": (C.c_int, [_vp]),
     "udt_check_async_error": (C.c_int, [_vp, C.c_size_t, _vp]),
     "udt_gemm_colstats_rows": (_i32, [C.POINTER(GemmDesc)]),
     "udt_gemm_colstats_slots": (_i32, [C.POINTER(GemmDesc)]),
@@ -76,6 +87,7 @@ SYMBOLS = {
     "udt_quantize_fp8": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _f32, _vp]),
     "udt_unet_input": (C.c_int, [_fp, _vp, _i32, _i32, _i32, _f32, _vp]),
     "udt_cfg_euler_step": (C.c_int, [_fp, _fp, _fp, _i32, _i32, _i32, _f32, _f32, _f32, _f32, _vp]),
+    "udt_sampler_step": (C.c_int, [_fp, _fp, _fp, _i32, _i32, _i32, _f32, _f32, _f32, _f32, _vp]),
     "udt_posterior_sample": (C.c_int, [_fp, _fp, _fp, _i32, _i32, _i32, _f32, _vp]),
     "udt_nchw_to_nhwc": (C.c_int, [_fp, _vp, _i32, _i32, _i64, _i32, _f32, _vp]),
     "udt_nhwc_to_nchw": (C.c_int, [_vp, _fp, _i32, _i32, _i64, _i32, _i32, _vp]),
