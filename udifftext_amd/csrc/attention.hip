@@ -385,16 +385,24 @@ __global__ void __launch_bounds__(256, 3) attn_d64_v2_kernel(const AttnParams p)
 #pragma unroll
         for (int r = 0; r < 16; ++r) o_acc[i][r] *= alpha;
     }
-    float psum = 0.f;
+    // exponent arguments and the row sum on PACKED fp32 ops (v_pk_fma_f32 / v_pk_add_f32: two elements per instruction at
+    // the scalar rate; the loop is bound by its VALU work — 32 quarter-rate v_exp_f32 plus ~100 other instructions per
+    // 16 MFMAs — not by the matrix pipe)
+    typedef float f32x2v __attribute__((ext_vector_type(2)));
+    const f32x2v c2 = {c, c}, m2 = {m_run, m_run};
+    f32x2v ps2 = {0.f, 0.f};
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float pv = fast_exp2(s[t][r] * c - m_run);
-        s[t][r] = pv;
-        psum += pv;
+      for (int r = 0; r < 16; r += 2) {
+        f32x2v e = {s[t][r], s[t][r + 1]};
+        e = __builtin_elementwise_fma(e, c2, -m2);
+        f32x2v pv = {fast_exp2(e[0]), fast_exp2(e[1])};
+        s[t][r] = pv[0];
+        s[t][r + 1] = pv[1];
+        ps2 += pv;
       }
-    l_run += psum;
+    l_run += ps2[0] + ps2[1];
     typedef short v4s __attribute__((ext_vector_type(4)));
     typedef __attribute__((address_space(3))) v4s* lds_v4s;
 #pragma unroll
