@@ -614,6 +614,40 @@ def test_noise_search_at_benchmarked_latent_size_vs_oracle(engine, cuda):
     _check("noise search: worst local loss vs oracle", torch.tensor([worst]), torch.tensor([max(scores)]), 3e-2)
 
 
+def test_noise_search_batched_candidates_match_one_at_a_time(engine, cuda, monkeypatch):
+    """the candidates of the noise search run as extra batch entries of shared UNet calls (up to 16 samples per call); every
+    candidate's score must equal the one-candidate-at-a-time score (a sample's result does not depend on its batch mates, up to
+    the launch plan's fp32 summation order), the same CPU draws are consumed, and the generator ends in the same state.
+    Batch of 2 images x 5 candidates at 32x32 latents: chunks of 5 candidates = 10 samples per call"""
+    from sgm.modules.diffusionmodules import sampling as S
+    from udifftext_amd import config as C, pipeline, synth
+    batch = synth.synthetic_batch(2, 256, 256, 6, seed=31)
+    torch.manual_seed(77)
+    batch, buc = pipeline.prepare_batch(batch, cuda)
+    c, uc = engine.conditioner.get_unconditional_conditioning(batch, batch_uc=buc, force_uc_zero_embeddings=["label"])
+    sampler = pipeline.init_sampling(50, 5.0, cuda)
+    cfgs = C.default_runtime_config(steps=50, batch_size=2, noise_iters=5)
+    import io, contextlib
+
+    def run(flag):
+        monkeypatch.setattr(S, "NOISE_BATCH", flag)
+        torch.manual_seed(4321)
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            x0 = sampler.get_init_noise(cfgs, engine, cond=c, batch=batch, uc=uc)
+        line = [l for l in buf.getvalue().splitlines() if l.startswith("Init local loss")][0]
+        return x0, float(line.split("Best")[1].split("Worst")[0]), float(line.split("Worst")[1]), torch.rand(1).item()
+
+    xa, ba, wa, ra = run(True)
+    xb, bb, wb, rb = run(False)
+    assert ra == rb                                             # K + 1 draws either way
+    assert abs(ba - bb) <= 2e-3 * abs(bb) + 1e-6 and abs(wa - wb) <= 2e-3 * abs(wb) + 1e-6, (ba, bb, wa, wb)
+    assert xa.shape == xb.shape == (2, 4, 32, 32)
+    # (the arg-min between candidates whose scores differ by less than the bf16 noise may legitimately differ; with these
+    #  seeds the winners are separated by > 1 % and must agree)
+    assert torch.equal(xa, xb)
+
+
 def test_predict_many_in_flight_with_noise_search(engine, cuda):
     """three batches in flight WITH the noise search (noise_iters > 0: the init-noise stepper of every lane plans its
     stream-K launches for the lane's share of the CUs — ADVICE round 2): same frames as predict() one batch at a time.

@@ -77,6 +77,8 @@ class EDMSampler(SingleStepDiffusionSampler):
         self.s_churn, self.s_tmin, self.s_tmax, self.s_noise = s_churn, s_tmin, s_tmax, s_noise
 
 
+# noise search: candidates as extra batch entries of one UNet call (0: one candidate at a time)
+NOISE_BATCH = os.environ.get("UDT_NOISE_BATCH", "1") != "0"
 DUAL_STREAM = os.environ.get("UDT_DUAL_STREAM", "1") != "0"
 
 
@@ -292,22 +294,36 @@ class EulerEDMSampler(EDMSampler):
         randn = rng.randn(shape).to(dev)
         if cfgs.noise_iters <= 0:
             return randn
-        stepper = _Stepper(model, cond, default(uc, cond), shape[0], shape[2:], self.guider.scale)
         sig = self._host_sigmas(2)
         mask, seg = batch["mask"], batch["seg_mask"]
-        cands, scores = [], []
-        for _ in range(cfgs.noise_iters):
-            x = randn.clone()
+        B, K = shape[0], int(cfgs.noise_iters)
+        uc = default(uc, cond)
+        # the reference draws the first candidate, then one more after scoring each (the last draw is never used but advances the
+        # generator): K + 1 draws in the same order
+        cands = [randn] + [rng.randn(shape).to(dev) for _ in range(K)]
+        cands, scores = cands[:K], []
+        # candidates are independent of each other (2 Euler steps + the local loss of THAT candidate's attention maps), so they
+        # run as extra batch entries of the same UNet calls: up to 16 samples (32 with the CFG pair) per call instead of K
+        # sequential 2-step runs on B samples — the reference-default workload (batch 1, noise_iters 10) is launch-latency-bound
+        # at 2 samples per call.  UDT_NOISE_BATCH=0: one candidate at a time (A/B, and the regime of the round-2 numbers)
+        G = max(1, min(K, 16 // max(1, B))) if NOISE_BATCH else 1
+        tile = lambda d, g: {k: (v.repeat((g,) + (1,) * (v.dim() - 1)) if torch.is_tensor(v) else v) for k, v in d.items()}
+        steppers = {}
+        for g0 in range(0, K, G):
+            chunk = cands[g0:g0 + G]
+            g = len(chunk)
+            stepper = steppers.get(g)
+            if stepper is None:
+                stepper = steppers[g] = _Stepper(model, tile(cond, g), tile(uc, g), g * B, shape[2:], self.guider.scale)
+            x = torch.cat(chunk, 0).clone()
             x *= (1.0 + sig[0] ** 2.0) ** 0.5
             ll = None
             for i in range(2):
                 stepper.step(x, sig[i], sig[i + 1], emit_maps=True)
                 ll = model.loss_fn.get_min_local_loss(stepper.unet.attn_map_cache, mask, seg)
-            cands.append(randn)
-            scores.append(ll[ll.shape[0] // 2:])
-            randn = rng.randn(shape).to(dev)
-        stepper.unet.clear_attn_map()
-        stepper.check()
+            scores.extend(ll[ll.shape[0] // 2:].reshape(g, B).unbind(0))
+            stepper.unet.clear_attn_map()
+            stepper.check()
         score = torch.stack(scores, 0)                                   # [iters, B]
         best = score.argmin(dim=0)                                        # first minimum, like the stable sort
         print(f"Init local loss: Best {score.min().item()} Worst {score.max().item()}")
