@@ -333,6 +333,11 @@ int udt_mask_downsample(const float* mask, float* out, int32_t B, int32_t H, int
 int udt_local_loss(const float* probs, const float* mask, const float* seg_mask, const float* gkernel9,
                    float* loss_accum, int32_t B, int32_t heads, int32_t size, int32_t L, int32_t seg_l,
                    int32_t Hm, int32_t Wm, void* stream);
+/* the same for n_samples = k * mask_batch maps scored against mask / seg row (sample % mask_batch): the candidates of the noise
+ * search (reference sampling.py get_init_noise, loss.py:192-235) as extra batch entries of one launch; loss_accum fp32 [n_samples] */
+int udt_local_loss_tiled(const float* probs, const float* mask, const float* seg_mask, const float* gkernel9,
+                         float* loss_accum, int32_t n_samples, int32_t mask_batch, int32_t heads, int32_t size, int32_t L,
+                         int32_t seg_l, int32_t Hm, int32_t Wm, void* stream);
 /* x bf16 += y bf16 (n elements, n % 8 == 0) ; utility for residuals outside GEMM epilogues */
 int udt_add_bf16(void* x, const void* y, int64_t n, void* stream);
 

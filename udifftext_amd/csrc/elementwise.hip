@@ -154,12 +154,13 @@ __global__ void mask_downsample_kernel(const float* __restrict__ m, float* __res
 __global__ void __launch_bounds__(256) local_loss_kernel(const float* __restrict__ probs, const float* __restrict__ mask,
                                                          const float* __restrict__ seg, const float* __restrict__ gk,
                                                          float* __restrict__ loss, int heads, int size, int L,
-                                                         int seg_l, int Hm, int Wm) {
+                                                         int seg_l, int Hm, int Wm, int mask_batch) {
   extern __shared__ __attribute__((aligned(16))) float llsm[];   // [size*size] map, [4] wave maxima, [1] best
   float* amap = llsm;
   float* red = llsm + size * size;
   float& best = red[4];
   const int b = blockIdx.x;
+  const int bm = b % mask_batch;                   // sample b is scored against mask / seg row b % mask_batch (tiled candidates)
   const int t = threadIdx.x;
   const int n = size * size;
   if (t == 0) best = INFINITY;
@@ -184,7 +185,7 @@ __global__ void __launch_bounds__(256) local_loss_kernel(const float* __restrict
         }
       // F.interpolate(mask, (size,size)) nearest: src = floor(dst * in / out)
       const int my = (int)(((long long)y * Hm) / size), mxx = (int)(((long long)x * Wm) / size);
-      const float mv = mask[((long long)b * Hm + my) * Wm + mxx];
+      const float mv = mask[((long long)bm * Hm + my) * Wm + mxx];
       mx = fmaxf(mx, mv * acc);
     }
 #pragma unroll
@@ -193,7 +194,7 @@ __global__ void __launch_bounds__(256) local_loss_kernel(const float* __restrict
     __syncthreads();
     if (t == 0) {
       const float m4 = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-      const float pl = m4 + (1.0f - seg[(long long)b * seg_l + l]);
+      const float pl = m4 + (1.0f - seg[(long long)bm * seg_l + l]);
       best = fminf(best, pl);
     }
     __syncthreads();
@@ -330,18 +331,31 @@ extern "C" int udt_mask_downsample(const float* mask, float* out, int32_t B, int
   return UDT_OK;
 }
 
-extern "C" int udt_local_loss(const float* probs, const float* mask, const float* seg_mask, const float* gkernel9,
-                              float* loss_accum, int32_t B, int32_t heads, int32_t size, int32_t L, int32_t seg_l,
-                              int32_t Hm, int32_t Wm, void* stream) {
+static int local_loss_impl(const float* probs, const float* mask, const float* seg_mask, const float* gkernel9, float* loss_accum,
+                           int32_t n_samples, int32_t mask_batch, int32_t heads, int32_t size, int32_t L, int32_t seg_l, int32_t Hm,
+                           int32_t Wm, void* stream) {
   if (!probs || !mask || !seg_mask || !gkernel9 || !loss_accum) return UDT_ERR_BAD_ARG;
-  if (B <= 0 || heads <= 0 || size <= 0 || size > 120 || L <= 0 || seg_l <= 0 || seg_l > L) return UDT_ERR_BAD_SHAPE;
+  if (n_samples <= 0 || mask_batch <= 0 || n_samples % mask_batch != 0 || heads <= 0 || size <= 0 || size > 120 || L <= 0 ||
+      seg_l <= 0 || seg_l > L) return UDT_ERR_BAD_SHAPE;
   UDT_STREAM;
   // 96x96 maps (768x768 inputs) need 36 KiB; the default dynamic-LDS limit is 64 KiB (120x120 floats + 32 B fit)
   const size_t smem = ((size_t)size * size + 8) * sizeof(float);
-  hipLaunchKernelGGL(local_loss_kernel, dim3(B), dim3(256), smem, s, probs, mask, seg_mask, gkernel9, loss_accum, heads,
-                     size, L, seg_l, Hm, Wm);
+  hipLaunchKernelGGL(local_loss_kernel, dim3(n_samples), dim3(256), smem, s, probs, mask, seg_mask, gkernel9, loss_accum, heads,
+                     size, L, seg_l, Hm, Wm, mask_batch);
   UDT_CHECK_LAUNCH();
   return UDT_OK;
+}
+
+extern "C" int udt_local_loss(const float* probs, const float* mask, const float* seg_mask, const float* gkernel9,
+                              float* loss_accum, int32_t B, int32_t heads, int32_t size, int32_t L, int32_t seg_l,
+                              int32_t Hm, int32_t Wm, void* stream) {
+  return local_loss_impl(probs, mask, seg_mask, gkernel9, loss_accum, B, B, heads, size, L, seg_l, Hm, Wm, stream);
+}
+
+extern "C" int udt_local_loss_tiled(const float* probs, const float* mask, const float* seg_mask, const float* gkernel9,
+                                    float* loss_accum, int32_t n_samples, int32_t mask_batch, int32_t heads, int32_t size, int32_t L,
+                                    int32_t seg_l, int32_t Hm, int32_t Wm, void* stream) {
+  return local_loss_impl(probs, mask, seg_mask, gkernel9, loss_accum, n_samples, mask_batch, heads, size, L, seg_l, Hm, Wm, stream);
 }
 
 extern "C" int udt_bias_add_bf16(const void* x, const float* bias, void* out, int64_t rows, int32_t C, void* stream) {

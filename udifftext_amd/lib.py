@@ -96,6 +96,7 @@ SYMBOLS = {
     "udt_timestep_embedding": (C.c_int, [_fp, _vp, _i32, _i32, _vp]),
     "udt_mask_downsample": (C.c_int, [_fp, _fp, _i32, _i32, _i32, _vp]),
     "udt_local_loss": (C.c_int, [_fp, _fp, _fp, _fp, _fp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "udt_local_loss_tiled": (C.c_int, [_fp, _fp, _fp, _fp, _fp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "udt_add_bf16": (C.c_int, [_vp, _vp, _i64, _vp]),
     "udt_debug_set": (C.c_int, [C.c_char_p, _i32]),
     "udt_bias_add_bf16": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _vp]),

@@ -684,10 +684,14 @@ def mask_downsample(mask: torch.Tensor) -> torch.Tensor:
 
 def local_loss_accumulate(probs: torch.Tensor, mask: torch.Tensor, seg_mask: torch.Tensor, gk9: torch.Tensor,
                           loss: torch.Tensor, heads: int, size: int) -> None:
+    """loss [n] += per-layer local-loss term of n = probs.shape[0] / heads samples; sample i is scored against
+    mask[i % B] / seg_mask[i % B] (B = mask.shape[0]; n a multiple of B: tiled candidates, or the uncond ‖ cond halves)"""
     B = mask.shape[0]
+    n = probs.shape[0] // heads
     Lc = probs.shape[-1]
-    L.check(L.load().udt_local_loss(_ptr(probs), _ptr(mask), _ptr(seg_mask), _ptr(gk9), _ptr(loss), B, heads, size, Lc,
-                                    seg_mask.shape[1], mask.shape[2], mask.shape[3], _stream()), "udt_local_loss")
+    assert probs.is_contiguous() and loss.is_contiguous() and loss.numel() == n and n % B == 0
+    L.check(L.load().udt_local_loss_tiled(_ptr(probs), _ptr(mask), _ptr(seg_mask), _ptr(gk9), _ptr(loss), n, B, heads, size, Lc,
+                                          seg_mask.shape[1], mask.shape[2], mask.shape[3], _stream()), "udt_local_loss_tiled")
 
 
 def add_(x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:

@@ -49,10 +49,12 @@ class FullLoss(StandardDiffusionLoss):
         g = g / g.sum()
         return g.view(1, 1, kernel_size, kernel_size).tile(out_channels, 1, 1, 1)
 
-    def get_min_local_loss(self, attn_map_cache, mask, seg_mask):
+    def get_min_local_loss(self, attn_map_cache, mask, seg_mask, cond_only: bool = False):
         """-> fp32 [n], n = batch of the attention maps (uncond ‖ cond).  mask [B,1,H,W], seg_mask [B, seg_l] with
         n a multiple of B: sample i of the maps is scored against mask[i % B] (for B = 1 this is the reference's
-        broadcast; for B > 1 the reference is undefined — SURVEY.md §8a row N — and this is the per-sample rule)."""
+        broadcast; for B > 1 the reference is undefined — SURVEY.md §8a row N — and this is the per-sample rule).
+        cond_only: score only the conditional half (the half every caller keeps, reference sampling.py: ``local_loss[B:]``)
+        -> fp32 [n / 2].  One launch per attention map, whatever n is."""
         mask = mask.float().contiguous()
         seg = seg_mask.float().contiguous()
         B = mask.shape[0]
@@ -66,10 +68,10 @@ class FullLoss(StandardDiffusionLoss):
                 continue
             n = am.shape[0] // heads
             assert n % B == 0 and seg.shape[1] <= am.shape[2]
+            first = n // 2 if cond_only else 0
+            assert first % B == 0
             if loss is None:
-                loss = torch.zeros((n,), dtype=torch.float32, device=am.device)
-            for r in range(n // B):
-                ops.local_loss_accumulate(am[r * B * heads:(r + 1) * B * heads], mask, seg, gk, loss[r * B:(r + 1) * B],
-                                          heads, size)
+                loss = torch.zeros((n - first,), dtype=torch.float32, device=am.device)
+            ops.local_loss_accumulate(am[first * heads:], mask, seg, gk, loss, heads, size)
             count += 1
         return loss / count

@@ -320,8 +320,8 @@ class EulerEDMSampler(EDMSampler):
             ll = None
             for i in range(2):
                 stepper.step(x, sig[i], sig[i + 1], emit_maps=True)
-                ll = model.loss_fn.get_min_local_loss(stepper.unet.attn_map_cache, mask, seg)
-            scores.extend(ll[ll.shape[0] // 2:].reshape(g, B).unbind(0))
+                ll = model.loss_fn.get_min_local_loss(stepper.unet.attn_map_cache, mask, seg, cond_only=True)
+            scores.extend(ll.reshape(g, B).unbind(0))
             stepper.unet.clear_attn_map()
             stepper.check()
         score = torch.stack(scores, 0)                                   # [iters, B]
