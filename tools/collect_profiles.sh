@@ -38,4 +38,10 @@ python $R/tools/pmc_mfma.py /tmp/pmc_mfma/p_counter_collection.csv > $O/mfma_uti
 (cd $R && python tools/check_lean_conv.py 2>/dev/null > $O/lean_conv.txt)
 (cd $R && UDT_DUAL_STREAM=0 python tools/trace_step.py 2>/dev/null > $O/trace_step.txt)
 (cd $R && python tools/bench_ops.py 2>/dev/null > $O/bench_ops.txt)
+# 9. yardsticks added in round 3: the same shapes on the vendor libraries, the VAE's head_dim-512 attention, the statistics epilogues,
+#    the reference-default workload (batch 1, noise_iters 10)
+(cd $R && python tools/bench_vs_vendor.py 2>/dev/null > $O/vs_vendor_libraries.txt)
+(cd $R && python tools/bench_attn512.py 2>/dev/null > $O/attn512.txt)
+(cd $R && python tools/bench_conv_stats.py 2>/dev/null > $O/stats_epilogue_cost.txt)
+(cd $R && python tools/bench_reference_default.py 2>/dev/null | tail -1 > $O/reference_default.txt)
 ls -la $O; cut -c1-400 $O/bench.json; cat $O/traffic.json | head -30; head -30 $O/mfma_util.json
