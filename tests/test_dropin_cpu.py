@@ -97,6 +97,22 @@ def test_prepare_packs_dedups_and_frees(small_engine):
     rep = eng.prepare()
     assert rep["vae_deduplicated"] == 1 and le.model is eng.first_stage_model
     assert len(eng.state_dict()) == n_keys                      # both prefixes still present
+    # a checkpoint that carries first_stage_model.* ONLY (the reference's training flow, diffusion.py:87-105) must not reach the
+    # LatentEncoder through the alias: the modules are split again and the conditioning VAE keeps its weights
+    import warnings
+    keep = {k: v.clone() for k, v in le.model.state_dict().items()}
+    only_fs = {k: v + 1.0 for k, v in eng.state_dict().items() if k.startswith("first_stage_model.")}
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        eng.load_state_dict(only_fs, strict=False)
+    assert any("undoing the VAE dedup" in str(x.message) for x in w)
+    assert le.model is not eng.first_stage_model
+    assert all(torch.equal(le.model.state_dict()[k], keep[k]) for k in keep)
+    k0 = next(iter(keep))
+    assert torch.equal(eng.first_stage_model.state_dict()[k0], keep[k0] + 1.0)
+    le.model.load_state_dict(eng.first_stage_model.state_dict())
+    rep = eng.prepare()
+    assert rep["vae_deduplicated"] == 1 and le.model is eng.first_stage_model
     # packed layouts exist for every evaluated module; fused children were not packed on their own
     blk = eng.model.diffusion_model.input_blocks[1][1].transformer_blocks[0]
     assert getattr(blk.attn1, "_pk", None) is not None and getattr(blk.attn1.to_q, "_pk", None) is None
@@ -217,7 +233,8 @@ def test_reference_util_and_predict_run_against_the_new_sgm():
 
 def test_sd2_inpainting_key_map():
     """the LDM-named SD-2 inpainting checkpoint the reference's training starts from (configs/train.yaml:5): UNet keys load
-    straight except attn2 / norm2, the autoencoder also fills the LatentEncoder's twin, CLIP / EMA / schedule entries drop"""
+    straight except attn2 / norm2, the autoencoder loads into first_stage_model only (the LatentEncoder keeps its own file's
+    weights, like the reference's strict=False load; mirroring is opt-in), CLIP / EMA / schedule entries drop"""
     from udifftext_amd import ckpt
     ref = json.load(open(os.path.join(GOLD, "state_dict_keys.json")))
     engine_keys = list(ref.keys())
@@ -231,7 +248,10 @@ def test_sd2_inpainting_key_map():
         sd[k] = torch.ones(1)
     sd.update({"cond_stage_model.model.ln_final.weight": torch.zeros(1), "model_ema.decay": torch.zeros(1), "betas": torch.zeros(1),
                "alphas_cumprod": torch.zeros(1), "sqrt_recip_alphas_cumprod": torch.zeros(1)})
-    mapped, rep = ckpt.map_sd2_inpainting(sd, engine_keys)
+    mapped0, rep0 = ckpt.map_sd2_inpainting(sd, engine_keys)
+    assert not rep0["duplicated_to_latent_encoder"] and not any(k.startswith("conditioner.") for k in mapped0)
+    assert any(k.startswith("conditioner.embedders.2.model.") for k in rep0["missing"])       # reported missing, as the reference does
+    mapped, rep = ckpt.map_sd2_inpainting(sd, engine_keys, mirror_to_latent_encoder=True)
     n_t = sum(1 for k in unet if ".t_attn." in k or ".t_norm." in k)
     assert n_t > 0 and len(rep["dropped_text_cross_attention"]) == n_t
     assert len(rep["loaded"]) == len(unet) - n_t + len(vae)

@@ -41,7 +41,7 @@ def env(cuda):
 
         @staticmethod
         def reset():
-            for k in ("lean", "lean_splitk", "lean_conv"):
+            for k in ("lean", "lean_splitk", "lean_conv", "wide_conv"):
                 L.check(lib.udt_debug_set(k.encode(), -1), "udt_debug_set " + k)
     yield Env
     Env.reset()
@@ -241,6 +241,69 @@ def test_lean_conv3x3_vs_torch(env, cuda, case):
             assert math.isfinite(e) and e < REL_RMS, f"conv3x3 lean_conv={lean_conv} {case}: rel rms {e:.3e}"
             outs[lean_conv] = out
         assert _rel(outs[1], outs[0]) < REL_RMS
+    finally:
+        env.reset()
+
+
+WIDE_CASES = [  # B, H, W, C, N, residual, rowvec, forced split-K (-1 = the plan's own choice)
+    (8, 64, 64, 320, 320, True, True, -1),         # L0 ResBlock convolution of the benchmarked call: 256 tiles, one per CU
+    (2, 64, 64, 320, 320, False, False, -1),       # few tiles (forced onto the wide kernel)
+    (8, 32, 32, 640, 640, True, True, -1),         # L1: 128 tiles -> two channel-chunk slices each
+    (8, 16, 16, 1280, 1280, False, True, -1),      # L2: 64 tiles -> four slices
+    (1, 16, 16, 64, 160, True, False, -1),         # one chunk, one tile
+    (3, 32, 48, 192, 480, True, True, 3),          # non-square map, three chunks cut three ways
+    (2, 96, 96, 320, 320, True, True, -1),         # config #4 (768 px) map
+    (2, 32, 32, 960, 640, False, False, 2),        # decoder input width (concatenated skip), odd chunk count per slice
+]
+
+
+@pytest.mark.parametrize("case", WIDE_CASES, ids=lambda c: "x".join(str(int(v)) for v in c))
+def test_wide_conv3x3_vs_torch_and_lean(env, cuda, case):
+    """wide.h wconv3_kernel (256 pixels x 160 channels per workgroup, one workgroup per CU) against torch conv2d in fp32 on the
+    same bf16-rounded inputs and against the lean 128-pixel kernel, incl. the ticket split-K over channel chunks, the epilogue
+    statistics (GroupNorm input) and run-to-run bit-reproducibility"""
+    B, H, W, C, N, res, rowvec, sk = case
+    g = torch.Generator(device="cpu").manual_seed(18)
+    x = torch.randn((B, H, W, C), generator=g).to(cuda).bfloat16()
+    w4 = (torch.randn((N, C, 3, 3), generator=g) / math.sqrt(9 * C)).to(cuda)
+    w4 = w4 * (1.0 + torch.arange(N, device=cuda)[:, None, None, None] / N)            # asymmetric in the output channel
+    b = torch.randn((N,), generator=g).to(cuda)
+    r = torch.randn((B, H, W, N), generator=g).to(cuda).bfloat16() if res else None
+    rv = torch.randn((B, N), generator=g).to(cuda) if rowvec else None
+    y = F.conv2d(x.float().permute(0, 3, 1, 2), w4.bfloat16().float(), b, padding=1).permute(0, 2, 3, 1)
+    if rv is not None:
+        y = y + rv[:, None, None, :]
+    if r is not None:
+        y = y + r.float()
+    w = env.packing.pack_conv(w4)
+    kw = dict(ksize=3, residual=r, rowvec=rv)
+    try:
+        env.dbg("wide_conv", 0)
+        lean = env.ops.conv2d(x, w, b, **kw)
+        env.dbg("wide_conv", 1)
+        env.dbg("lean_splitk", sk)
+        out = env.ops.conv2d(x, w, b, **kw)
+        again = env.ops.conv2d(x, w, b, **kw)
+        st_out = env.ops.conv2d(x, w, b, colstats=True, **kw)
+        torch.cuda.synchronize()
+        e = _rel(out, y)
+        assert math.isfinite(e) and e < REL_RMS, f"wide conv3x3 {case}: rel rms {e:.3e}"
+        assert (out.float() - y).abs().max().item() <= 3e-2 * y.abs().max().item()
+        assert _rel(out, lean) < REL_RMS
+        assert torch.equal(out, again), "wide convolution changed bits between two launches"
+        st = env.ops.gn_stats_of(st_out)
+        assert st is not None and torch.equal(st_out, out)
+        tot = st.data.reshape(B, st.slots_per_sample, N, 2).sum(1)
+        o = out.float().reshape(B, H * W, N)
+        ref = torch.stack([o.sum(1), (o * o).sum(1)], dim=-1)
+        assert ((tot - ref).abs() <= 2e-4 * ref.abs() + 2e-2 * math.sqrt(H * W)).all()
+        if N % 64 == 0:
+            gamma = (1 + 0.1 * torch.randn((N,), generator=g)).to(cuda)
+            beta = (0.1 * torch.randn((N,), generator=g)).to(cuda)
+            got = env.ops.group_norm_from_stats(st_out, st, gamma, beta, 32, 1e-5, True)
+            want = F.silu(F.group_norm(out.float().permute(0, 3, 1, 2), 32, gamma, beta, 1e-5)).permute(0, 2, 3, 1)
+            torch.cuda.synchronize()
+            assert _rel(got, want) < 6e-3
     finally:
         env.reset()
 

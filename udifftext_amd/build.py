@@ -20,7 +20,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-u
 
 
 def _deps_mtime() -> float:
-    hdrs = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "gemm8.h"), os.path.join(CSRC, "conv3p.h"), os.path.join(CSRC, "lean.h"), os.path.join(HERE, "..", "include", "udt_kernels.h")]
+    hdrs = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "gemm8.h"), os.path.join(CSRC, "conv3p.h"), os.path.join(CSRC, "lean.h"), os.path.join(CSRC, "wide.h"), os.path.join(HERE, "..", "include", "udt_kernels.h")]
     return max(os.path.getmtime(h) for h in hdrs)
 
 

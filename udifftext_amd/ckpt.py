@@ -9,9 +9,11 @@ keys as the reference).  The reference's TRAINING starts from Stability's SD-2 i
                               (text cross-attention over CLIP tokens), which UDiffText replaces by ``t_attn`` / ``t_norm``
                               over the character-level LabelEncoder tokens (attention.py:265-341): dropped, t_attn/t_norm stay
                               at their initialisation (reported as missing, as the reference's load does);
-    first_stage_model.*       load straight into the AutoencoderKL — and, because the engine's LatentEncoder holds a second
-                              copy of the same autoencoder (configs/*/textdesign_sd_2.yaml:70,91), are ALSO mapped onto
-                              ``conditioner.embedders.<i>.model.*``;
+    first_stage_model.*       load straight into the AutoencoderKL ONLY, like the reference's ``load_state_dict(strict=False)``
+                              (diffusion.py:87-105): the engine's LatentEncoder holds its own copy of the autoencoder, filled
+                              from its own ``ckpt_path`` (AE_inpainting_2.safetensors, configs/*/textdesign_sd_2.yaml:71,91), so
+                              ``conditioner.embedders.<i>.model.*`` are reported as missing.  ``mirror_to_latent_encoder=True``
+                              (opt-in, NOT reference behaviour) copies the autoencoder onto that twin as well;
     cond_stage_model.* / model_ema.* / the DDPM schedule buffers (betas, alphas_cumprod, ...)   have no counterpart: dropped.
 
 ``map_sd2_inpainting`` performs that mapping on a state dict and reports what it did; nothing here touches the GPU.
@@ -29,7 +31,8 @@ _SCHEDULE = re.compile(r"^(betas|alphas_cumprod|alphas_cumprod_prev|sqrt_.*|log_
 _TEXT_XATTN = re.compile(r"\.transformer_blocks\.\d+\.(attn2|norm2)\.")
 
 
-def map_sd2_inpainting(sd: Dict[str, torch.Tensor], engine_keys: Iterable[str]) -> Tuple[Dict[str, torch.Tensor], Dict[str, list]]:
+def map_sd2_inpainting(sd: Dict[str, torch.Tensor], engine_keys: Iterable[str],
+                       mirror_to_latent_encoder: bool = False) -> Tuple[Dict[str, torch.Tensor], Dict[str, list]]:
     """LDM-named SD-2 inpainting state dict -> (state dict in UDiffText names, report).
     report = {"loaded", "duplicated_to_latent_encoder", "dropped_text_cross_attention", "dropped_other", "missing"}"""
     engine_keys = list(engine_keys)
@@ -45,7 +48,7 @@ def map_sd2_inpainting(sd: Dict[str, torch.Tensor], engine_keys: Iterable[str]) 
         elif k in have:
             out[k] = v
             rep["loaded"].append(k)
-            if k.startswith("first_stage_model."):
+            if mirror_to_latent_encoder and k.startswith("first_stage_model."):
                 for pre in twin:
                     k2 = pre + k[len("first_stage_model."):]
                     if k2 in have:
@@ -57,8 +60,10 @@ def map_sd2_inpainting(sd: Dict[str, torch.Tensor], engine_keys: Iterable[str]) 
     return out, rep
 
 
-def load_sd2_inpainting(engine, sd: Dict[str, torch.Tensor]) -> Dict[str, list]:
-    """map + ``load_state_dict(strict=False)``; shape mismatches raise like any load"""
-    mapped, rep = map_sd2_inpainting(sd, engine.state_dict().keys())
+def load_sd2_inpainting(engine, sd: Dict[str, torch.Tensor], mirror_to_latent_encoder: bool = False) -> Dict[str, list]:
+    """map + ``load_state_dict(strict=False)``; shape mismatches raise like any load.  An engine whose LatentEncoder was
+    pointed at ``first_stage_model`` by ``prepare(dedup_vae=True)`` gets its own autoencoder back first
+    (DiffusionEngine._check_vae_alias), so the conditioning VAE keeps its weights as in the reference."""
+    mapped, rep = map_sd2_inpainting(sd, engine.state_dict().keys(), mirror_to_latent_encoder)
     engine.load_state_dict(mapped, strict=False)
     return rep

@@ -463,6 +463,7 @@ __global__ void __launch_bounds__(256) gemm_fixup_kernel(const GemmParams p) {
 #include "gemm8.h"
 #include "conv3p.h"
 #include "lean.h"
+#include "wide.h"
 
 struct TilePlan {
   int bm, bn;
@@ -847,6 +848,9 @@ bool lean_plan(const udt_gemm_desc* d, LeanPlan& t, bool want_stats) {
   if ((reinterpret_cast<uintptr_t>(d->out) | reinterpret_cast<uintptr_t>(d->residual) | reinterpret_cast<uintptr_t>(d->bias) |
        reinterpret_cast<uintptr_t>(d->rowvec) | reinterpret_cast<uintptr_t>(d->ln_colsum)) & 15) return false;
   if (d->rowvec && ((d->ld_rowvec > 0 ? d->ld_rowvec : d->N) % 4 != 0)) return false;
+  // forced configurations: 1, 2, 3, 6 only (5 = the 128 x 160 tile is chosen here, for plain N = 320 / 960 outputs: its wave
+  // grid has no GEGLU form); anything else falls back to the 8-wave kernels instead of silently taking a default instance
+  if (mode > 0 && mode != 1 && mode != 2 && mode != 3 && mode != 6) return false;
   t.cfg = (mode > 0) ? mode : 1;
   if (!geglu && d->N % 160 == 0 && d->N % 128 != 0 && t.cfg == 1) t.cfg = 5;
   // many tiles and a wide output: the 256 x 256 tile (8 waves, one workgroup per CU) halves the LDS-DMA instructions per MFMA.
@@ -940,6 +944,18 @@ hipError_t launch_lean(const lg::LParams& lp, const LeanPlan& t, bool geglu, boo
 // ---- lean 3x3 convolution (lean.h lconv3_kernel): host side ------------------------------------------------------------
 // udt_debug_set("lean_conv", v): -1 automatic (default: on), 0 off, 1 on
 std::atomic<int> g_lean_conv{-1};
+// udt_debug_set("wide_conv", v): -1 automatic (default: where a launch fills the CUs with 256-pixel x 160-channel tiles),
+// 0 off, 1 wherever the geometry allows (wide.h wconv3_kernel)
+std::atomic<int> g_wide_conv{-2};
+int wide_conv_mode() {
+  int v = g_wide_conv.load(std::memory_order_relaxed);
+  if (v == -2) {
+    const char* e = getenv("UDT_WIDE_CONV");
+    v = e ? atoi(e) : -1;
+    g_wide_conv.store(v, std::memory_order_relaxed);
+  }
+  return v;
+}
 #ifdef UDT_MEASURE
 std::atomic<int> g_lconv_dbg{0};   // cost attribution of the lean convolution's loop (C3Params.dbg): wrong results
 #endif
@@ -958,8 +974,23 @@ bool lean_conv_plan(const udt_gemm_desc* d, lg::C3Params& c, bool want_stats) {
   if (d->N < 128 || d->N % 8 != 0 || d->C1 <= 0 || d->C1 % 64 != 0) return false;
   const bool ups = d->upsample != 0;
   if (d->Hout != (d->Hin << (ups ? 1 : 0)) || d->Wout != (d->Win << (ups ? 1 : 0))) return false;
-  // pixel tile: 16 x 8 (two MFMA row tiles per wave), or 8 x 8 for the small maps (8 x 8, 24 x 24, ...)
-  if (d->Wout % 16 == 0 && d->Hout % 8 == 0) { c.geo = ups ? 2 : 0; c.tw = 16; c.th = 8; }
+  // pixel tile: 16 x 8 (two MFMA row tiles per wave), or 8 x 8 for the small maps (8 x 8, 24 x 24, ...); 16 x 16 pixels x 160
+  // channels on the wide kernel (wide.h: one workgroup per CU) when its tiles — cut into channel-chunk slices where needed —
+  // give every CU a unit
+  c.bn = 128; c.wgm = 2;
+  bool wide = false;
+  {
+    const int wm = wide_conv_mode();
+    if (wm != 0 && !ups && d->N % 160 == 0 && d->Wout % 16 == 0 && d->Hout % 16 == 0) {
+      const long long wt = (long long)(d->M / 256) * (d->N / 160);
+      const int ch = d->C1 / 64;
+      long long sk = 1;
+      if (wt * 2 <= device_cus() && ch >= 10) { sk = device_cus() / wt; if (sk > ch / 5) sk = ch / 5; }
+      wide = (wm > 0) || (wt * sk * 8 >= (long long)device_cus() * 7);
+    }
+  }
+  if (wide) { c.geo = 3; c.tw = 16; c.th = 16; c.bn = 160; c.wgm = 4; }
+  else if (d->Wout % 16 == 0 && d->Hout % 8 == 0) { c.geo = ups ? 2 : 0; c.tw = 16; c.th = 8; }
   else if (!ups && d->Wout % 8 == 0 && d->Hout % 8 == 0) { c.geo = 1; c.tw = 8; c.th = 8; }
   else return false;
   if (d->ldo % 8 != 0 || (d->residual && d->ldr % 8 != 0)) return false;
@@ -977,17 +1008,16 @@ bool lean_conv_plan(const udt_gemm_desc* d, lg::C3Params& c, bool want_stats) {
   c.alpha = d->alpha;
   c.tiles_x = d->Wout / c.tw; c.tiles_y = d->Hout / c.th;
   c.tiles_m = c.B * c.tiles_x * c.tiles_y;
-  c.tiles_n = (d->N + 127) / 128;
+  c.tiles_n = (d->N + c.bn - 1) / c.bn;
   c.tiles = c.tiles_m * c.tiles_n;
   c.chunks = c.C / 64;
-  const int slots = 2 * device_cus();
+  const int slots = (c.geo == 3 ? 1 : 2) * device_cus();
   int sk = 1;
   const int knob = lean_splitk_knob();
   if (c.tiles <= 1023) {
-    if (knob > 1) sk = knob;
-    else if (knob < 0 && c.tiles * 2 <= slots && c.chunks >= 10) sk = slots / c.tiles;
-    if (sk > c.chunks / 5) sk = c.chunks / 5;
-    while (sk > 1 && (long long)c.tiles * sk * c.tw * c.th * 128 * 4 > (64LL << 20)) --sk;
+    if (knob > 1) { sk = knob; if (sk > c.chunks) sk = c.chunks; }          // forced (tests / A-B): any cut the chunks allow
+    else if (knob < 0 && c.tiles * 2 <= slots && c.chunks >= 10) { sk = slots / c.tiles; if (sk > c.chunks / 5) sk = c.chunks / 5; }
+    while (sk > 1 && (long long)c.tiles * sk * c.tw * c.th * c.bn * 4 > (64LL << 20)) --sk;
     if (sk < 1) sk = 1;
   }
   c.ch_per = (c.chunks + sk - 1) / sk;
@@ -995,7 +1025,7 @@ bool lean_conv_plan(const udt_gemm_desc* d, lg::C3Params& c, bool want_stats) {
   c.G = round_workgroups(c.tiles * c.splitk);
   // tile order: ~64 concurrently resident tiles per XCD; n_block weight tiles per patch (conv3p's rule)
   {
-    const double patch = (double)((ups ? c.tw / 2 : c.tw) + 2) * ((ups ? c.th / 2 : c.th) + 2) * c.C * 2.0, wtile = 9.0 * 128 * c.C * 2.0;
+    const double patch = (double)((ups ? c.tw / 2 : c.tw) + 2) * ((ups ? c.th / 2 : c.th) + 2) * c.C * 2.0, wtile = 9.0 * c.bn * c.C * 2.0;
     int nb = g_n_block.load(std::memory_order_relaxed);
     if (nb <= 0) nb = (int)(std::sqrt(64.0 * patch / wtile) + 0.5);
     if (nb < 1) nb = 1;
@@ -1009,7 +1039,7 @@ bool lean_conv_plan(const udt_gemm_desc* d, lg::C3Params& c, bool want_stats) {
 }
 
 size_t lean_conv_workspace(const lg::C3Params& c) {
-  return c.splitk > 1 ? G8_HEADER_BYTES + (size_t)c.tiles * c.splitk * c.tw * c.th * 128 * sizeof(float) : 0;
+  return c.splitk > 1 ? G8_HEADER_BYTES + (size_t)c.tiles * c.splitk * c.tw * c.th * c.bn * sizeof(float) : 0;
 }
 
 template <int TW, int TH, bool UPS, bool STATS>
@@ -1026,6 +1056,19 @@ hipError_t launch_lconv3(const lg::C3Params& c3, hipStream_t s) {
   return c3.colstats ? launch_lconv3s<TW, TH, UPS, true>(c3, s) : launch_lconv3s<TW, TH, UPS, false>(c3, s);
 }
 
+template <bool STATS>
+hipError_t launch_wconv3s(const lg::C3Params& c3, hipStream_t s) {
+  static AttrOnce once;
+  constexpr int smem = wd::WGeo::SMEM;
+  hipError_t e = once.ensure(reinterpret_cast<const void*>(wd::wconv3_kernel<STATS>), smem);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL((wd::wconv3_kernel<STATS>), dim3(c3.G), dim3(256), smem, s, c3);
+  return hipGetLastError();
+}
+hipError_t launch_wconv3(const lg::C3Params& c3, hipStream_t s) {
+  return c3.colstats ? launch_wconv3s<true>(c3, s) : launch_wconv3s<false>(c3, s);
+}
+
 // would this problem run on a lean kernel WITH a statistics-emitting epilogue?  (udt_gemm_colstats_rows / _slots, asked by
 // the caller before it allocates the statistics and sets udt_gemm_desc.colstats)
 bool lean_stats_probe(const udt_gemm_desc* d, int& rows, int& slots) {
@@ -1033,8 +1076,8 @@ bool lean_stats_probe(const udt_gemm_desc* d, int& rows, int& slots) {
   {
     lg::C3Params c3;
     if (lean_conv_plan(d, c3, true)) {
-      rows = c3.tw * c3.th / 2;                                   // two wave pixel blocks per tile
-      slots = c3.tiles_m * 2;
+      rows = c3.tw * c3.th / c3.wgm;                              // one slot per wave pixel block of a tile
+      slots = c3.tiles_m * c3.wgm;
       return true;
     }
   }
@@ -1058,6 +1101,7 @@ extern "C" int udt_debug_set(const char* key, int32_t value) {
   if (!strcmp(key, "lean")) { g_lean.store(value < 0 ? -2 : value); return UDT_OK; }
   if (!strcmp(key, "lean_splitk")) { g_lean_splitk.store(value); return UDT_OK; }
   if (!strcmp(key, "lean_conv")) { g_lean_conv.store(value < 0 ? -1 : (value ? 1 : 0)); return UDT_OK; }
+  if (!strcmp(key, "wide_conv")) { g_wide_conv.store(value < 0 ? -1 : (value ? 1 : 0)); return UDT_OK; }
 #ifdef UDT_MEASURE
   if (!strcmp(key, "lconv_dbg")) { g_lconv_dbg.store(value); return UDT_OK; }
   static const struct { const char* k; int bit; } bits[] = {{"no_xchg", 28}, {"no_epi", 27}, {"no_store", 26}, {"no_res", 25},
@@ -1257,7 +1301,8 @@ extern "C" int udt_gemm(const udt_gemm_desc* d, void* workspace, size_t workspac
         case 2: el = launch_lean<8, 4, 2, 2, 2, 3>(lp, lt, geglu, ln, s); break;
         case 3: el = launch_lean<4, 2, 2, 2, 2, 3>(lp, lt, geglu, ln, s); break;
         case 6: el = launch_lean<8, 2, 4, 4, 2, 2, 1>(lp, lt, geglu, ln, s); break;
-        default: el = launch_lean<4, 4, 1, 1, 5, 2>(lp, lt, false, ln, s); break;
+        case 5: el = geglu ? hipErrorInvalidValue : launch_lean<4, 4, 1, 1, 5, 2>(lp, lt, false, ln, s); break;
+        default: el = hipErrorInvalidValue; break;
       }
       if (el != hipSuccess) return udt_set_hip_error(el);
       return UDT_OK;
@@ -1277,12 +1322,12 @@ extern "C" int udt_gemm(const udt_gemm_desc* d, void* workspace, size_t workspac
       UdtProfScope profc(cls, s);
       if (profc.rec) {
         char tag[96];
-        snprintf(tag, sizeof(tag), "lconv3%s M=%d N=%d K=%d %dx%d tile=%dx%d units=%d splitk=%d nb=%d", d->upsample ? "+up" : "", d->M, d->N, d->K,
+        snprintf(tag, sizeof(tag), "%s%s M=%d N=%d K=%d %dx%d tile=%dx%d units=%d splitk=%d nb=%d", c3.geo == 3 ? "wconv3" : "lconv3", d->upsample ? "+up" : "", d->M, d->N, d->K,
                  d->Hin, d->Win, c3.tw, c3.th, c3.tiles * c3.splitk, c3.splitk, c3.n_block);
         udt_prof_tag(profc.rec, tag);
       }
-      const hipError_t ec = c3.geo == 2 ? launch_lconv3<16, 8, true>(c3, s) : c3.geo == 1 ? launch_lconv3<8, 8, false>(c3, s)
-                                                                                          : launch_lconv3<16, 8, false>(c3, s);
+      const hipError_t ec = c3.geo == 3 ? launch_wconv3(c3, s) : c3.geo == 2 ? launch_lconv3<16, 8, true>(c3, s)
+                            : c3.geo == 1 ? launch_lconv3<8, 8, false>(c3, s) : launch_lconv3<16, 8, false>(c3, s);
       if (ec != hipSuccess) return udt_set_hip_error(ec);
       return UDT_OK;
     }

@@ -577,7 +577,8 @@ struct C3Params {
   int* counters;
   float* slabs;
   float* colstats;         // STATS kernels: fp32 [tiles_m * 2][N][2] per-(wave pixel block, channel) (sum, sum of squares)
-  int geo, tw, th;         // host side: kernel instance (0: 16x8, 1: 8x8, 2: 16x8 upsampling) and its pixel tile
+  int geo, tw, th;         // host side: kernel instance (0: 16x8, 1: 8x8, 2: 16x8 upsampling, 3: wide.h 16x16 x 160 channels) and its pixel tile
+  int bn, wgm;             // host side: output channels per tile, wave pixel blocks per tile (statistics slots)
   int dbg;                 // measurement builds only (UDT_DBG): bit 0 no weight DMA, 1 no patch DMA, 2 no MFMA, 3 no LDS fragment reads
 };
 

@@ -63,10 +63,15 @@ class DiffusionEngine(nn.Module):
             return
         a, b = alias
         differ = any(k.startswith(a) and (b + k[len(a):]) in sd and not torch.equal(sd[k].cpu(), sd[b + k[len(a):]].cpu()) for k in sd)
-        if differ:
+        # a checkpoint with only ONE of the two prefixes (the reference's training flow loads first_stage_model.* alone,
+        # diffusion.py:87-105) must not be written through the alias into the other module
+        has_a = any(k.startswith(a) for k in sd)
+        has_b = any(k.startswith(b) for k in sd)
+        if differ or (has_a != has_b):
             import copy
             import warnings
-            warnings.warn("the checkpoint holds DIFFERENT weights under %s and %s: undoing the VAE dedup of prepare()" % (a, b))
+            warnings.warn(("the checkpoint holds DIFFERENT weights under %s and %s" % (a, b) if differ else
+                           "the checkpoint holds only one of %s / %s" % (a, b)) + ": undoing the VAE dedup of prepare()")
             for emb in self.conditioner.embedders:
                 if getattr(emb, "model", None) is self.first_stage_model:
                     emb.model = copy.deepcopy(self.first_stage_model)
