@@ -979,14 +979,25 @@ bool lean_conv_plan(const udt_gemm_desc* d, lg::C3Params& c, bool want_stats) {
   // give every CU a unit
   c.bn = 128; c.wgm = 2;
   bool wide = false;
+  int wide_slots = device_cus();
   {
+    // measured (tools/bench_wide_conv.py, profiles/r04_wide_conv.txt): 1.25-1.3x at the 64x64 level (256 tiles of a UNet call on 8
+    // samples: one per CU, no half-empty third channel tile), 1.03-1.2x at 32x32 with two channel-chunk slices per tile, slower
+    // where the tiles need four slices (16x16 level: the slab round trip) or fill the last round of workgroups badly.  A launch
+    // that shares the device with s - 1 other streams (cu_share) aims at its share of the CUs: the two CFG halves of a lone batch
+    // run 128 tiles each, side by side
     const int wm = wide_conv_mode();
     if (wm != 0 && !ups && d->N % 160 == 0 && d->Wout % 16 == 0 && d->Hout % 16 == 0) {
+      const int cus = device_cus(), share = d->cu_share > 1 ? d->cu_share : 1;
+      wide_slots = cus / share > 0 ? cus / share : 1;
       const long long wt = (long long)(d->M / 256) * (d->N / 160);
       const int ch = d->C1 / 64;
       long long sk = 1;
-      if (wt * 2 <= device_cus() && ch >= 10) { sk = device_cus() / wt; if (sk > ch / 5) sk = ch / 5; }
-      wide = (wm > 0) || (wt * sk * 8 >= (long long)device_cus() * 7);
+      if (wt * 2 <= wide_slots && ch >= 10) { sk = wide_slots / wt; if (sk > ch / 5) sk = ch / 5; }
+      const long long units = wt * sk;
+      const long long rounds = (units + cus - 1) / cus;
+      const double eff = units > cus ? (double)units / (double)(rounds * cus) : ((double)units * share >= cus ? 1.0 : (double)units * share / cus);
+      wide = (wm > 0) || (sk <= 2 && eff >= 0.85);
     }
   }
   if (wide) { c.geo = 3; c.tw = 16; c.th = 16; c.bn = 160; c.wgm = 4; }
@@ -1011,7 +1022,7 @@ bool lean_conv_plan(const udt_gemm_desc* d, lg::C3Params& c, bool want_stats) {
   c.tiles_n = (d->N + c.bn - 1) / c.bn;
   c.tiles = c.tiles_m * c.tiles_n;
   c.chunks = c.C / 64;
-  const int slots = (c.geo == 3 ? 1 : 2) * device_cus();
+  const int slots = c.geo == 3 ? wide_slots : 2 * device_cus();
   int sk = 1;
   const int knob = lean_splitk_knob();
   if (c.tiles <= 1023) {
