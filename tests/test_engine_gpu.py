@@ -712,3 +712,86 @@ def test_checkpoint_load_prepare_free_masters_matches_goldens(engine, cond256, e
     _check("ckpt -> prepare(free_masters): 10-step latent vs reference", z.cpu(), eg["g9_latent"], 6e-2)
     del fresh
     torch.cuda.empty_cache()
+
+
+def test_unet_call_at_768_batch8_vs_oracle(engine, cuda):
+    """BASELINE config #4 at its STATED batch: 768x768 -> 96x96 latents, batch 8 -> 16 samples per UNet call (uc half first),
+    12-character contexts — the tile / split-K / wide-convolution plans of that call (1152 convolution tiles at the first
+    level, 9216-token self-attention on 16 samples) — against the fp32 CPU oracle on one unconditional and one conditional
+    sample (samples are independent: per-sample GroupNorm / LayerNorm / attention)"""
+    from oracle import nets, spec
+    from udifftext_amd import synth
+    torch.manual_seed(41)
+    B = 8
+    le = engine.conditioner.embedders[0]
+    ctx = le(synth.synthetic_batch(B, 768, 768, 12, seed=9)["label"])
+    tctx = torch.cat([torch.zeros_like(ctx), ctx])
+    x = torch.randn((2 * B, 9, 96, 96), device=cuda)
+    ts = torch.full((2 * B,), 521, device=cuda)
+    eps = engine.model.diffusion_model(x, timesteps=ts, t_context=tctx)
+    assert eps.shape == (2 * B, 4, 96, 96)
+    pick = [3, 12]
+    sd = {k: v.detach().float().cpu() for k, v in engine.state_dict().items() if k.startswith("model.")}
+    with torch.no_grad():
+        ref = nets.unet_forward(sd, x[pick].cpu(), ts[pick].cpu(), tctx[pick].float().cpu(), spec.EngineConfig().unet)
+    _check("UNet eps at 96x96 latents, 16 samples (config #4 call, batch 8) vs oracle", eps[pick].cpu(), ref, 2e-2, 8e-2)
+
+
+def test_768_batch8_predict_properties(engine, cuda):
+    """config #4 end to end at its stated batch (768x768, 12 characters, batch 8, 2 steps): shapes, range, determinism, and
+    image independence (image 5 of the batch == the same image sampled in a batch of its own with the same noise)"""
+    from udifftext_amd import config as C, parallel, pipeline, synth
+    sampler = pipeline.init_sampling(2, 5.0, cuda)
+    cfgs = C.default_runtime_config(steps=2, batch_size=8, noise_iters=0)
+    gb = synth.synthetic_batch(8, 768, 768, 12, seed=3)
+    seeds = [parallel.image_seed(99, i) for i in range(8)]
+    outs = [pipeline.predict_many(cfgs, engine, sampler, [{k: (v.clone() if isinstance(v, torch.Tensor) else list(v)) for k, v in gb.items()}],
+                                  cuda, in_flight=1, fuse=1, image_seeds=[seeds])[0] for _ in range(2)]
+    (s1, z1), (s2, z2) = outs
+    assert s1.shape == (8, 3, 768, 768) and z1.shape == (8, 4, 96, 96)
+    assert torch.isfinite(s1).all() and float(s1.min()) >= 0.0 and float(s1.max()) <= 1.0
+    assert torch.equal(z1, z2) and torch.equal(s1, s2)
+    cfg1 = C.default_runtime_config(steps=2, batch_size=1, noise_iters=0)
+    one = pipeline.predict_many(cfg1, engine, sampler, [parallel.slice_batch(gb, 5, 6)], cuda, in_flight=1, fuse=1, image_seeds=[seeds[5:6]])[0]
+    # a batch of 1 takes other tile / split-K plans: agreement at bf16-rounding level, amplified over 2 steps
+    _check("768x768: image 5 of a batch of 8 vs the same image alone (2 steps)", z1[5:6].cpu(), one[1].cpu(), 3e-2)
+
+
+def _nccl_world1(cuda):
+    import socket
+    import torch.distributed as dist
+    if dist.is_initialized():
+        return dist, False
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=cuda)
+    return dist, True
+
+
+@pytest.mark.parametrize("n_images,fp8", [(8, False), (4, True)])
+def test_predict_sharded_under_nccl_world1(engine, cuda, monkeypatch, n_images, fp8):
+    """the multi-GPU entry on ONE GPU: parallel.predict_sharded under torch.distributed's nccl (= RCCL) backend with a world
+    of one — per-image seeds, micro-batches of 4 on two lanes, and the all_gather_into_tensor of the frames through RCCL —
+    for config #3's per-GPU share (8 images) and, with the fp8 linears, config #5's (4 images).  Frames must equal
+    pipeline.predict_many on the same micro-batches and seeds (the collective of a world of one is a copy)."""
+    import sgm.modules.hipnn as H
+    from udifftext_amd import config as C, parallel, pipeline, synth
+    monkeypatch.setattr(H, "FP8_LINEARS", fp8)
+    dist, mine = _nccl_world1(cuda)
+    try:
+        sampler = pipeline.init_sampling(2, 5.0, cuda)
+        cfgs = C.default_runtime_config(steps=2, batch_size=4, noise_iters=0)
+        gb = synth.synthetic_batch(n_images, 512, 512, 9, seed=77)
+        clone = lambda b: {k: (v.clone() if isinstance(v, torch.Tensor) else list(v)) for k, v in b.items()}
+        frames = parallel.predict_sharded(cfgs, engine, sampler, [clone(gb)], [123], dist=dist, micro_batch=4, in_flight=2, fuse=1, device=cuda)
+        assert len(frames) == 1 and frames[0].shape == (n_images, 3, 512, 512) and frames[0].is_cuda
+        micro = [parallel.slice_batch(clone(gb), a, min(a + 4, n_images)) for a in range(0, n_images, 4)]
+        seeds = [[parallel.image_seed(123, i) for i in range(a, min(a + 4, n_images))] for a in range(0, n_images, 4)]
+        ref = pipeline.predict_many(cfgs, engine, sampler, micro, cuda, in_flight=2, fuse=1, image_seeds=seeds)
+        ref = torch.cat([s for s, _ in ref], 0)
+        assert torch.equal(frames[0], ref), "frames through the RCCL all-gather differ from predict_many"
+        assert torch.isfinite(frames[0]).all() and float(frames[0].min()) >= 0.0 and float(frames[0].max()) <= 1.0
+    finally:
+        if mine:
+            dist.destroy_process_group()

@@ -183,29 +183,30 @@ def test_single_process_is_identity():
     assert parallel.gather_frames(x, None) is x
 
 
-# ---- lane grouping of pipeline.predict_many (host logic, stub engine) ----------------------------------------------
-@pytest.mark.parametrize("n_batches,in_flight,expect", [(4, 3, [2, 2]), (5, 3, [3, 2]), (7, 3, [3, 2, 2]), (6, 3, [3, 3]),
-                                                        (2, 3, [2]), (3, 1, [1, 1, 1])])
-def test_predict_many_balances_lane_groups(n_batches, in_flight, expect):
-    """4 batches on 3 lanes run as 2 + 2, never 3 + 1 (a lone batch runs at the one-at-a-time rate); results keep
-    the input order and the per-batch CPU draw order"""
+# ---- lane assignment of pipeline.predict_many (host logic, stub engine) -------------------------------------------
+@pytest.mark.parametrize("n_batches,in_flight,fuse,expect", [(4, 3, 1, [(0, 3), (1, 3), (2, 3), (0, 3)]), (5, 3, 1, [(0, 3), (1, 3), (2, 3), (0, 3), (1, 3)]),
+                                                             (2, 3, 1, [(0, 2), (1, 2)]), (3, 1, 1, [(0, 1), (0, 1), (0, 1)]),
+                                                             (5, 2, 2, [(0, 2), (1, 2), (0, 2)])])
+def test_predict_many_free_running_lanes(n_batches, in_flight, fuse, expect):
+    """sampling batch u runs on lane u % lanes, every lane planned for 1 / lanes of the CUs (never more lanes than sampling
+    batches); results keep the input order and the per-batch CPU draw order whatever the lane count"""
     from udifftext_amd import config as C, pipeline
 
     class Rec(_StubSampler):
-        groups = []
+        calls = []
 
-        def sample_in_flight(self, model, xs, conds, ucs, init_step=0, deferred_checks=None, streams=None):
-            Rec.groups.append(len(xs))
-            return super().sample_in_flight(model, xs, conds, ucs, init_step)
+        def sample_lane(self, model, x, cond, uc, slot, n_lanes, init_step=0, deferred_checks=None):
+            Rec.calls.append((slot, n_lanes))
+            return super().sample_in_flight(model, [x], [cond], [uc], init_step)[0]
 
-    Rec.groups = []
+    Rec.calls = []
     cfgs = C.default_runtime_config(steps=2, batch_size=2, noise_iters=0)
     batches = [_global_batch(2, 100 + i) for i in range(n_batches)]
     torch.manual_seed(7)
-    outs = pipeline.predict_many(cfgs, _StubModel(), Rec(), batches, torch.device("cpu"), in_flight=in_flight, fuse=1)
-    assert Rec.groups == expect and len(outs) == n_batches
+    outs = pipeline.predict_many(cfgs, _StubModel(), Rec(), batches, torch.device("cpu"), in_flight=in_flight, fuse=fuse)
+    assert Rec.calls == expect and len(outs) == n_batches
     torch.manual_seed(7)
-    seq = pipeline.predict_many(cfgs, _StubModel(), Rec(), [_global_batch(2, 100 + i) for i in range(n_batches)],
+    seq = pipeline.predict_many(cfgs, _StubModel(), _StubSampler(), [_global_batch(2, 100 + i) for i in range(n_batches)],
                                 torch.device("cpu"), in_flight=1, fuse=1)
     for (a, _), (b, _) in zip(outs, seq):
         assert torch.equal(a, b)

@@ -30,8 +30,10 @@ def image_seed(global_seed: int, image_index: int) -> int:
 
 def gather_frames(frames: torch.Tensor, dist=None) -> torch.Tensor:
     """[B_local, 3, H, W] on every rank -> [B_local * world, 3, H, W] on every rank (rank-major order)."""
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+    if dist is None or not dist.is_initialized():
         return frames
+    # (a world of ONE still goes through the collective: the RCCL path then runs on a single-GPU box too — the GPU tests and
+    #  bench.py's UDT_BENCH_FORCE_DIST use that; it is a device-to-device copy)
     world = dist.get_world_size()
     frames = frames.contiguous()
     out = torch.empty((world * frames.shape[0],) + tuple(frames.shape[1:]), dtype=frames.dtype, device=frames.device)
@@ -77,7 +79,7 @@ def predict_sharded(cfgs, model, sampler, global_batches: Sequence[dict], global
     if predict_many is None:
         from udifftext_amd import pipeline
         predict_many = pipeline.predict_many
-    on = dist is not None and dist.is_initialized() and dist.get_world_size() > 1
+    on = dist is not None and dist.is_initialized()
     rank = dist.get_rank() if on else 0
     world = dist.get_world_size() if on else 1
     micro, seeds, owner = [], [], []          # micro-batches of all global batches, in order

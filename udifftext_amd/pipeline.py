@@ -69,6 +69,10 @@ def prepare_batch(batch: dict, device: torch.device) -> Tuple[dict, dict]:
     buc["txt"] = batch["ntxt"] if "ntxt" in batch else ["" for _ in batch["txt"]]
     if "label" in batch:
         buc["label"] = ["" for _ in batch["label"]]
+    # host-side knowledge for the conditioner: every tensor of buc is a clone of batch's (it then shares the masked-image
+    # encoder pass between c and uc without comparing the two tensors on the device)
+    buc["_udt_clone_of"] = batch
+    buc["_udt_changed"] = ("txt", "label")
     return batch, buc
 
 
@@ -99,6 +103,8 @@ def _cat_cond(conds):
     for k in conds[0]:
         v = conds[0][k]
         out[k] = torch.cat([c[k] for c in conds], 0) if isinstance(v, torch.Tensor) else v
+        if isinstance(v, torch.Tensor) and all(getattr(c[k], "_udt_all_zero", False) for c in conds):
+            out[k]._udt_all_zero = True          # (host-side tag of force-zeroed embeddings, GeneralConditioner.forward)
     return out
 
 
@@ -116,9 +122,9 @@ def predict_many(cfgs, model, sampler, batches, device: Optional[torch.device] =
                  fuse: Optional[int] = None, image_seeds: Optional[list] = None):
     """``predict`` over a list of batches in throughput mode: ``fuse`` consecutive batches are concatenated into one
     sampling batch, and up to ``in_flight`` such batches are processed concurrently, each on its own launch stream
-    (a lane): conditioning (VAE encoder, label encoder) and the VAE decode run on the lane's stream next to the other
-    lanes' work, the sampling loops replay their hipGraphs side by side (EulerEDMSampler.sample_in_flight), and the
-    host only synchronises once, at the end — so the decodes of one group overlap the conditioning of the next.
+    (a lane): conditioning (VAE encoder, label encoder), the sampling loop's hipGraph replays (EulerEDMSampler.sample_lane)
+    and the VAE decode of a batch are enqueued back to back on its lane's stream; the lanes run free of each other and the
+    host only synchronises once, at the end.
     Conditioning and noise draws stay per input batch, in the order and from the CPU generator that calling
     ``predict`` batch by batch would use; decoding runs on the fused batch.
     ``image_seeds[k]`` (optional): one seed per image of batch k — its draws then come from per-image generators
@@ -138,50 +144,54 @@ def predict_many(cfgs, model, sampler, batches, device: Optional[torch.device] =
     on = (lambda lane: torch.cuda.stream(lane)) if gpu else (lambda lane: contextlib.nullcontext())
     after = (lambda a, b: a.wait_stream(b)) if gpu else (lambda a, b: None)       # stream a continues after stream b
     out, checks, keep = [], [], []
-    # groups of up to n lanes, balanced: 4 sampling batches on 3 lanes run as 2 + 2, not 3 + 1 (a lone batch runs at
-    # the one-at-a-time rate)
-    units = -(-len(batches) // f)
-    n_groups = max(1, -(-units // n))
-    sizes = [units // n_groups + (1 if g < units % n_groups else 0) for g in range(n_groups)]
-    starts = [f * sum(sizes[:g]) for g in range(n_groups)]
-    for k, lanes_used in zip(starts, sizes):
-        group = batches[k:k + lanes_used * f]
-        fx, fc, fuc, spans = [], [], [], []
-        for lane, i in zip(lanes, range(0, len(group), f)):
-            # one lane: the conditioning of its (up to f) input batches, fused into one sampling batch
-            after(lane, main)
-            xs, cs, ucs, sizes = [], [], [], []
-            with on(lane), ops.launch_context(cu_share=n):
-                for gi in range(i, min(i + f, len(group))):
-                    b, buc = prepare_batch(group[gi], device)
-                    seeds = image_seeds[k + gi] if image_seeds is not None else None
-                    with (rng.per_image(seeds) if seeds is not None else contextlib.nullcontext()):
-                        c, uc = model.conditioner.get_unconditional_conditioning(
-                            b, batch_uc=buc, force_uc_zero_embeddings=cfgs.force_uc_zero_embeddings)
-                        xs.append(sampler.get_init_noise(cfgs, model, cond=c, batch=b, uc=uc))
-                    cs.append(c)
-                    ucs.append(uc)
-                    sizes.append(xs[-1].shape[0])
-                if any(x.shape[1:] != xs[0].shape[1:] for x in xs):
-                    raise ValueError("batches fused into one sampling batch need one image size (use fuse=1)")
-                fx.append(torch.cat(xs, 0) if len(xs) > 1 else xs[0])
-                fc.append(_cat_cond(cs) if len(cs) > 1 else cs[0])
-                fuc.append(_cat_cond(ucs) if len(ucs) > 1 else ucs[0])
-            spans.append(sizes)
-            keep.append((xs, cs, ucs))        # tensors of a lane stream that other streams read: alive until the sync
-        for lane in lanes:
-            after(main, lane)
-        zs = sampler.sample_in_flight(model, fx, fc, fuc, init_step=cfgs.init_step, deferred_checks=checks,
-                                      streams=lanes if gpu and n > 1 else None)
-        keep.append((fx, fc, fuc, zs))
-        for lane, z, span in zip(lanes, zs, spans):
-            after(lane, main)
-            with on(lane), ops.launch_context(cu_share=n):
-                img = torch.clamp((model.decode_first_stage(z) + 1.0) / 2.0, min=0.0, max=1.0)
-            o = 0
-            for nb in span:
-                out.append((img[o:o + nb], z[o:o + nb]))
-                o += nb
+    # FREE-RUNNING lanes (round 4): sampling batch u runs on lane u % n — conditioning, the sampling loop's graph replays and
+    # the decode are enqueued back to back on the lane's stream, with no event shared between lanes: a lane starts its next
+    # batch the moment its previous decode is done, and the conditioning / decode phases of one lane (eager launches, ~25 ms)
+    # run beside the other lanes' sampling.  Nothing below synchronises the host: the noise draws travel through pinned
+    # memory (rng.randn_on), the zero-context test and the c / uc image comparison are host-side flags.  (Round 3 ran the
+    # lanes in lock-stepped groups with a cross-lane join before and after every sampling loop: ~35 ms of each 1.28 s group
+    # had no sampling running, and a slow lane held the others.)
+    lane_sampler = getattr(sampler, "sample_lane", None)
+    units = [list(range(i, min(i + f, len(batches)))) for i in range(0, len(batches), f)]
+    n_used = min(n, len(units)) if units else 1
+    for lane in lanes[:n_used]:
+        after(lane, main)
+    import os
+    _join = os.environ.get("UDT_LANE_JOIN", "0") != "0"       # TEMPORARY measurement switch (A/B against the round-3 group joins)
+    for u, idx in enumerate(units):
+        lane = lanes[u % n_used]
+        if _join and gpu and u % n_used == 0 and u > 0:
+            for ln in lanes[:n_used]:
+                after(main, ln)
+            for ln in lanes[:n_used]:
+                after(ln, main)
+        xs, cs, ucs, sizes = [], [], [], []
+        with on(lane), ops.launch_context(cu_share=n_used):
+            for gi in idx:
+                b, buc = prepare_batch(batches[gi], device)
+                seeds = image_seeds[gi] if image_seeds is not None else None
+                with (rng.per_image(seeds) if seeds is not None else contextlib.nullcontext()):
+                    c, uc = model.conditioner.get_unconditional_conditioning(
+                        b, batch_uc=buc, force_uc_zero_embeddings=cfgs.force_uc_zero_embeddings)
+                    xs.append(sampler.get_init_noise(cfgs, model, cond=c, batch=b, uc=uc))
+                cs.append(c)
+                ucs.append(uc)
+                sizes.append(xs[-1].shape[0])
+            if any(x.shape[1:] != xs[0].shape[1:] for x in xs):
+                raise ValueError("batches fused into one sampling batch need one image size (use fuse=1)")
+            fx = torch.cat(xs, 0) if len(xs) > 1 else xs[0]
+            fc = _cat_cond(cs) if len(cs) > 1 else cs[0]
+            fuc = _cat_cond(ucs) if len(ucs) > 1 else ucs[0]
+            if lane_sampler is not None:
+                z = lane_sampler(model, fx, fc, fuc, slot=u % n_used, n_lanes=n_used, init_step=cfgs.init_step, deferred_checks=checks)
+            else:       # (stub samplers of the CPU tests: the group interface, one batch at a time)
+                z = sampler.sample_in_flight(model, [fx], [fc], [fuc], init_step=cfgs.init_step, deferred_checks=checks)[0]
+            img = torch.clamp((model.decode_first_stage(z) + 1.0) / 2.0, min=0.0, max=1.0)
+        keep.append((xs, cs, ucs, fx, fc, fuc, z))     # tensors of a lane stream: alive until the final synchronisation
+        o = 0
+        for nb in sizes:
+            out.append((img[o:o + nb], z[o:o + nb]))
+            o += nb
     for lane in lanes:
         after(main, lane)
     for chk in checks:

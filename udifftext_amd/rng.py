@@ -36,6 +36,28 @@ def randn(shape: Sequence[int]) -> torch.Tensor:
     return torch.cat([torch.randn((1,) + shape[1:], generator=g) for g in gens], 0)
 
 
+def randn_on(shape: Sequence[int], device) -> torch.Tensor:
+    """the same draw as ``randn`` (same generator(s), same values), delivered on ``device``: drawn into page-locked host
+    memory and copied with a non-blocking, stream-ordered transfer.  A pageable ``.to(device)`` blocks the host until every
+    kernel already queued on the current stream has run — with several batches in flight (pipeline.predict_many) that stalls
+    the launch thread for a whole sampling loop.  The pinned block stays alive until the copy has run (PyTorch's caching
+    host allocator records the stream use)."""
+    device = torch.device(device)
+    if device.type != "cuda":
+        return randn(shape).to(device)
+    shape = tuple(int(s) for s in shape)
+    gens = _state.gens
+    host = torch.empty(shape, dtype=torch.float32, pin_memory=True)
+    if gens is None:
+        torch.randn(shape, out=host)
+    else:
+        if len(gens) != shape[0]:
+            raise ValueError(f"per-image noise source holds {len(gens)} generators, draw asks for batch {shape[0]}")
+        for i, g in enumerate(gens):
+            torch.randn((1,) + shape[1:], generator=g, out=host[i:i + 1])
+    return host.to(device, non_blocking=True)
+
+
 @contextlib.contextmanager
 def per_image(seeds: Sequence[int]):
     """draws inside come from one generator per image (seeded here; each context starts fresh streams)"""

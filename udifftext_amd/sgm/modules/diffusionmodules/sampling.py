@@ -16,7 +16,7 @@ from __future__ import annotations
 
 import os
 import sys
-from typing import Dict, Union
+from typing import Dict, Optional, Union
 
 import numpy as np
 import torch
@@ -82,6 +82,13 @@ NOISE_BATCH = os.environ.get("UDT_NOISE_BATCH", "1") != "0"
 DUAL_STREAM = os.environ.get("UDT_DUAL_STREAM", "1") != "0"
 
 
+def _all_zero(t: torch.Tensor) -> bool:
+    """is the (unconditional) text context exactly zero?  GeneralConditioner tags force-zeroed embeddings on the host
+    (``_udt_all_zero``); anything else is asked on the device (one host sync)"""
+    flag = getattr(t, "_udt_all_zero", None)
+    return bool(flag) if flag is not None else not bool(t.any())
+
+
 def weights_fingerprint(model) -> int:
     """changes whenever a parameter of ``model`` is re-assigned, moved or written in place (load_state_dict,
     init_from_ckpt, .to()): captured hipGraphs bake in the device pointers of the packed weights, so the graph caches
@@ -117,7 +124,7 @@ class _Stepper:
         self.t_fused = self.unet.prepare_fused_tattn(self.t_kv)           # ... folded further into the fused t_attn tables
         # force_uc_zero_embeddings=["label"] (reference sample loop) makes the unconditional context exactly zero:
         # its cross-attention is then x + to_out.bias — one host sync per sampling run buys half of every t_attn
-        self.zero_ctx_rows = batch_size if not bool(uc["t_crossattn"].any()) else 0
+        self.zero_ctx_rows = batch_size if _all_zero(uc["t_crossattn"]) else 0
         # two launch streams: the unconditional and the conditional half of the CFG pair never meet before the
         # guidance step, so each runs the UNet on its own HIP stream, planned for half of the CUs.  Measured on
         # MI355X: one stream leaves the chip idle during every kernel's ramp-up / epilogue / tail (a half-GPU plan
@@ -221,7 +228,7 @@ class _GraphedSteps:
     def rebind(self, cond, uc) -> bool:
         """refresh the static conditioning buffers for a new batch; False if the launch sequence would differ"""
         st = self.st
-        zero_rows = st.B if not bool(uc["t_crossattn"].any()) else 0
+        zero_rows = st.B if _all_zero(uc["t_crossattn"]) else 0
         if zero_rows != st.zero_ctx_rows or cond["concat"].shape[0] != st.B:
             return False
         ctx = torch.cat((uc["t_crossattn"], cond["t_crossattn"]), 0)
@@ -291,7 +298,7 @@ class EulerEDMSampler(EDMSampler):
         H, W = batch["target_size_as_tuple"][0]
         shape = (cfgs.batch_size, cfgs.channel, int(H) // cfgs.factor, int(W) // cfgs.factor)
         dev = cond["concat"].device
-        randn = rng.randn(shape).to(dev)
+        randn = rng.randn_on(shape, dev)
         if cfgs.noise_iters <= 0:
             return randn
         sig = self._host_sigmas(2)
@@ -300,7 +307,7 @@ class EulerEDMSampler(EDMSampler):
         uc = default(uc, cond)
         # the reference draws the first candidate, then one more after scoring each (the last draw is never used but advances the
         # generator): K + 1 draws in the same order
-        cands = [randn] + [rng.randn(shape).to(dev) for _ in range(K)]
+        cands = [randn] + [rng.randn_on(shape, dev) for _ in range(K)]
         cands, scores = cands[:K], []
         # candidates are independent of each other (2 Euler steps + the local loss of THAT candidate's attention maps), so they
         # run as extra batch entries of the same UNet calls: up to 16 samples (32 with the CFG pair) per call instead of K
@@ -437,6 +444,52 @@ class EulerEDMSampler(EDMSampler):
             else:
                 gs.st.check()
         return outs
+
+    def sample_lane(self, model, x, cond, uc, slot: int, n_lanes: int, init_step=0, deferred_checks: Optional[list] = None):
+        """the sampling loop of ONE batch on the CURRENT stream, as lane ``slot`` of ``n_lanes`` free-running lanes
+        (pipeline.predict_many): rebind this lane's runner to the batch, enqueue all graph replays, return the latent — no
+        host synchronisation and no event shared with the other lanes, so a lane runs condition -> sample -> decode back to
+        back while the launch thread is already feeding the next lane.  Launches are planned for 1 / n_lanes of the CUs
+        (cu_share), as in ``sample_in_flight``.  The runner's error-word check goes to ``deferred_checks``."""
+        if n_lanes <= 1 or not self.use_graphs:
+            return self(model, x, cond=cond, uc=uc, init_step=init_step)
+        self._check_fast_path()
+        require_gpu(x, "EulerEDMSampler")
+        uc = default(uc, cond)
+        sig = self._host_sigmas(None)
+        steps = list(self.get_sigma_gen(len(sig), init_step=init_step))
+        cache = self.__dict__.setdefault("_in_flight", {})
+        fp = weights_fingerprint(model)
+        key = (slot, n_lanes, id(model), tuple(x.shape), len(sig), float(self.guider.scale), tuple(sig[:2]), x.device.index)
+        gs = cache.get(key)
+        if gs is not None and gs.fingerprint != fp:            # weights changed: the captured pointers are stale
+            cache.pop(key)
+            gs = None
+        if gs is None or not gs.rebind(cond, uc):
+            gs = _GraphedSteps(model, cond, uc, x.shape[0], x.shape[2:], self.guider.scale, sig, cu_share=n_lanes)
+            cache.pop(key, None)
+            while len(cache) >= 8:                              # every runner owns a memory pool: keep the newest few
+                cache.pop(next(iter(cache)))
+            cache[key] = gs
+        lane = torch.cuda.current_stream()
+        missing = [i for i in steps if i not in gs.graphs]
+        if missing:
+            # first use of this lane / shape: capture on the runner's own stream (a capture synchronises the device once)
+            gs.capture_stream.wait_stream(lane)
+            for i in missing:
+                gs._capture(i)
+            lane.wait_stream(gs.capture_stream)
+        gs.x.copy_(x.float())
+        gs.x.mul_((1.0 + sig[0] ** 2.0) ** 0.5)
+        for i in steps:
+            gs.graphs[i].replay()
+        out = gs.x.clone()
+        if deferred_checks is not None:
+            if gs.st.check not in deferred_checks:
+                deferred_checks.append(gs.st.check)
+        else:
+            gs.st.check()
+        return out
 
     def _run_graphed(self, model, x, cond, uc, sig, init_step):
         """replay (capturing on first use) the hipGraphs of this sampling configuration; None -> eager launches"""

@@ -20,7 +20,7 @@ class DiagonalGaussianDistribution(object):
 
     def sample(self, scale: float = 1.0) -> torch.Tensor:
         B, h, w, _ = self.parameters.shape
-        noise = rng.randn((B, 4, h, w)).to(device=self.parameters.device)
+        noise = rng.randn_on((B, 4, h, w), self.parameters.device)
         if self.deterministic:
             noise = torch.zeros_like(noise)
         return ops.posterior_sample(self.parameters, noise, scale)

@@ -98,6 +98,7 @@ class GeneralConditioner(nn.Module):
                     e = expand_dims_like(keep, e) * e
                 if zeroed:
                     e = torch.zeros_like(e)
+                    e._udt_all_zero = True           # known on the host: consumers need no device round trip to find out
                 output[key] = torch.cat((output[key], e), self.KEY2CATDIM[key]) if key in output else e
         return output
 
@@ -111,7 +112,10 @@ class GeneralConditioner(nn.Module):
         for e in self.embedders:
             if hasattr(e, "share_between_calls"):
                 k = e.input_key
-                same = (buc[k] is batch_c[k]) or (buc[k].shape == batch_c[k].shape and bool(torch.equal(buc[k], batch_c[k])))
+                # (pipeline.prepare_batch marks its unconditional batch as a clone of the conditional one: no device-side
+                #  comparison — a host sync that would stall the launch thread while other batches are in flight)
+                same = (buc[k] is batch_c[k]) or (buc.get("_udt_clone_of") is batch_c and k not in buc.get("_udt_changed", ())) \
+                    or (buc[k].shape == batch_c[k].shape and bool(torch.equal(buc[k], batch_c[k])))
                 e.share_between_calls(same)
         try:
             c = self(batch_c)
@@ -277,7 +281,10 @@ class LabelEncoder(AbstractEmbModel):
             assert len(label) <= self.max_len
             idx = [self.character.find(c) + 1 for c in label]
             rows.append(idx + [0] * (self.max_len - len(idx)))
-        return torch.tensor(rows, device=next(self.parameters()).device)
+        dev = next(self.parameters()).device
+        if dev.type != "cuda":
+            return torch.tensor(rows, device=dev)
+        return torch.tensor(rows).pin_memory().to(dev, non_blocking=True)     # (a pageable copy would block the launch thread)
 
     def get_embeddings(self, x):
         require_gpu(x, "LabelEncoder")
