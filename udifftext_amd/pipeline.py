@@ -156,15 +156,8 @@ def predict_many(cfgs, model, sampler, batches, device: Optional[torch.device] =
     n_used = min(n, len(units)) if units else 1
     for lane in lanes[:n_used]:
         after(lane, main)
-    import os
-    _join = os.environ.get("UDT_LANE_JOIN", "0") != "0"       # TEMPORARY measurement switch (A/B against the round-3 group joins)
     for u, idx in enumerate(units):
         lane = lanes[u % n_used]
-        if _join and gpu and u % n_used == 0 and u > 0:
-            for ln in lanes[:n_used]:
-                after(main, ln)
-            for ln in lanes[:n_used]:
-                after(ln, main)
         xs, cs, ucs, sizes = [], [], [], []
         with on(lane), ops.launch_context(cu_share=n_used):
             for gi in idx:
