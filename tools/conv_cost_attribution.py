@@ -36,8 +36,11 @@ def graph_time(fn_list, reps=5):
 MODES = [(0, "full"), (1, "no W dma"), (2, "no patch dma"), (3, "no dma"), (4, "no mfma"), (8, "no lds reads"), (12, "dma only"),
          (11, "mfma only"), (7, "lds reads only"), (15, "barriers only")]
 dbg("lean_conv", 1)
+WIDE = len(sys.argv) > 1 and sys.argv[1] == "wide"          # the wide kernel (wide.h) instead of the lean one
+dbg("wide_conv", 1 if WIDE else 0)
 print(f"{'conv':26s}" + "".join(f"{n:>15s}" for _, n in MODES))
-for B, H, C, N in [(8, 32, 640, 640), (8, 64, 320, 320), (8, 16, 1280, 1280), (8, 8, 1280, 1280), (16, 32, 640, 640), (13, 32, 640, 640)]:
+for B, H, C, N in ([(8, 64, 320, 320), (8, 64, 960, 320), (8, 32, 1280, 640)] if WIDE else
+                   [(8, 32, 640, 640), (8, 64, 320, 320), (8, 16, 1280, 1280), (8, 8, 1280, 1280), (16, 32, 640, 640), (13, 32, 640, 640)]):
     xs = [torch.randn((B, H, H, C), device=dev).bfloat16() for _ in range(4)]
     w = packing.pack_conv(torch.randn((N, C, 3, 3), device=dev) / math.sqrt(C * 9))
     b = torch.zeros((N,), device=dev)

@@ -18,6 +18,11 @@
 // empty: 17 % of the MFMAs of the biggest launches), and the patch of a pixel tile is staged twice instead of three
 // times (L2 -> LDS traffic, roofline.traffic).  Levels with fewer than one tile per CU cut the channel chunks into slices
 // (ticket split-K of lean.h).
+// Measured and rejected (profiles/r04_wide_cost_attribution.txt): moving every LDS-DMA request to a FIFTH "loader" wave (the
+// four MFMA waves then execute only barrier + 28 fragment reads + 40 MFMAs per tap; all waves capped at 256 registers) —
+// 62.7 vs 58.7 us on 8x64x64 320->320.  The attribution says why: MFMAs alone 0.64 us per tap, MFMAs + fragment reads 0.73,
+// MFMAs + DMA (no reads) 0.65, all three 1.06 — whichever wave issues them, the LDS-DMA writes and the ds_read_b128 stream
+// contend for the LDS port (112 KiB of reads + 25 KiB of DMA writes per tap and CU), and the MFMAs starve behind the reads.
 // Replaces nn.Conv2d(k=3, pad=1) of ResBlock (reference openaimodel.py:183-187,218-231) where the output channels are a
 // multiple of 160 and the map a multiple of 16 x 16.
 #pragma once
@@ -188,6 +193,7 @@ __global__ void __launch_bounds__(256, 1) wconv3_kernel(const C3Params p) {
       }
       bf16x8_t fx[2][TM], fw[2][TN];
       auto read_ks = [&](int ks, int slot2) {
+        if (UDT_DBG(p.dbg, 3)) return;                       // (measurement builds: no fragment reads)
 #pragma unroll
         for (int t = 0; t < TM; ++t) fx[slot2][t] = lds_read_frag(pbuf + arow[t] + (((ks * 2 + hi) ^ aswz[t]) << 4));
         const int slot = ((ks * 2 + hi) ^ swz_w) << 4;
@@ -206,14 +212,25 @@ __global__ void __launch_bounds__(256, 1) wconv3_kernel(const C3Params p) {
           const int ahead = tap + NR - 1;
           int s2 = st + NR - 1;
           if (s2 >= NR) s2 -= NR;
-          if (ahead < 9) issue_w(s2, c, ahead);
-          else issue_w(s2, cn, ahead - 9);
-          if constexpr (tap < PTAPS) issue_patch_part((c + 1) & 1, cn, tap);
+          if (!UDT_DBG(p.dbg, 0)) {
+            if (ahead < 9) issue_w(s2, c, ahead);
+            else issue_w(s2, cn, ahead - 9);
+          }
+          if constexpr (tap < PTAPS) {
+            if (!UDT_DBG(p.dbg, 1)) issue_patch_part((c + 1) & 1, cn, tap);
+          }
         }
+        if (UDT_DBG(p.dbg, 2)) {                             // (measurement builds: fragments kept alive, no MFMAs)
 #pragma unroll
-        for (int tm = 0; tm < TM; ++tm)
+          for (int tm = 0; tm < TM; ++tm) asm volatile("" ::"v"(fx[ks & 1][tm]));
 #pragma unroll
-          for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = mfma32(fw[ks & 1][tn], fx[ks & 1][tm], acc[tm][tn]);
+          for (int tn = 0; tn < TN; ++tn) asm volatile("" ::"v"(fw[ks & 1][tn]));
+        } else {
+#pragma unroll
+          for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = mfma32(fw[ks & 1][tn], fx[ks & 1][tm], acc[tm][tn]);
+        }
       }
       // the order the scheduler is asked for (one straight-line region per tap)
       __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
