@@ -115,8 +115,13 @@ def test_prepare_packs_dedups_and_frees(small_engine):
     assert rep["vae_deduplicated"] == 1 and le.model is eng.first_stage_model
     # packed layouts exist for every evaluated module; fused children were not packed on their own
     blk = eng.model.diffusion_model.input_blocks[1][1].transformer_blocks[0]
-    assert getattr(blk.attn1, "_pk", None) is not None and getattr(blk.attn1.to_q, "_pk", None) is None
-    wqk, wv = blk.attn1.packed()                  # one fused q|k|v matrix (the flash kernel reads V row-major)
+    # the LayerNorm-folded layouts serve attn1 / GEGLU (UDT_LN_GEMM, default on): prepare() packs THOSE, not the plain ones
+    assert H.LN_GEMM and getattr(blk.attn1, "_pkln", None) is not None and getattr(blk.attn1, "_pk", None) is None
+    assert getattr(blk.attn1.to_q, "_pk", None) is None
+    wf, c_ln, s_ln = blk.attn1.packed_ln(blk.norm1)
+    ref_f = (torch.cat([blk.attn1.to_q.weight, blk.attn1.to_k.weight, blk.attn1.to_v.weight]) * blk.norm1.weight[None, :]).to(torch.bfloat16)
+    assert torch.equal(wf, ref_f) and c_ln.shape[0] == wf.shape[0] == s_ln.shape[0]
+    wqk, wv = blk.attn1.packed()                  # (on demand) one fused q|k|v matrix: the flash kernel reads V row-major
     ref_qk = torch.cat([blk.attn1.to_q.weight, blk.attn1.to_k.weight, blk.attn1.to_v.weight]).to(torch.bfloat16)
     assert torch.equal(wqk, ref_qk) and wv is None
     # release the fp32 masters: the caches keep serving, the parameters are gone
@@ -124,7 +129,8 @@ def test_prepare_packs_dedups_and_frees(small_engine):
     rep = eng.prepare(free_masters=True)
     after = sum(p.numel() for p in eng.parameters())
     assert rep["freed_bytes"] > 0 and after < 0.1 * before
-    assert torch.equal(blk.attn1.packed()[0], ref_qk) and blk.attn1.to_q.weight.numel() == 0
+    assert torch.equal(blk.attn1.packed_ln(blk.norm1)[0], ref_f) and blk.attn1.to_q.weight.numel() == 0
+    assert torch.equal(blk.attn1.packed()[0], ref_qk)            # (the plain layout built above stays cached)
     assert isinstance(blk.norm1, H.LayerNorm) and blk.norm1.weight.numel() > 0        # norms stay (consumed as fp32)
     w, b = eng.model.diffusion_model._emb_pack()
     assert w.shape[0] == sum(rb.out_channels for rb in eng.model.diffusion_model._resblocks)

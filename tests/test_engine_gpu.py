@@ -796,3 +796,64 @@ def test_predict_sharded_under_nccl_world1(engine, cuda, monkeypatch, n_images, 
     finally:
         if mine:
             dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("switch", ["UDT_LEAN=0", "UDT_LEAN_CONV=0", "UDT_WIDE_CONV=0", "UDT_LEAN_SPLITK=1", "UDT_GN_EPI=0", "UDT_LN_GEMM=0",
+                                    "UDT_DUAL_STREAM=0", "fused text cross-attention off"])
+def test_unet_call_with_each_switch_in_its_non_default_position(engine, cuda, monkeypatch, switch):
+    """every surviving launch-path switch (the environment variables are read once at import / first use,
+    so the test sets what they set) gives the same UNet call as the default path up to the other kernel family's rounding:
+    8 samples at 32x32 latents (all four levels incl. 4x4 maps) — rel RMS <= 1.5e-2 between the two paths, each finite.
+    UDT_GRAPHS, UDT_FP8, UDT_FUSE_GN, UDT_ATTN512 and UDT_NOISE_BATCH have tests of their own above."""
+    import sgm.modules.attention as A
+    import sgm.modules.diffusionmodules.sampling as S
+    import sgm.modules.hipnn as H
+    from udifftext_amd import lib as L, synth
+    lib = L.load()
+    torch.manual_seed(77)
+    B = 4
+    le = engine.conditioner.embedders[0]
+    ctx = le(synth.synthetic_batch(B, 256, 256, 6, seed=8)["label"])
+    tctx = torch.cat([torch.zeros_like(ctx), ctx])
+    x = torch.randn((2 * B, 9, 32, 32), device=cuda)
+    ts = torch.full((2 * B,), 333, device=cuda)
+    unet = engine.model.diffusion_model
+    ref = unet(x, timesteps=ts, t_context=tctx).float()
+    keys = []
+    try:
+        if switch.startswith("UDT_LEAN=") or switch.startswith("UDT_LEAN_CONV=") or switch.startswith("UDT_WIDE_CONV=") or switch.startswith("UDT_LEAN_SPLITK="):
+            key = {"UDT_LEAN": "lean", "UDT_LEAN_CONV": "lean_conv", "UDT_WIDE_CONV": "wide_conv", "UDT_LEAN_SPLITK": "lean_splitk"}[switch.split("=")[0]]
+            L.check(lib.udt_debug_set(key.encode(), int(switch.split("=")[1])), "udt_debug_set")
+            keys.append(key)
+            if key == "lean":                                   # (UDT_LEAN=0 also switches these two off at import)
+                monkeypatch.setattr(H, "LN_GEMM", False)
+                monkeypatch.setattr(H, "GN_EPI", False)
+        elif switch == "UDT_GN_EPI=0":
+            monkeypatch.setattr(H, "GN_EPI", False)
+            monkeypatch.setattr(H, "EMIT_STATS", H.FUSE_GN)
+        elif switch == "UDT_LN_GEMM=0":
+            monkeypatch.setattr(H, "LN_GEMM", False)
+        elif switch == "UDT_DUAL_STREAM=0":
+            monkeypatch.setattr(S, "DUAL_STREAM", False)
+        else:
+            monkeypatch.setattr(A, "TATTN_FUSED", False)
+        if switch == "UDT_DUAL_STREAM=0":
+            # the switch lives in the sampler's step: one Euler step through _Stepper with and without the two-stream split
+            c = {"t_crossattn": ctx, "concat": torch.randn((B, 5, 32, 32), device=cuda)}
+            uc = {"t_crossattn": torch.zeros_like(ctx), "concat": c["concat"].clone()}
+            outs = []
+            for dual in (True, False):
+                st = S._Stepper(engine, c, uc, B, (32, 32), 5.0, two_streams=dual)
+                z = x[:B, :4].clone().float().contiguous()
+                st.step(z, 5.0, 4.0)
+                st.check()
+                outs.append(z.clone())
+            got, ref = outs[1], outs[0]
+        else:
+            got = unet(x, timesteps=ts, t_context=tctx).float()
+        torch.cuda.synchronize()
+    finally:
+        for k in keys:
+            L.check(lib.udt_debug_set(k.encode(), -1), "udt_debug_set")
+    assert torch.isfinite(got).all()
+    _check(f"UNet call with {switch} vs the default path", got.cpu(), ref.cpu(), 1.5e-2)

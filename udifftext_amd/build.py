@@ -14,13 +14,13 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libudt_kernels.so")
-SOURCES = ["api.hip", "gemm.hip", "attention.hip", "tattn.hip", "norm.hip", "elementwise.hip", "pack.hip"]
+SOURCES = ["api.hip", "gemm.hip", "lean.hip", "attention.hip", "tattn.hip", "norm.hip", "elementwise.hip", "pack.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"] + os.environ.get("UDT_EXTRA_FLAGS", "").split()
 
 
 def _deps_mtime() -> float:
-    hdrs = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "gemm8.h"), os.path.join(CSRC, "conv3p.h"), os.path.join(CSRC, "lean.h"), os.path.join(CSRC, "wide.h"), os.path.join(HERE, "..", "include", "udt_kernels.h")]
+    hdrs = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "gemm8.h"), os.path.join(CSRC, "conv3p.h"), os.path.join(CSRC, "lean.h"), os.path.join(CSRC, "wide.h"), os.path.join(CSRC, "tile_common.h"), os.path.join(CSRC, "lean_params.h"), os.path.join(HERE, "..", "include", "udt_kernels.h")]
     return max(os.path.getmtime(h) for h in hdrs)
 
 

@@ -860,9 +860,9 @@ static int attn_fwd_impl(bool vrow, const void* q, const void* k, const void* vt
     udt_prof_tag(prof.rec, tag);
   }
   dim3 grid((nq + 127) / 128, batch * heads);
-  // UDT_ATTN_V2=0: the first-generation loop (A/B measurements).  The v2 kernel addresses K / V through 31-bit buffer offsets
-  static const int v2 = [] { const char* e = getenv("UDT_ATTN_V2"); return (e && e[0] == '0') ? 0 : 1; }();
-  if (vrow && v2 && (long long)nk * ldk * 2 < (1LL << 31) && (long long)nk * ldvt * 2 < (1LL << 31)) {
+  if (vrow) {
+    // row-major V: the three-stage kernel; it addresses K / V through 31-bit buffer offsets
+    if ((long long)nk * ldk * 2 >= (1LL << 31) || (long long)nk * ldvt * 2 >= (1LL << 31)) return UDT_ERR_BAD_SHAPE;
     static std::atomic<int> attr_done{0};
     constexpr int smem = A2_NST * A2_STAGE;
     if (!attr_done.load()) {
@@ -871,8 +871,9 @@ static int attn_fwd_impl(bool vrow, const void* q, const void* k, const void* vt
       attr_done.store(1);
     }
     hipLaunchKernelGGL(attn_d64_v2_kernel, grid, dim3(256), smem, s, p);
-  } else if (vrow) hipLaunchKernelGGL(attn_d64_kernel<true>, grid, dim3(256), 0, s, p);
-  else hipLaunchKernelGGL(attn_d64_kernel<false>, grid, dim3(256), 0, s, p);
+  } else {
+    hipLaunchKernelGGL(attn_d64_kernel<false>, grid, dim3(256), 0, s, p);      // V^T operand (udt_attn_fwd)
+  }
   UDT_CHECK_LAUNCH();
   return UDT_OK;
 }
@@ -922,9 +923,8 @@ extern "C" int udt_attn512_fwd(const void* q, const void* k, const void* v, void
     snprintf(tag, sizeof(tag), "attn512 B=%d nq=%d nk=%d", batch, nq, nk);
     udt_prof_tag(prof.rec, tag);
   }
-  // 64 queries (eight waves) per workgroup when that still gives every CU work; 32 otherwise (UDT_ATTN512_TQ=1|2 forces one: A/B)
-  static const int tq_force = [] { const char* e = getenv("UDT_ATTN512_TQ"); return e ? atoi(e) : 0; }();
-  const bool two = tq_force ? tq_force == 2 : ((long long)((nq + 63) / 64) * batch >= 224);
+  // 64 queries (eight waves) per workgroup when that still gives every CU work; 32 otherwise
+  const bool two = (long long)((nq + 63) / 64) * batch >= 224;
   static std::atomic<int> attr_done{0};
   if (!attr_done.load()) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_d512_q32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, a5_smem<1>());

@@ -32,7 +32,13 @@
 #include <atomic>
 #include <cmath>
 
+// lean.hip: launchers of the lean / wide kernel families (argument blocks: lean_params.h, passed as opaque pointers because
+// each translation unit keeps its own internal-linkage copy of the types)
+hipError_t udt_lean_launch_gemm(int cfg, const void* lparams, int smem, int G, int geglu, int ln, hipStream_t s);
+hipError_t udt_lean_launch_conv3(const void* c3params, hipStream_t s);
+
 namespace {
+#include "tile_common.h"
 
 struct GemmParams {
   const uint16_t* a;
@@ -64,8 +70,6 @@ struct GemmParams {
   int G;
 };
 
-constexpr int BK = 64;          // K elements per tile (128 bytes per row)
-constexpr int ROW_BYTES = 128;
 constexpr int SLAB_FLOATS = 16 * 256 * 4;   // one parked 4-wave accumulator set
 
 // ------------------------------------------------------------------------------------------------ epilogue
@@ -203,14 +207,6 @@ UDT_DEVINL void decode_tile(const GemmParams& p, int tile, int& batch, int& m0, 
   const int tn = blk * p.n_block + (r - tm * nbw);
   m0 = tm * BM;
   n0 = tn * BN;
-}
-
-// workgroup -> iteration-range index.  Blocks are dispatched round-robin over the 8 XCDs (block b -> XCD b % 8,
-// speed heuristic only); give every XCD a contiguous slice of the iteration space so that its private L2 sees
-// neighbouring tiles (which share the weight column tile).
-UDT_DEVINL int range_index(int g, int G) {
-  if ((G & 7) != 0) return g;
-  return (g & 7) * (G >> 3) + (g >> 3);
 }
 
 template <int BM, int BN, int WGM, int WGN, bool CONV, bool TRANS>
@@ -462,8 +458,7 @@ __global__ void __launch_bounds__(256) gemm_fixup_kernel(const GemmParams p) {
 
 #include "gemm8.h"
 #include "conv3p.h"
-#include "lean.h"
-#include "wide.h"
+#include "lean_params.h"
 
 struct TilePlan {
   int bm, bn;
@@ -501,21 +496,6 @@ int resident_slots(const udt_gemm_desc* d) {
   const int s = resident_slots_all() / share;
   return s < 2 ? 2 : s;
 }
-
-// hipFuncSetAttribute(max dynamic LDS) once per (kernel, device); thread-safe
-struct AttrOnce {
-  std::atomic<unsigned> done{0};
-  hipError_t ensure(const void* fn, int bytes) {
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) dev = 0;
-    if (done.load(std::memory_order_acquire) & (1u << dev)) return hipSuccess;
-    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-    if (e != hipSuccess) return e;
-    // the persistent kernels assume >= 1 resident workgroup per CU with this much LDS; ask the runtime once
-    done.fetch_or(1u << dev, std::memory_order_release);
-    return hipSuccess;
-  }
-};
 
 TilePlan plan_tiles(const udt_gemm_desc* d) {
   TilePlan t;
@@ -581,10 +561,8 @@ hipError_t launch_cfg(const GemmParams& p, const TilePlan& t, hipStream_t s) {
 constexpr size_t G8_HEADER_BYTES = 4096;     // flags[<=1023] + err word, ahead of the slabs
 
 // Tuning knobs (udt_debug_set; every setting gives correct results): kernel generation, tile order, epilogue form.
-std::atomic<int> g_impl{-1};     // 8: deep-pipelined 8-wave kernel (default), 4: first-generation 4-wave kernel
 std::atomic<int> g_n_block{-1};  // tile order of plain GEMMs: -1 automatic (~2 MiB weight blocks), 0 off (M-fastest), n forced
 std::atomic<int> g_rows_epi{1};  // row-coalesced (LDS-transposed) epilogues; 0 = direct accumulator-layout stores
-std::atomic<int> g_conv3p{-1};   // patch-staged 3x3 convolution kernel on (1) / off (0)
 #ifdef UDT_MEASURE
 std::atomic<int> g_dbg_bits{0};  // cost-attribution modes that switch parts of the finishing code OFF (wrong results):
                                  // compiled only into measurement builds (-DUDT_MEASURE), never into the product library
@@ -595,18 +573,10 @@ constexpr int PUBLIC_FLAGS = UDT_GEMM_OUT_F32 | UDT_GEMM_GEGLU | UDT_GEMM_RELU |
 inline int k_tile(const udt_gemm_desc* d) { return (d->flags & UDT_GEMM_FP8) ? 128 : BK; }   // K elements per 128-byte row
 inline int elem_bytes(const udt_gemm_desc* d) { return (d->flags & UDT_GEMM_FP8) ? 1 : 2; }
 
-int gemm_impl() {
-  int v = g_impl.load(std::memory_order_relaxed);
-  if (v < 0) {
-    const char* e = getenv("UDT_GEMM_IMPL");
-    v = (e && e[0] == '4') ? 4 : 8;
-    g_impl.store(v, std::memory_order_relaxed);
-  }
-  return v;
-}
-
+// the 8-wave kernels serve everything the lean family declines, except outputs of <= 64 columns (the UNet's 4-channel output
+// convolution): those keep the first-generation 4-wave kernel with its 256 x 64 tile
 bool use_gemm8(const udt_gemm_desc* d) {
-  if (gemm_impl() == 4 || d->N <= 64) return false;
+  if (d->N <= 64) return false;
   const long long ldw = d->ldw > 0 ? d->ldw : d->K;
   // buffer-descriptor addressing uses 31-bit byte offsets per batch element
   if (!(d->flags & UDT_GEMM_CONV) && (long long)d->M * d->lda * elem_bytes(d) >= (1LL << 31)) return false;
@@ -617,23 +587,18 @@ bool use_gemm8(const udt_gemm_desc* d) {
 // Launch a multiple of 8 workgroups so that range_index() can hand every XCD (block b runs on XCD b % 8) one contiguous
 // slice of the iteration space: neighbouring tiles then share one L2 (the patch / A rows across N tiles, the weight
 // column tile across M tiles, and the stream-K slabs between neighbours).  The padding workgroups own empty ranges and
-// exit at once.  UDT_G_ROUND8=0 restores the exact count (A/B measurements).
-int round_workgroups(int G) {
-  static const int on = [] { const char* e = getenv("UDT_G_ROUND8"); return (e && e[0] == '0') ? 0 : 1; }();
-  return (on && G > 8) ? ((G + 7) & ~7) : G;
-}
+// exit at once (+1 % images/s in round 2's same-box A/B).
+int round_workgroups(int G) { return G > 8 ? ((G + 7) & ~7) : G; }
 
 // Several launch streams in flight (cu_share > 1): what counts is the CU-time a launch consumes, not its latency.  Cutting
 // tiles (stream-K) buys latency with CU-time — slab round trips, two prologues per tile, and all partners resident at
 // once: measured alone on the chip, 8x32x32 640->640 costs 256 x 90 us of CU-time at full width but 32 x 340 us on 32
 // workgroups (tools/bench_cu_share.py).  Whole tiles need no residency (nobody waits), so they queue on whatever CU is
 // free.  Used when there are at least ~3/4 as many tiles as the stream's share of workgroup slots.
-// UDT_WHOLE_NUM / UDT_WHOLE_DEN override the 3/4 (A/B measurements); cu_share 1 keeps the latency plans.
+// cu_share 1 keeps the latency plans.
 bool prefer_whole_tiles(const udt_gemm_desc* d, int tiles) {
-  static const int num = [] { const char* e = getenv("UDT_WHOLE_NUM"); return e ? atoi(e) : 3; }();
-  static const int den = [] { const char* e = getenv("UDT_WHOLE_DEN"); return (e && atoi(e) > 0) ? atoi(e) : 4; }();
-  if (d->cu_share <= 1 || num <= 0) return false;
-  return (long long)tiles * den >= (long long)(resident_slots(d) / 2) * num;
+  if (d->cu_share <= 1) return false;
+  return (long long)tiles * 4 >= (long long)(resident_slots(d) / 2) * 3;
 }
 
 TilePlan plan_tiles8(const udt_gemm_desc* d) {
@@ -678,23 +643,14 @@ hipError_t launch8(const g8::Params& pp, const TilePlan& t, hipStream_t s) {
 
 // ---- patch-staged 3x3 convolution: host side -------------------------------------------------------------------
 // gn: the launch applies GroupNorm on the staged patch (the only variant that reads a second source)
-bool upsample3p_enabled() {      // UDT_CONV3P_UPS=0: upsampling convolutions stay on the gather kernel (A/B measurements)
-  static const int on = [] { const char* e = getenv("UDT_CONV3P_UPS"); return (e && e[0] == '0') ? 0 : 1; }();
-  return on != 0;
-}
-
 bool conv3p_geometry(const udt_gemm_desc* d, c3p::Geo& ge, bool gn) {
-  int on = g_conv3p.load(std::memory_order_relaxed);
-  if (on < 0) {
-    const char* e = getenv("UDT_CONV3P");
-    on = (e && e[0] == '0') ? 0 : 1;
-    g_conv3p.store(on, std::memory_order_relaxed);
-  }
-  if (!on || gemm_impl() == 4) return false;
+  // since round 4 this 8-wave kernel only serves the launches that apply GroupNorm(+SiLU) on the staged patch
+  // (udt_gn_silu_conv3x3_fwd, UDT_FUSE_GN=1): every plain 3x3 / stride 1 convolution runs on the lean / wide kernels, what
+  // those decline (maps that are not multiples of 8, fewer than 128 output channels) on the gathered gemm8_kernel<CONV>
+  if (!gn) return false;
   if (!(d->flags & UDT_GEMM_CONV) || d->ksize != 3 || d->stride != 1) return false;
   const bool ups = d->upsample != 0;
-  // nearest x2 upsampling folded in: the 256x128 plain variant only (one source, no GroupNorm / statistics)
-  if (ups && (gn || d->colstats || d->C2 != 0 || (d->N % 160 == 0 && d->N % 128 != 0) || !upsample3p_enabled())) return false;
+  if (ups) return false;
   if (d->pad_t != 1 || d->pad_l != 1 || d->N <= 64) return false;
   if (d->Hout != (d->Hin << (ups ? 1 : 0)) || d->Wout != (d->Win << (ups ? 1 : 0))) return false;
   if (d->flags & (UDT_GEMM_GEGLU | UDT_GEMM_TRANSPOSED)) return false;
@@ -788,8 +744,9 @@ int colstats_slots(const udt_gemm_desc* d) {
 
 // ---- lean co-resident GEMM family (lean.h): host side --------------------------------------------------------------
 // udt_debug_set("lean", v): -1 automatic (default), 0 off, 1 = 4 waves / 128x128 / 2 stages (two workgroups per CU),
-// 2 = 8 waves / 256x128 / 3 stages (one per CU), 3 = 4 waves / 128x128 / 3 stages (one per CU) — every setting gives
-// the same results up to fp32 summation order (split-K); A/B measurements (tools/bench_gemm_shapes.py)
+// 6 = 8 waves / 256x256 / 2 stages (one per CU) — every setting gives the same results up to fp32 summation order
+// (split-K); A/B measurements (tools/bench_gemm_shapes.py).  (Round 3's forced-only 256x128 and three-stage 128x128
+// configurations measured slower on every UNet shape and are gone.)
 std::atomic<int> g_lean{-1};
 std::atomic<int> g_lean_splitk{-2};   // -1 automatic, 1 = never split, n = force n slices where K allows (-2: read UDT_LEAN_SPLITK)
 int lean_splitk_knob() {
@@ -801,15 +758,11 @@ int lean_splitk_knob() {
   }
   return v;
 }
-// UDT_LEAN_STATS=0: statistics-emitting launches stay on the 8-wave kernels (A/B)
-bool lean_stats_enabled() {
-  static const int on = [] { const char* e = getenv("UDT_LEAN_STATS"); return (e && e[0] == '0') ? 0 : 1; }();
-  return on != 0;
-}
+bool lean_stats_enabled() { return true; }     // statistics-emitting launches run on the lean kernels wherever a lean plan exists
 
 struct LeanPlan {
   int stats_rows = 0;      // rows per colstats slot when the launch emits statistics (lean.h wave_colstats), else 0
-  int cfg;                 // 1, 2, 3 as above; 5 = 4 waves / 128x160 / 2 stages (N = 320, 960)
+  int cfg;                 // 1, 6 as above; 5 = 4 waves / 128x160 / 2 stages (N = 320, 960)
   int bm, bn, nw, smem;
   int tiles_m, tiles_n, tiles, nkt, splitk, kt_per, G, n_block;
 };
@@ -826,7 +779,7 @@ int lean_mode() {
 
 bool lean_plan(const udt_gemm_desc* d, LeanPlan& t, bool want_stats) {
   const int mode = lean_mode();
-  if (mode == 0 || gemm_impl() == 4) return false;
+  if (mode == 0) return false;
   constexpr int unsupported = UDT_GEMM_OUT_F32 | UDT_GEMM_RELU | UDT_GEMM_TRANSPOSED | UDT_GEMM_SILU_OUT | UDT_GEMM_FP8;
   if (d->flags & unsupported) return false;
   // 1x1 / stride-1 convolutions are plain GEMMs over the pixels; two NHWC sources (the UNet's skip concat in front of a
@@ -848,9 +801,9 @@ bool lean_plan(const udt_gemm_desc* d, LeanPlan& t, bool want_stats) {
   if ((reinterpret_cast<uintptr_t>(d->out) | reinterpret_cast<uintptr_t>(d->residual) | reinterpret_cast<uintptr_t>(d->bias) |
        reinterpret_cast<uintptr_t>(d->rowvec) | reinterpret_cast<uintptr_t>(d->ln_colsum)) & 15) return false;
   if (d->rowvec && ((d->ld_rowvec > 0 ? d->ld_rowvec : d->N) % 4 != 0)) return false;
-  // forced configurations: 1, 2, 3, 6 only (5 = the 128 x 160 tile is chosen here, for plain N = 320 / 960 outputs: its wave
+  // forced configurations: 1 and 6 only (5 = the 128 x 160 tile is chosen here, for plain N = 320 / 960 outputs: its wave
   // grid has no GEGLU form); anything else falls back to the 8-wave kernels instead of silently taking a default instance
-  if (mode > 0 && mode != 1 && mode != 2 && mode != 3 && mode != 6) return false;
+  if (mode > 0 && mode != 1 && mode != 6) return false;
   t.cfg = (mode > 0) ? mode : 1;
   if (!geglu && d->N % 160 == 0 && d->N % 128 != 0 && t.cfg == 1) t.cfg = 5;
   // many tiles and a wide output: the 256 x 256 tile (8 waves, one workgroup per CU) halves the LDS-DMA instructions per MFMA.
@@ -870,8 +823,6 @@ bool lean_plan(const udt_gemm_desc* d, LeanPlan& t, bool want_stats) {
   }
   switch (t.cfg) {
     case 1: t.nw = 4; t.bm = 128; t.bn = 128; t.smem = 2 * (128 + 128) * ROW_BYTES; break;
-    case 2: t.nw = 8; t.bm = 256; t.bn = 128; t.smem = 3 * (256 + 128) * ROW_BYTES; break;
-    case 3: t.nw = 4; t.bm = 128; t.bn = 128; t.smem = 3 * (128 + 128) * ROW_BYTES; break;
     case 5: t.nw = 4; t.bm = 128; t.bn = 160; t.smem = 128 * 160 * 4; break;          // the fp32 staging rows exceed the ring
     case 6: t.nw = 8; t.bm = 256; t.bn = 256; t.smem = 2 * (256 + 256) * ROW_BYTES; break;   // one per CU: 128x64 per wave
     default: return false;
@@ -914,33 +865,6 @@ size_t lean_workspace(const LeanPlan& t) {
   return t.splitk > 1 ? G8_HEADER_BYTES + (size_t)t.tiles * t.splitk * t.bm * t.bn * sizeof(float) : 0;
 }
 
-template <int NW, int WGM, int WGN, int TM, int TN, int NST, int TMB = TM>
-hipError_t launch_lean(const lg::LParams& lp, const LeanPlan& t, bool geglu, bool ln, hipStream_t s) {
-  static AttrOnce once[5];
-  const void* fn;
-  const bool stats = lp.colstats != nullptr;
-  if constexpr (NW == 4 && NST == 2) {                    // (the two kernels with a statistics-emitting epilogue)
-    if (stats) {
-      fn = (const void*)lg::lgemm_kernel<NW, WGM, WGN, TM, TN, NST, false, false, TMB, true>;
-      hipError_t e = once[4].ensure(fn, t.smem);
-      if (e != hipSuccess) return e;
-      void* args[] = {const_cast<lg::LParams*>(&lp)};
-      return hipLaunchKernel(fn, dim3(t.G), dim3(NW * 64), args, t.smem, s);
-    }
-  }
-  if (stats) return hipErrorInvalidValue;
-  if constexpr (TN == 2) {
-    fn = geglu ? (ln ? (const void*)lg::lgemm_kernel<NW, WGM, WGN, TM, TN, NST, true, true, TMB> : (const void*)lg::lgemm_kernel<NW, WGM, WGN, TM, TN, NST, true, false, TMB>)
-               : (ln ? (const void*)lg::lgemm_kernel<NW, WGM, WGN, TM, TN, NST, false, true, TMB> : (const void*)lg::lgemm_kernel<NW, WGM, WGN, TM, TN, NST, false, false, TMB>);
-  } else {
-    fn = ln ? (const void*)lg::lgemm_kernel<NW, WGM, WGN, TM, TN, NST, false, true, TMB> : (const void*)lg::lgemm_kernel<NW, WGM, WGN, TM, TN, NST, false, false, TMB>;
-  }
-  hipError_t e = once[(geglu ? 2 : 0) + (ln ? 1 : 0)].ensure(fn, t.smem);
-  if (e != hipSuccess) return e;
-  void* args[] = {const_cast<lg::LParams*>(&lp)};
-  return hipLaunchKernel(fn, dim3(t.G), dim3(NW * 64), args, t.smem, s);
-}
-
 // ---- lean 3x3 convolution (lean.h lconv3_kernel): host side ------------------------------------------------------------
 // udt_debug_set("lean_conv", v): -1 automatic (default: on), 0 off, 1 on
 std::atomic<int> g_lean_conv{-1};
@@ -967,7 +891,7 @@ bool lean_conv_plan(const udt_gemm_desc* d, lg::C3Params& c, bool want_stats) {
     on = (e && e[0] == '0') ? 0 : 1;
     g_lean_conv.store(on, std::memory_order_relaxed);
   }
-  if (!on || gemm_impl() == 4 || lean_mode() == 0) return false;
+  if (!on || lean_mode() == 0) return false;
   if (d->flags != UDT_GEMM_CONV || d->ksize != 3 || d->stride != 1 || d->pad_t != 1 || d->pad_l != 1) return false;
   if (d->C2 != 0 || d->in_scsh || d->colscale || d->batch > 1) return false;
   if (want_stats && !lean_stats_enabled()) return false;
@@ -1053,33 +977,6 @@ size_t lean_conv_workspace(const lg::C3Params& c) {
   return c.splitk > 1 ? G8_HEADER_BYTES + (size_t)c.tiles * c.splitk * c.tw * c.th * c.bn * sizeof(float) : 0;
 }
 
-template <int TW, int TH, bool UPS, bool STATS>
-hipError_t launch_lconv3s(const lg::C3Params& c3, hipStream_t s) {
-  static AttrOnce once;
-  constexpr int smem = lg::C3Geo<TW, TH, UPS>::SMEM;
-  hipError_t e = once.ensure(reinterpret_cast<const void*>(lg::lconv3_kernel<TW, TH, UPS, STATS>), smem);
-  if (e != hipSuccess) return e;
-  hipLaunchKernelGGL((lg::lconv3_kernel<TW, TH, UPS, STATS>), dim3(c3.G), dim3(256), smem, s, c3);
-  return hipGetLastError();
-}
-template <int TW, int TH, bool UPS>
-hipError_t launch_lconv3(const lg::C3Params& c3, hipStream_t s) {
-  return c3.colstats ? launch_lconv3s<TW, TH, UPS, true>(c3, s) : launch_lconv3s<TW, TH, UPS, false>(c3, s);
-}
-
-template <bool STATS>
-hipError_t launch_wconv3s(const lg::C3Params& c3, hipStream_t s) {
-  static AttrOnce once;
-  constexpr int smem = wd::WGeo::SMEM;
-  hipError_t e = once.ensure(reinterpret_cast<const void*>(wd::wconv3_kernel<STATS>), smem);
-  if (e != hipSuccess) return e;
-  hipLaunchKernelGGL((wd::wconv3_kernel<STATS>), dim3(c3.G), dim3(256), smem, s, c3);
-  return hipGetLastError();
-}
-hipError_t launch_wconv3(const lg::C3Params& c3, hipStream_t s) {
-  return c3.colstats ? launch_wconv3s<true>(c3, s) : launch_wconv3s<false>(c3, s);
-}
-
 // would this problem run on a lean kernel WITH a statistics-emitting epilogue?  (udt_gemm_colstats_rows / _slots, asked by
 // the caller before it allocates the statistics and sets udt_gemm_desc.colstats)
 bool lean_stats_probe(const udt_gemm_desc* d, int& rows, int& slots) {
@@ -1105,8 +1002,6 @@ bool lean_stats_probe(const udt_gemm_desc* d, int& rows, int& slots) {
 
 extern "C" int udt_debug_set(const char* key, int32_t value) {
   if (!key) return UDT_ERR_BAD_ARG;
-  if (!strcmp(key, "gemm_impl")) { if (value != 4 && value != 8) return UDT_ERR_BAD_ARG; g_impl.store(value); return UDT_OK; }
-  if (!strcmp(key, "conv3p")) { g_conv3p.store(value ? 1 : 0); return UDT_OK; }
   if (!strcmp(key, "n_block")) { g_n_block.store(value); return UDT_OK; }
   if (!strcmp(key, "rows_epi")) { g_rows_epi.store(value ? 1 : 0); return UDT_OK; }
   if (!strcmp(key, "lean")) { g_lean.store(value < 0 ? -2 : value); return UDT_OK; }
@@ -1307,14 +1202,7 @@ extern "C" int udt_gemm(const udt_gemm_desc* d, void* workspace, size_t workspac
       }
       const bool geglu = (d->flags & UDT_GEMM_GEGLU) != 0, ln = d->ln_colsum != nullptr;
       hipError_t el;
-      switch (lt.cfg) {
-        case 1: el = launch_lean<4, 2, 2, 2, 2, 2>(lp, lt, geglu, ln, s); break;
-        case 2: el = launch_lean<8, 4, 2, 2, 2, 3>(lp, lt, geglu, ln, s); break;
-        case 3: el = launch_lean<4, 2, 2, 2, 2, 3>(lp, lt, geglu, ln, s); break;
-        case 6: el = launch_lean<8, 2, 4, 4, 2, 2, 1>(lp, lt, geglu, ln, s); break;
-        case 5: el = geglu ? hipErrorInvalidValue : launch_lean<4, 4, 1, 1, 5, 2>(lp, lt, false, ln, s); break;
-        default: el = hipErrorInvalidValue; break;
-      }
+      el = udt_lean_launch_gemm(lt.cfg, &lp, lt.smem, lt.G, geglu ? 1 : 0, ln ? 1 : 0, s);
       if (el != hipSuccess) return udt_set_hip_error(el);
       return UDT_OK;
     }
@@ -1337,8 +1225,7 @@ extern "C" int udt_gemm(const udt_gemm_desc* d, void* workspace, size_t workspac
                  d->Hin, d->Win, c3.tw, c3.th, c3.tiles * c3.splitk, c3.splitk, c3.n_block);
         udt_prof_tag(profc.rec, tag);
       }
-      const hipError_t ec = c3.geo == 3 ? launch_wconv3(c3, s) : c3.geo == 2 ? launch_lconv3<16, 8, true>(c3, s)
-                            : c3.geo == 1 ? launch_lconv3<8, 8, false>(c3, s) : launch_lconv3<16, 8, false>(c3, s);
+      const hipError_t ec = udt_lean_launch_conv3(&c3, s);
       if (ec != hipSuccess) return udt_set_hip_error(ec);
       return UDT_OK;
     }
@@ -1351,12 +1238,11 @@ extern "C" int udt_gemm(const udt_gemm_desc* d, void* workspace, size_t workspac
       {
         // XCD-aware tile order.  An XCD's L2 sees ~S = min(tiles, workgroups) / 8 neighbouring tiles at a time; taking
         // them as (S / nb) patches x nb weight tiles costs (S / nb) * patch + nb * weight-tile bytes of L2 fills:
-        // least at nb = sqrt(S * patch / weight tile).  UDT_C3P_NBLOCK forces a value (A/B measurements).
-        static const int knob = [] { const char* e = getenv("UDT_C3P_NBLOCK"); return e ? atoi(e) : -1; }();
+        // least at nb = sqrt(S * patch / weight tile)
         const double patch = (double)cp.geo.prows_img * cp.geo.NI * cp.geo.C * 2.0;
         const double wtile = 9.0 * t3.bn * cp.geo.C * 2.0;
         const double S = (double)(t3.tiles < t3.G ? t3.tiles : t3.G) / 8.0;
-        int nb = knob > 0 ? knob : (int)(std::sqrt((S < 1.0 ? 1.0 : S) * patch / wtile) + 0.5);
+        int nb = (int)(std::sqrt((S < 1.0 ? 1.0 : S) * patch / wtile) + 0.5);
         if (nb < 1) nb = 1;
         if (nb > t3.tiles_n) nb = t3.tiles_n;
         p.n_block = nb;
@@ -1387,16 +1273,9 @@ extern "C" int udt_gemm(const udt_gemm_desc* d, void* workspace, size_t workspac
         udt_prof_tag(prof3.rec, tag);
       }
       hipError_t e3;
-      const int variant = (d->in_scsh ? 2 : 0) | (d->colstats ? 1 : 0);
-      if (d->upsample) {
-        e3 = launch3p<4, 2, 2, 2, false, false, true>(cp, t3, s);
-      } else if (t3.bn == 160) {
-        e3 = variant == 3 ? launch3p<8, 1, 1, 5, true, true>(cp, t3, s) : variant == 2 ? launch3p<8, 1, 1, 5, true, false>(cp, t3, s)
-           : variant == 1 ? launch3p<8, 1, 1, 5, false, true>(cp, t3, s) : launch3p<8, 1, 1, 5, false, false>(cp, t3, s);
-      } else {
-        e3 = variant == 3 ? launch3p<4, 2, 2, 2, true, true>(cp, t3, s) : variant == 2 ? launch3p<4, 2, 2, 2, true, false>(cp, t3, s)
-           : variant == 1 ? launch3p<4, 2, 2, 2, false, true>(cp, t3, s) : launch3p<4, 2, 2, 2, false, false>(cp, t3, s);
-      }
+      const bool st3 = d->colstats != nullptr;             // (GroupNorm-on-patch instances only: conv3p_geometry)
+      if (t3.bn == 160) e3 = st3 ? launch3p<8, 1, 1, 5, true, true>(cp, t3, s) : launch3p<8, 1, 1, 5, true, false>(cp, t3, s);
+      else e3 = st3 ? launch3p<4, 2, 2, 2, true, true>(cp, t3, s) : launch3p<4, 2, 2, 2, true, false>(cp, t3, s);
       if (e3 != hipSuccess) return udt_set_hip_error(e3);
       return UDT_OK;
     }
@@ -1484,14 +1363,11 @@ extern "C" int udt_gemm(const udt_gemm_desc* d, void* workspace, size_t workspac
     udt_prof_tag(prof.rec, tag);
   }
 
-  hipError_t e;
-  if (t.bm == 256) {
-    e = conv ? launch_cfg<256, 64, 4, 1, true, false>(p, t, s) : launch_cfg<256, 64, 4, 1, false, false>(p, t, s);
-  } else if (trans) {
-    e = launch_cfg<128, 128, 2, 2, false, true>(p, t, s);
-  } else {
-    e = conv ? launch_cfg<128, 128, 2, 2, true, false>(p, t, s) : launch_cfg<128, 128, 2, 2, false, false>(p, t, s);
-  }
+  // the first-generation 4-wave kernel survives in ONE geometry, 256 x 64 tiles for outputs of <= 64 columns (the UNet's
+  // 4-channel output convolution); its 128 x 128 instances (round 1) are gone: transposed / GEGLU outputs that narrow, or operands
+  // beyond the 31-bit buffer offsets of the newer kernels, are not part of this path
+  if (t.bm != 256) return UDT_ERR_BAD_SHAPE;
+  const hipError_t e = conv ? launch_cfg<256, 64, 4, 1, true, false>(p, t, s) : launch_cfg<256, 64, 4, 1, false, false>(p, t, s);
   if (e != hipSuccess) return udt_set_hip_error(e);
   return UDT_OK;
 }

@@ -720,20 +720,6 @@ UDT_DEVINL void raw_barrier() {
   asm volatile("" ::: "memory");
 }
 
-template <int N>
-UDT_DEVINL void wait_vm() {
-  static_assert(N >= 0 && N <= 63, "vmcnt is a 6-bit immediate");
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
-
-// 16-byte LDS-DMA through a buffer descriptor: uniform base (SGPRs) + per-lane byte offset + scalar byte offset.
-// A per-lane offset >= num_records (OOB) makes the load return zeros — used for rows past M / N and conv padding.
-UDT_DEVINL void buf_lds16(__amdgpu_buffer_rsrc_t rsrc, void* lds_wave_base, unsigned voff, int soff) {
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voff, soff,
-                                           0, 0);
-}
-constexpr unsigned OOB = 0x80000000u;
-
 // WGM x WGN waves, each TM x TN MFMA tiles of 32x32
 // STATS: the row-coalesced epilogues also emit the output's column statistics (udt_gemm_desc.colstats) — a separate
 // kernel, so that the plain one keeps its instruction stream and register allocation

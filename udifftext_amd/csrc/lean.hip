@@ -1,0 +1,85 @@
+// lean.hip — the lean (co-resident, lean.h) and wide (wide.h) MFMA kernel families and their launchers; planned and
+// dispatched by gemm.hip (lean_plan / lean_conv_plan), which hands over filled argument blocks (lean_params.h).
+// A translation unit of its own so that the two halves of the GEMM code compile in parallel.
+#include "common.h"
+#include <stdio.h>
+#include <stdlib.h>
+#include <atomic>
+
+namespace {
+#include "tile_common.h"
+#include "lean_params.h"
+#include "lean.h"
+#include "wide.h"
+
+template <int NW, int WGM, int WGN, int TM, int TN, int NST, int TMB = TM>
+hipError_t launch_lean(const lg::LParams& lp, int smem, int G, bool geglu, bool ln, hipStream_t s) {
+  static AttrOnce once[5];
+  const void* fn;
+  const bool stats = lp.colstats != nullptr;
+  if constexpr (NW == 4 && NST == 2) {                    // (the two kernels with a statistics-emitting epilogue)
+    if (stats) {
+      fn = (const void*)lg::lgemm_kernel<NW, WGM, WGN, TM, TN, NST, false, false, TMB, true>;
+      hipError_t e = once[4].ensure(fn, smem);
+      if (e != hipSuccess) return e;
+      void* args[] = {const_cast<lg::LParams*>(&lp)};
+      return hipLaunchKernel(fn, dim3(G), dim3(NW * 64), args, smem, s);
+    }
+  }
+  if (stats) return hipErrorInvalidValue;
+  if constexpr (TN == 2) {
+    fn = geglu ? (ln ? (const void*)lg::lgemm_kernel<NW, WGM, WGN, TM, TN, NST, true, true, TMB> : (const void*)lg::lgemm_kernel<NW, WGM, WGN, TM, TN, NST, true, false, TMB>)
+               : (ln ? (const void*)lg::lgemm_kernel<NW, WGM, WGN, TM, TN, NST, false, true, TMB> : (const void*)lg::lgemm_kernel<NW, WGM, WGN, TM, TN, NST, false, false, TMB>);
+  } else {
+    fn = ln ? (const void*)lg::lgemm_kernel<NW, WGM, WGN, TM, TN, NST, false, true, TMB> : (const void*)lg::lgemm_kernel<NW, WGM, WGN, TM, TN, NST, false, false, TMB>;
+  }
+  hipError_t e = once[(geglu ? 2 : 0) + (ln ? 1 : 0)].ensure(fn, smem);
+  if (e != hipSuccess) return e;
+  void* args[] = {const_cast<lg::LParams*>(&lp)};
+  return hipLaunchKernel(fn, dim3(G), dim3(NW * 64), args, smem, s);
+}
+
+template <int TW, int TH, bool UPS, bool STATS>
+hipError_t launch_lconv3s(const lg::C3Params& c3, hipStream_t s) {
+  static AttrOnce once;
+  constexpr int smem = lg::C3Geo<TW, TH, UPS>::SMEM;
+  hipError_t e = once.ensure(reinterpret_cast<const void*>(lg::lconv3_kernel<TW, TH, UPS, STATS>), smem);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL((lg::lconv3_kernel<TW, TH, UPS, STATS>), dim3(c3.G), dim3(256), smem, s, c3);
+  return hipGetLastError();
+}
+template <int TW, int TH, bool UPS>
+hipError_t launch_lconv3(const lg::C3Params& c3, hipStream_t s) {
+  return c3.colstats ? launch_lconv3s<TW, TH, UPS, true>(c3, s) : launch_lconv3s<TW, TH, UPS, false>(c3, s);
+}
+
+template <bool STATS>
+hipError_t launch_wconv3s(const lg::C3Params& c3, hipStream_t s) {
+  static AttrOnce once;
+  constexpr int smem = wd::WGeo::SMEM;
+  hipError_t e = once.ensure(reinterpret_cast<const void*>(wd::wconv3_kernel<STATS>), smem);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL((wd::wconv3_kernel<STATS>), dim3(c3.G), dim3(256), smem, s, c3);
+  return hipGetLastError();
+}
+hipError_t launch_wconv3(const lg::C3Params& c3, hipStream_t s) {
+  return c3.colstats ? launch_wconv3s<true>(c3, s) : launch_wconv3s<false>(c3, s);
+}
+
+}  // namespace
+
+hipError_t udt_lean_launch_gemm(int cfg, const void* lparams, int smem, int G, int geglu, int ln, hipStream_t s) {
+  const lg::LParams& lp = *static_cast<const lg::LParams*>(lparams);
+  switch (cfg) {
+    case 1: return launch_lean<4, 2, 2, 2, 2, 2>(lp, smem, G, geglu != 0, ln != 0, s);
+    case 6: return launch_lean<8, 2, 4, 4, 2, 2, 1>(lp, smem, G, geglu != 0, ln != 0, s);
+    case 5: return geglu ? hipErrorInvalidValue : launch_lean<4, 4, 1, 1, 5, 2>(lp, smem, G, false, ln != 0, s);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+hipError_t udt_lean_launch_conv3(const void* c3params, hipStream_t s) {
+  const lg::C3Params& c3 = *static_cast<const lg::C3Params*>(c3params);
+  return c3.geo == 3 ? launch_wconv3(c3, s) : c3.geo == 2 ? launch_lconv3<16, 8, true>(c3, s)
+         : c3.geo == 1 ? launch_lconv3<8, 8, false>(c3, s) : launch_lconv3<16, 8, false>(c3, s);
+}

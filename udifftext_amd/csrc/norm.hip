@@ -424,7 +424,7 @@ int gn_strip_groups(long long HW, int C1, int C2, int G) {
   // Measured on MI355X (B = 4, one launch stream): 64x64x320 strips (320 KiB) 41 us vs 28 us for the stats + apply pair,
   // 32x32x640 (80 KiB) 22 vs 23.5, 16x16x1280 (20 KiB) 12 vs 20.6, 8x8x1280 (5 KiB) 12 vs 20: a strip is walked by ONE
   // workgroup, so only small strips (the launch-latency-bound levels) take this kernel
-  static const long long limit_kb = [] { const char* e = getenv("UDT_GN_STRIP_KB"); return e ? atoll(e) : 64LL; }();
+  constexpr long long limit_kb = 64;
   const long long bytes = HW * cw * 2;
   if (bytes > (limit_kb << 10)) return 0;
   return gw;

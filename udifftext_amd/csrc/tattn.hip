@@ -356,8 +356,8 @@ extern "C" int udt_tattn_fused(const void* x, void* out, const void* A, const fl
   // few token tiles (the 16x16 / 8x8 levels): split the output channels over up to 4 workgroups per tile so that the
   // launch covers >= ~128 CUs; every split recomputes the statistics and scores of its tile (a third of the work)
   // (round 3: up to 8 splits and a full chip of workgroups — the launch is a chain of L2-latency-bound steps, so idle CUs
-  //  are the one thing that is free; UDT_TATTN_SPLIT_WGS overrides the workgroup target for A/B measurements)
-  static const unsigned target = [] { const char* e = getenv("UDT_TATTN_SPLIT_WGS"); return e ? (unsigned)atoi(e) : 256u; }();
+  //  are the one thing that is free)
+  constexpr unsigned target = 256u;
   p.nsplit = 1;
   while (p.nsplit < 8 && grid * p.nsplit < target) p.nsplit *= 2;
   if (TT == 64) {

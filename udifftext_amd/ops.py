@@ -134,7 +134,7 @@ def run_gemm(d: L.GemmDesc, device, fused_gn: bool = False) -> None:
         L.check(lib.udt_gemm(C.byref(d), ws_ptr, ws_bytes, _stream()), "udt_gemm")
 
 
-GN_STRIP = os.environ.get("UDT_GN_STRIP", "1") != "0"       # one-launch strip GroupNorm where the shape allows (A/B switch)
+GN_STRIP = True       # one-launch strip GroupNorm where the shape allows (tests switch it off to compare with the two-kernel path)
 
 
 class GnStats(NamedTuple):
@@ -160,6 +160,13 @@ def _attach_colstats(d: L.GemmDesc, out: torch.Tensor, n_cols: int, rows_per_bat
     d.colstats = st.data_ptr()
     out.gn_stats = GnStats(st, rows_per_batch // rows)
     return True
+
+
+def _drop_stale_stats(out: Optional[torch.Tensor]) -> None:
+    """a caller-provided ``out=`` tensor may still carry the statistics of an earlier launch into it: this launch emits none,
+    so a GroupNorm reading ``out.gn_stats`` afterwards must not find the old ones"""
+    if out is not None and getattr(out, "gn_stats", None) is not None:
+        del out.gn_stats
 
 
 def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, *, out: Optional[torch.Tensor] = None,
@@ -188,8 +195,8 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
                   M=M, N=N, K=K, lda=x2.stride(0), ldo=ldo, ldr=(residual.stride(0) if residual is not None else 0),
                   rows_per_batch=rows_per_batch, ld_rowvec=(rowvec.stride(0) if rowvec is not None else 0), flags=flags,
                   alpha=alpha)
-    if colstats and rows_per_batch > 0 and out.is_contiguous():
-        _attach_colstats(d, out, n_cols, rows_per_batch)
+    if not (colstats and rows_per_batch > 0 and out.is_contiguous() and _attach_colstats(d, out, n_cols, rows_per_batch)):
+        _drop_stale_stats(out)
     run_gemm(d, x.device)
     if WORK_COUNTER is not None:
         count_work("gemm", 2.0 * M * N * K)
@@ -222,7 +229,15 @@ def ln_linear(x: torch.Tensor, w_folded: torch.Tensor, c: torch.Tensor, s: torch
     if need:
         ws = _ws(need, x.device)
         ws_ptr, ws_bytes = ws.data_ptr(), ws.numel()
-    L.check(lib.udt_ln_gemm_fwd(C.byref(d), ws_ptr, ws_bytes, _stream()), "udt_ln_gemm_fwd")
+    rc = lib.udt_ln_gemm_fwd(C.byref(d), ws_ptr, ws_bytes, _stream())
+    if rc in (-1, -2) and x.is_cuda:            # UDT_ERR_BAD_SHAPE / UDT_ERR_BAD_ARG
+        # the LayerNorm-folded form exists on the lean kernels only: a problem their plan declines (lean kernels switched off at
+        # run time through udt_debug_set, unaligned out / residual pointers, > 2 GiB operands) says so loudly instead of
+        # surfacing as a bare status code from inside a transformer block
+        raise L.UdtError(f"udt_ln_gemm_fwd declined M={M} N={N} K={K} flags={flags:#x} (status {rc}): the LayerNorm-folded GEMM "
+                         "needs the lean kernel family (UDT_LEAN / udt_debug_set('lean') != 0) and 16-byte aligned operands; "
+                         "set UDT_LN_GEMM=0 to run layernorm + GEMM instead")
+    L.check(rc, "udt_ln_gemm_fwd")
     if WORK_COUNTER is not None:
         count_work("gemm", 2.0 * M * N * K)
         count_work("gemm_bytes", 2.0 * (M * K + N * K) + out.numel() * out.element_size()
@@ -294,8 +309,8 @@ def conv2d(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
         assert in_scsh.dtype == torch.float32 and in_scsh.is_contiguous() and in_scsh.numel() == B * (C1 + C2) * 2
         d.in_scsh = in_scsh.data_ptr()
         d.in_act = int(in_act)
-    if colstats:
-        _attach_colstats(d, out, N, Ho * Wo)
+    if not (colstats and _attach_colstats(d, out, N, Ho * Wo)):
+        _drop_stale_stats(out)
     if in_scsh is not None:
         run_gemm(d, x.device, fused_gn=True)
     else:

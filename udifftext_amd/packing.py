@@ -93,7 +93,9 @@ def pack_ln_linear(w: torch.Tensor, b, gamma: torch.Tensor, beta: torch.Tensor, 
         wf, bf = wf[perm], bf[perm]
     wp = pack_linear(wf * gamma.float()[None, :])
     s = wp[:, :w.shape[1]].float().sum(dim=1).contiguous()
-    c = (wf @ beta.float() + bf).contiguous()
+    c = pad_bias((wf @ beta.float() + bf).contiguous())          # (padded like W' and s: the kernel reads 4-wide c and s vectors)
+    if c.shape[0] != wp.shape[0]:
+        raise ValueError(f"pack_ln_linear: {w.shape[0]} output rows are not a multiple of the bias padding")
     return wp, c, s
 
 

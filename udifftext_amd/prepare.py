@@ -49,6 +49,16 @@ def prepare(engine, free_masters: bool = False, dedup_vae: bool = True) -> Dict[
         unet = engine.model.diffusion_model
         fused.update(id(rb.emb_layers[1]) for rb in unet._resblocks)
         roots = [m for m in engine.modules() if isinstance(m, H._Packed) and id(m) not in fused]
+        # where the LayerNorm-folded layouts serve the forward pass (BasicTransformerBlock: fold = LN_GEMM and not fp8), the plain
+        # q|k|v and GEGLU layouts of the UNet's blocks are never read: not packed (~270 MB of bf16 for the SD-2 UNet)
+        from sgm.modules.attention import BasicTransformerBlock as _BTB
+        fold_on = H.LN_GEMM and not H.FP8_LINEARS
+        ln_only = set()
+        if fold_on:
+            for m in unet.modules():
+                if isinstance(m, _BTB):
+                    ln_only.update((id(m.attn1), id(m.ff.net[0])))
+            roots = [m for m in roots if id(m) not in ln_only]
         seen = set()
         for m in roots:
             if id(m) in seen:
@@ -84,7 +94,7 @@ def prepare(engine, free_masters: bool = False, dedup_vae: bool = True) -> Dict[
         if free_masters:
             victims = []
             for m in engine.modules():
-                if isinstance(m, H._Packed) and (id(m) in seen or id(m) in fused):
+                if isinstance(m, H._Packed) and (id(m) in seen or id(m) in fused or (id(m) in ln_only and getattr(m, "_pkln_frozen", False))):
                     m._pk_frozen = True
                     victims += list(m.parameters(recurse=False))
                     if hasattr(m, "own_masters"):

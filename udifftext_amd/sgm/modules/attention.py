@@ -23,9 +23,10 @@ from . import hipnn as H
 from .diffusionmodules.util import zero_module
 
 
-# UDT_TATTN_FUSED=0: the text cross-attention branch runs as layernorm -> to_q GEMM -> short-context attention -> to_out GEMM
-# (the reference's op sequence); default: one udt_tattn_fused launch on per-batch folded tables (csrc/tattn.hip)
-TATTN_FUSED = os.environ.get("UDT_TATTN_FUSED", "1") != "0"
+# The text cross-attention branch runs as ONE udt_tattn_fused launch on per-batch folded tables (csrc/tattn.hip); the
+# reference's op sequence (layernorm -> to_q GEMM -> short-context attention -> to_out GEMM) remains for the calls that must
+# return attention probabilities (noise search) and for contexts the tables do not cover (1 token, > 12 tokens).
+TATTN_FUSED = True          # (tests switch it off to compare the two forms)
 
 
 class GEGLU(H._Packed):
@@ -140,8 +141,7 @@ class CrossAttention(H._Packed):
 
 
 # One q|k|v GEMM per self-attention (reference attention.py:193-199 applies three bias-free Linears to the same input) and
-# the flash kernel reads V row-major (udt_attn_rowv_fwd).  UDT_QKV_ONE_GEMM=0: q|k GEMM + transposed-output V GEMM.
-QKV_ONE_GEMM = os.environ.get("UDT_QKV_ONE_GEMM", "1") != "0"
+# the flash kernel reads V row-major (udt_attn_rowv_fwd).  (Round 2's q|k GEMM + transposed-output V GEMM form is gone.)
 
 
 class MemoryEfficientCrossAttention(H._Packed):
@@ -166,15 +166,11 @@ class MemoryEfficientCrossAttention(H._Packed):
         return [self.to_q, self.to_k, self.to_v]
 
     def _pack(self):
-        if QKV_ONE_GEMM:                 # one q|k|v projection; the flash kernel transposes V tiles out of LDS itself
-            return H.fuse_rows(self.to_q.weight, self.to_k.weight, self.to_v.weight), None
-        return H.fuse_rows(self.to_q.weight, self.to_k.weight), packing.pack_linear(self.to_v.weight)
+        # one q|k|v projection; the flash kernel transposes V tiles out of LDS itself
+        return H.fuse_rows(self.to_q.weight, self.to_k.weight, self.to_v.weight), None
 
     def _pack_fp8(self):
-        if QKV_ONE_GEMM:
-            return packing.pack_linear_fp8(torch.cat([self.to_q.weight, self.to_k.weight, self.to_v.weight], 0)), None
-        return (packing.pack_linear_fp8(torch.cat([self.to_q.weight, self.to_k.weight], 0)),
-                packing.pack_linear_fp8(self.to_v.weight))
+        return packing.pack_linear_fp8(torch.cat([self.to_q.weight, self.to_k.weight, self.to_v.weight], 0)), None
 
     def _pack_ln(self, gamma, beta):
         return packing.pack_ln_linear(torch.cat([self.to_q.weight, self.to_k.weight, self.to_v.weight], 0), None, gamma, beta)
@@ -190,27 +186,16 @@ class MemoryEfficientCrossAttention(H._Packed):
         else:
             B, N, C = x.shape
             x2 = x.reshape(B * N, C)
-        if QKV_ONE_GEMM:
-            if fp8:
-                (wqkv, sqkv), _ = self.packed_fp8()
-                qkv = ops.linear_fp8(x, wqkv, sqkv).reshape(B, N, 3 * inner)
-            elif ln is not None:
-                wf, c, sv = self.packed_ln(ln)
-                qkv = ops.ln_linear(x2, wf, c, sv, eps=ln.eps).reshape(B, N, 3 * inner)
-            else:
-                qkv = ops.linear(x2, self.packed()[0]).reshape(B, N, 3 * inner)
-            o = ops.attention_rowv(qkv[..., :inner], qkv[..., inner:2 * inner], qkv[..., 2 * inner:], self.heads,
-                                   self.dim_head ** -0.5)
+        if fp8:
+            (wqkv, sqkv), _ = self.packed_fp8()
+            qkv = ops.linear_fp8(x, wqkv, sqkv).reshape(B, N, 3 * inner)
+        elif ln is not None:
+            wf, c, sv = self.packed_ln(ln)
+            qkv = ops.ln_linear(x2, wf, c, sv, eps=ln.eps).reshape(B, N, 3 * inner)
         else:
-            if fp8:
-                (wqk, sqk), (wv, sv) = self.packed_fp8()
-                qk = ops.linear_fp8(x, wqk, sqk).reshape(B, N, 2 * inner)
-                vt = ops.linear_fp8(x, wv, sv, flags=H.GEMM_TRANSPOSED, rows_per_batch=N)
-            else:
-                wqk, wv = self.packed()
-                qk = ops.linear(x2, wqk).reshape(B, N, 2 * inner)
-                vt = ops.linear(x2, wv, flags=H.GEMM_TRANSPOSED, rows_per_batch=N)       # [B, inner, N]
-            o = ops.attention(qk[..., :inner], qk[..., inner:], vt, self.heads, self.dim_head ** -0.5)
+            qkv = ops.linear(x2, self.packed()[0]).reshape(B, N, 3 * inner)
+        o = ops.attention_rowv(qkv[..., :inner], qkv[..., inner:2 * inner], qkv[..., 2 * inner:], self.heads,
+                               self.dim_head ** -0.5)
         res = residual.reshape(B * N, -1) if residual is not None else None
         return self.to_out[0](o.reshape(B * N, inner), residual=res).reshape(B, N, -1)
 
@@ -238,7 +223,7 @@ class BasicTransformerBlock(nn.Module):
         half of a CFG pair under force_uc_zero_embeddings) — their t_attn branch is x + to_out.bias, no GEMMs.
         t_fused: the block's folded context tables (ops.TattnTables for the samples of x) -> one fused launch."""
         fp8 = H.FP8_LINEARS
-        fold = H.LN_GEMM and not fp8 and QKV_ONE_GEMM          # LayerNorm inside the consuming GEMM (udt_ln_gemm_fwd)
+        fold = H.LN_GEMM and not fp8                            # LayerNorm inside the consuming GEMM (udt_ln_gemm_fwd)
         ln = (lambda norm, t: norm.forward_fp8(t.reshape(-1, t.shape[-1]))) if fp8 else (lambda norm, t: norm(t))
         x = self.attn1(x, residual=x, ln=self.norm1) if fold else self.attn1(ln(self.norm1, x), residual=x)
         if hasattr(self, "t_attn"):

@@ -131,7 +131,7 @@ class MemoryEfficientAttnBlock(H._Packed):
                 s = ops.bmm_nt(qk[:, q0:q1, :C], qk[..., C:], alpha=C ** -0.5)           # [B, q1 - q0, N]
                 ops.softmax_rows_(s)
                 ops.bmm_nt(s, vt, out=o[:, q0:q1])
-        out = ops.linear(o.reshape(B * N, C), wo, bo, residual=x.reshape(B * N, C), rows_per_batch=N, colstats=True)
+        out = ops.linear(o.reshape(B * N, C), wo, bo, residual=x.reshape(B * N, C), rows_per_batch=N, colstats=H.want_stats(B, N, C))
         return H.carry_stats(out.reshape(B, Hh, Ww, C), out)
 
 

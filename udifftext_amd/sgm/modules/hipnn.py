@@ -58,8 +58,7 @@ FP8_LINEARS = os.environ.get("UDT_FP8", "0") != "0"
 # every transformer block (reference attention.py:310-339) run as ONE launch on the raw residual stream — the normalised
 # activation never exists in memory.  UDT_LN_GEMM=0 restores layernorm kernel + GEMM (A/B measurements); the fp8 path
 # keeps its own LayerNorm -> e4m3 kernel.
-LN_GEMM = os.environ.get("UDT_LN_GEMM", "1") != "0" and os.environ.get("UDT_LEAN", "") != "0" \
-    and os.environ.get("UDT_GEMM_IMPL", "") != "4"
+LN_GEMM = os.environ.get("UDT_LN_GEMM", "1") != "0" and os.environ.get("UDT_LEAN", "") != "0"
 
 
 def carry_stats(dst: torch.Tensor, src: torch.Tensor) -> torch.Tensor:
@@ -93,6 +92,10 @@ class _Packed(nn.Module):
 
     def packed(self):
         if getattr(self, "_pk_frozen", False):
+            if not hasattr(self, "_pk"):
+                raise L.UdtError(f"{type(self).__name__}: prepare(free_masters=True) kept only the LayerNorm-folded layout of this "
+                                 "module (UDT_LN_GEMM on) and released the fp32 masters — the plain layout cannot be built any "
+                                 "more; reload the checkpoint into a fresh engine to change the launch path")
             return self._pk
         key = self._key()
         if getattr(self, "_pk_key", None) != key:
