@@ -2,6 +2,7 @@
 
     python tools/ab_step.py zero                      # zero-context shortcut on / off
     python tools/ab_step.py dbg:rows_epi 1 0          # a tuning knob of udt_debug_set
+    python tools/ab_step.py py:sgm.modules.hipnn.GN_FOLD_PROJ_IN 1 0     # a module-level Python switch (values through eval)
     python tools/ab_step.py multi "" no_epi=1 ...     # cost attribution: needs a MEASUREMENT build of the library
                                                       # (UDT_EXTRA_FLAGS=-DUDT_MEASURE python -m udifftext_amd.build --force)
 """
@@ -55,6 +56,12 @@ elif which.startswith("dbg:"):
     from udifftext_amd import lib as L
     vals = [int(v) for v in (sys.argv[2:] or ["1", "0"])]
     variants = {f"{key}={v}": (lambda v=v: L.check(L.load().udt_debug_set(key.encode(), v), "dbg")) for v in vals}
+elif which.startswith("py:"):
+    import importlib
+    modname, attr = which[3:].rsplit(".", 1)
+    mod = importlib.import_module(modname)
+    vals = [eval(v) for v in (sys.argv[2:] or ["True", "False"])]
+    variants = {f"{attr}={v}": (lambda v=v: setattr(mod, attr, v)) for v in vals}
 else:
     raise SystemExit(__doc__)
 for name, fn in variants.items():
