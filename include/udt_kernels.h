@@ -273,15 +273,6 @@ int udt_gn_finalize(const float* stats1, int32_t slots1, int32_t C1, const float
                     const float* gamma, const float* beta, float* scsh, int32_t B, int64_t HW, int32_t G, float eps,
                     void* stream);
 
-/* GroupNorm WITHOUT activation in front of a linear layer, folded into per-sample weights — SpatialTransformer's `norm` ->
- * `proj_in` (reference sgm/modules/attention.py:404-407):  (x o scale_b + shift_b) W^T + bias = x (W o scale_b)^T + (bias + W shift_b).
- *   scsh from udt_gn_finalize (fp32 [B][K/64][2][64]); w bf16 [N, ldw] (K % 64 == 0, columns K..ldw zero); bias fp32 [N] or NULL.
- *   w_out bf16 [B][N][ldw], bias_out fp32 [B][N].  The consumer is udt_gemm with batch = B, stride_w = N * ldw, the raw rows
- *   of sample b as its batch element b and bias_out as `rowvec` (rows_per_batch = rows of a sample): the normalised activation
- *   never exists in memory.  Worth it where the weight matrix is small against the activation (the 64x64 / 32x32 levels). */
-int udt_gn_fold_linear(const float* scsh, const void* w, const float* bias, void* w_out, float* bias_out, int32_t B, int32_t N,
-                       int32_t K, int32_t ldw, void* stream);
-
 /* GroupNorm (+ SiLU) from a finished scale / shift table: y = act(x * scale[b, c] + shift[b, c]) with `scsh` as written by
  * udt_gn_finalize from the column statistics the PRODUCERS of x (and x2) emitted in their epilogues (udt_gemm_desc.colstats) —
  * the statistics pass over the tensor is gone, this is the one remaining read + write of reference GroupNorm32 -> SiLU

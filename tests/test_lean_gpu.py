@@ -454,40 +454,3 @@ def test_strip_groupnorm_from_epilogue_statistics(env, cuda, B, H, C, N):
     torch.cuda.synchronize()
     assert _rel(got, want) < 6e-3
     assert (got.float() - two.float()).abs().max().item() <= 4e-2
-
-
-@pytest.mark.parametrize("B,HW,C,N", [(8, 4096, 320, 320), (4, 1024, 640, 640), (2, 2304, 640, 640), (3, 256, 128, 192)])
-def test_groupnorm_folded_into_per_sample_linear(env, cuda, B, HW, C, N):
-    """SpatialTransformer's norm -> proj_in without the normalised tensor (reference attention.py:404-407): epilogue statistics ->
-    udt_gn_finalize -> udt_gn_fold_linear (W_b = W o scale_b, bias_b = bias + W shift_b) -> ONE flat lean GEMM on the RAW rows
-    with per-sample weights, against torch GroupNorm(32) -> Linear in fp32 and against the unfused kernels"""
-    g = torch.Generator(device="cpu").manual_seed(31)
-    # per-sample and per-channel offsets / gains: the statistics really differ between samples and groups
-    x = (torch.randn((B, HW, C), generator=g) * (0.5 + torch.rand((B, 1, C), generator=g)) + torch.randn((B, 1, C), generator=g)).to(cuda).bfloat16()
-    w = (torch.randn((N, C), generator=g) / math.sqrt(C)).to(cuda) * (1.0 + torch.arange(N, device=cuda)[:, None] / N)
-    b = torch.randn((N,), generator=g).to(cuda)
-    gamma = (1 + 0.2 * torch.randn((C,), generator=g)).to(cuda)
-    beta = (0.2 * torch.randn((C,), generator=g)).to(cuda)
-    # producer statistics: a 1x1 "identity-like" producer is not needed — emit them with the two-kernel statistics of the ops layer
-    wp, bp = env.packing.pack_linear(w), env.packing.pad_bias(b)
-    want = F.linear(F.group_norm(x.float().permute(0, 2, 1), 32, gamma, beta, 1e-6).permute(0, 2, 1), wp[:, :C].float(), b)
-    # statistics the way a producer emits them: [slots, C, 2] sums over 64-row blocks
-    rows = 64
-    xs = x.float().reshape(B * HW // rows, rows, C)
-    st = env.ops.GnStats(torch.stack([xs.sum(1), (xs * xs).sum(1)], dim=-1).contiguous(), HW // rows)
-    scsh = env.ops.gn_finalize(st, C, None, 0, gamma, beta, B, HW, 32, 1e-6)
-    wb, bb = env.ops.gn_fold_linear(scsh, wp, bp)
-    got = env.ops.linear_per_sample(x, wb, bb, n_out=wp.shape[0])
-    two = env.ops.linear(env.ops.group_norm(x, gamma, beta, 32, 1e-6, False).reshape(B * HW, C), wp, bp).reshape(B, HW, -1)
-    torch.cuda.synchronize()
-    assert got.shape == (B, HW, wp.shape[0])
-    e = _rel(got[..., :N], want)
-    assert math.isfinite(e) and e < 8e-3, f"GroupNorm folded into the linear vs torch: rel rms {e:.3e}"
-    assert _rel(got, two) < 1e-2
-    # the folded weights themselves: W o scale per sample, bias + W shift
-    scale = scsh[:, :, 0, :].reshape(B, C)
-    shift = scsh[:, :, 1, :].reshape(B, C)
-    ref_w = (wp[:, :C].float()[None] * scale[:, None, :]).bfloat16()
-    assert torch.equal(wb[:, :, :C], ref_w)
-    ref_b = bp[None, :] + torch.einsum("nk,bk->bn", wp[:, :C].float(), shift)
-    assert (bb - ref_b).abs().max().item() <= 1e-4 * ref_b.abs().max().item() + 1e-4

@@ -1167,36 +1167,11 @@ extern "C" int udt_gemm(const udt_gemm_desc* d, void* workspace, size_t workspac
   p.n_block = 1;
   p.alpha = d->alpha;
   const int cls = (conv && d->ksize == 3) ? 0 : 1;
-  // A batched GEMM whose activations and outputs are ONE contiguous row block per batch element (stride_a = M lda, stride_out =
-  // M ldo) is a flat GEMM over batch * M rows with per-sample WEIGHTS (stride_w): the form the GroupNorm-folded proj_in takes
-  // (udt_gn_fold_linear; reference attention.py:404-407 `norm` -> `proj_in`).  The lean kernels take it when a tile never
-  // straddles two samples.
-  udt_gemm_desc dflat;
-  long long w_bstride = 0;
-  if (batch > 1 && !conv && !trans && !fp8 && !d->colstats && d->stride_a == (long long)d->M * d->lda && d->stride_out == (long long)d->M * d->ldo &&
-      (!d->residual || d->stride_res == (long long)d->M * d->ldr) && d->M % 256 == 0 && (long long)batch * d->M < (1LL << 31) &&
-      (!d->rowvec || d->rows_per_batch == d->M)) {
-    dflat = *d;
-    dflat.M = batch * d->M;
-    dflat.batch = 1;
-    dflat.rows_per_batch = d->M;
-    w_bstride = d->stride_w;
-    LeanPlan probe;
-    if (lean_plan(&dflat, probe, false) && probe.splitk == 1) {
-      d = &dflat;
-      p.M = dflat.M;
-      p.rows_per_batch = dflat.rows_per_batch;
-    } else {
-      w_bstride = 0;
-    }
-  }
-  if (batch > 1 && d->rowvec && w_bstride == 0) return UDT_ERR_BAD_SHAPE;   // (a per-sample row vector exists for the flat form only)
   {
     LeanPlan lt;
     if (lean_plan(d, lt, d->colstats != nullptr)) {
       lg::LParams lp;
       lp.colstats = d->colstats;
-      lp.w_bstride = w_bstride;
       const bool conv1 = (d->flags & UDT_GEMM_CONV) != 0;
       lp.a = p.a; lp.a2 = (conv1 && d->C2 > 0) ? p.a2 : nullptr; lp.w = p.w; lp.bias = p.bias; lp.res = p.res; lp.rowvec = p.rowvec;
       lp.ln_s = d->ln_colsum;

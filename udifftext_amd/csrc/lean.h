@@ -135,10 +135,7 @@ __global__ void __launch_bounds__(NW * 64, 2) lgemm_kernel(const LParams p) {
   if (kt1 > p.nkt) kt1 = p.nkt;
 
   const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.a), 0, p.a_bytes, 0x00020000);
-  // per-sample weights (GroupNorm folded into the following linear: W_b = W o scale_b, udt_gn_fold_linear): the tile's rows all
-  // belong to one sample (the host checks BM | rows_per_batch)
-  const uint16_t* const wbase = p.w_bstride ? p.w + (long long)(m0 / p.rows_per_batch) * p.w_bstride : p.w;
-  const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(wbase), 0, p.w_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.w), 0, p.w_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsrc_a2 =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.a2 ? p.a2 : p.a), 0, p.a2 ? p.a2_bytes : 0u, 0x00020000);
   unsigned a_voff[A_INSTR], a2_voff[A_INSTR], w_voff[B_INSTR];

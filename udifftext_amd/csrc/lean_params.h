@@ -26,8 +26,6 @@ struct LParams {
   int* counters;           // split-K: [tiles] arrival tickets, zero between launches
   float* slabs;            // split-K: [tiles * splitk][BM * BN] fp32
   float* colstats;         // STATS kernels: fp32 [row slots][N][2] (sum, sum of squares) of the stored values, one slot per wave row block
-  long long w_bstride;     // per-sample weights (elements between the [N, ldw] matrices of consecutive samples; a tile's rows belong
-                           // to sample m0 / rows_per_batch), 0 = one weight matrix
 };
 
 struct C3Params {

@@ -604,66 +604,7 @@ __global__ void __launch_bounds__(256) gn_finalize_kernel(const float* __restric
   }
 }
 
-// GroupNorm (no activation) in front of a linear layer, folded into the layer's weights per sample:
-//   (x o scale_b + shift_b) W^T + bias = x (W o scale_b)^T + (bias + W shift_b)
-// one workgroup = 8 weight rows of one sample; 32 lanes per row walk K in 16-byte steps, the bias term is a row dot product
-__global__ void __launch_bounds__(256) gn_fold_linear_kernel(const float* __restrict__ scsh, const uint16_t* __restrict__ w,
-                                                             const float* __restrict__ bias, uint16_t* __restrict__ wb,
-                                                             float* __restrict__ biasb, int N, int K, int ldw) {
-  const int b = blockIdx.y;
-  const int row = blockIdx.x * 8 + (threadIdx.x >> 5);
-  const int l = threadIdx.x & 31;
-  const float* sc = scsh + (long long)b * (K / 64) * 128;
-  float dot = 0.f;
-  if (row < N) {
-    const uint16_t* wr = w + (long long)row * ldw;
-    uint16_t* wo = wb + ((long long)b * N + row) * ldw;
-    for (int k = l * 8; k < ldw; k += 256) {
-      const u32x4 v = *reinterpret_cast<const u32x4*>(wr + k);
-      u32x4 o = {0u, 0u, 0u, 0u};
-      if (k < K) {
-        const float* scp = sc + (k >> 6) * 128 + (k & 63);
-        const f32x4 s0 = *reinterpret_cast<const f32x4*>(scp), s1 = *reinterpret_cast<const f32x4*>(scp + 4);
-        const f32x4 h0 = *reinterpret_cast<const f32x4*>(scp + 64), h1 = *reinterpret_cast<const f32x4*>(scp + 68);
-        float e[8];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { e[2 * j] = bf16_lo(v[j]); e[2 * j + 1] = bf16_hi(v[j]); }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          dot += e[j] * h0[j] + e[4 + j] * h1[j];
-          e[j] *= s0[j];
-          e[4 + j] *= s1[j];
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) o[j] = pack_bf16x2(e[2 * j], e[2 * j + 1]);
-      }
-      *reinterpret_cast<u32x4*>(wo + k) = o;
-    }
-  }
-  dot = row16_sum(dot);
-  dot = xor16_sum(dot);                                   // the 32 lanes of a row are lanes 0..31 or 32..63 of a wave
-  if (l == 0 && row < N) biasb[(long long)b * N + row] = dot + (bias ? bias[row] : 0.f);
-}
-
 }  // namespace
-
-extern "C" int udt_gn_fold_linear(const float* scsh, const void* w, const float* bias, void* w_out, float* bias_out, int32_t B,
-                                  int32_t N, int32_t K, int32_t ldw, void* stream) {
-  if (!scsh || !w || !w_out || !bias_out) return UDT_ERR_BAD_ARG;
-  if (B <= 0 || N <= 0 || K <= 0 || K % 64 != 0 || ldw < K || ldw % 8 != 0 || B > 65535) return UDT_ERR_BAD_SHAPE;
-  if ((reinterpret_cast<uintptr_t>(w) | reinterpret_cast<uintptr_t>(w_out) | reinterpret_cast<uintptr_t>(scsh)) & 15) return UDT_ERR_BAD_SHAPE;
-  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  UdtProfScope prof(4, s);
-  if (prof.rec) {
-    char tag[96];
-    snprintf(tag, sizeof(tag), "gn_fold_linear B=%d N=%d K=%d", B, N, K);
-    udt_prof_tag(prof.rec, tag);
-  }
-  hipLaunchKernelGGL(gn_fold_linear_kernel, dim3((N + 7) / 8, B), dim3(256), 0, s, scsh, reinterpret_cast<const uint16_t*>(w), bias,
-                     reinterpret_cast<uint16_t*>(w_out), bias_out, N, K, ldw);
-  UDT_CHECK_LAUNCH();
-  return UDT_OK;
-}
 
 extern "C" int udt_gn_finalize(const float* stats1, int32_t slots1, int32_t C1, const float* stats2, int32_t slots2,
                                int32_t C2, const float* gamma, const float* beta, float* scsh, int32_t B, int64_t HW,

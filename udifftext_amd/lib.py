@@ -63,7 +63,6 @@ SYMBOLS = {
     "udt_gn_silu_conv3x3_fwd": (C.c_int, [C.POINTER(GemmDesc), _vp, C.c_size_t, _vp]),
     "udt_ln_gemm_fwd": (C.c_int, [C.POINTER(GemmDesc), _vp, C.c_size_t, _vp]),
     "udt_gn_finalize": (C.c_int, [_fp, _i32, _i32, _fp, _i32, _i32, _fp, _fp, _fp, _i32, _i64, _i32, _f32, _vp]),
-    "udt_gn_fold_linear": (C.c_int, [_fp, _vp, _fp, _vp, _fp, _i32, _i32, _i32, _i32, _vp]),
     "udt_gn_apply_scsh": (C.c_int, [_vp, _vp, _vp, _fp, _i32, _i64, _i32, _i32, _i32, _vp]),
     "udt_gn_strip_stats": (C.c_int, [_vp, _vp, _vp, _fp, _i32, _fp, _i32, _fp, _fp, _i32, _i64, _i32, _i32, _i32, _f32, _i32, _vp]),
     "udt_attn_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32,

@@ -520,44 +520,6 @@ def gn_finalize(st1: GnStats, C1: int, st2: Optional[GnStats], C2: int, gamma: t
     return scsh
 
 
-def gn_fold_linear(scsh: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor]):
-    """GroupNorm (no activation) folded into the following linear layer, per sample (udt_gn_fold_linear):
-    scsh [B, K/64, 2, 64] from gn_finalize, w packed bf16 [N, Kpad], bias fp32 [N] -> (w_b bf16 [B, N, Kpad], bias_b fp32 [B, N])"""
-    _bf16(w)
-    assert w.is_contiguous() and scsh.is_contiguous() and scsh.dtype == torch.float32
-    B, K = scsh.shape[0], scsh.shape[1] * 64
-    N, ldw = w.shape
-    wb = torch.empty((B, N, ldw), dtype=torch.bfloat16, device=w.device)
-    bb = torch.empty((B, N), dtype=torch.float32, device=w.device)
-    L.check(L.load().udt_gn_fold_linear(_ptr(scsh), _ptr(w), _ptr(bias), _ptr(wb), _ptr(bb), B, N, K, ldw, _stream()),
-            "udt_gn_fold_linear")
-    return wb, bb
-
-
-def linear_per_sample(x: torch.Tensor, wb: torch.Tensor, bias_b: torch.Tensor, *, n_out: Optional[int] = None,
-                      out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """out[b] = x[b] @ wb[b]^T + bias_b[b]: x bf16 [B, M, K] contiguous, wb bf16 [B, N, Kpad] (gn_fold_linear), bias_b fp32 [B, N].
-    One launch: a batched udt_gemm whose row blocks are contiguous — the lean kernels run it as a flat GEMM with per-sample
-    weights, bias_b rides in as the per-sample row vector."""
-    _bf16(x); _bf16(wb)
-    assert x.dim() == 3 and x.is_contiguous() and wb.is_contiguous() and bias_b.is_contiguous()
-    B, M, K = x.shape
-    N = wb.shape[1] if n_out is None else n_out
-    assert wb.shape[0] == B and wb.shape[2] >= K and bias_b.shape[0] == B
-    if out is None:
-        out = torch.empty((B, M, N), dtype=torch.bfloat16, device=x.device)
-    d = gemm_desc(a=_ptr(x), w=_ptr(wb), rowvec=_ptr(bias_b), out=_ptr(out), M=M, N=N, K=K, lda=K, ldw=wb.shape[2], ldo=out.stride(1),
-                  batch=B, stride_a=M * K, stride_w=wb.shape[1] * wb.shape[2], stride_out=out.stride(0), rows_per_batch=M,
-                  ld_rowvec=bias_b.stride(0))
-    _drop_stale_stats(out)
-    run_gemm(d, x.device)
-    if WORK_COUNTER is not None:
-        count_work("gemm", 2.0 * B * M * N * K)
-        count_work("gemm_bytes", 2.0 * B * (M * K + N * K + M * N))
-        count_work("gemm_launches", 1.0)
-    return out
-
-
 def gn_strip_ok(B: int, HW: int, C1: int, C2: int, groups: int) -> bool:
     """would group_norm run this shape as ONE strip launch (statistics + apply)?"""
     return bool(GN_STRIP and L.load().udt_gn_strip_ok(B, HW, C1, C2, groups))

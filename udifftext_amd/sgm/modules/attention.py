@@ -286,17 +286,7 @@ class SpatialTransformer(nn.Module):
         """x: bf16 NHWC [B, H, W, C]"""
         B, Hh, Ww, C = x.shape
         N = Hh * Ww
-        st = ops.gn_stats_of(x) if (H.GN_EPI and H.GN_FOLD_PROJ_IN and H.LN_GEMM) else None
-        if st is not None and C % 64 == 0 and N % 256 == 0 and C <= N and self.proj_in.bias is not None:
-            # GroupNorm folded into per-sample proj_in weights: statistics from the producer's epilogue -> scale / shift table ->
-            # W_b = W o scale_b, bias_b = bias + W shift_b -> ONE GEMM on the raw rows (hipnn.GN_FOLD_PROJ_IN)
-            scsh = ops.gn_finalize(st, C, None, 0, self.norm.weight, self.norm.bias, B, N, self.norm.num_groups, self.norm.eps)
-            w, b = self.proj_in.packed()
-            wb, bb = ops.gn_fold_linear(scsh, w, b)
-            t = ops.linear_per_sample(x.reshape(B, N, C), wb, bb, n_out=w.shape[0])
-            H.count_flops("gn_folded_into_proj_in", 1)
-        else:
-            t = self.proj_in(self.norm(x).reshape(B * N, C)).reshape(B, N, -1)
+        t = self.proj_in(self.norm(x).reshape(B * N, C)).reshape(B, N, -1)
         for i, blk in enumerate(self.transformer_blocks):
             t = blk(t, t_context=t_context, t_kv=(t_kv[i] if t_kv is not None else None), emit_map=emit_map,
                     zero_ctx_rows=zero_ctx_rows, t_fused=(t_fused[i] if t_fused is not None else None))

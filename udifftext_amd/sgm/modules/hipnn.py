@@ -61,13 +61,6 @@ FP8_LINEARS = os.environ.get("UDT_FP8", "0") != "0"
 LN_GEMM = os.environ.get("UDT_LN_GEMM", "1") != "0" and os.environ.get("UDT_LEAN", "") != "0"
 
 
-# GroupNorm -> Linear without the normalised tensor: where a GroupNorm without activation feeds a linear layer (SpatialTransformer's
-# `norm` -> `proj_in`, reference attention.py:404-407) and the weight matrix is small against the activation (64x64 / 32x32 levels),
-# the per-(sample, channel) scale / shift is folded into per-sample weights (udt_gn_fold_linear) and the GEMM reads the RAW rows:
-# the udt_gn_apply_scsh pass (one read + one write of the activation) is gone.  (tests switch it off to compare the two forms)
-GN_FOLD_PROJ_IN = True
-
-
 def carry_stats(dst: torch.Tensor, src: torch.Tensor) -> torch.Tensor:
     """a reshape / view makes a new tensor object: hand the producer's column statistics over"""
     st = ops.gn_stats_of(src)
