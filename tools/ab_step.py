@@ -64,9 +64,36 @@ elif which.startswith("py:"):
     variants = {f"{attr}={v}": (lambda v=v: setattr(mod, attr, v)) for v in vals}
 else:
     raise SystemExit(__doc__)
-for name, fn in variants.items():
-    fn(); run(3)
-for rnd in range(4):
+if os.environ.get("AB_EAGER"):
+    # eager launches: host-bound (~25 us of Python / ctypes per launch) — only differences in LAUNCH COUNT show
     for name, fn in variants.items():
-        fn()
-        print(f"round {rnd} {name:14s} {run(10):.3f} ms/step", flush=True)
+        fn(); run(3)
+    for rnd in range(4):
+        for name, fn in variants.items():
+            fn()
+            print(f"round {rnd} {name:14s} {run(10):.3f} ms/step (eager)", flush=True)
+    raise SystemExit(0)
+# default: every variant captures ten sampler steps into hipGraphs (as the sampler runs them); rounds replay them alternately
+import sgm.modules.diffusionmodules.sampling as S
+runners = {}
+for name, fn in variants.items():
+    fn()
+    gs = S._GraphedSteps(model, c, uc, B, (size // 8, size // 8), 5.0, sig)
+    gs.x.copy_(x)
+    for i in range(5, 15):
+        gs._capture(i)
+    runners[name] = gs
+def replay(gs):
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    with torch.cuda.stream(gs.capture_stream):
+        gs.graphs[5].replay()
+        e0.record()
+        for i in range(5, 15):
+            gs.graphs[i].replay()
+        e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / 10
+for rnd in range(5):
+    for name, gs in runners.items():
+        print(f"round {rnd} {name:28s} {replay(gs):.3f} ms/step (graph replay, uc / c halves on two streams)", flush=True)
