@@ -14,7 +14,7 @@ from udifftext_amd import pipeline, synth
 from sgm.modules.diffusionmodules.sampling import _Stepper
 dev = torch.device("cuda", 0)
 torch.set_grad_enabled(False)
-B, size = 4, 512
+B, size = int(os.environ.get("AB_B", "4")), int(os.environ.get("AB_SIZE", "512"))     # (AB_B=1: the reference-default batch)
 model = pipeline.build_engine(dev)
 sampler = pipeline.init_sampling(50, 5.0, dev)
 b = synth.synthetic_batch(B, size, size, 9, seed=0)

@@ -1,4 +1,5 @@
-"""one convolution / GEMM shape launched N times (for rocprofv3 --pmc passes): python tools/pmc_one_conv.py conv B H C N [up] | gemm M N K [geglu]"""
+"""one convolution / GEMM / self-attention shape launched 20 times (for rocprofv3 --pmc passes):
+python tools/pmc_one_conv.py conv B H C N [up] | gemm M N K [geglu] | attn B heads N"""
 import math, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -14,6 +15,12 @@ if kind == "conv":
     b = torch.zeros((N,), device=dev)
     for _ in range(20):
         ops.conv2d(x, w, b, upsample=up)
+elif kind == "attn":
+    B, Hh, N = [int(v) for v in sys.argv[2:5]]
+    qkv = torch.randn((B, N, 3 * Hh * 64), device=dev).bfloat16()
+    Cc = Hh * 64
+    for _ in range(20):
+        ops.attention_rowv(qkv[..., :Cc], qkv[..., Cc:2 * Cc], qkv[..., 2 * Cc:], Hh, 0.125)
 else:
     M, N, K = [int(v) for v in sys.argv[2:5]]
     g = len(sys.argv) > 5 and sys.argv[5] == "1"
