@@ -81,14 +81,15 @@ def parse():
 
 
 def measured_traffic():
-    """HBM bytes per launch of c3p::conv3p_kernel (the dominant kernel) over one batch of this workload, from the
-    committed rocprofv3 PMC passes (profiles/rNN_traffic.json, newest round; tools/collect_profiles.sh +
+    """HBM bytes per launch of the patch-staged 3x3 convolution kernels (wd::wconv3_kernel + lg::lconv3_kernel: the dominant
+    kernels) over one batch of this workload, from the committed rocprofv3 PMC passes (profiles/rNN_traffic.json, newest round; tools/collect_profiles.sh +
     tools/pmc_extrapolate.py: FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, separate passes).  Counter collection
     cannot run inside the timed region, hence the file; None if absent."""
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")), reverse=True):
         try:
             d = json.load(open(path))
-            return float((d.get("conv3") or d["conv3p"])["hbm_bytes_per_launch"]), os.path.basename(path)
+            src = os.path.basename(path) + (" @ " + str(d["head"]) if d.get("head") else "")      # the commit it was collected at
+            return float((d.get("conv3") or d["conv3p"])["hbm_bytes_per_launch"]), src
         except Exception:
             continue
     return None, None
@@ -427,13 +428,14 @@ def main():
                     "share_of_mfma_class_time": ms / max(conv_ms + gemm_ms + attn_ms, 1e-9)}
 
         import sgm.modules.hipnn as Hn
-        conv = cls("3x3 convolution: lg::lconv3_kernel (lean co-resident, LDS-staged patches) / c3p::conv3p_kernel (" + ("GroupNorm+SiLU "
-                   "on the staged patch" if Hn.FUSE_GN else "remaining geometries") + ") + g8::gemm8_kernel<CONV> (stride-2 gathers), UNet + VAE",
+        conv = cls("3x3 convolution: wd::wconv3_kernel (256 px x 160 ch per workgroup, one per CU) + lg::lconv3_kernel (lean co-resident), both "
+                   "LDS-staged patches" + (" / c3p::conv3p_kernel (GroupNorm+SiLU on the staged patch)" if Hn.FUSE_GN else "") +
+                   " + g8::gemm8_kernel<CONV> (stride-2 gathers), UNet + VAE",
                    conv_flops, conv_bytes, conv_ms, conv_launches)
         conv.update({"traffic": traffic, "traffic_source": traffic_file,
                      "traffic_hbm_gbps": (traffic / (conv["avg_launch_us"] * 1e-6) / 1e9) if traffic else None,
                      "traffic_frac_of_hbm_peak": (traffic / (conv["avg_launch_us"] * 1e-6) / PEAK_HBM) if traffic else None,
-                     "traffic_scope": "patch-staged 3x3 launches (lg::lconv3_kernel + c3p::conv3p_kernel: %d of the %d launches of the class): algorithmic "
+                     "traffic_scope": "patch-staged 3x3 launches (wd::wconv3_kernel + lg::lconv3_kernel: %d of the %d launches of the class): algorithmic "
                                       "%.1f MB per launch" % (int(c3p_launches), conv_launches, c3p_bytes / max(c3p_launches, 1) / 1e6),
                      "measured_on": "one eager single-stream pass of one local batch right after the timed region: HIP "
                                     "events around every launch, each kernel alone on the chip (the timed region replays "

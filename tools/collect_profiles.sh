@@ -1,18 +1,29 @@
 #!/bin/bash
-# run on the GPU box: bench line + rocprofv3 kernel stats (timed regime and single-stream regime) + PMC traffic + MFMA util
-# usage: tools/collect_profiles.sh [round-tag]   -> gpurun_out/<tag>/ (copy what should be judged into profiles/)
+# run on the GPU box: bench line + rocprofv3 kernel stats (timed regime and single-stream regime) + PMC traffic + MFMA util + the
+# per-round yardsticks.   usage: tools/collect_profiles.sh <round-tag> <git HEAD sha>   -> gpurun_out/<tag>/
+# Every file it writes names the commit it was measured at (first line "# HEAD <sha>" for text / csv, a "head" field for json):
+# the box has no .git, so the caller passes `git rev-parse HEAD` (copy what should be judged into profiles/ afterwards).
 R=$GRAFT_REPO_ROOT; [ -z "$R" ] && R=/root/repo
-TAG=${1:-r03}
+TAG=${1:-r04}
+export UDT_HEAD=${2:-unknown}
 O=$R/gpurun_out/$TAG; mkdir -p $O
+stamp() { for f in "$@"; do [ -f "$f" ] && sed -i "1i # HEAD $UDT_HEAD" "$f"; done; }
+jstamp() { for f in "$@"; do [ -s "$f" ] && python - "$f" <<PY
+import json, sys
+p = sys.argv[1]
+d = json.load(open(p)); d["head"] = "$UDT_HEAD"; json.dump(d, open(p, "w"))
+PY
+done; }
 cd /tmp && export TMPDIR=/tmp
 # 1. the bench line (default flags = what the driver runs)
-(cd $R && python bench.py 2>$O/bench.err | tail -1 > $O/bench.json)
-# 2. kernel trace + stats of the bench command (hipGraph replay, 2 batches in flight)
-rm -rf /tmp/rpA; rocprofv3 --kernel-trace --stats -d /tmp/rpA -o t -- python $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-mode-table 2>/dev/null | tail -1 > $O/bench_under_rocprof_inflight.json
+(cd $R && python bench.py 2>$O/bench.err | tail -1 > $O/bench.json); jstamp $O/bench.json
+# 2. kernel trace + stats of the bench command (hipGraph replay, three batches in flight)
+rm -rf /tmp/rpA; rocprofv3 --kernel-trace --stats -d /tmp/rpA -o t -- python $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-mode-table --no-reference-default 2>/dev/null | tail -1 > $O/bench_under_rocprof_inflight.json
 python $R/tools/rocpd_summary.py $(find /tmp/rpA -name "*.db" | head -1) > $O/kernel_stats_inflight.csv
 # 3. the regime the roofline events are taken in: eager launches, one stream, one batch at a time
-rm -rf /tmp/rpB; UDT_GRAPHS=0 UDT_DUAL_STREAM=0 rocprofv3 --kernel-trace --stats -d /tmp/rpB -o t -- python $R/bench.py --steps 1 --warmup 1 --in-flight 1 --fuse 1 --no-cpu-baseline --no-mode-table 2>/dev/null | tail -1 > $O/bench_under_rocprof_single.json
+rm -rf /tmp/rpB; UDT_GRAPHS=0 UDT_DUAL_STREAM=0 rocprofv3 --kernel-trace --stats -d /tmp/rpB -o t -- python $R/bench.py --steps 1 --warmup 1 --in-flight 1 --fuse 1 --no-cpu-baseline --no-mode-table --no-reference-default 2>/dev/null | tail -1 > $O/bench_under_rocprof_single.json
 python $R/tools/rocpd_summary.py $(find /tmp/rpB -name "*.db" | head -1) > $O/kernel_stats_single_stream.csv
+jstamp $O/bench_under_rocprof_inflight.json $O/bench_under_rocprof_single.json; stamp $O/kernel_stats_inflight.csv $O/kernel_stats_single_stream.csv
 # 4. HBM traffic of the 3x3-conv kernels: PMC passes (no tracing domains) over one batch of the bench workload.
 #    rocprofv3's counter collection dies after ~6000 dispatches on this image, so a 2-step and a 10-step batch are
 #    profiled and extrapolated to 50 steps (tools/pmc_extrapolate.py)
@@ -26,22 +37,18 @@ rm -rf /tmp/pmc_mfma
 UDT_GRAPHS=0 UDT_DUAL_STREAM=0 timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d /tmp/pmc_mfma -o p -- python $R/tools/predict_once.py 4 > /dev/null 2>&1
 python $R/tools/pmc_mfma.py /tmp/pmc_mfma/p_counter_collection.csv > $O/mfma_util.json
 # 6. config #4 (768x768, batch 8, 12 characters) and the fp8-linears mode (config #5's arithmetic on one GPU)
-(cd $R && python bench.py --size 768 --batch 8 --chars 12 --steps 3 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_config4_768.json)
-(cd $R && python bench.py --fp8 --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_fp8.json)
-# 7. launch-mode sweeps on this box: batches in flight, and one convolution / GEMM planned for 1/s of the CUs
-(cd $R && for n in 1 2 3 4 5 6; do python bench.py --in-flight $n --steps 12 --warmup 3 --no-cpu-baseline --no-mode-table 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('in_flight $n: %.3f images/s, %.1f ms per batch of 4' % (d['value'], d['ms_per_step']))"; done > $O/in_flight_sweep.txt)
-(cd $R && python tools/bench_cu_share.py 2>/dev/null > $O/cu_share_sweep.txt)
-(cd $R && python tools/probes/stream_queues.py 12 2>/dev/null > $O/stream_queue_probe.txt)
+(cd $R && python bench.py --size 768 --batch 8 --chars 12 --steps 3 --warmup 1 --no-cpu-baseline --no-reference-default 2>/dev/null | tail -1 > $O/bench_config4_768.json)
+(cd $R && python bench.py --fp8 --no-cpu-baseline --no-reference-default 2>/dev/null | tail -1 > $O/bench_fp8.json)
+jstamp $O/bench_config4_768.json $O/bench_fp8.json
+# 7. launch-mode sweep on this box: batches in flight
+(cd $R && for n in 1 2 3 4 5 6; do python bench.py --in-flight $n --steps 12 --warmup 3 --no-cpu-baseline --no-mode-table --no-reference-default 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('in_flight $n: %.3f images/s, %.1f ms per batch of 4' % (d['value'], d['ms_per_step']))"; done > $O/in_flight_sweep.txt)
 (cd $R && python tools/phase_times.py 2>/dev/null | grep -E "alone|predict_many|sampling only" > $O/phase_times.txt)
-# 8. round 3: GEMM shapes (lean family vs the 8-wave kernels), lean convolution vs conv3p (independent / dependent chains), trace of one step
+# 8. per-shape tables: GEMM shapes (lean family vs the 8-wave kernels), wide vs lean convolution, trace of one step, op micro-benchmarks
 (cd $R && python tools/bench_gemm_shapes.py lean=0 lean=-1 2>/dev/null > $O/gemm_shapes.txt)
-(cd $R && python tools/check_lean_conv.py 2>/dev/null > $O/lean_conv.txt)
+(cd $R && python tools/bench_wide_conv.py 2>/dev/null > $O/wide_conv.txt)
 (cd $R && UDT_DUAL_STREAM=0 python tools/trace_step.py 2>/dev/null > $O/trace_step.txt)
 (cd $R && python tools/bench_ops.py 2>/dev/null > $O/bench_ops.txt)
-# 9. yardsticks added in round 3: the same shapes on the vendor libraries, the VAE's head_dim-512 attention, the statistics epilogues,
-#    the reference-default workload (batch 1, noise_iters 10)
-(cd $R && python tools/bench_vs_vendor.py 2>/dev/null > $O/vs_vendor_libraries.txt)
 (cd $R && python tools/bench_attn512.py 2>/dev/null > $O/attn512.txt)
-(cd $R && python tools/bench_conv_stats.py 2>/dev/null > $O/stats_epilogue_cost.txt)
 (cd $R && python tools/bench_reference_default.py 2>/dev/null | tail -1 > $O/reference_default.txt)
-ls -la $O; cut -c1-400 $O/bench.json; cat $O/traffic.json | head -30; head -30 $O/mfma_util.json
+stamp $O/in_flight_sweep.txt $O/phase_times.txt $O/gemm_shapes.txt $O/wide_conv.txt $O/trace_step.txt $O/bench_ops.txt $O/attn512.txt $O/reference_default.txt
+ls -la $O; cut -c1-400 $O/bench.json; cat $O/traffic.json | head -40; head -30 $O/mfma_util.json

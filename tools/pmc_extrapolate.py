@@ -16,8 +16,10 @@ def totals(path, counter):
             continue
         k = r["Kernel_Name"]
         keys = []
-        if "lconv3_kernel" in k:
-            keys = ["lconv3", "conv3"]               # lean patch-staged kernel (round 3); "conv3" = every patch-staged 3x3 launch
+        if "wconv3_kernel" in k:
+            keys = ["wconv3", "conv3"]               # wide patch-staged kernel (round 4); "conv3" = every patch-staged 3x3 launch
+        elif "lconv3_kernel" in k:
+            keys = ["lconv3", "conv3"]               # lean patch-staged kernel (round 3)
         elif "conv3p_kernel" in k:
             keys = ["conv3p", "conv3"]
         elif "gemm8_kernel" in k and "true, false" in k:
@@ -32,8 +34,6 @@ f2, nf2 = totals(sys.argv[1], "FETCH_SIZE"); w2, nw2 = totals(sys.argv[2], "WRIT
 f10, nf10 = totals(sys.argv[3], "FETCH_SIZE"); w10, nw10 = totals(sys.argv[4], "WRITE_SIZE")
 out = {}
 for k in f10:
-    if nf10[k] <= nf2[k] and k != "conv3":
-        pass
     def ext(t2, t10):
         u = (t10 - t2) / 8.0
         return 50 * u + (t2 - 2 * u)
@@ -43,4 +43,6 @@ for k in f10:
     out[k] = {"launches": int(round(n50)), "fetch_bytes_per_launch": fetch, "write_bytes_per_launch": write,
               "hbm_bytes_per_launch": fetch + write,
               "per_sampler_step_launches": (nf10[k] - nf2[k]) / 8.0, "runs": {"steps2_launches": nf2[k], "steps10_launches": nf10[k]}}
+import os
+out["head"] = os.environ.get("UDT_HEAD", "unknown")      # the commit these counters were collected at (tools/collect_profiles.sh)
 print(json.dumps(out, indent=1))

@@ -18,4 +18,7 @@ for k in busy:
     if busy[k] > 0 and act[k] > 0:
         out[k] = {"launches": n[k], "mfma_busy_cycles_per_launch": busy[k] / n[k], "active_cycles_per_launch": act[k] / n[k],
                   "mfma_util": busy[k] / (act[k] * 32 * 4)}
-print(json.dumps(dict(sorted(out.items(), key=lambda kv: -kv[1]["mfma_busy_cycles_per_launch"] * kv[1]["launches"])), indent=1))
+import os
+res = dict(sorted(out.items(), key=lambda kv: -kv[1]["mfma_busy_cycles_per_launch"] * kv[1]["launches"]))
+res["head"] = os.environ.get("UDT_HEAD", "unknown")       # the commit these counters were collected at
+print(json.dumps(res, indent=1))
