@@ -468,6 +468,25 @@ def test_flash_attention(ops, cuda, B, H, N, Nk):
     _close(out2, out, what=f"attn rowv vs V^T {B,H,N,Nk}")
 
 
+@pytest.mark.parametrize("B,H,N,Nk", [(2, 20, 256, 256), (1, 5, 200, 136), (1, 3, 72, 1096), (3, 2, 130, 40), (2, 10, 1024, 1024)])
+def test_flash_attention_row_major_v_ragged_shapes(ops, cuda, B, H, N, Nk):
+    """udt_attn_rowv_fwd (the UNet's self-attention kernel) on ragged query / key counts on both sides of a 128-query block / a
+    64-key tile boundary, several samples and heads: signal-relative tolerance against torch SDPA in fp32, bit-reproducible"""
+    Cc = H * 64
+    qkv = _rand((B, max(N, Nk), 3 * Cc), cuda, seed=5).bfloat16()
+    q, k, v = qkv[:, :N, :Cc], qkv[:, :Nk, Cc:2 * Cc], qkv[:, :Nk, 2 * Cc:]
+    qh = q.float().reshape(B, N, H, 64).permute(0, 2, 1, 3)
+    kh = k.float().reshape(B, Nk, H, 64).permute(0, 2, 1, 3)
+    vh = v.float().reshape(B, Nk, H, 64).permute(0, 2, 1, 3)
+    ref = F.scaled_dot_product_attention(qh, kh, vh).permute(0, 2, 1, 3).reshape(B, N, Cc)
+    out = ops.attention_rowv(q, k, v, H, 0.125)
+    again = ops.attention_rowv(q, k, v, H, 0.125)
+    torch.cuda.synchronize()
+    _close(out, ref, what=f"attn rowv {B,H,N,Nk}")
+    _close_signal(out, ref, what=f"attn rowv {B,H,N,Nk}")
+    assert torch.equal(out, again)
+
+
 def test_flash_attention_spike(ops, cuda):
     """a key row that dominates one query late in the sequence (forces a large online-softmax rescale)"""
     B, H, N = 1, 5, 512
