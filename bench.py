@@ -465,8 +465,8 @@ def main():
             "images_per_s_reference_default": ref_default,
             "images_per_s_by_launch_mode": dict(other_modes, **{"value": value}),
             "unet_ms_per_sampler_step": unet_ms,
-            "unet_ms_note": f"one batch of {args.batch} alone on the whole GPU (latency of one UNet call on its CFG pair + "
-                            "the fused CFG/Euler update); with batches in flight the per-batch cost is lower",
+            "unet_ms_note": f"one batch of {args.batch} alone on the whole GPU (latency of one UNet call on its CFG pair, one launch "
+                            "stream, + the fused CFG/Euler update); with batches in flight the per-batch cost is lower",
             "config": {"workload": f"{args.size}x{args.size}, {args.sampler_steps} Euler/DDIM(eta 0) steps, CFG 5.0, {args.chars}-char "
                                    f"labels, noise_iters 0; global batch {G} per step sharded over {world} GPU(s) = {per_rank} "
                                    f"images per GPU in micro-batches of {args.batch}: every UNet call runs ONE batch of "

@@ -799,7 +799,7 @@ def test_predict_sharded_under_nccl_world1(engine, cuda, monkeypatch, n_images, 
 
 
 @pytest.mark.parametrize("switch", ["UDT_LEAN=0", "UDT_LEAN_CONV=0", "UDT_WIDE_CONV=0", "UDT_LEAN_SPLITK=1", "UDT_GN_EPI=0", "UDT_LN_GEMM=0",
-                                    "UDT_DUAL_STREAM=0", "fused text cross-attention off"])
+                                    "UDT_DUAL_STREAM=1", "fused text cross-attention off"])
 def test_unet_call_with_each_switch_in_its_non_default_position(engine, cuda, monkeypatch, switch):
     """every surviving launch-path switch (the environment variables are read once at import / first use,
     so the test sets what they set) gives the same UNet call as the default path up to the other kernel family's rounding:
@@ -833,16 +833,16 @@ def test_unet_call_with_each_switch_in_its_non_default_position(engine, cuda, mo
             monkeypatch.setattr(H, "EMIT_STATS", H.FUSE_GN)
         elif switch == "UDT_LN_GEMM=0":
             monkeypatch.setattr(H, "LN_GEMM", False)
-        elif switch == "UDT_DUAL_STREAM=0":
-            monkeypatch.setattr(S, "DUAL_STREAM", False)
+        elif switch == "UDT_DUAL_STREAM=1":
+            monkeypatch.setattr(S, "DUAL_STREAM", True)
         else:
             monkeypatch.setattr(A, "TATTN_FUSED", False)
-        if switch == "UDT_DUAL_STREAM=0":
+        if switch == "UDT_DUAL_STREAM=1":
             # the switch lives in the sampler's step: one Euler step through _Stepper with and without the two-stream split
             c = {"t_crossattn": ctx, "concat": torch.randn((B, 5, 32, 32), device=cuda)}
             uc = {"t_crossattn": torch.zeros_like(ctx), "concat": c["concat"].clone()}
             outs = []
-            for dual in (True, False):
+            for dual in (False, True):
                 st = S._Stepper(engine, c, uc, B, (32, 32), 5.0, two_streams=dual)
                 z = x[:B, :4].clone().float().contiguous()
                 st.step(z, 5.0, 4.0)

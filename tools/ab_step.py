@@ -96,4 +96,4 @@ def replay(gs):
     return e0.elapsed_time(e1) / 10
 for rnd in range(5):
     for name, gs in runners.items():
-        print(f"round {rnd} {name:28s} {replay(gs):.3f} ms/step (graph replay, uc / c halves on two streams)", flush=True)
+        print(f"round {rnd} {name:28s} {replay(gs):.3f} ms/step (graph replay)", flush=True)

@@ -3,7 +3,7 @@ launches of the same problem on ROTATING buffers, so every launch reads HBM-cold
 list of udt_debug_set settings:   python tools/bench_gemm_shapes.py n_block=-1 n_block=0 n_block=2 ...
 Prints one row per shape: microseconds and TFLOP/s per setting."""
 import math, os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.environ.get("UDT_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import udifftext_amd
 from udifftext_amd import lib as L, ops, packing

@@ -79,7 +79,10 @@ class EDMSampler(SingleStepDiffusionSampler):
 
 # noise search: candidates as extra batch entries of one UNet call (0: one candidate at a time)
 NOISE_BATCH = os.environ.get("UDT_NOISE_BATCH", "1") != "0"
-DUAL_STREAM = os.environ.get("UDT_DUAL_STREAM", "1") != "0"
+# UDT_DUAL_STREAM=1: the uc / c halves of a LONE batch's UNet call on two streams.  Default OFF since round 4: with the wide
+# convolution (one 256-pixel tile per CU for the full 8-sample call) one stream is 1.5 % faster (9.60 vs 9.75 ms per step,
+# profiles/r04_ab_dual_stream.txt); rounds 1-3 gained 3-8 % from the split
+DUAL_STREAM = os.environ.get("UDT_DUAL_STREAM", "0") != "0"
 
 
 def _all_zero(t: torch.Tensor) -> bool:
