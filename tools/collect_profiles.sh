@@ -14,6 +14,9 @@ p = sys.argv[1]
 d = json.load(open(p)); d["head"] = "$UDT_HEAD"; json.dump(d, open(p, "w"))
 PY
 done; }
+# 0. the GPU test suite and the smoke test at this commit
+(cd $R && python -m pytest tests -m gpu -q 2>&1 | tail -4 | grep -v "^$" > $O/gpu_tests.log; python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | grep smoke >> $O/gpu_tests.log)
+stamp $O/gpu_tests.log
 cd /tmp && export TMPDIR=/tmp
 # 1. the bench line (default flags = what the driver runs)
 (cd $R && python bench.py 2>$O/bench.err | tail -1 > $O/bench.json); jstamp $O/bench.json
