@@ -209,6 +209,20 @@ int udt_attn512_fwd(const void* q, const void* k, const void* v, void* o,
                     int64_t q_bstride, int64_t k_bstride, int64_t v_bstride, int64_t o_bstride,
                     float scale, void* stream);
 
+/* The same product with the KEYS split over workgroups (flash-decoding form) for grids whose query tiles alone leave most of
+ * the 256 CUs idle — a single 512 x 512 image is 64 query tiles, each walking all 4096 keys: the keys are cut into up to 8
+ * slices of >= 256 keys, every (query tile, slice) workgroup parks its unnormalised fp32 partial O and (running maximum, row
+ * sum) in `workspace`, and a merge launch on the same stream combines the slices in index order (deterministic).
+ *   udt_attn512_workspace_bytes : bytes the split form needs for (batch, nq, nk); 0 = the grid is large enough, no split.
+ *   udt_attn512_split_fwd       : as udt_attn512_fwd; workspace 16-byte aligned, >= the bytes above (UDT_ERR_WORKSPACE
+ *                                 otherwise); with workspace == NULL, or when no split is planned, it IS udt_attn512_fwd. */
+size_t udt_attn512_workspace_bytes(int32_t batch, int32_t nq, int32_t nk);
+int udt_attn512_split_fwd(const void* q, const void* k, const void* v, void* o,
+                          int32_t batch, int32_t nq, int32_t nk,
+                          int32_t ldq, int32_t ldk, int32_t ldv, int32_t ldo,
+                          int64_t q_bstride, int64_t k_bstride, int64_t v_bstride, int64_t o_bstride,
+                          float scale, void* workspace, size_t workspace_bytes, void* stream);
+
 /* Masked small attention (the OCR scorer's decoder: nn.MultiheadAttention of PARSeq's DecoderLayer, reference
  * src/parseq/strhub/models/parseq/modules.py:35-36,57-70 -> torch's scaled-dot-product with attn_mask and
  * key_padding_mask).  Few queries against a short key set, any head_dim that is a multiple of 8 up to 64:

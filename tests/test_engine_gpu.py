@@ -387,8 +387,8 @@ def test_vae_at_512_vs_oracle(engine, cuda):
 
 
 def test_vae_decode_flash_attention_d512_vs_oracle_and_block_form(engine, cuda, monkeypatch):
-    """the VAE mid-block attention through udt_attn512_fwd (forced: a single 64x64 latent has too few query blocks for the
-    automatic rule to pick it) against the oracle, and against the GEMM -> softmax -> GEMM block form on the same latent"""
+    """the VAE mid-block attention through the flash kernel (a single 64x64 latent: the key-split form, udt_attn512_split_fwd)
+    against the oracle, and against the GEMM -> softmax -> GEMM block form on the same latent"""
     from oracle import nets, spec
     from sgm.modules.diffusionmodules import model as vmodel
     cfg = spec.EngineConfig()
@@ -399,8 +399,7 @@ def test_vae_decode_flash_attention_d512_vs_oracle_and_block_form(engine, cuda, 
     with torch.no_grad():
         ref_d = nets.vae_decode(sd, z, cfg.vae)
     monkeypatch.setattr(vmodel, "ATTN_FLASH_512", "1")
-    assert vmodel._flash512(4, 4096) and not vmodel._flash512(1, 4096)        # batch of 4: flash; one image: block form
-    monkeypatch.setattr(vmodel, "ATTN_FLASH_512", "2")
+    assert vmodel._flash512(4, 4096) and vmodel._flash512(1, 4096)
     dec_flash = fs.decode(z.to(cuda))
     monkeypatch.setattr(vmodel, "ATTN_FLASH_512", "0")
     dec_block = fs.decode(z.to(cuda))

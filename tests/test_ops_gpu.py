@@ -528,6 +528,45 @@ def test_flash_attention_d512(ops, cuda, B, N, Nk):
     _close_signal(out, ref, what=f"attn512 {B,N,Nk}")
     # the same launch twice: bit-identical (the four waves sum the partial score tiles in a fixed order)
     assert torch.equal(out, ops.attention_d512(q, k, v, 512 ** -0.5))
+    # the key-split form (planned by the library for the small grids: (1, 4096, 4096), (1, 33, 2050), (2, 1024, 1024) ...) and the
+    # one-workgroup-per-query-tile form agree to the rounding of the output
+    whole = ops.attention_d512(q, k, v, 512 ** -0.5, key_split=False)
+    _close_signal(whole, ref, what=f"attn512 without key split {B,N,Nk}")
+    _close_signal(out, whole.float(), rel_rms=8e-3, what=f"attn512 key split vs whole {B,N,Nk}")
+
+
+def test_flash_attention_d512_key_split_contract(ops, cuda):
+    """udt_attn512_workspace_bytes / udt_attn512_split_fwd: the plan (split only when the query tiles leave CUs idle and there are
+    >= 512 keys), a short workspace is refused, NULL workspace = the unsplit kernel, and a spike in the LAST key slice survives the
+    merge (its slice's maximum dominates the others)"""
+    import ctypes as C
+    from udifftext_amd import lib as L
+    lib = L.load()
+    assert lib.udt_attn512_workspace_bytes(4, 4096, 4096) == 0            # 256 query tiles: no split
+    assert lib.udt_attn512_workspace_bytes(1, 4096, 4096) == 1 * 4 * 4096 * 514 * 4
+    assert lib.udt_attn512_workspace_bytes(1, 64, 4096) == 1 * 7 * 64 * 514 * 4
+    assert lib.udt_attn512_workspace_bytes(1, 9216, 9216) == 1 * 5 * 9216 * 514 * 4        # 144 query tiles: three rounds of a fifth
+    assert lib.udt_attn512_workspace_bytes(1, 64, 300) == 0               # fewer than two slices of 8 tiles
+    assert lib.udt_attn512_workspace_bytes(0, 64, 4096) == 0
+    B, N = 1, 2048
+    q = _rand((B, N, 512), cuda, seed=4).bfloat16()
+    k = _rand((B, N, 512), cuda, seed=5).bfloat16()
+    v = _rand((B, N, 512), cuda, seed=6).bfloat16()
+    k[0, N - 3] = (q[0, 5].float() * 3).bfloat16()
+    ref = F.scaled_dot_product_attention(q.float(), k.float(), v.float())
+    out = ops.attention_d512(q, k, v, 512 ** -0.5)
+    _close_signal(out, ref, what="attn512 key split, spike in the last slice")
+    _close_signal(out[0, 5], ref[0, 5], what="attn512 key split, the spiked row")
+    need = lib.udt_attn512_workspace_bytes(B, N, N)
+    assert need > 0
+    o2 = torch.empty_like(out)
+    small = torch.empty((need - 16,), dtype=torch.uint8, device=cuda)
+    args = (q.data_ptr(), k.data_ptr(), v.data_ptr(), o2.data_ptr(), B, N, N, 512, 512, 512, 512, N * 512, N * 512, N * 512, N * 512, 512 ** -0.5)
+    st = torch.cuda.current_stream().cuda_stream
+    assert lib.udt_attn512_split_fwd(*args, small.data_ptr(), need - 16, st) == -3          # UDT_ERR_WORKSPACE
+    assert lib.udt_attn512_split_fwd(*args, None, 0, st) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(o2, ops.attention_d512(q, k, v, 512 ** -0.5, key_split=False))
 
 
 def test_flash_attention_d512_spike_and_block_form(ops, cuda):

@@ -469,6 +469,11 @@ struct Attn512Params {
   int ldq, ldk, ldv, ldo;
   long long sq, sk, sv, so;
   float scale_log2e;
+  // key split (udt_attn512_split_fwd): workgroup z of ksplit walks key tiles [z * kt_per, (z + 1) * kt_per) and parks its
+  // UNNORMALISED partial result — fp32 O [b][z][nq][512] and (running maximum, row sum) [b][z][nq][2] — for the merge kernel
+  int ksplit, kt_per;
+  float* part_o;
+  float* part_ml;
 };
 constexpr int A5_KEYS = 32;
 constexpr int A5_SUB = A5_KEYS * 128;              // one [32 keys][64 dims] sub-tile
@@ -563,13 +568,16 @@ UDT_DEVINL void attn_d512_body(const Attn512Params& p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) o_acc[i][r] = 0.f;
   float m_run = -INFINITY, l_run = 0.f;
-  const int ntiles = (p.nk + A5_KEYS - 1) / A5_KEYS;
+  // this workgroup's key tiles: all of them, or slice blockIdx.z of the key split
+  const int kt_begin = p.ksplit > 1 ? (int)blockIdx.z * p.kt_per : 0;
+  int ntiles = (p.nk + A5_KEYS - 1) / A5_KEYS;
+  if (p.ksplit > 1 && kt_begin + p.kt_per < ntiles) ntiles = kt_begin + p.kt_per;
   const float c = p.scale_log2e;
   // issue order: K(0) V(0) K(1) | tile t: [top barrier] V(t+1) ... [exchange barrier] K(t+2)
-  stage_k(0);
-  stage_v(0);
-  if (ntiles > 1) stage_k(1);
-  for (int kt = 0; kt < ntiles; ++kt) {
+  stage_k(kt_begin);
+  stage_v(kt_begin);
+  if (kt_begin + 1 < ntiles) stage_k(kt_begin + 1);
+  for (int kt = kt_begin; kt < ntiles; ++kt) {
     const int st = kt & 1;
     // K(kt) landed: the loads behind it are V(kt) and K(kt+1) (PCS + PCS per wave) while both exist
     if (kt + 2 < ntiles) wait_vm<2 * PCS>(); else wait_vm<0>();
@@ -678,6 +686,26 @@ UDT_DEVINL void attn_d512_body(const Attn512Params& p) {
     }
   }
   const float l_tot = l_run + __shfl_xor(l_run, 32);
+  if (p.ksplit > 1) {
+    // park the slice: unnormalised O (fp32, this wave's 128 dims of its 32 queries) and, once per query, (m, l)
+    if (qok) {
+      const long long row = ((long long)b * p.ksplit + blockIdx.z) * p.nq + qi;
+      float* po = p.part_o + row * 512;
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+          const int d = d0 + t * 32 + qd * 8 + hi * 4;
+          f32x4 v = {o_acc[t][qd * 4 + 0], o_acc[t][qd * 4 + 1], o_acc[t][qd * 4 + 2], o_acc[t][qd * 4 + 3]};
+          *reinterpret_cast<f32x4*>(po + d) = v;
+        }
+      if (dw == 0 && hi == 0) {
+        f32x2 ml = {m_run, l_tot};
+        *reinterpret_cast<f32x2*>(p.part_ml + row * 2) = ml;
+      }
+    }
+    return;
+  }
   const float inv = 1.0f / l_tot;
   if (qok) {
 #pragma unroll
@@ -690,6 +718,29 @@ UDT_DEVINL void attn_d512_body(const Attn512Params& p) {
         *reinterpret_cast<u32x2*>(O + (long long)qi * p.ldo + d) = pk;
       }
   }
+}
+
+// merge of the key split: per query, O = sum_z 2^(m_z - m) O_z / sum_z 2^(m_z - m) l_z with m = max_z m_z (the slices carry
+// their running maxima in the log2 domain); 128 threads = one query, four dims each; slices in index order -> deterministic
+__global__ void __launch_bounds__(128) attn_d512_merge_kernel(const float* __restrict__ part_o, const float* __restrict__ part_ml,
+                                                              uint16_t* __restrict__ o, int nq, int ksplit, int ldo, long long so) {
+  const int qi = blockIdx.x, b = blockIdx.y, t = threadIdx.x;
+  float m = -INFINITY;
+  for (int z = 0; z < ksplit; ++z) m = fmaxf(m, part_ml[(((long long)b * ksplit + z) * nq + qi) * 2]);
+  float l = 0.f;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (int z = 0; z < ksplit; ++z) {
+    const long long row = ((long long)b * ksplit + z) * nq + qi;
+    const f32x2 ml = *reinterpret_cast<const f32x2*>(part_ml + row * 2);
+    const float w = fast_exp2(ml[0] - m);
+    l += w * ml[1];
+    const f32x4 v = *reinterpret_cast<const f32x4*>(part_o + row * 512 + t * 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[e] += w * v[e];
+  }
+  const float inv = 1.0f / l;
+  u32x2 pk = {pack_bf16x2(acc[0] * inv, acc[1] * inv), pack_bf16x2(acc[2] * inv, acc[3] * inv)};
+  *reinterpret_cast<u32x2*>(o + (long long)b * so + (long long)qi * ldo + t * 4) = pk;
 }
 
 // (two plain kernels around the template body: a launch bound that depends on a template parameter left the host stub of an
@@ -894,10 +945,33 @@ extern "C" int udt_attn_rowv_fwd(const void* q, const void* k, const void* v, vo
                        o_bstride, scale, stream);
 }
 
-extern "C" int udt_attn512_fwd(const void* q, const void* k, const void* v, void* o, int32_t batch, int32_t nq, int32_t nk,
-                               int32_t ldq, int32_t ldk, int32_t ldv, int32_t ldo,
-                               int64_t q_bstride, int64_t k_bstride, int64_t v_bstride, int64_t o_bstride,
-                               float scale, void* stream) {
+// key split plan: when the query tiles alone leave most CUs idle (a single image: 64 workgroups, each walking all 4096 keys
+// alone), the keys are cut into up to 8 slices of >= 8 tiles (256 keys).  The slice count minimises the length of the launch in
+// units of one unsplit workgroup — rounds of 256 workgroups (one per CU) x 1/slices — plus 2 % per slice for the parked partial
+// results and the merge (64 query tiles: 4 slices, one round of a quarter; 144 tiles (768 x 768): 5 slices, three rounds of a fifth)
+static int a5_key_split(int batch, int nq, int nk) {
+  const long long wgs = (long long)((nq + 63) / 64) * batch;
+  if (wgs >= 192) return 1;
+  const int ntiles = (nk + A5_KEYS - 1) / A5_KEYS;
+  int best = 1;
+  double best_cost = 1.0;
+  for (int ks = 2; ks <= 8 && ks * 8 <= ntiles; ++ks) {
+    const double cost = (double)((wgs * ks + 255) / 256) / ks + 0.02 * ks;
+    if (cost < best_cost - 1e-9) best_cost = cost, best = ks;
+  }
+  return best;
+}
+
+extern "C" size_t udt_attn512_workspace_bytes(int32_t batch, int32_t nq, int32_t nk) {
+  if (batch <= 0 || nq <= 0 || nk <= 0) return 0;
+  const int ks = a5_key_split(batch, nq, nk);
+  return ks > 1 ? (size_t)batch * ks * nq * (512 + 2) * sizeof(float) : 0;
+}
+
+static int attn512_impl(const void* q, const void* k, const void* v, void* o, int32_t batch, int32_t nq, int32_t nk,
+                        int32_t ldq, int32_t ldk, int32_t ldv, int32_t ldo,
+                        int64_t q_bstride, int64_t k_bstride, int64_t v_bstride, int64_t o_bstride,
+                        float scale, void* workspace, size_t workspace_bytes, void* stream) {
   if (!q || !k || !v || !o) return UDT_ERR_BAD_ARG;
   if (batch <= 0 || nq <= 0 || nk <= 0) return UDT_ERR_BAD_SHAPE;
   if (ldq % 8 != 0 || ldk % 8 != 0 || ldv % 8 != 0 || ldo % 4 != 0 || ldq < 512 || ldk < 512 || ldv < 512 || ldo < 512) return UDT_ERR_BAD_SHAPE;
@@ -916,15 +990,29 @@ extern "C" int udt_attn512_fwd(const void* q, const void* k, const void* v, void
   p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo;
   p.sq = q_bstride; p.sk = k_bstride; p.sv = v_bstride; p.so = o_bstride;
   p.scale_log2e = scale * 1.4426950408889634f;
+  p.ksplit = 1; p.kt_per = 0; p.part_o = nullptr; p.part_ml = nullptr;
+  if (workspace) {
+    const int ks = a5_key_split(batch, nq, nk);
+    if (ks > 1) {
+      const size_t need = (size_t)batch * ks * nq * (512 + 2) * sizeof(float);
+      if (workspace_bytes < need || (reinterpret_cast<uintptr_t>(workspace) & 15)) return UDT_ERR_WORKSPACE;
+      const int ntiles_all = (nk + A5_KEYS - 1) / A5_KEYS;
+      p.kt_per = (ntiles_all + ks - 1) / ks;
+      p.ksplit = (ntiles_all + p.kt_per - 1) / p.kt_per;       // (<= ks: every slice owns at least one tile)
+      p.part_o = reinterpret_cast<float*>(workspace);
+      p.part_ml = p.part_o + (size_t)batch * p.ksplit * nq * 512;
+      if (p.ksplit < 2) p.ksplit = 1;
+    }
+  }
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   UdtProfScope prof(2, s);
   if (prof.rec) {
     char tag[96];
-    snprintf(tag, sizeof(tag), "attn512 B=%d nq=%d nk=%d", batch, nq, nk);
+    snprintf(tag, sizeof(tag), "attn512 B=%d nq=%d nk=%d ksplit=%d", batch, nq, nk, p.ksplit);
     udt_prof_tag(prof.rec, tag);
   }
   // 64 queries (eight waves) per workgroup when that still gives every CU work; 32 otherwise
-  const bool two = (long long)((nq + 63) / 64) * batch >= 224;
+  const bool two = (long long)((nq + 63) / 64) * batch * p.ksplit >= 224;
   static std::atomic<int> attr_done{0};
   if (!attr_done.load()) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_d512_q32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, a5_smem<1>());
@@ -932,10 +1020,31 @@ extern "C" int udt_attn512_fwd(const void* q, const void* k, const void* v, void
     if (e != hipSuccess) return udt_set_hip_error(e);
     attr_done.store(1);
   }
-  if (two) hipLaunchKernelGGL(attn_d512_q64_kernel, dim3((nq + 63) / 64, batch), dim3(512), a5_smem<2>(), s, p);
-  else hipLaunchKernelGGL(attn_d512_q32_kernel, dim3((nq + 31) / 32, batch), dim3(256), a5_smem<1>(), s, p);
+  if (two) hipLaunchKernelGGL(attn_d512_q64_kernel, dim3((nq + 63) / 64, batch, p.ksplit), dim3(512), a5_smem<2>(), s, p);
+  else hipLaunchKernelGGL(attn_d512_q32_kernel, dim3((nq + 31) / 32, batch, p.ksplit), dim3(256), a5_smem<1>(), s, p);
   UDT_CHECK_LAUNCH();
+  if (p.ksplit > 1) {
+    hipLaunchKernelGGL(attn_d512_merge_kernel, dim3(nq, batch), dim3(128), 0, s, p.part_o, p.part_ml, p.o, nq, p.ksplit, ldo,
+                       (long long)o_bstride);
+    UDT_CHECK_LAUNCH();
+  }
   return UDT_OK;
+}
+
+extern "C" int udt_attn512_fwd(const void* q, const void* k, const void* v, void* o, int32_t batch, int32_t nq, int32_t nk,
+                               int32_t ldq, int32_t ldk, int32_t ldv, int32_t ldo,
+                               int64_t q_bstride, int64_t k_bstride, int64_t v_bstride, int64_t o_bstride,
+                               float scale, void* stream) {
+  return attn512_impl(q, k, v, o, batch, nq, nk, ldq, ldk, ldv, ldo, q_bstride, k_bstride, v_bstride, o_bstride, scale, nullptr, 0,
+                      stream);
+}
+
+extern "C" int udt_attn512_split_fwd(const void* q, const void* k, const void* v, void* o, int32_t batch, int32_t nq, int32_t nk,
+                                     int32_t ldq, int32_t ldk, int32_t ldv, int32_t ldo,
+                                     int64_t q_bstride, int64_t k_bstride, int64_t v_bstride, int64_t o_bstride,
+                                     float scale, void* workspace, size_t workspace_bytes, void* stream) {
+  return attn512_impl(q, k, v, o, batch, nq, nk, ldq, ldk, ldv, ldo, q_bstride, k_bstride, v_bstride, o_bstride, scale, workspace,
+                      workspace_bytes, stream);
 }
 
 extern "C" int udt_xattn_fwd(const void* q, const void* k, const void* v, void* o, float* probs, int32_t batch,

@@ -70,6 +70,9 @@ SYMBOLS = {
     "udt_attn_rowv_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32,
                                     _i64, _i64, _i64, _i64, _f32, _vp]),
     "udt_attn512_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i64, _i64, _i64, _i64, _f32, _vp]),
+    "udt_attn512_workspace_bytes": (C.c_size_t, [_i32, _i32, _i32]),
+    "udt_attn512_split_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i64, _i64, _i64, _i64, _f32,
+                                        _vp, C.c_size_t, _vp]),
     "udt_xattn_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _fp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp]),
     "udt_mattn_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _fp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32,
                                 _i64, _i64, _i64, _i64, _f32, _vp]),

@@ -362,9 +362,11 @@ def attention_rowv(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int
 
 
 def attention_d512(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: float,
-                   out: Optional[torch.Tensor] = None) -> torch.Tensor:
+                   out: Optional[torch.Tensor] = None, key_split: bool = True) -> torch.Tensor:
     """single-head flash attention with head_dim 512 (the VAE mid-block attention): q, k, v [B, N, 512] row views, e.g. the
-    column ranges of one q|k|v projection.  Returns o [B, Nq, 512]; no [Nq, Nk] score tensor is materialised."""
+    column ranges of one q|k|v projection.  Returns o [B, Nq, 512]; no [Nq, Nk] score tensor is materialised.
+    ``key_split``: grids too small to fill the CUs (a single image) split the keys over workgroups and merge
+    (udt_attn512_split_fwd; the library plans the split, the scratch for the partial results is allocated here)."""
     _bf16(q); _bf16(k); _bf16(v)
     B, Nq = q.shape[0], q.shape[1]
     Nk = k.shape[1]
@@ -372,10 +374,19 @@ def attention_d512(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: flo
     assert q.stride(2) == 1 and k.stride(2) == 1 and v.stride(2) == 1
     if out is None:
         out = torch.empty((B, Nq, 512), dtype=torch.bfloat16, device=q.device)
-    L.check(L.load().udt_attn512_fwd(_ptr(q), _ptr(k), _ptr(v), _ptr(out), B, Nq, Nk,
-                                     q.stride(1), k.stride(1), v.stride(1), out.stride(1),
-                                     q.stride(0), k.stride(0), v.stride(0), out.stride(0), scale, _stream()),
-            "udt_attn512_fwd")
+    lib = L.load()
+    need = int(lib.udt_attn512_workspace_bytes(B, Nq, Nk)) if key_split else 0
+    if need:
+        scratch = torch.empty((need,), dtype=torch.uint8, device=q.device)
+        L.check(lib.udt_attn512_split_fwd(_ptr(q), _ptr(k), _ptr(v), _ptr(out), B, Nq, Nk,
+                                          q.stride(1), k.stride(1), v.stride(1), out.stride(1),
+                                          q.stride(0), k.stride(0), v.stride(0), out.stride(0), scale, _ptr(scratch), need, _stream()),
+                "udt_attn512_split_fwd")
+    else:
+        L.check(lib.udt_attn512_fwd(_ptr(q), _ptr(k), _ptr(v), _ptr(out), B, Nq, Nk,
+                                    q.stride(1), k.stride(1), v.stride(1), out.stride(1),
+                                    q.stride(0), k.stride(0), v.stride(0), out.stride(0), scale, _stream()),
+                "udt_attn512_fwd")
     if WORK_COUNTER is not None:
         count_work("attn", 4.0 * B * Nq * Nk * 512)
         count_work("attn_bytes", 2.0 * B * 512 * (2 * Nq + 2 * Nk))

@@ -71,17 +71,15 @@ class ResnetBlock(nn.Module):
         return self.conv2(h, residual=skip, norm=self.norm2, norm_silu=True, colstats=True)
 
 
-# The VAE mid-block attention (one head of 512 dims) runs on the flash kernel udt_attn512_fwd when its grid of 64-query
-# workgroups covers at least half of the CUs (a batch of 4 at 512 x 512: 256 workgroups, 283 us vs 326 us for the block form);
-# a single image (64 workgroups, each walking all 4096 keys alone) is faster as GEMM -> softmax -> GEMM in query blocks
-# (159 us vs 222 us, profiles/r03_attn512.txt).  UDT_ATTN512=0 never / 2 always uses the flash kernel (A/B).
+# The VAE mid-block attention (one head of 512 dims) runs on the flash kernel (udt_attn512_fwd; a batch of 4 at 512 x 512: 256
+# workgroups of 64 queries, 282 us vs 337 us for GEMM -> softmax -> GEMM in query blocks).  Grids that leave CUs idle — a single
+# image: 64 workgroups, each walking all 4096 keys alone, 222 us — go through its key-split form (udt_attn512_split_fwd, round 4:
+# 84 us vs 156 us for the block form; one 768 x 768 image 366 vs 607 us; profiles/r04_attn512.txt).  UDT_ATTN512=0: block form (A/B).
 ATTN_FLASH_512 = os.environ.get("UDT_ATTN512", "1")
 
 
 def _flash512(batch: int, n: int) -> bool:
-    if ATTN_FLASH_512 == "0":
-        return False
-    return ATTN_FLASH_512 == "2" or ((n + 63) // 64) * batch >= 128
+    return ATTN_FLASH_512 != "0"
 
 
 class MemoryEfficientAttnBlock(H._Packed):
