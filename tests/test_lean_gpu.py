@@ -147,6 +147,53 @@ def test_ln_gemm_fwd_vs_torch(env, cuda, M, N, K, geglu):
     assert _rel(out, two) < REL_RMS_LN
 
 
+@pytest.mark.parametrize("M,N,K,geglu", [(32768, 2560, 320, True), (32768, 960, 320, False), (777, 2560, 320, True),
+                                         (1000, 1024, 320, False), (16384, 2560, 320, True), (300, 128, 320, False),
+                                         (65536, 2560, 320, True)])
+def test_row_resident_ln_gemm_vs_torch_and_lean(env, cuda, M, N, K, geglu):
+    """rowres.h (rgemm_kernel: the rows' A fragments resident in registers, weights streamed in 64-row chunks; forced with
+    udt_debug_set("lean", 7), automatic for the 64 x 64 level's GEGLU / q|k|v projections) against torch layer_norm -> linear
+    (-> GEGLU) in fp32 and against the tiled lean kernel on the same packed weights; ragged M (a partial 256-row block, a partial
+    wave), one chunk, column splits (16384 rows: 4 splits of 10 chunks; 65536: 2 splits), and the automatic plan's choice"""
+    g = torch.Generator(device="cpu").manual_seed(15)
+    x = (torch.randn((M, K), generator=g) * 1.5 + 0.3).to(cuda).bfloat16()
+    w = (torch.randn((N, K), generator=g) / math.sqrt(K)).to(cuda)
+    b = torch.randn((N,), generator=g).to(cuda)
+    gamma = (1 + 0.1 * torch.randn((K,), generator=g)).to(cuda)
+    beta = (0.05 * torch.randn((K,), generator=g)).to(cuda)
+    y = F.layer_norm(x.float(), (K,), gamma, beta, 1e-5) @ w.t() + b
+    if geglu:
+        y = y[:, :N // 2] * F.gelu(y[:, N // 2:])
+    fl = env.GEGLU if geglu else 0
+    wf, cf, sf = env.packing.pack_ln_linear(w, b, gamma, beta, geglu=geglu)
+    try:
+        env.dbg("lean", 7)
+        out = env.ops.ln_linear(x, wf, cf, sf, flags=fl)
+        torch.cuda.synchronize()
+        e = _rel(out, y)
+        assert math.isfinite(e) and e < REL_RMS_LN, f"row-resident ln_gemm: rel rms {e:.3e}"
+        assert torch.equal(out, env.ops.ln_linear(x, wf, cf, sf, flags=fl)), "not reproducible"
+        env.dbg("lean", 1)
+        tiled = env.ops.ln_linear(x, wf, cf, sf, flags=fl)
+        torch.cuda.synchronize()
+        # the two kernels differ by fp32 rounding in front of the bf16 rounding: a few outputs land on the neighbouring bf16
+        d = (out.float() - tiled.float()).abs()
+        assert (d <= 2.0 ** -7 * tiled.float().abs() + 1e-6).all(), "more than one bf16 step from the tiled kernel"
+        assert (d > 0).float().mean().item() < 0.02
+        env.dbg("lean", -1)
+        env.dbg("rowres", 0)
+        off = env.ops.ln_linear(x, wf, cf, sf, flags=fl)
+        env.dbg("rowres", 1)
+        auto = env.ops.ln_linear(x, wf, cf, sf, flags=fl)
+        torch.cuda.synchronize()
+        assert _rel(off, y) < REL_RMS_LN and _rel(auto, y) < REL_RMS_LN
+        if M >= 16384:
+            assert torch.equal(auto, out), "the automatic plan should take the row-resident kernel here"
+    finally:
+        env.reset()
+        env.dbg("rowres", 1)
+
+
 def test_ln_gemm_constant_rows_and_large_mean(env, cuda):
     """edge cases of the folded form: a constant row (variance 0 -> rstd = 1/sqrt(eps), output = c exactly as torch gives
     beta W^T + b) and rows with a mean far from 0 (the x W'^T - mean s cancellation)"""

@@ -7,7 +7,7 @@
                                                       # (UDT_EXTRA_FLAGS=-DUDT_MEASURE python -m udifftext_amd.build --force)
 """
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.environ.get("UDT_ROOT") or os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import udifftext_amd
 from udifftext_amd import pipeline, synth

@@ -1,7 +1,7 @@
 """VAE mid-block attention (one head, 512 dims): the flash kernel (udt_attn512_fwd) vs the query-block GEMM -> softmax -> GEMM
 form, per map size.   python tools/bench_attn512.py"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.environ.get("UDT_ROOT") or os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import udifftext_amd
 import udifftext_amd.lib

@@ -1,6 +1,6 @@
 """Micro-benchmark of the hot kernels at the UNet's shapes (config #2: 8 samples in flight)."""
 import math, os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.environ.get("UDT_ROOT") or os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import udifftext_amd
 from udifftext_amd import ops, packing, lib as L

@@ -2,7 +2,7 @@
 3x3 shapes: `indep` = 20 back-to-back launches on rotating buffers inside a hipGraph, `chain` = 20 DEPENDENT launches (each
 reads the previous output or takes it as residual: what a network step looks like).   python tools/bench_wide_conv.py"""
 import math, os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.environ.get("UDT_ROOT") or os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import udifftext_amd
 from udifftext_amd import lib as L, ops, packing

@@ -20,19 +20,25 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-u
 
 
 def _deps_mtime() -> float:
-    hdrs = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "gemm8.h"), os.path.join(CSRC, "conv3p.h"), os.path.join(CSRC, "lean.h"), os.path.join(CSRC, "wide.h"), os.path.join(CSRC, "tile_common.h"), os.path.join(CSRC, "lean_params.h"), os.path.join(HERE, "..", "include", "udt_kernels.h")]
+    hdrs = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "gemm8.h"), os.path.join(CSRC, "conv3p.h"), os.path.join(CSRC, "lean.h"), os.path.join(CSRC, "wide.h"), os.path.join(CSRC, "rowres.h"), os.path.join(CSRC, "tile_common.h"), os.path.join(CSRC, "lean_params.h"), os.path.join(HERE, "..", "include", "udt_kernels.h")]
     return max(os.path.getmtime(h) for h in hdrs)
 
 
 def _compile(src: str, force: bool) -> str:
     s = os.path.join(CSRC, src)
     o = os.path.join(OBJ, src.replace(".hip", ".o"))
-    if not force and os.path.exists(o) and os.path.getmtime(o) >= max(os.path.getmtime(s), _deps_mtime()):
+    # an object is current only for the flags it was compiled with (a measurement build — UDT_EXTRA_FLAGS=-DUDT_MEASURE ... — must
+    # never be linked into the product library because its objects happen to be newer than the sources)
+    stamp, flags = o + ".flags", " ".join(FLAGS)
+    same_flags = os.path.exists(stamp) and open(stamp).read() == flags
+    if not force and same_flags and os.path.exists(o) and os.path.getmtime(o) >= max(os.path.getmtime(s), _deps_mtime()):
         return o
     cmd = [HIPCC, *FLAGS, "-c", s, "-o", o]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")
+    with open(stamp, "w") as f:
+        f.write(flags)
     if r.stderr.strip():
         sys.stderr.write(r.stderr)
     return o

@@ -762,7 +762,8 @@ bool lean_stats_enabled() { return true; }     // statistics-emitting launches r
 
 struct LeanPlan {
   int stats_rows = 0;      // rows per colstats slot when the launch emits statistics (lean.h wave_colstats), else 0
-  int cfg;                 // 1, 6 as above; 5 = 4 waves / 128x160 / 2 stages (N = 320, 960)
+  int cfg;                 // 1, 6 as above; 5 = 4 waves / 128x160 / 2 stages (N = 320, 960); 7 = row-resident (rowres.h: tiles_n =
+                           // column splits, kt_per = 64-column chunks per split)
   int bm, bn, nw, smem;
   int tiles_m, tiles_n, tiles, nkt, splitk, kt_per, G, n_block;
 };
@@ -775,6 +776,18 @@ int lean_mode() {
     g_lean.store(v, std::memory_order_relaxed);
   }
   return v;
+}
+
+// udt_debug_set("rowres", v): 1 (default) the row-resident kernel where it applies, 0 never (A/B; UDT_ROWRES in the environment)
+std::atomic<int> g_rowres{-1};
+bool rowres_on() {
+  int v = g_rowres.load(std::memory_order_relaxed);
+  if (v < 0) {
+    const char* e = getenv("UDT_ROWRES");
+    v = (e && e[0] == '0') ? 0 : 1;
+    g_rowres.store(v, std::memory_order_relaxed);
+  }
+  return v != 0;
 }
 
 bool lean_plan(const udt_gemm_desc* d, LeanPlan& t, bool want_stats) {
@@ -803,7 +816,31 @@ bool lean_plan(const udt_gemm_desc* d, LeanPlan& t, bool want_stats) {
   if (d->rowvec && ((d->ld_rowvec > 0 ? d->ld_rowvec : d->N) % 4 != 0)) return false;
   // forced configurations: 1 and 6 only (5 = the 128 x 160 tile is chosen here, for plain N = 320 / 960 outputs: its wave
   // grid has no GEGLU form); anything else falls back to the 8-wave kernels instead of silently taking a default instance
-  if (mode > 0 && mode != 1 && mode != 6) return false;
+  if (mode > 0 && mode != 1 && mode != 6 && mode != 7) return false;
+  // 7 = rowres.h: the LayerNorm-folded projections with K = 320 and enough rows to give every CU a 256-row block: the rows'
+  // A fragments stay in registers, the weights stream through LDS in 64-row chunks; automatic where it applies
+  if (mode == 7 || (mode < 0 && rowres_on())) {
+    if (ln && !want_stats && d->K == 320 && d->N % 64 == 0 && !d->residual && !d->rowvec && !conv1) {
+      const int tiles_m = (d->M + 255) / 256, chunks = d->N / 64;
+      int ns = (device_cus() + tiles_m - 1) / tiles_m;           // column splits: one workgroup per CU ...
+      if (ns > chunks / 4) ns = chunks / 4;                       // ... of at least 4 chunks (the A load amortised)
+      const int cmax = geglu ? 20 : 16;                           // (column constants of <= 20 / 16 chunks in LDS, rowres.h)
+      const int ns_min = (chunks + cmax - 1) / cmax;
+      if (ns < ns_min) ns = ns_min;
+      // automatic where measured faster than the tiled kernels (profiles/r04_rowres.txt): GEGLU from ~3/4 of the CUs busy
+      // (16384 rows: 48 vs 59 us; 32768: 90 vs 103 us), the plain epilogue only with every CU busy (32768 x 960: 36.6 vs 38.2 us;
+      // 16384 rows: slower)
+      const long long wgs = (long long)tiles_m * ns;
+      if (ns >= 1 && (mode == 7 || (geglu ? wgs * 4 >= 3LL * device_cus() : wgs >= device_cus()))) {
+        t.cfg = 7; t.stats_rows = 0; t.nw = 4; t.bm = 256; t.bn = 64; t.smem = 0;
+        t.tiles_m = tiles_m; t.kt_per = (chunks + ns - 1) / ns; t.tiles_n = (chunks + t.kt_per - 1) / t.kt_per;
+        t.tiles = t.tiles_m * t.tiles_n; t.nkt = d->K / BK; t.splitk = 1; t.n_block = 1;
+        t.G = round_workgroups(t.tiles);
+        return true;
+      }
+    }
+    if (mode == 7) return false;
+  }
   t.cfg = (mode > 0) ? mode : 1;
   if (!geglu && d->N % 160 == 0 && d->N % 128 != 0 && t.cfg == 1) t.cfg = 5;
   // many tiles and a wide output: the 256 x 256 tile (8 waves, one workgroup per CU) halves the LDS-DMA instructions per MFMA.
@@ -1005,6 +1042,7 @@ extern "C" int udt_debug_set(const char* key, int32_t value) {
   if (!strcmp(key, "n_block")) { g_n_block.store(value); return UDT_OK; }
   if (!strcmp(key, "rows_epi")) { g_rows_epi.store(value ? 1 : 0); return UDT_OK; }
   if (!strcmp(key, "lean")) { g_lean.store(value < 0 ? -2 : value); return UDT_OK; }
+  if (!strcmp(key, "rowres")) { g_rowres.store(value); return UDT_OK; }
   if (!strcmp(key, "lean_splitk")) { g_lean_splitk.store(value); return UDT_OK; }
   if (!strcmp(key, "lean_conv")) { g_lean_conv.store(value < 0 ? -1 : (value ? 1 : 0)); return UDT_OK; }
   if (!strcmp(key, "wide_conv")) { g_wide_conv.store(value < 0 ? -1 : (value ? 1 : 0)); return UDT_OK; }

@@ -11,6 +11,7 @@ namespace {
 #include "lean_params.h"
 #include "lean.h"
 #include "wide.h"
+#include "rowres.h"
 
 template <int NW, int WGM, int WGN, int TM, int TN, int NST, int TMB = TM>
 hipError_t launch_lean(const lg::LParams& lp, int smem, int G, bool geglu, bool ln, hipStream_t s) {
@@ -62,6 +63,16 @@ hipError_t launch_wconv3s(const lg::C3Params& c3, hipStream_t s) {
   hipLaunchKernelGGL((wd::wconv3_kernel<STATS>), dim3(c3.G), dim3(256), smem, s, c3);
   return hipGetLastError();
 }
+template <int KT, bool GEGLU>
+hipError_t launch_rowres(const lg::LParams& lp, int G, hipStream_t s) {
+  static AttrOnce once;
+  constexpr int smem = rr::RGeo<KT, GEGLU>::SMEM;
+  hipError_t e = once.ensure(reinterpret_cast<const void*>(rr::rgemm_kernel<KT, GEGLU>), smem);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL((rr::rgemm_kernel<KT, GEGLU>), dim3(G), dim3(256), smem, s, lp);
+  return hipGetLastError();
+}
+
 hipError_t launch_wconv3(const lg::C3Params& c3, hipStream_t s) {
   return c3.colstats ? launch_wconv3s<true>(c3, s) : launch_wconv3s<false>(c3, s);
 }
@@ -74,6 +85,9 @@ hipError_t udt_lean_launch_gemm(int cfg, const void* lparams, int smem, int G, i
     case 1: return launch_lean<4, 2, 2, 2, 2, 2>(lp, smem, G, geglu != 0, ln != 0, s);
     case 6: return launch_lean<8, 2, 4, 4, 2, 2, 1>(lp, smem, G, geglu != 0, ln != 0, s);
     case 5: return geglu ? hipErrorInvalidValue : launch_lean<4, 4, 1, 1, 5, 2>(lp, smem, G, false, ln != 0, s);
+    case 7:                                               // rowres.h: LayerNorm-folded, K = 320, rows resident in registers
+      if (!ln || lp.K != 320) return hipErrorInvalidValue;
+      return geglu ? launch_rowres<5, true>(lp, G, s) : launch_rowres<5, false>(lp, G, s);
     default: return hipErrorInvalidValue;
   }
 }
