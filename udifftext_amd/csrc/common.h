@@ -55,6 +55,28 @@ UDT_DEVINL float gelu_erf_f(float x) {
   return 0.5f * x * (1.0f + erf);
 }
 
+// GEGLU output x * GELU(g) from PRE-SCALED operands xs = GEGLU_XS * x, gs = GEGLU_GS * g (the callers fold the two constants into
+// their bias / LayerNorm / alpha multipliers): the same Abramowitz-Stegun erf as gelu_erf_f with
+//   gs = g / sqrt(2) * sqrt(log2 e)  ->  exp(-z^2) = exp2(-gs^2),  1 + p z = 1 + (p / sqrt(log2 e)) |gs|
+//   x GELU(g) = 0.5 x g + 0.5 x |g| erf(|g| / sqrt 2) = xs gs + xs |gs| (1 - poly e)
+// 13 VALU instructions (two transcendental) instead of 17 behind un-scaled operands: the scaling multiplies, the sign transfer
+// and the 0.5 (1 + erf) step are gone.  The hot GEGLU epilogues (lean.h, rowres.h) are VALU-issue bound (profiles/r04_rowres.txt).
+constexpr float GEGLU_GS = 0.70710678118654752f * 1.2011224087864498f;     // 1/sqrt(2) * sqrt(log2 e)
+constexpr float GEGLU_XS = 0.5f / GEGLU_GS;
+UDT_DEVINL float geglu_scaled(float xs, float gs) {
+  const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f / 1.2011224087864498f, fabsf(gs), 1.0f));
+  float poly = 1.061405429f;
+  poly = poly * t - 1.453152027f;
+  poly = poly * t + 1.421413741f;
+  poly = poly * t - 0.284496736f;
+  poly = poly * t + 0.254829592f;
+  poly = poly * t;
+  const float e = __builtin_amdgcn_exp2f(-(gs * gs));
+  const float ha = xs * fabsf(gs);
+  const float hs = __builtin_fmaf(xs, gs, ha);
+  return __builtin_fmaf(-ha, poly * e, hs);
+}
+
 // 16-byte global -> LDS DMA.  `lds_wave_base` must be wave-uniform; lane l lands at base + 16*l.
 UDT_DEVINL void glds16(const void* gsrc, void* lds_wave_base) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,

@@ -365,18 +365,26 @@ __global__ void __launch_bounds__(NW * 64, 2) lgemm_kernel(const LParams p) {
           sg = *reinterpret_cast<const f32x4*>(p.ln_s + n + 32);
         }
       }
+      // operands of geglu_scaled: the scales GEGLU_XS / GEGLU_GS ride on the bias and on the row multipliers
+#pragma unroll
+      for (int r = 0; r < 4; ++r) bx[r] *= GEGLU_XS, bg[r] *= GEGLU_GS;
 #pragma unroll
       for (int tm = 0; tm < TM; ++tm) {
         const int row = tm * 32 + l31;
+        const float xm = ln_rstd[tm] * p.alpha * GEGLU_XS, gm = ln_rstd[tm] * p.alpha * GEGLU_GS;   // (not LN: rstd = 1, mean = 0)
+        const float xa = -ln_mean[tm] * xm, ga = -ln_mean[tm] * gm;
         float o[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          float x = acc[tm][0][q * 4 + r], g = acc[tm][1][q * 4 + r];
+          float x, g;
           if constexpr (LN) {
-            x = ln_rstd[tm] * (x - ln_mean[tm] * sx[r]);
-            g = ln_rstd[tm] * (g - ln_mean[tm] * sg[r]);
+            x = xm * acc[tm][0][q * 4 + r] + (xa * sx[r] + bx[r]);
+            g = gm * acc[tm][1][q * 4 + r] + (ga * sg[r] + bg[r]);
+          } else {
+            x = xm * acc[tm][0][q * 4 + r] + bx[r];
+            g = gm * acc[tm][1][q * 4 + r] + bg[r];
           }
-          o[r] = (x * p.alpha + bx[r]) * gelu_erf_f(g * p.alpha + bg[r]);
+          o[r] = geglu_scaled(x, g);
         }
         u32x2 pk = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
         *reinterpret_cast<u32x2*>(wb + row * 64 + ((q ^ (row & 3)) << 4) + hi * 8) = pk;

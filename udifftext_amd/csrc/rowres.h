@@ -100,7 +100,10 @@ __global__ void __launch_bounds__(256, 1) rgemm_kernel(const lg::LParams p) {
     for (int i = tid; i < ncol; i += 256) {
       const int n = c0 * 64 + i;
       float* d = reinterpret_cast<float*>(cst) + (i >> 6) * 128 + (i & 63);
-      d[0] = p.bias ? p.bias[n] : 0.f;
+      // GEGLU: the bias carries the operand scale of geglu_scaled (columns [0, 32) of a chunk are x, [32, 64) the gate); the
+      // LayerNorm column sums are multiplied by the row's (scaled) a_add
+      const float bsc = GEGLU ? ((i & 32) ? GEGLU_GS : GEGLU_XS) : 1.0f;
+      d[0] = p.bias ? p.bias[n] * bsc : 0.f;
       d[64] = p.ln_s[n];
     }
   }
@@ -108,6 +111,8 @@ __global__ void __launch_bounds__(256, 1) rgemm_kernel(const lg::LParams p) {
   // ---- this wave's rows: A fragments (B operand of out^T = W x^T: 8 consecutive k at 16 ks + 8 hi of row l31) + LN statistics
   bf16x8_t xf[KS][2];
   float a_mul[2], a_add[2];                              // out = a_mul * acc + a_add * s_n + c_n
+  float g_mul[2], g_add[2];                              // GEGLU: the gate's multipliers (a_* then belong to x), both with the
+                                                         // operand scales of geglu_scaled folded in
 #pragma unroll
   for (int tm = 0; tm < 2; ++tm) {
     const int m = m0 + tm * 32 + l31;
@@ -129,8 +134,10 @@ __global__ void __launch_bounds__(256, 1) rgemm_kernel(const lg::LParams p) {
     const float mean = s / (float)p.K;
     const float var = fmaxf(q / (float)p.K - mean * mean, 0.f);
     const float rstd = __builtin_amdgcn_rsqf(var + p.ln_eps);
-    a_mul[tm] = rstd * p.alpha;
-    a_add[tm] = -mean * rstd * p.alpha;
+    a_mul[tm] = rstd * p.alpha * (GEGLU ? GEGLU_XS : 1.0f);
+    a_add[tm] = -mean * a_mul[tm];
+    g_mul[tm] = rstd * p.alpha * GEGLU_GS;
+    g_add[tm] = -mean * g_mul[tm];
   }
 
   f32x16 acc[2][2][2];                                   // [ping-pong][tm][tn]
@@ -169,8 +176,8 @@ __global__ void __launch_bounds__(256, 1) rgemm_kernel(const lg::LParams p) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const float x = a_mul[tm] * ac[tm][0][q * 4 + r] + (a_add[tm] * sx[r] + bx[r]);
-            const float g = a_mul[tm] * ac[tm][1][q * 4 + r] + (a_add[tm] * sg[r] + bg[r]);
-            o[r] = x * gelu_erf_f(g);
+            const float g = g_mul[tm] * ac[tm][1][q * 4 + r] + (g_add[tm] * sg[r] + bg[r]);
+            o[r] = geglu_scaled(x, g);
           }
           u32x2 pk = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
           *reinterpret_cast<u32x2*>(stg + row * 64 + ((q ^ (row & 3)) << 4) + hi * 8) = pk;
@@ -281,8 +288,8 @@ __global__ void __launch_bounds__(256, 1) rgemm_kernel(const lg::LParams p) {
         for (int rr2 = 0; rr2 < 2; ++rr2) {
           const int r = half * 2 + rr2;
           const float x = a_mul[tm] * ao[tm][0][q * 4 + r] + (a_add[tm] * k2[r] + k0[r]);
-          const float g = a_mul[tm] * ao[tm][1][q * 4 + r] + (a_add[tm] * k3[r] + k1[r]);
-          o[r] = x * gelu_erf_f(g);
+          const float g = g_mul[tm] * ao[tm][1][q * 4 + r] + (g_add[tm] * k3[r] + k1[r]);
+          o[r] = geglu_scaled(x, g);
         }
         if (half == 1) {
           const int row = tm * 32 + l31;
