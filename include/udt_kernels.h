@@ -240,10 +240,11 @@ int udt_mattn_fwd(const void* q, const void* k, const void* v, void* o, const fl
 /* The text cross-attention branch of a transformer block as ONE kernel (csrc/tattn.hip):
  *   out = x + to_out(softmax(to_q(LayerNorm(x)) K^T * scale) V) + bias        reference sgm/modules/attention.py:140-174,326-333
  * The context is constant during sampling and has L <= 12 tokens, so udt_tattn_prepare folds it ONCE per batch into
- * per-sample tables (exact re-association): A' [B][hp][C] bf16 (LayerNorm gamma, to_q and K folded; hp = udt_tattn_hp(heads)
+ * per-sample tables, opaque to the caller (exact re-association; stored in the MFMA fragment order of the consuming kernel): A' [B][hp][C] bf16 (LayerNorm gamma, to_q and K folded; hp = udt_tattn_hp(heads)
  * = 16 columns per head, rounded up to 32), sc [B][hp][2] fp32 (the LayerNorm mean / beta terms), BmT [B][C][hp] bf16 (V and
- * to_out folded).  udt_tattn_fused then needs only the raw rows: x, out bf16 [B * n_tok, C] (C = 64 * heads <= 1280,
- * n_tok % 64 == 0, or % 32 for C > 640); the first `zero_samples` samples attend to an all-zero context and get
+ * to_out folded).  udt_tattn_fused then needs only the raw rows: x, out bf16 [B * n_tok, C]; the kernel is
+ * instantiated for the UNet's three widths — C = 64 * heads with heads = 5, 10, 20 — anything else is UDT_ERR_BAD_SHAPE
+ * (n_tok % 64 == 0, or % 32 for C = 1280); the first `zero_samples` samples attend to an all-zero context and get
  * x + bias (no tables needed when zero_samples == B).
  *   kv: bf16 [B, L, ldkv], k in columns [0, C), v in [C, 2C) (the hoisted to_k|to_v projection); wq: bf16 [C, ldwq] (to_q
  *   weight, rows = output features), wo: bf16 [C, ldwo] (to_out weight); gamma / beta: t_norm; bias: to_out bias. */

@@ -1,7 +1,7 @@
 """Fused text cross-attention launch (udt_tattn_fused) at the UNet's four levels, 8 samples (4 with zero context), in a
 dependent chain inside a hipGraph (out of launch i is x of launch i + 1).   python tools/bench_tattn.py"""
 import math, os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.environ.get("UDT_ROOT") or os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import udifftext_amd
 from udifftext_amd import ops, packing

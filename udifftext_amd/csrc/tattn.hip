@@ -11,6 +11,7 @@
 // and the LayerNorm is folded as well: with A' = diag(gamma) A,  s_j = sum_k A'_kj,  c_j = sum_k beta_k A_kj,
 //   S_j = rstd * (x . A'_j - mean * s_j) + c_j
 // so the kernel multiplies the RAW token rows — no normalised copy, no q, no per-head attention launch:
+// (round 4: the two tables are stored FRAGMENT-MAJOR — see tattn_prepare_a_kernel — not as the row-major matrices named here)
 //   x tile (TT tokens, staged once in LDS: also the residual) -> row mean / rstd -> S = x A' on the MFMAs ->
 //   softmax over each head's 16-column group (12 real + 4 padded columns whose c_j = -1e30) -> P (bf16, LDS) ->
 //   out^T = Bm^T P^T on the MFMAs -> + bias + x -> store.
@@ -26,7 +27,11 @@ namespace {
 
 constexpr int TA_THREADS = 512;        // 8 waves: the MFMA phases are chains of L2-latency-bound steps, more waves hide more of it
 constexpr int TA_WAVES = TA_THREADS / 64;
-constexpr int TA_AHEAD = 5;          // A' K-tiles in flight per wave (the UNet's C / 64 = 5, 10, 20 are multiples)
+// The MFMA phases read their weight-side fragments (A', Bm^T) straight from L2, each once per workgroup: a launch is ONE round of
+// workgroups whose length is a chain of L2 round trips (~1.5 us each), so what counts is how many a wave needs.  Round 4: the
+// sizes are template parameters (NKT = C / 64 K-tiles, hp = 16 NKS score columns), the A' ring holds up to 10 K-tiles (160
+// registers: 2 round trips per score tile at C = 1280 instead of 4), a tile's WHOLE Bm^T row (NKS fragments) is requested before
+// its MFMA chain (1 round trip instead of 5), and the first score tile's A' loads are issued before the wave waits for its x rows.
 
 struct TattnParams {
   const uint16_t* x;       // [M, C] bf16
@@ -48,12 +53,13 @@ UDT_DEVINL f32x16 zero16() {
   return z;
 }
 
-// TT tokens per workgroup (64, or 32 for C = 1280 so that the x tile fits in LDS), 8 waves
-template <int TT>
+// TT tokens per workgroup (64, or 32 for C = 1280 so that the x tile fits in LDS), 8 waves; NKT = C / 64, NKS = hp / 16
+template <int TT, int NKT, int NKS>
 __global__ void __launch_bounds__(TA_THREADS) tattn_fused_kernel(const TattnParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int C = p.C, hp = p.hp;
-  const int nkt = C >> 6;                                   // 64-channel K-tiles of the x tile
+  constexpr int C = NKT * 64, hp = NKS * 16;
+  constexpr int nkt = NKT;                                  // 64-channel K-tiles of the x tile
+  constexpr int TA_AHEAD = NKT <= 10 ? NKT : 8;             // A' K-tiles in flight per wave (C = 1280: 8, the register file is the limit)
   char* const xs = smem;                                    // [nkt][TT][128 B], XOR-swizzled 16-byte slots
   float* const stats = reinterpret_cast<float*>(smem + (size_t)nkt * TT * 128);        // [TT][2]: mean, rstd
   const int prs = hp * 2 + 16;                              // padded row stride of the P tile (bytes)
@@ -67,6 +73,20 @@ __global__ void __launch_bounds__(TA_THREADS) tattn_fused_kernel(const TattnPara
   const int b = (int)(tok0 / p.n_tok);
   const uint16_t* xg = p.x + tok0 * C;
   uint16_t* og = p.out + tok0 * C;
+
+  // ---- the first score tile's A' fragments: independent of x, requested before anything is waited for -----------------
+  const uint16_t* Ab = p.A + (long long)b * hp * C;
+  constexpr int jt = hp >> 5;                               // 32-column tiles of the scores
+  constexpr int tiles1 = jt * (TT / 32);
+  bf16x8_t ar[TA_AHEAD][4];
+  const bool live = b >= p.zero_samples;
+  if (live && wave < tiles1) {
+    const uint16_t* arow = Ab + (long long)(wave / (TT / 32)) * (32 * C) + lane * 8;
+#pragma unroll
+    for (int u = 0; u < TA_AHEAD; ++u)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) ar[u][ks] = *reinterpret_cast<const bf16x8_t*>(arow + (u * 4 + ks) * 512);
+  }
 
   // ---- x tile -> LDS by LDS-DMA: piece = (K-tile kt, 8-row group rg); lane -> row rg*8 + lane/8, slot lane%8 ----------
   {
@@ -131,42 +151,37 @@ __global__ void __launch_bounds__(TA_THREADS) tattn_fused_kernel(const TattnPara
   __syncthreads();
 
   // ---- S^T = A' x^T  (D rows = score columns j, D cols = tokens: a lane owns one token) -> softmax -> P in LDS ---------
-  const uint16_t* Ab = p.A + (long long)b * hp * C;
   const float* scb = p.sc + (long long)b * hp * 2;
-  const int jt = hp >> 5;                                   // 32-column tiles of the scores
-  const int tiles1 = jt * (TT / 32);
   for (int t = wave; t < tiles1; t += TA_WAVES) {
     const int rt = t % (TT / 32), ct = t / (TT / 32);
     const int row = rt * 32 + l31;                          // this lane's token (as MFMA column)
     const int swz = (l31 >> 1) & 7;                         // (row >> 1) & 7 with row = rt*32 + l31
-    const uint16_t* arow = Ab + (long long)(ct * 32 + l31) * C + hi * 8;
+    const uint16_t* arow = Ab + (long long)ct * (32 * C) + lane * 8;          // fragment-major tables: 1 KiB per (K-tile, k-step)
     f32x16 acc = zero16();
     // the A' fragments come straight from L2 (each is used once per workgroup): loads run TA_AHEAD K-tiles ahead of the MFMAs
-    // (a register ring, the K loop unrolled by its length; two ahead left an L2 round trip exposed every other K-tile)
-    bf16x8_t ar[TA_AHEAD][4];
+    // (a register ring, the K loop fully unrolled; the first tile's ring was filled at kernel entry)
+    if (t != wave) {
 #pragma unroll
-    for (int u = 0; u < TA_AHEAD; ++u)
+      for (int u = 0; u < TA_AHEAD; ++u)
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) ar[u][ks] = *reinterpret_cast<const bf16x8_t*>(arow + (u < nkt ? u : 0) * 64 + ks * 16);
-    for (int kt0 = 0; kt0 < nkt; kt0 += TA_AHEAD) {
+        for (int ks = 0; ks < 4; ++ks) ar[u][ks] = *reinterpret_cast<const bf16x8_t*>(arow + (u * 4 + ks) * 512);
+    }
 #pragma unroll
-      for (int u = 0; u < TA_AHEAD; ++u) {
-        const int kt = kt0 + u;
-        if (kt < nkt) {
-          const char* xrow = xs + ((size_t)kt * TT + row) * 128;
-          bf16x8_t af[4], xf[4];
+    for (int kt = 0; kt < nkt; ++kt) {
+      const int u = kt % TA_AHEAD;
+      const char* xrow = xs + ((size_t)kt * TT + row) * 128;
+      bf16x8_t af[4], xf[4];
 #pragma unroll
-          for (int ks = 0; ks < 4; ++ks) {
-            af[ks] = ar[u][ks];
-            xf[ks] = lds_read_frag(xrow + (((ks * 2 + hi) ^ swz) << 4));
-          }
-          const int ktn = (kt + TA_AHEAD < nkt) ? kt + TA_AHEAD : kt;
-#pragma unroll
-          for (int ks = 0; ks < 4; ++ks) ar[u][ks] = *reinterpret_cast<const bf16x8_t*>(arow + ktn * 64 + ks * 16);
-#pragma unroll
-          for (int ks = 0; ks < 4; ++ks) acc = mfma32(af[ks], xf[ks], acc);
-        }
+      for (int ks = 0; ks < 4; ++ks) {
+        af[ks] = ar[u][ks];
+        xf[ks] = lds_read_frag(xrow + (((ks * 2 + hi) ^ swz) << 4));
       }
+      if (kt + TA_AHEAD < nkt) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) ar[u][ks] = *reinterpret_cast<const bf16x8_t*>(arow + ((kt + TA_AHEAD) * 4 + ks) * 512);
+      }
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) acc = mfma32(af[ks], xf[ks], acc);
     }
     const float mean = stats[row * 2], rstd = stats[row * 2 + 1];
     // reg r <-> column j = ct*32 + (r&3) + 8*(r>>2) + 4*hi; regs 0..7 lie in the tile's first head, 8..15 in the second
@@ -210,27 +225,20 @@ __global__ void __launch_bounds__(TA_THREADS) tattn_fused_kernel(const TattnPara
   const uint16_t* Bb = p.BmT + (long long)b * C * hp;
   const int ct_lo = (int)blockIdx.y * (C >> 5) / p.nsplit, ct_hi = ((int)blockIdx.y + 1) * (C >> 5) / p.nsplit;
   const int tiles2 = (ct_hi - ct_lo) * (TT / 32);
-  const int nks = hp >> 4;                                  // 16-wide k-steps over the score columns
+  constexpr int nks = NKS;                                  // 16-wide k-steps over the score columns
   for (int t = wave; t < tiles2; t += TA_WAVES) {
     const int rt = t % (TT / 32), ct = ct_lo + t / (TT / 32);
     const int row = rt * 32 + l31;
-    const uint16_t* brow = Bb + (long long)(ct * 32 + l31) * hp + hi * 8;
+    const uint16_t* brow = Bb + (long long)ct * (32 * hp) + lane * 8;
     const char* prow = pl + (size_t)row * prs + hi * 16;
     f32x16 acc = zero16();
-    bf16x8_t bn[4];                                         // Bm^T fragments four k-steps ahead (L2 latency)
+    bf16x8_t bn[NKS];                                       // the tile's whole Bm^T row: one L2 round trip in front of the chain
 #pragma unroll
-    for (int i = 0; i < 4; ++i) bn[i] = *reinterpret_cast<const bf16x8_t*>(brow + (i < nks ? i : 0) * 16);
-    for (int ks = 0; ks < nks; ks += 2) {
-      const bf16x8_t b0 = bn[0], b1 = bn[1];
-      bn[0] = bn[2];
-      bn[1] = bn[3];
-      const int k2 = (ks + 4 < nks) ? ks + 4 : ks;
-      bn[2] = *reinterpret_cast<const bf16x8_t*>(brow + k2 * 16);
-      bn[3] = *reinterpret_cast<const bf16x8_t*>(brow + k2 * 16 + 16);
-      const bf16x8_t p0 = *reinterpret_cast<const bf16x8_t*>(prow + ks * 32);
-      const bf16x8_t p1 = *reinterpret_cast<const bf16x8_t*>(prow + ks * 32 + 32);
-      acc = mfma32(b0, p0, acc);
-      acc = mfma32(b1, p1, acc);
+    for (int i = 0; i < NKS; ++i) bn[i] = *reinterpret_cast<const bf16x8_t*>(brow + i * 512);
+#pragma unroll
+    for (int ks = 0; ks < nks; ++ks) {
+      const bf16x8_t pf = *reinterpret_cast<const bf16x8_t*>(prow + ks * 32);
+      acc = mfma32(bn[ks], pf, acc);
     }
     if (tok0 + row < p.M) {
       const int swz = (row >> 1) & 7;
@@ -259,10 +267,16 @@ __global__ void __launch_bounds__(256) tattn_prepare_a_kernel(const uint16_t* __
   __shared__ float red[2][4];
   const int j = blockIdx.x, b = blockIdx.y, t = threadIdx.x;
   const int h = j >> 4, i = j & 15;
-  uint16_t* arow = A + ((long long)b * hp + j) * C;
+  // FRAGMENT-MAJOR layout (round 4): the 16 bytes a lane of tattn_fused_kernel loads for (score tile j / 32, K-tile k / 64,
+  // k-step) are contiguous with its neighbours' — every fragment load is one 1-KiB run of whole cache lines
+  uint16_t* const Ab = A + (long long)b * hp * C;
+  const int nkt = C >> 6;
+  auto aoff = [&](int k) {
+    return ((((long long)(j >> 5) * nkt + (k >> 6)) * 4 + ((k >> 4) & 3)) * 64 + ((k >> 3) & 1) * 32 + (j & 31)) * 8 + (k & 7);
+  };
   float* scj = sc + ((long long)b * hp + j) * 2;
   if (h >= heads || i >= L) {
-    for (int k = t; k < C; k += 256) arow[k] = 0;
+    for (int k = t; k < C; k += 256) Ab[aoff(k)] = 0;
     if (t == 0) { scj[0] = 0.f; scj[1] = -1e30f; }
     return;
   }
@@ -274,7 +288,7 @@ __global__ void __launch_bounds__(256) tattn_prepare_a_kernel(const uint16_t* __
 #pragma unroll 8
     for (int d = 0; d < 64; ++d) a += bf16_bits_to_f32(wq[(long long)(h * 64 + d) * ldwq + k]) * kvec[d];
     const uint32_t pk = pack_bf16x2(a * gamma[k], 0.f);
-    arow[k] = (uint16_t)(pk & 0xffffu);
+    Ab[aoff(k)] = (uint16_t)(pk & 0xffffu);
     s += bf16_lo(pk);
     c += beta[k] * a;
   }
@@ -305,7 +319,9 @@ __global__ void __launch_bounds__(256) tattn_prepare_b_kernel(const uint16_t* __
 #pragma unroll 8
     for (int d = 0; d < 64; ++d) a += bf16_bits_to_f32(vr[d]) * bf16_bits_to_f32(wr[d]);
   }
-  BmT[idx] = (uint16_t)(pack_bf16x2(a, 0.f) & 0xffffu);
+  // fragment-major: (channel tile c / 32, k-step j / 16) -> 64 lanes x 16 bytes
+  const long long off = ((((long long)(c >> 5) * (hp >> 4) + (j >> 4)) * 64) + ((j >> 3) & 1) * 32 + (c & 31)) * 8 + (j & 7);
+  BmT[(long long)b * C * hp + off] = (uint16_t)(pack_bf16x2(a, 0.f) & 0xffffu);
 }
 
 }  // namespace
@@ -351,7 +367,7 @@ extern "C" int udt_tattn_fused(const void* x, void* out, const void* A, const fl
     snprintf(tag, sizeof(tag), "tattn_fused B=%d n=%d C=%d zero=%d", B, n_tok, C, zero_samples);
     udt_prof_tag(prof.rec, tag);
   }
-  static bool attr64 = false, attr32 = false;                // (max dynamic LDS; set once per process — one device per process)
+  static bool attr_done[3] = {false, false, false};          // (max dynamic LDS; set once per process — one device per process)
   const unsigned grid = (unsigned)(p.M / TT);
   // few token tiles (the 16x16 / 8x8 levels): split the output channels over up to 4 workgroups per tile so that the
   // launch covers >= ~128 CUs; every split recomputes the statistics and scores of its tile (a third of the work)
@@ -360,21 +376,21 @@ extern "C" int udt_tattn_fused(const void* x, void* out, const void* A, const fl
   constexpr unsigned target = 256u;
   p.nsplit = 1;
   while (p.nsplit < 8 && grid * p.nsplit < target) p.nsplit *= 2;
-  if (TT == 64) {
-    if (!attr64) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(tattn_fused_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024);
-      if (e != hipSuccess) return udt_set_hip_error(e);
-      attr64 = true;
-    }
-    hipLaunchKernelGGL(tattn_fused_kernel<64>, dim3(grid, p.nsplit), dim3(TA_THREADS), smem, s, p);
-  } else {
-    if (!attr32) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(tattn_fused_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024);
-      if (e != hipSuccess) return udt_set_hip_error(e);
-      attr32 = true;
-    }
-    hipLaunchKernelGGL(tattn_fused_kernel<32>, dim3(grid, p.nsplit), dim3(TA_THREADS), smem, s, p);
+  // instances: the UNet's three widths (C = 320 / 640 / 1280 with 5 / 10 / 20 heads: hp = 80 -> padded 96, 160, 320)
+  const void* fn = nullptr;
+  int which = -1;
+  if (C == 320 && p.hp == 96) { fn = reinterpret_cast<const void*>(tattn_fused_kernel<64, 5, 6>); which = 0; }
+  else if (C == 640 && p.hp == 160) { fn = reinterpret_cast<const void*>(tattn_fused_kernel<64, 10, 10>); which = 1; }
+  else if (C == 1280 && p.hp == 320) { fn = reinterpret_cast<const void*>(tattn_fused_kernel<32, 20, 20>); which = 2; }
+  else return UDT_ERR_BAD_SHAPE;
+  if (!attr_done[which]) {
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024);
+    if (e != hipSuccess) return udt_set_hip_error(e);
+    attr_done[which] = true;
   }
+  void* args[] = {&p};
+  hipError_t el = hipLaunchKernel(fn, dim3(grid, p.nsplit), dim3(TA_THREADS), args, smem, s);
+  if (el != hipSuccess) return udt_set_hip_error(el);
   UDT_CHECK_LAUNCH();
   return UDT_OK;
 }
