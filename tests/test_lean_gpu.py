@@ -41,7 +41,7 @@ def env(cuda):
 
         @staticmethod
         def reset():
-            for k in ("lean", "lean_splitk", "lean_conv", "wide_conv"):
+            for k in ("lean", "lean_splitk", "lean_conv", "wide_conv", "rowres"):
                 L.check(lib.udt_debug_set(k.encode(), -1), "udt_debug_set " + k)
     yield Env
     Env.reset()

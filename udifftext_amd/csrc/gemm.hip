@@ -778,17 +778,10 @@ int lean_mode() {
   return v;
 }
 
-// udt_debug_set("rowres", v): 1 (default) the row-resident kernel where it applies, 0 never (A/B; UDT_ROWRES in the environment)
-std::atomic<int> g_rowres{-1};
-bool rowres_on() {
-  int v = g_rowres.load(std::memory_order_relaxed);
-  if (v < 0) {
-    const char* e = getenv("UDT_ROWRES");
-    v = (e && e[0] == '0') ? 0 : 1;
-    g_rowres.store(v, std::memory_order_relaxed);
-  }
-  return v != 0;
-}
+// udt_debug_set("rowres", v): 1 (default) the row-resident kernel where it applies, 0 never (same-process A/B, tools/ab_step.py;
+// a tuning knob of the debug interface like "lean_splitk", not an environment switch)
+std::atomic<int> g_rowres{1};
+bool rowres_on() { return g_rowres.load(std::memory_order_relaxed) != 0; }
 
 bool lean_plan(const udt_gemm_desc* d, LeanPlan& t, bool want_stats) {
   const int mode = lean_mode();
@@ -1042,7 +1035,7 @@ extern "C" int udt_debug_set(const char* key, int32_t value) {
   if (!strcmp(key, "n_block")) { g_n_block.store(value); return UDT_OK; }
   if (!strcmp(key, "rows_epi")) { g_rows_epi.store(value ? 1 : 0); return UDT_OK; }
   if (!strcmp(key, "lean")) { g_lean.store(value < 0 ? -2 : value); return UDT_OK; }
-  if (!strcmp(key, "rowres")) { g_rowres.store(value); return UDT_OK; }
+  if (!strcmp(key, "rowres")) { g_rowres.store(value < 0 ? 1 : (value ? 1 : 0)); return UDT_OK; }
   if (!strcmp(key, "lean_splitk")) { g_lean_splitk.store(value); return UDT_OK; }
   if (!strcmp(key, "lean_conv")) { g_lean_conv.store(value < 0 ? -1 : (value ? 1 : 0)); return UDT_OK; }
   if (!strcmp(key, "wide_conv")) { g_wide_conv.store(value < 0 ? -1 : (value ? 1 : 0)); return UDT_OK; }
