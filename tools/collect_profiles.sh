@@ -15,7 +15,7 @@ d = json.load(open(p)); d["head"] = "$UDT_HEAD"; json.dump(d, open(p, "w"))
 PY
 done; }
 # 0. the GPU test suite and the smoke test at this commit
-(cd $R && python -m pytest tests -m gpu -q 2>&1 | tail -4 | grep -v "^$" > $O/gpu_tests.log; python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | grep smoke >> $O/gpu_tests.log)
+(cd $R && python -m pytest tests -m gpu -q 2>&1 | grep -E "passed|failed|error" | tail -3 > $O/gpu_tests.log; python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | grep smoke >> $O/gpu_tests.log)
 stamp $O/gpu_tests.log
 cd /tmp && export TMPDIR=/tmp
 # 1. the bench line (default flags = what the driver runs)
