@@ -813,7 +813,9 @@ bool lean_plan(const udt_gemm_desc* d, LeanPlan& t, bool want_stats) {
   // 7 = rowres.h: the LayerNorm-folded projections with K = 320 and enough rows to give every CU a 256-row block: the rows'
   // A fragments stay in registers, the weights stream through LDS in 64-row chunks; automatic where it applies
   if (mode == 7 || (mode < 0 && rowres_on())) {
-    if (ln && !want_stats && d->K == 320 && d->N % 64 == 0 && !d->residual && !d->rowvec && !conv1) {
+    // (its A fragments are 16-byte vector loads straight from global memory: a 16-byte aligned base; lda % 8 == 0 is checked above)
+    if (ln && !want_stats && d->K == 320 && d->N % 64 == 0 && !d->residual && !d->rowvec && !conv1 &&
+        (reinterpret_cast<uintptr_t>(d->a) & 15) == 0) {
       const int tiles_m = (d->M + 255) / 256, chunks = d->N / 64;
       int ns = (device_cus() + tiles_m - 1) / tiles_m;           // column splits: one workgroup per CU ...
       if (ns > chunks / 4) ns = chunks / 4;                       // ... of at least 4 chunks (the A load amortised)
