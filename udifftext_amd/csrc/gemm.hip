@@ -983,7 +983,9 @@ bool lean_conv_plan(const udt_gemm_desc* d, lg::C3Params& c, bool want_stats) {
   const int knob = lean_splitk_knob();
   if (c.tiles <= 1023) {
     if (knob > 1) { sk = knob; if (sk > c.chunks) sk = c.chunks; }          // forced (tests / A-B): any cut the chunks allow
-    else if (knob < 0 && c.tiles * 2 <= slots && c.chunks >= 10) { sk = slots / c.tiles; if (sk > c.chunks / 5) sk = c.chunks / 5; }
+    // (slices of >= 4 chunks = 36 taps; round 4: was >= 5 — 8 x 8 maps, 1280 -> 1280 on 8 samples: 5 slices 29.2 us, 4 slices 32.1 us,
+    //  profiles/r04_pair_conv_rejected.txt)
+    else if (knob < 0 && c.tiles * 2 <= slots && c.chunks >= 10) { sk = slots / c.tiles; if (sk > c.chunks / 4) sk = c.chunks / 4; }
     while (sk > 1 && (long long)c.tiles * sk * c.tw * c.th * c.bn * 4 > (64LL << 20)) --sk;
     if (sk < 1) sk = 1;
   }
