@@ -56,25 +56,30 @@ UDT_DEVINL float gelu_erf_f(float x) {
 }
 
 // GEGLU output x * GELU(g) from PRE-SCALED operands xs = GEGLU_XS * x, gs = GEGLU_GS * g (the callers fold the two constants into
-// their bias / LayerNorm / alpha multipliers): the same Abramowitz-Stegun erf as gelu_erf_f with
-//   gs = g / sqrt(2) * sqrt(log2 e)  ->  exp(-z^2) = exp2(-gs^2),  1 + p z = 1 + (p / sqrt(log2 e)) |gs|
-//   x GELU(g) = 0.5 x g + 0.5 x |g| erf(|g| / sqrt 2) = xs gs + xs |gs| (1 - poly e)
-// 13 VALU instructions (two transcendental) instead of 17 behind un-scaled operands: the scaling multiplies, the sign transfer
-// and the 0.5 (1 + erf) step are gone.  The hot GEGLU epilogues (lean.h, rowres.h) are VALU-issue bound (profiles/r04_rowres.txt).
+// their bias / LayerNorm / alpha multipliers), exact-erf GELU (F.gelu default):
+//   x GELU(g) = 0.5 x g + 0.5 x |g| erf(|g| / sqrt 2) = xs gs + xs |gs| (1 - erfc(z)),   z = |g| / sqrt 2 = |gs| / sqrt(log2 e)
+// with erfc(z) = 2^P(|gs|): log2 erfc is smooth and nearly quadratic, a degree-6 polynomial through the origin (least squares on
+// Chebyshev nodes of z in [0, 6], weighted by erfc, so that the ABSOLUTE error of erfc is what is minimised) is within 2.9e-7 of
+// erfc — the accuracy of Abramowitz-Stegun 7.1.26 (1.5e-7), which gelu_erf_f uses, without its reciprocal: 11 VALU instructions, ONE
+// transcendental, against 13 with two for the A-S form on the same pre-scaled operands (and 17 + 2 behind un-scaled ones).  fp32
+// evaluation over g in [-12, 12]: max |error| / (|x g| + 1e-3) = 3.5e-7, identical to the A-S form's 3.4e-7 (tools/fit_erfc_poly.py
+// regenerates the coefficients and the comparison).  |gs| is clamped at z = 6 (erfc < 2e-17) before the polynomial.
+// The hot GEGLU epilogues (lean.h, rowres.h) are bound by this arithmetic (profiles/r04_rowres.txt, r04_rowmlp_rejected.txt).
 constexpr float GEGLU_GS = 0.70710678118654752f * 1.2011224087864498f;     // 1/sqrt(2) * sqrt(log2 e)
 constexpr float GEGLU_XS = 0.5f / GEGLU_GS;
 UDT_DEVINL float geglu_scaled(float xs, float gs) {
-  const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f / 1.2011224087864498f, fabsf(gs), 1.0f));
-  float poly = 1.061405429f;
-  poly = poly * t - 1.453152027f;
-  poly = poly * t + 1.421413741f;
-  poly = poly * t - 0.284496736f;
-  poly = poly * t + 0.254829592f;
-  poly = poly * t;
-  const float e = __builtin_amdgcn_exp2f(-(gs * gs));
+  const float t = fminf(fabsf(gs), 7.2067347f);
+  float P = 5.1346913e-05f;
+  P = P * t - 0.001489955f;
+  P = P * t + 0.014895574f;
+  P = P * t - 0.086436f;
+  P = P * t - 0.636406f;
+  P = P * t - 1.3553386f;
+  P = P * t;
+  const float e = __builtin_amdgcn_exp2f(P);              // erfc(|g| / sqrt 2)
   const float ha = xs * fabsf(gs);
   const float hs = __builtin_fmaf(xs, gs, ha);
-  return __builtin_fmaf(-ha, poly * e, hs);
+  return __builtin_fmaf(-ha, e, hs);
 }
 
 // 16-byte global -> LDS DMA.  `lds_wave_base` must be wave-uniform; lane l lands at base + 16*l.
