@@ -91,6 +91,13 @@ typedef enum {
                                           alpha = 1 / activation scale, colscale = per-channel weight
                                           scale.  Linears only (plain / GEGLU / transposed), N > 64.   */
 
+#define UDT_GEMM_MX8         (1 << 7)  /* config #5, second generation: a is an MX8 activation — OCP e4m3
+                                          bytes [M, lda] + one E8M0 block scale per 32 K-elements of a
+                                          row (a_scale) — and w is e4m3 [N, ldw] + per-channel fp32 scales
+                                          (colscale); K % 128 == 0, lda / ldw % 16 == 0.  Plain, LayerNorm-
+                                          folded (rowstat_in) and GEGLU epilogues on the lean kernel family;
+                                          see the q8_out / rowstat_* fields.                              */
+
 typedef struct {
   /* operands */
   const void* a;        /* bf16 [M, lda] (plain) or NHWC source 1 [B, Hin, Win, C1] (conv)        */
@@ -136,6 +143,21 @@ typedef struct {
      row's mean / rstd from the A tiles it streams and computes out = rstd (x w^T - mean s) + c.  K = normalised width. */
   const float* ln_colsum;
   float ln_eps;
+  /* MX8 activations (UDT_GEMM_MX8 and the emitting epilogues; reference call sites: every nn.Linear of the transformer blocks,
+     attention.py:44-70,193-199,375-411).  An MX8 activation of C columns is (elements: e4m3 bytes [M, ld >= C];
+     scales: uint32 [ceil(C / 128)][M], byte j of dword (t, m) = E8M0 scale of columns [128 t + 32 j, + 32) of row m:
+     value = e4m3 * 2^(scale - 127)).                                                                                   */
+  const void* a_scale;     /* UDT_GEMM_MX8: the block scales of `a`                                                     */
+  void* q8_out;            /* optional second output: the result (after bias / residual / GEGLU, as rounded for `out`) again
+                              as an MX8 activation for the next GEMM; with UDT_GEMM_GEGLU `out` may then be NULL.  Lean
+                              128 x 128 plans only (udt_gemm_rowstat_parts > 0), N % 32 == 0 (GEGLU: N % 64 == 0)         */
+  void* q8_scale;          /* its block scales (see above)                                                               */
+  int32_t ld_q8;           /* bytes between rows of q8_out (% 8 == 0)                                                    */
+  float* rowstat_out;      /* optional, with q8_out (not GEGLU): fp32 [udt_gemm_rowstat_parts(d)][M][2] partial (sum, sum of
+                              squares) of every result row — the LayerNorm statistics of a LayerNorm-folded MX8 consumer  */
+  const float* rowstat_in; /* UDT_GEMM_MX8 with ln_colsum: the partial row statistics of `a` its producer emitted,
+                              fp32 [rowstat_in_parts][M][2]; summed in index order (deterministic)                        */
+  int32_t rowstat_in_parts;
 } udt_gemm_desc;
 
 /* workspace (bytes) udt_gemm needs for this problem (split-K slabs); 0 if none.  The first 4 KiB of a workspace are
@@ -149,6 +171,9 @@ int udt_gemm(const udt_gemm_desc* d, void* workspace, size_t workspace_bytes, vo
  * slots_per_sample = rows_per_batch / rows) and the number of slots.  0 = this problem cannot emit them (transposed /
  * GEGLU / fp32 outputs, first-generation kernel, rows_per_batch not a multiple of the slot). */
 int32_t udt_gemm_colstats_rows(const udt_gemm_desc* d);
+/* Parts of the partial row statistics (rowstat_out) udt_gemm would emit for this problem = N / (columns per wave of the plan);
+ * 0 = the plan has no MX8-emitting epilogue (q8_out / rowstat_out must then be NULL). */
+int32_t udt_gemm_rowstat_parts(const udt_gemm_desc* d);
 int32_t udt_gemm_colstats_slots(const udt_gemm_desc* d);
 /* 1 if udt_gemm accepts `in_scsh` for this problem (patch-staged 3x3 convolution geometry; one or two NHWC sources). */
 int32_t udt_gemm_in_scsh_ok(const udt_gemm_desc* d);

@@ -1,0 +1,179 @@
+"""BASELINE config #5, second generation: the MX8 (e4m3 elements + E8M0 block scales) linears of the transformer blocks — the
+lean GEMM's FP8 / EMIT instances (csrc/lean.h), the MX8-emitting epilogues of the producers (lean GEMM, fused text
+cross-attention, flash attention, GroupNorm apply) — against plain PyTorch fp32 restatements on the SAME quantised operands
+(tests/mx8_ref.py decodes the kernels' format), through the C ABI.  ``pytest -m gpu``.
+
+Reference ops: every nn.Linear of sgm/modules/attention.py:44-70 (GEGLU / FeedForward), :193-199 (to_q / to_k / to_v / to_out),
+:375-411 (proj_in / proj_out), with the LayerNorms of :310-339 folded in.
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+import mx8_ref
+
+pytestmark = pytest.mark.gpu
+
+# stated tolerances
+#   GEMM on given e4m3 operands vs fp32 torch on the same dequantised operands: fp32 accumulation order + ONE bf16 rounding
+REL_GEMM = 5e-3
+#   an emitted MX8 activation vs the bf16 result it twins: e4m3 rounding, 3 mantissa bits: relative rms 2^-4 / sqrt(12) * ~1.4
+REL_Q8 = 4e-2
+
+
+def _rel(a, b):
+    a, b = a.float(), b.float()
+    return ((a - b).pow(2).mean().sqrt() / b.pow(2).mean().sqrt().clamp_min(1e-30)).item()
+
+
+@pytest.fixture(scope="module")
+def env(cuda):
+    import udifftext_amd  # noqa: F401
+    from udifftext_amd import lib as L, ops as O, packing as P
+    lib = L.load()
+    assert lib.udt_device_arch_ok() == 1, "tests expect a gfx950 device"
+
+    class Env:
+        ops, packing, GEGLU, lib_mod = O, P, L.GEMM_GEGLU, L
+    return Env
+
+
+def _check_q8(q8, ref_bf16, stats=True):
+    """an emitted Mx8Act against the bf16 tensor it twins: decoded values, block scales tight (amax / scale in (224, 448]),
+    partial row statistics"""
+    dec = mx8_ref.decode(q8.data, q8.scale)
+    ref = ref_bf16.float()
+    assert _rel(dec, ref) < REL_Q8
+    M, K = ref.shape
+    amax = ref.reshape(M, K // 32, 32).abs().amax(dim=2)
+    qmax = q8.data.view(torch.float8_e4m3fn).float().reshape(M, K // 32, 32).abs().amax(dim=2)
+    live = amax > 1e-20
+    assert float(qmax[live].max()) <= 448.0
+    assert float((qmax[live] > 200.0).float().mean()) > 0.99      # every block uses the top binades (bf16 vs fp32 amax: a few ulps)
+    # element-wise: |dec - ref| <= half an e4m3 step at the block's scale (2^-4 of the value's binade, <= amax / 16) + the bf16 rounding
+    # of the twin
+    bound = (amax / 14.0)[:, :, None].expand(M, K // 32, 32).reshape(M, K) + ref.abs() * 2.0 ** -7 + 1e-30
+    assert bool(((dec - ref).abs() <= bound).all())
+    if stats and q8.stats is not None:
+        s = q8.stats.sum(dim=0)
+        assert torch.allclose(s[:, 0], ref.sum(dim=1), rtol=2e-2, atol=2e-2 * float(ref.abs().sum(dim=1).mean()))
+        assert torch.allclose(s[:, 1], ref.pow(2).sum(dim=1), rtol=2e-2)
+
+
+@pytest.mark.parametrize("M,N,K,res", [(2048, 1280, 1280, True), (8192, 640, 640, False), (520, 1280, 1280, True),
+                                       (2048, 640, 2560, True)])
+def test_bf16_linear_emits_mx8_twin_and_row_statistics(env, cuda, M, N, K, res):
+    """proj_in in config #5: a bf16 GEMM whose epilogue also writes its result as an MX8 activation + partial row statistics"""
+    g = torch.Generator(device="cpu").manual_seed(1)
+    x = torch.randn((M, K), generator=g).to(cuda).bfloat16()
+    w = (torch.randn((N, K), generator=g) / math.sqrt(K)).to(cuda)
+    b = torch.randn((N,), generator=g).to(cuda)
+    r = (torch.randn((M, N), generator=g) * 3).to(cuda).bfloat16() if res else None
+    # rows of very different magnitude: the block scales must follow them
+    x = (x.float() * torch.logspace(-2, 2, M, device=cuda)[:, None]).bfloat16()
+    wp = env.packing.pack_linear(w)
+    plain = env.ops.linear(x, wp, b, residual=r)
+    out = env.ops.linear(x, wp, b, residual=r, emit_q8=True, emit_rowstats=True)
+    q8 = env.ops.mx8_of(out)
+    assert q8 is not None and q8.stats is not None and q8.stats.shape[0] == N // 64
+    assert torch.equal(out, plain)                               # the bf16 result is the non-emitting kernel's, bit for bit
+    _check_q8(q8, out)
+
+
+def _mx8_operands(env, dev, M, N, K, seed, geglu=False, ln=False):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    x = torch.randn((M, K), generator=g).to(dev)
+    x = x * torch.logspace(-1, 1, M, device=dev)[:, None] + (0.3 if ln else 0.0)
+    w = (torch.randn((N, K), generator=g) / math.sqrt(K)).to(dev) * (1.0 + torch.arange(N, device=dev)[:, None] / N)
+    b = torch.randn((N,), generator=g).to(dev)
+    xq, xs = mx8_ref.encode(x)
+    return x, mx8_ref.decode(xq, xs), xq, xs, w, b, g
+
+
+@pytest.mark.parametrize("M,N,K,res,stats", [(2048, 1280, 5120, True, False), (8192, 640, 2560, True, False),
+                                             (2048, 1280, 1280, True, True), (8192, 640, 640, False, True),
+                                             (520, 1280, 1280, True, False), (200, 256, 128, False, False)])
+def test_mx8_linear_vs_torch_on_the_same_quantised_operands(env, cuda, M, N, K, res, stats):
+    """ff.net[2] / to_out / proj_out in config #5 (plain epilogue; proj_out also emits the next GroupNorm's column statistics)"""
+    x, xd, xq, xs, w, b, g = _mx8_operands(env, cuda, M, N, K, seed=2)
+    wq, cs = env.packing.pack_linear_fp8(w)
+    wd = wq.view(torch.float8_e4m3fn).float() * cs[:, None]
+    r = torch.randn((M, N), generator=g).to(cuda).bfloat16() if res else None
+    ref = xd @ wd.t() + b + (r.float() if res else 0.0)
+    act = env.ops.Mx8Act(xq, xs)
+    rpb = M // 8 if (stats and M % 8 == 0) else 0
+    out = env.ops.linear_mx8(act, wq, cs, b, residual=r, rows_per_batch=rpb, colstats=stats)
+    assert _rel(out, ref) < REL_GEMM
+    if stats:
+        st = env.ops.gn_stats_of(out)
+        assert st is not None
+        tot = st.data.reshape(8, st.slots_per_sample, N, 2).sum(dim=1)
+        o3 = out.float().reshape(8, M // 8, N)
+        assert torch.allclose(tot[..., 0], o3.sum(dim=1), rtol=1e-3, atol=1e-2 * float(o3.abs().sum(dim=1).mean()))
+    # the same launch with the MX8 twin of its result (ff.net[2] -> proj_out)
+    if N % 128 == 0 and not stats:
+        out2 = env.ops.linear_mx8(act, wq, cs, b, residual=r, emit_q8=True)
+        assert torch.equal(out2, out)
+        _check_q8(env.ops.mx8_of(out2), out2, stats=False)
+    # against the UN-quantised product: the price of e4m3 operands (reported, loosely bounded)
+    full = x @ w.t() + b + (r.float() if res else 0.0)
+    print(f"mx8 linear {M}x{N}x{K}: vs same-operand fp32 {_rel(out, ref):.2e}, vs unquantised fp32 {_rel(out, full):.2e}")
+    assert _rel(out, full) < 6e-2
+
+
+@pytest.mark.parametrize("M,N,K", [(2048, 3840, 1280), (8192, 1920, 640), (520, 3840, 1280)])
+def test_mx8_layernorm_folded_linear(env, cuda, M, N, K):
+    """attn1's q|k|v in config #5: LayerNorm folded into an MX8 GEMM, the row statistics from the producer's partial sums"""
+    x, xd, xq, xs, w, _, g = _mx8_operands(env, cuda, M, N, K, seed=3, ln=True)
+    gamma = (1.0 + 0.2 * torch.randn((K,), generator=g)).to(cuda)
+    beta = (0.1 * torch.randn((K,), generator=g)).to(cuda)
+    wq, cs, c, s = env.packing.pack_ln_linear_mx8(w, None, gamma, beta)
+    # partial statistics as a producer would emit them: P parts of K / P columns each, of the UN-quantised rows
+    P = K // 64
+    parts = torch.stack([x.reshape(M, P, 64).sum(dim=2).t(), x.reshape(M, P, 64).pow(2).sum(dim=2).t()], dim=2).contiguous()
+    act = env.ops.Mx8Act(xq, xs, parts)
+    out = env.ops.linear_mx8(act, wq, cs, ln_c=c, ln_s=s, eps=1e-5)
+    mean = x.mean(dim=1, keepdim=True)
+    rstd = (x.var(dim=1, unbiased=False, keepdim=True) + 1e-5).rsqrt()
+    wd = wq.view(torch.float8_e4m3fn).float() * cs[:, None]
+    ref = rstd * (xd @ wd.t() - mean * s[None, :]) + c[None, :]
+    assert _rel(out, ref) < REL_GEMM
+    full = F.layer_norm(x, (K,), gamma, beta, 1e-5) @ w.t()
+    print(f"mx8 ln-linear {M}x{N}x{K}: vs same-operand fp32 {_rel(out, ref):.2e}, vs unquantised fp32 {_rel(out, full):.2e}")
+    assert _rel(out, full) < 6e-2
+
+
+@pytest.mark.parametrize("M,N,K", [(2048, 10240, 1280), (8192, 5120, 640), (520, 10240, 1280)])
+def test_mx8_layernorm_folded_geglu_emits_mx8_hidden(env, cuda, M, N, K):
+    """ff.net[0] in config #5: LayerNorm + GEGLU on MX8 operands, the hidden activation written as MX8 only"""
+    x, xd, xq, xs, w, b, g = _mx8_operands(env, cuda, M, N, K, seed=4, ln=True)
+    gamma = (1.0 + 0.2 * torch.randn((K,), generator=g)).to(cuda)
+    beta = (0.1 * torch.randn((K,), generator=g)).to(cuda)
+    wq, cs, c, s = env.packing.pack_ln_linear_mx8(w, b, gamma, beta, geglu=True)
+    P = K // 64
+    parts = torch.stack([x.reshape(M, P, 64).sum(dim=2).t(), x.reshape(M, P, 64).pow(2).sum(dim=2).t()], dim=2).contiguous()
+    act = env.ops.Mx8Act(xq, xs, parts)
+    both = env.ops.linear_mx8(act, wq, cs, ln_c=c, ln_s=s, flags=env.GEGLU, emit_q8=True)
+    only = env.ops.linear_mx8(act, wq, cs, ln_c=c, ln_s=s, flags=env.GEGLU, emit_q8=True, want_bf16=False)
+    mean = x.mean(dim=1, keepdim=True)
+    rstd = (x.var(dim=1, unbiased=False, keepdim=True) + 1e-5).rsqrt()
+    wd = wq.view(torch.float8_e4m3fn).float() * cs[:, None]
+    y = rstd * (xd @ wd.t() - mean * s[None, :]) + c[None, :]
+    inv = torch.empty(N, dtype=torch.long)
+    inv[env.packing.geglu_permutation(N // 2)] = torch.arange(N)
+    y = y[:, inv.to(cuda)]                                          # back to [x | gate] order
+    ref = y[:, :N // 2] * F.gelu(y[:, N // 2:])
+    assert _rel(both, ref) < 8e-3
+    _check_q8(env.ops.mx8_of(both), both, stats=False)
+    assert isinstance(only, env.ops.Mx8Act)
+    assert torch.equal(only.data, env.ops.mx8_of(both).data) and torch.equal(only.scale, env.ops.mx8_of(both).scale)
+
+
+def test_mx8_problems_outside_the_lean_family_are_refused(env, cuda):
+    """UDT_GEMM_MX8 has no fallback kernel: a problem the lean plan declines is an error, not a silent bf16 read of e4m3 bytes"""
+    x, xd, xq, xs, w, b, g = _mx8_operands(env, cuda, 256, 64, 128, seed=5)          # N <= 64: first-generation kernel territory
+    wq, cs = env.packing.pack_linear_fp8(w)
+    with pytest.raises(ValueError):
+        env.ops.linear_mx8(env.ops.Mx8Act(xq, xs), wq, cs, b)

@@ -117,6 +117,67 @@ UDT_DEVINL f32x16 mfma32_fp8(i32x8_t a, i32x8_t b, f32x16 c) {
   return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 0, 0, 0, 127, 0, 127);
 }
 
+// MX (microscaling) form of the same instruction.  The 64 k of one instruction are TWO scale blocks, k in [0, 32) and [32, 64);
+// lane (row l31, half h) holds k = 16 h + [0, 16) in registers 0..3 and k = 32 + 16 h + [0, 16) in registers 4..7, and byte OPSEL of
+// the scale VGPR of the row's h = 0 lane scales block 0, the h = 1 lane's byte block 1 (tools/probes/mx_scale_layout.cpp,
+// mx_elem_block.cpp, mx_scale_diag.cpp — measured on MI355X; NOT "a lane scales its own 32 elements").  Here the ACTIVATION
+// fragment (the MFMA's B operand, see gemm.hip: the weight fragment is the A operand) carries the block scales, the weight side
+// keeps the unit scale (its per-output-channel fp32 scale is applied to the accumulators).  OPSEL is an instruction immediate.
+template <int OPSEL>
+UDT_DEVINL f32x16 mfma32_mx8(i32x8_t w, i32x8_t x, f32x16 c, int scale) {
+  return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(w, x, c, 0, 0, 0, 127, OPSEL, scale);
+}
+
+// ---- MX8 activations: OCP e4m3 elements + one E8M0 scale per 32 consecutive K-elements of a row ---------------------------
+// Layout in memory (udt_gemm_desc.a_scale / q8_scale): elements [M][K] bytes; scales as uint32 [K / 128][M] — dword (kt, m)
+// holds the four block scales of K-tile kt of row m (byte j = block 4 kt + j), so a consumer lane fetches the scales of a whole
+// 128-element LDS row with one aligned, row-coalesced dword load.
+// The scale of a block is the smallest power of two 2^(s-127) with amax / 2^(s-127) <= 448 (the largest e4m3): the conversion
+// never saturates, and every block uses the top two binades of the format.
+UDT_DEVINL uint32_t mx8_scale_byte(float amax) {
+  // amax <= 1.75 * 2^p  <=>  amax * 4/7 <= 2^p; the constant sits a few ulps ABOVE 4/7, so a boundary case picks the coarser scale
+  const uint32_t e = (__float_as_uint(amax * 0.57142866f) >> 23) & 0xffu;
+  return e > 7u ? e - 7u : 0u;
+}
+UDT_DEVINL float mx8_inv_scale(uint32_t s) { return __uint_as_float((254u - s) << 23); }     // 2^(127 - s), s <= 247
+UDT_DEVINL uint32_t mx8_pack4(float a, float b, float c, float d) {
+  int r = 0;
+  r = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, r, false);
+  r = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, r, true);
+  return (uint32_t)r;
+}
+template <int CTRL>
+UDT_DEVINL float dpp_max(float v) {
+  const int t = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false);
+  return fmaxf(v, __builtin_bit_cast(float, t));
+}
+// Row layout (a lane owns 8 consecutive columns, the 4 lanes of an aligned quad own one 32-column block): quantise the block;
+// returns the lane's 8 bytes, `sbyte` = the block's scale (the same in all four lanes)
+UDT_DEVINL u32x2 mx8_quant_row8(const float (&o)[8], uint32_t& sbyte) {
+  float a = fmaxf(fmaxf(fmaxf(fabsf(o[0]), fabsf(o[1])), fmaxf(fabsf(o[2]), fabsf(o[3]))),
+                  fmaxf(fmaxf(fabsf(o[4]), fabsf(o[5])), fmaxf(fabsf(o[6]), fabsf(o[7]))));
+  a = dpp_max<0xB1>(a);       // lane ^ 1
+  a = dpp_max<0x4E>(a);       // lane ^ 2
+  sbyte = mx8_scale_byte(a);
+  const float m = mx8_inv_scale(sbyte);
+  u32x2 r = {mx8_pack4(o[0] * m, o[1] * m, o[2] * m, o[3] * m), mx8_pack4(o[4] * m, o[5] * m, o[6] * m, o[7] * m)};
+  return r;
+}
+// Accumulator layout of a 32 x 32 MFMA tile whose D rows are the CHANNELS (lane = (row l31, half hi) holds channels
+// 8 q + 4 hi + e, q = 0..3, e = 0..3, of its row's 32-channel block; the other 16 sit in lane ^ 32): quantise the block;
+// out[q] = the 4 bytes of channels 8 q + 4 hi .. + 3
+UDT_DEVINL void mx8_quant_acc16(const float (&v)[16], uint32_t (&out)[4], uint32_t& sbyte) {
+  float a = 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) a = fmaxf(a, fabsf(v[r]));
+  const auto sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, a), false, false);
+  a = fmaxf(__builtin_bit_cast(float, (unsigned)sw[0]), __builtin_bit_cast(float, (unsigned)sw[1]));
+  sbyte = mx8_scale_byte(a);
+  const float m = mx8_inv_scale(sbyte);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) out[q] = mx8_pack4(v[q * 4] * m, v[q * 4 + 1] * m, v[q * 4 + 2] * m, v[q * 4 + 3] * m);
+}
+
 // ---- cross-lane sums without LDS traffic ---------------------------------------------------------------------------
 // DPP row operations (quad_perm / row_ror inside a row of 16 lanes) and the gfx950 row / half swaps add a value over
 // lane groups in the VALU — no ds_bpermute round trips (measured: a __shfl_xor butterfly over the 32 row lanes of an

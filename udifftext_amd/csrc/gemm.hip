@@ -569,9 +569,9 @@ std::atomic<int> g_dbg_bits{0};  // cost-attribution modes that switch parts of 
 #endif
 constexpr int INTERNAL_DIRECT_EPI = 1 << 30;   // kernel-side flag bit, never part of the public flag set
 constexpr int PUBLIC_FLAGS = UDT_GEMM_OUT_F32 | UDT_GEMM_GEGLU | UDT_GEMM_RELU | UDT_GEMM_TRANSPOSED | UDT_GEMM_CONV |
-                             UDT_GEMM_SILU_OUT | UDT_GEMM_FP8;
-inline int k_tile(const udt_gemm_desc* d) { return (d->flags & UDT_GEMM_FP8) ? 128 : BK; }   // K elements per 128-byte row
-inline int elem_bytes(const udt_gemm_desc* d) { return (d->flags & UDT_GEMM_FP8) ? 1 : 2; }
+                             UDT_GEMM_SILU_OUT | UDT_GEMM_FP8 | UDT_GEMM_MX8;
+inline int k_tile(const udt_gemm_desc* d) { return (d->flags & (UDT_GEMM_FP8 | UDT_GEMM_MX8)) ? 128 : BK; }   // K elements per 128-byte row
+inline int elem_bytes(const udt_gemm_desc* d) { return (d->flags & (UDT_GEMM_FP8 | UDT_GEMM_MX8)) ? 1 : 2; }
 
 // the 8-wave kernels serve everything the lean family declines, except outputs of <= 64 columns (the UNet's 4-channel output
 // convolution): those keep the first-generation 4-wave kernel with its 256 x 64 tile
@@ -794,16 +794,35 @@ bool lean_plan(const udt_gemm_desc* d, LeanPlan& t, bool want_stats) {
   if (conv1 && (d->ksize != 1 || d->stride != 1 || d->upsample || d->pad_t != 0 || d->pad_l != 0 || d->Hout != d->Hin ||
                 d->Wout != d->Win || d->C1 % BK != 0 || d->C2 % BK != 0 || d->ln_colsum || (d->flags & UDT_GEMM_GEGLU)))
     return false;
-  if (d->batch > 1 || d->in_scsh || d->colscale) return false;
+  const bool mx8 = (d->flags & UDT_GEMM_MX8) != 0;          // e4m3 operands, MX block scales on A (lean.h FP8)
+  const bool emit = d->q8_out != nullptr;                   // the result again as an MX8 activation (lean.h EMIT)
+  if (d->batch > 1 || d->in_scsh || (d->colscale != nullptr) != mx8) return false;
   const bool geglu = (d->flags & UDT_GEMM_GEGLU) != 0;
   const bool ln = d->ln_colsum != nullptr;
   if (want_stats && (geglu || ln || !lean_stats_enabled())) return false;
-  if (d->N <= 64 || d->N % 8 != 0 || d->K % BK != 0 || (!conv1 && d->lda % 8 != 0) || d->ldo % 8 != 0) return false;
+  if (mx8 || emit) {
+    // instances (lean.hip launch_lean_mx8): bf16 plain + emit; fp8 plain (+ emit | + statistics), fp8 LayerNorm-folded plain,
+    // fp8 LayerNorm-folded GEGLU + emit — all on the 128 x 128 configuration
+    if (conv1 || d->rowvec || mode == 0 || (mode > 0 && mode != 1)) return false;
+    if (mx8 && (!d->a_scale || d->K % 128 != 0 || d->lda % 16 != 0 || (d->ldw > 0 && d->ldw % 16 != 0))) return false;
+    if (mx8 && ln && (!d->rowstat_in || d->rowstat_in_parts <= 0)) return false;
+    if (!mx8 && (geglu || ln)) return false;
+    if (mx8 && geglu != (ln && emit)) return false;
+    if (mx8 && ln && !geglu && emit) return false;
+    if (emit && (want_stats || !d->q8_scale || d->ld_q8 % 8 != 0 || d->N % (geglu ? 64 : 32) != 0)) return false;
+    if (d->rowstat_out && (!emit || geglu)) return false;
+    if ((reinterpret_cast<uintptr_t>(d->q8_out) | reinterpret_cast<uintptr_t>(d->colscale)) & 15) return false;
+  } else if (d->rowstat_out || d->rowstat_in) {
+    return false;
+  }
+  const int KT = mx8 ? 128 : BK;                            // K elements per 128-byte LDS row
+  if (d->N <= 64 || d->N % 8 != 0 || d->K % KT != 0 || (!conv1 && d->lda % 8 != 0) || (d->ldo % 8 != 0 && d->out)) return false;
   if (d->residual && d->ldr % 8 != 0) return false;
   if (geglu && (d->N % 64 != 0 || d->residual || d->rowvec)) return false;
   const long long ldw = d->ldw > 0 ? d->ldw : d->K;
   const long long lda_eff = conv1 ? (d->C1 > d->C2 ? d->C1 : d->C2) : d->lda;
   if ((long long)d->M * lda_eff * 2 >= (1LL << 31) || (long long)d->N * ldw * 2 >= (1LL << 31)) return false;
+  if (d->M >= (1 << 28)) return false;                      // (MX8 scale / statistics indices)
   if ((reinterpret_cast<uintptr_t>(d->out) | reinterpret_cast<uintptr_t>(d->residual) | reinterpret_cast<uintptr_t>(d->bias) |
        reinterpret_cast<uintptr_t>(d->rowvec) | reinterpret_cast<uintptr_t>(d->ln_colsum)) & 15) return false;
   if (d->rowvec && ((d->ld_rowvec > 0 ? d->ld_rowvec : d->N) % 4 != 0)) return false;
@@ -812,7 +831,7 @@ bool lean_plan(const udt_gemm_desc* d, LeanPlan& t, bool want_stats) {
   if (mode > 0 && mode != 1 && mode != 6 && mode != 7) return false;
   // 7 = rowres.h: the LayerNorm-folded projections with K = 320 and enough rows to give every CU a 256-row block: the rows'
   // A fragments stay in registers, the weights stream through LDS in 64-row chunks; automatic where it applies
-  if (mode == 7 || (mode < 0 && rowres_on())) {
+  if (!mx8 && !emit && (mode == 7 || (mode < 0 && rowres_on()))) {
     // (its A fragments are 16-byte vector loads straight from global memory: a 16-byte aligned base; lda % 8 == 0 is checked above)
     if (ln && !want_stats && d->K == 320 && d->N % 64 == 0 && !d->residual && !d->rowvec && !conv1 &&
         (reinterpret_cast<uintptr_t>(d->a) & 15) == 0) {
@@ -837,11 +856,13 @@ bool lean_plan(const udt_gemm_desc* d, LeanPlan& t, bool want_stats) {
     if (mode == 7) return false;
   }
   t.cfg = (mode > 0) ? mode : 1;
+  if (!mx8 && !emit) {
   if (!geglu && d->N % 160 == 0 && d->N % 128 != 0 && t.cfg == 1) t.cfg = 5;
   // many tiles and a wide output: the 256 x 256 tile (8 waves, one workgroup per CU) halves the LDS-DMA instructions per MFMA.
   // Measured (profiles/r03_gemm_shapes_256.txt): faster from ~2 tiles per CU up (32768x2560x320 GEGLU 93 -> 81 us,
   // 32768x960x320 33 -> 32 us), slower below (every M <= 2048 shape)
   if (mode <= 0 && d->N >= 768 && (long long)((d->M + 255) / 256) * ((d->N + 255) / 256) >= 2LL * device_cus()) t.cfg = 6;
+  }
   t.stats_rows = 0;
   if (want_stats) {
     // statistics-emitting epilogues exist for the two 4-wave plain kernels; a slot = one wave row block, inside one sample
@@ -849,6 +870,7 @@ bool lean_plan(const udt_gemm_desc* d, LeanPlan& t, bool want_stats) {
       if (mode > 0) return false;
       t.cfg = (d->N % 160 == 0 && d->N % 128 != 0) ? 5 : 1;
     }
+    if (mx8) t.cfg = 1;
     t.stats_rows = t.cfg == 1 ? 64 : 32;
     const int rpb = d->rows_per_batch > 0 ? d->rows_per_batch : d->M;
     if (rpb % t.stats_rows != 0) return false;
@@ -867,7 +889,7 @@ bool lean_plan(const udt_gemm_desc* d, LeanPlan& t, bool want_stats) {
   t.tiles_m = (d->M + t.bm - 1) / t.bm;
   t.tiles_n = (d->N + t.bn - 1) / t.bn;
   t.tiles = t.tiles_m * t.tiles_n;
-  t.nkt = d->K / BK;
+  t.nkt = d->K / KT;
   // split K when the tiles alone leave most of the chip idle: slices of >= 4 K-tiles, ~1.5 units per workgroup slot
   const int slots = device_cus() * ((t.cfg == 1 || t.cfg == 5) ? 2 : 1);
   int sk = 1;
@@ -876,7 +898,7 @@ bool lean_plan(const udt_gemm_desc* d, LeanPlan& t, bool want_stats) {
     if (knob > 1) sk = knob;
     // measured (profiles/r03_gemm_shapes_lean_splitk.txt): a slice costs ~10 us of slab round trip + ticket, so K is cut
     // only when it is deep (>= 40 K-tiles) and the tiles leave more than half of the workgroup slots idle
-    else if (knob < 0 && t.tiles * 2 <= slots && t.nkt >= 40) { sk = slots / t.tiles; if (sk > t.nkt / 16) sk = t.nkt / 16; }
+    else if (knob < 0 && t.tiles * 2 <= slots && t.nkt >= (mx8 ? 20 : 40)) { sk = slots / t.tiles; if (sk > t.nkt / (mx8 ? 8 : 16)) sk = t.nkt / (mx8 ? 8 : 16); }
     if (sk > t.nkt / 4) sk = t.nkt / 4;
     while (sk > 1 && (long long)t.tiles * sk * t.bm * t.bn * 4 > (64LL << 20)) --sk;    // slabs stay inside the workspace
     if (sk < 1) sk = 1;
@@ -1077,6 +1099,16 @@ extern "C" int udt_check_async_error(void* workspace, size_t workspace_bytes, vo
 
 extern "C" int32_t udt_gemm_colstats_rows(const udt_gemm_desc* d) { return d ? colstats_rows(d) : 0; }
 extern "C" int32_t udt_gemm_colstats_slots(const udt_gemm_desc* d) { return d ? colstats_slots(d) : 0; }
+extern "C" int32_t udt_gemm_rowstat_parts(const udt_gemm_desc* d) {
+  if (!d || d->M <= 0 || d->N <= 0 || d->K <= 0) return 0;
+  // the MX8-emitting epilogues live on the 128 x 128 lean configuration: two wave columns of 64 -> one part per 64 output columns
+  udt_gemm_desc t = *d;
+  alignas(16) static const uint64_t probe_dst[2] = {0, 0};              // (plan-only: a 16-byte aligned stand-in for q8_out / q8_scale)
+  if (!t.q8_out) { t.q8_out = const_cast<uint64_t*>(probe_dst); t.q8_scale = const_cast<uint64_t*>(probe_dst); if (t.ld_q8 <= 0) t.ld_q8 = (t.N + 15) / 16 * 16; }
+  LeanPlan lt;
+  if (!lean_plan(&t, lt, false) || lt.cfg != 1 || (d->flags & UDT_GEMM_GEGLU)) return 0;
+  return (d->N + 63) / 64;
+}
 extern "C" int32_t udt_gemm_in_scsh_ok(const udt_gemm_desc* d) {
   if (!d || d->K <= 0 || d->K % BK != 0) return 0;
   c3p::Geo ge;
@@ -1124,16 +1156,23 @@ extern "C" size_t udt_gemm_workspace_bytes(const udt_gemm_desc* d) {
 }
 
 extern "C" int udt_gemm(const udt_gemm_desc* d, void* workspace, size_t workspace_bytes, void* stream) {
-  if (!d || !d->a || !d->w || !d->out) return UDT_ERR_BAD_ARG;
+  if (!d || !d->a || !d->w) return UDT_ERR_BAD_ARG;
   if (d->M <= 0 || d->N <= 0 || d->K <= 0) return UDT_ERR_BAD_SHAPE;
   if (d->K % k_tile(d) != 0) return UDT_ERR_BAD_SHAPE;
   if (d->N % 4 != 0) return UDT_ERR_BAD_SHAPE;
   const bool fp8 = (d->flags & UDT_GEMM_FP8) != 0;
+  const bool mx8 = (d->flags & UDT_GEMM_MX8) != 0;
+  if (mx8 || d->q8_out || d->rowstat_out || d->rowstat_in) {
+    // MX8 operands / the MX8-emitting epilogues exist on the lean 128 x 128 kernels only (lean_plan): say so instead of falling
+    // through to a kernel that would read e4m3 bytes as bf16
+    LeanPlan lt8;
+    if (fp8 || !lean_plan(d, lt8, d->colstats != nullptr)) return UDT_ERR_BAD_ARG;
+  }
   if (fp8) {
     // e4m3 operands: plain / GEGLU / transposed linears on the 8-wave kernel only
     if ((d->flags & (UDT_GEMM_CONV | UDT_GEMM_OUT_F32)) || d->colstats || d->in_scsh || !use_gemm8(d)) return UDT_ERR_BAD_ARG;
     if (d->lda % 16 != 0 || (d->ldw > 0 && d->ldw % 16 != 0)) return UDT_ERR_BAD_SHAPE;
-  } else if (d->colscale) {
+  } else if (d->colscale && !mx8) {
     return UDT_ERR_BAD_ARG;
   }
   const bool conv = (d->flags & UDT_GEMM_CONV) != 0;
@@ -1150,6 +1189,7 @@ extern "C" int udt_gemm(const udt_gemm_desc* d, void* workspace, size_t workspac
   } else {
     if (d->lda < d->K || d->lda % 8 != 0) return UDT_ERR_BAD_SHAPE;
   }
+  if (!d->out && !(d->q8_out && (d->flags & UDT_GEMM_GEGLU))) return UDT_ERR_BAD_ARG;
   if (trans) {
     if (d->rows_per_batch <= 0 || d->rows_per_batch % 4 != 0 || d->M % d->rows_per_batch != 0)
       return UDT_ERR_BAD_SHAPE;
@@ -1189,6 +1229,7 @@ extern "C" int udt_gemm(const udt_gemm_desc* d, void* workspace, size_t workspac
   p.lda = d->lda; p.ldo = d->ldo; p.ldr = d->ldr;
   p.ldw = d->ldw > 0 ? d->ldw : d->K;
   if (p.ldw < d->K || p.ldw % 8 != 0) return UDT_ERR_BAD_SHAPE;
+  if (mx8 && d->lda < d->K) return UDT_ERR_BAD_SHAPE;
   p.sA = d->stride_a; p.sW = d->stride_w; p.sO = d->stride_out; p.sR = d->stride_res;
   p.Hin = d->Hin; p.Win = d->Win; p.C1 = d->C1; p.C2 = d->C2; p.Hout = d->Hout; p.Wout = d->Wout;
   p.ksz = d->ksize; p.stride = d->stride; p.pad_t = d->pad_t; p.pad_l = d->pad_l; p.ups = d->upsample ? 1 : 0;
@@ -1219,8 +1260,13 @@ extern "C" int udt_gemm(const udt_gemm_desc* d, void* workspace, size_t workspac
       lp.alpha = d->alpha; lp.ln_eps = d->ln_eps;
       lp.tiles_m = lt.tiles_m; lp.tiles_n = lt.tiles_n; lp.n_block = lt.n_block; lp.tiles = lt.tiles;
       lp.nkt = lt.nkt; lp.splitk = lt.splitk; lp.kt_per = lt.kt_per;
-      lp.a_bytes = (unsigned)((long long)d->M * lp.lda * 2);
-      lp.w_bytes = (unsigned)((long long)d->N * p.ldw * 2);
+      lp.a_bytes = (unsigned)((long long)d->M * lp.lda * elem_bytes(d));
+      lp.w_bytes = (unsigned)((long long)d->N * p.ldw * elem_bytes(d));
+      lp.a_scale = mx8 ? reinterpret_cast<const uint32_t*>(d->a_scale) : nullptr;
+      lp.colscale = d->colscale;
+      lp.rowstat_in = d->rowstat_in; lp.rowstat_in_parts = d->rowstat_in_parts;
+      lp.q8_out = reinterpret_cast<uint8_t*>(d->q8_out); lp.q8_scale = reinterpret_cast<uint32_t*>(d->q8_scale); lp.ld_q8 = d->ld_q8;
+      lp.rowstat_out = d->rowstat_out;
       lp.G = lt.G;
       lp.counters = nullptr; lp.slabs = nullptr;
       if (lt.splitk > 1) {
@@ -1231,8 +1277,8 @@ extern "C" int udt_gemm(const udt_gemm_desc* d, void* workspace, size_t workspac
       UdtProfScope profl(cls, s);
       if (profl.rec) {
         char tag[96];
-        snprintf(tag, sizeof(tag), "lean%d M=%d N=%d K=%d fl=0x%x ln=%d tile=%dx%d units=%d splitk=%d", lt.cfg, d->M, d->N, d->K, d->flags,
-                 d->ln_colsum ? 1 : 0, lt.bm, lt.bn, lt.tiles * lt.splitk, lt.splitk);
+        snprintf(tag, sizeof(tag), "lean%d%s%s M=%d N=%d K=%d fl=0x%x ln=%d tile=%dx%d units=%d splitk=%d", lt.cfg, mx8 ? "-mx8" : "", d->q8_out ? "+q8" : "",
+                 d->M, d->N, d->K, d->flags, d->ln_colsum ? 1 : 0, lt.bm, lt.bn, lt.tiles * lt.splitk, lt.splitk);
         udt_prof_tag(profl.rec, tag);
       }
       const bool geglu = (d->flags & UDT_GEMM_GEGLU) != 0, ln = d->ln_colsum != nullptr;

@@ -84,9 +84,21 @@ UDT_DEVINL void wave_colstats(char* wl, int lane, const float (&cs)[8], const fl
 
 // NW waves as WGM x WGN, each TM x TN MFMA tiles of 32x32; NST ring stages; GEGLU: weight rows packed [32 x | 32 gate]
 // per 64-column wave block (TN == 2); LN: LayerNorm folded into the weights, row statistics from the A fragments
-template <int NW, int WGM, int WGN, int TM, int TN, int NST, bool GEGLU, bool LN, int TMB = TM, bool STATS = false>
+// FP8 (udt_gemm_desc UDT_GEMM_MX8, BASELINE config #5): A and W are OCP e4m3 bytes — the LDS image is the same 128-byte rows, now
+// 128 K-elements per tile = two v_mfma_scale_f32_32x32x64_f8f6f4 steps — A carries MX block scales (one E8M0 byte per 32
+// K-elements of a row, fetched per K-tile as ONE dword per row straight into a register), W a per-output-channel fp32 scale that
+// multiplies the accumulators in the epilogue; twice the FLOPs per staged byte, per fragment read and per matrix-pipe cycle.
+// With LN the row statistics cannot come from the e4m3 fragments (no packed dot on bytes): the PRODUCER of A emitted partial row
+// sums (rowstat_in), summed here in a fixed order.
+// EMIT: the epilogue also writes its result as an MX8 activation for the next GEMM (q8_out / q8_scale; GEGLU: `out` may then be
+// null — the hidden activation exists as e4m3 only) and, for a LayerNorm-folded consumer, the partial row statistics (rowstat_out).
+template <int NW, int WGM, int WGN, int TM, int TN, int NST, bool GEGLU, bool LN, int TMB = TM, bool STATS = false, bool FP8 = false,
+          bool EMIT = false>
 __global__ void __launch_bounds__(NW * 64, 2) lgemm_kernel(const LParams p) {
   static_assert(!STATS || (!GEGLU && !LN), "statistics-emitting epilogue: plain linears / 1x1 convolutions");
+  static_assert(!FP8 || NST == 2, "the fp8 loop is written for the two-stage ring");
+  static_assert(!EMIT || (TN * 4) % 4 == 0, "a 32-column block = 4 lanes of the row layout");
+  constexpr int EB = FP8 ? 1 : 2;                       // bytes per operand element
   static_assert(TM % TMB == 0, "epilogue passes of TMB row tiles");
   static_assert(WGM * WGN == NW, "wave grid");
   static_assert(!GEGLU || TN == 2, "GEGLU pairs the two 32-column tiles of a wave");
@@ -133,7 +145,13 @@ __global__ void __launch_bounds__(NW * 64, 2) lgemm_kernel(const LParams p) {
   const int kt0 = slice * p.kt_per;
   int kt1 = kt0 + p.kt_per;
   if (kt1 > p.nkt) kt1 = p.nkt;
-
+  // (measured and rejected, profiles/r05_krot_rejected.txt: rotating every tile's K range — tile (tm, tn) starts at K-tile
+  //  ((tm + tn) mod 8) * nk / 8 and wraps — so that the eight co-resident workgroups that stream the same A rows / weight rows ask for
+  //  DIFFERENT K-tiles of it at any moment: 8192x640x2560 37 -> 54 us, 2048x1280x5120 42 -> 61 us, nothing gained anywhere.  The
+  //  lock-step is what makes the sharing work: eight simultaneous requests for one line are one fetch; staggered, the XCD's L2 has to
+  //  hold eight K-tiles of every shared operand instead of one)
+  const int nk = kt1 - kt0;
+  auto kreal = [&](int i) { return kt0 + i; };           // i-th K-tile this workgroup processes
   const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.a), 0, p.a_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.w), 0, p.w_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsrc_a2 =
@@ -148,7 +166,7 @@ __global__ void __launch_bounds__(NW * 64, 2) lgemm_kernel(const LParams p) {
     const int row = idx * 8 + l3;
     const int koff = (pslot ^ ((row >> 1) & 7)) * 8;
     const int m = m0 + row;
-    a_voff[i] = (m < p.M) ? (unsigned)(((long long)m * p.lda + koff) * 2) : OOB;
+    a_voff[i] = (m < p.M) ? (unsigned)((long long)m * p.lda * EB + koff * 2) : OOB;
     a2_voff[i] = (m < p.M) ? (unsigned)(((long long)m * p.lda2 + koff) * 2) : OOB;
   }
 #pragma unroll
@@ -159,7 +177,7 @@ __global__ void __launch_bounds__(NW * 64, 2) lgemm_kernel(const LParams p) {
     const int row = idx * 8 + l3;
     const int koff = (pslot ^ ((row >> 1) & 7)) * 8;
     const int n = n0 + row;
-    w_voff[i] = (n < p.N) ? (unsigned)(((long long)n * p.ldw + koff) * 2) : OOB;
+    w_voff[i] = (n < p.N) ? (unsigned)((long long)n * p.ldw * EB + koff * 2) : OOB;
   }
   auto stage = [&](int st, int kt) {
     char* abuf = smem + st * STAGE_BYTES;
@@ -180,7 +198,19 @@ __global__ void __launch_bounds__(NW * 64, 2) lgemm_kernel(const LParams p) {
   //  wait) or from a dedicated fifth wave — made the UNet's GEMMs 10-60 % SLOWER: a touch is 64 separate line requests)
 #pragma unroll
   for (int s = 0; s < NST - 1; ++s)
-    if (kt0 + s < kt1) stage(s, kt0 + s);
+    if (s < nk) stage(s, kreal(s));
+  // FP8: the block scales of this lane's rows, one dword per row and K-tile (the 4 blocks of the 128-element tile), fetched one tile ahead
+  const uint32_t* asp[TM];
+  uint32_t asc_nxt[TM];
+  if constexpr (FP8) {
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+      int m = m0 + row0 + tm * 32 + l31;
+      if (m >= p.M) m = p.M - 1;                         // (rows past M stage zeros: any scale will do)
+      asp[tm] = p.a_scale + m;
+      asc_nxt[tm] = (nk > 0) ? asp[tm][(long long)kreal(0) * p.M] : 0x7f7f7f7fu;
+    }
+  }
 
   f32x16 acc[TM][TN];
 #pragma unroll
@@ -192,21 +222,73 @@ __global__ void __launch_bounds__(NW * 64, 2) lgemm_kernel(const LParams p) {
   float rs[TM], rq[TM];                                 // LN: this lane's half-K share of sum x, sum x^2 of its rows
 #pragma unroll
   for (int i = 0; i < TM; ++i) rs[i] = rq[i] = 0.f;
+  if constexpr (LN && FP8) {
+    // row statistics from the producer's partial sums: the two half-waves take alternate parts (xor32_sum below joins them)
+    if (WGN == 1 || wn == 0) {
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm) {
+        int m = m0 + row0 + tm * 32 + l31;
+        if (m >= p.M) m = p.M - 1;
+        const f32x2* sp = reinterpret_cast<const f32x2*>(p.rowstat_in) + m;
+        for (int pp = hi; pp < p.rowstat_in_parts; pp += 2) {
+          const f32x2 v = sp[(long long)pp * p.M];
+          rs[tm] += v[0];
+          rq[tm] += v[1];
+        }
+      }
+    }
+  }
 
   const int a_frag_row = (row0 + l31) * ROW_BYTES;
   const int b_frag_row = (col0 + l31) * ROW_BYTES;
   int st = 0;
-  for (int kt = kt0; kt < kt1; ++kt) {
-    if (NST > 2 && kt + NST - 2 < kt1) wait_vm<LPT*(NST > 2 ? NST - 2 : 0)>();
+  for (int kt = 0; kt < nk; ++kt) {   // (kt counts this workgroup's steps; kreal(kt) is the K-tile it processes)
+    if (NST > 2 && kt + NST - 2 < nk) wait_vm<LPT*(NST > 2 ? NST - 2 : 0)>();
     else wait_vm<0>();
     raw_barrier();                    // K-tile kt visible to all waves; the stage read in the previous iteration is free
-    if (kt + NST - 1 < kt1) {
+    int asc[TM];
+    if constexpr (FP8) {
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm) asc[tm] = (int)(asc_nxt[tm] >> (8 * hi));   // byte 2 ks: block 2 ks + hi of the tile
+    }
+    if (kt + NST - 1 < nk) {
       int s2 = st + NST - 1;
       if (s2 >= NST) s2 -= NST;
-      stage(s2, kt + NST - 1);
+      const int kn = kreal(kt + NST - 1);
+      stage(s2, kn);
+      if constexpr (FP8) {
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) asc_nxt[tm] = asp[tm][(long long)kn * p.M];
+      }
     }
     const char* abuf = smem + st * STAGE_BYTES;
     const char* bbuf = abuf + A_BYTES;
+    if constexpr (FP8) {
+      // k-step ks = 64 K-elements = the scale blocks 2 ks and 2 ks + 1: a lane feeds 16 bytes of each (common.h mfma32_mx8)
+      i32x8_t xf[2][TM], wf[2][TN];
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const int slot0 = ((ks * 4 + hi) ^ swz) << 4, slot1 = ((ks * 4 + 2 + hi) ^ swz) << 4;
+#pragma unroll
+        for (int t = 0; t < TM; ++t)
+          xf[ks][t] = lds_read_frag32(abuf + a_frag_row + t * 32 * ROW_BYTES + slot0, abuf + a_frag_row + t * 32 * ROW_BYTES + slot1);
+#pragma unroll
+        for (int t = 0; t < TN; ++t)
+          wf[ks][t] = lds_read_frag32(bbuf + b_frag_row + t * 32 * ROW_BYTES + slot0, bbuf + b_frag_row + t * 32 * ROW_BYTES + slot1);
+      }
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = mfma32_mx8<0>(wf[0][tn], xf[0][tm], acc[tm][tn], asc[tm]);
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = mfma32_mx8<2>(wf[1][tn], xf[1][tm], acc[tm][tn], asc[tm]);
+      if constexpr (TM * TN <= 5) {
+        __builtin_amdgcn_sched_group_barrier(0x100, 4 * (TM + TN), 0);    // all fragment reads of the K-tile ...
+        __builtin_amdgcn_sched_group_barrier(0x008, 2 * TM * TN, 0);      // ... ahead of its MFMAs
+      }
+    } else {
     bf16x8_t xf[4][TM], wf[4][TN];
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
@@ -240,6 +322,7 @@ __global__ void __launch_bounds__(NW * 64, 2) lgemm_kernel(const LParams p) {
       __builtin_amdgcn_sched_group_barrier(0x100, 4 * (TM + TN), 0);    // all fragment reads of the K-tile ...
       __builtin_amdgcn_sched_group_barrier(0x008, 4 * TM * TN, 0);      // ... ahead of its MFMAs (gemm8.h)
     }                                                                   // (128 x 64 wave tiles: the scheduler's own interleave)
+    }
     st = st + 1;
     if (st >= NST) st = 0;
   }
@@ -355,7 +438,12 @@ __global__ void __launch_bounds__(NW * 64, 2) lgemm_kernel(const LParams p) {
     for (int q = 0; q < 4; ++q) {                         // (q outer: one column group's constants live at a time)
       const int n = n0 + col0 + q * 8 + hi * 4;
       f32x4 bx = {0.f, 0.f, 0.f, 0.f}, bg = bx, sx = bx, sg = bx;
+      f32x4 wx = {1.f, 1.f, 1.f, 1.f}, wg = wx;             // FP8: the weight rows' scales
       if (n < p.N) {
+        if constexpr (FP8) {
+          wx = *reinterpret_cast<const f32x4*>(p.colscale + n);
+          wg = *reinterpret_cast<const f32x4*>(p.colscale + n + 32);
+        }
         if (p.bias) {
           bx = *reinterpret_cast<const f32x4*>(p.bias + n);
           bg = *reinterpret_cast<const f32x4*>(p.bias + n + 32);
@@ -377,12 +465,14 @@ __global__ void __launch_bounds__(NW * 64, 2) lgemm_kernel(const LParams p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           float x, g;
+          float ax = acc[tm][0][q * 4 + r], ag = acc[tm][1][q * 4 + r];
+          if constexpr (FP8) ax *= wx[r], ag *= wg[r];
           if constexpr (LN) {
-            x = xm * acc[tm][0][q * 4 + r] + (xa * sx[r] + bx[r]);
-            g = gm * acc[tm][1][q * 4 + r] + (ga * sg[r] + bg[r]);
+            x = xm * ax + (xa * sx[r] + bx[r]);
+            g = gm * ag + (ga * sg[r] + bg[r]);
           } else {
-            x = xm * acc[tm][0][q * 4 + r] + bx[r];
-            g = gm * acc[tm][1][q * 4 + r] + bg[r];
+            x = xm * ax + bx[r];
+            g = gm * ag + bg[r];
           }
           o[r] = geglu_scaled(x, g);
         }
@@ -398,7 +488,19 @@ __global__ void __launch_bounds__(NW * 64, 2) lgemm_kernel(const LParams p) {
       const int row = i * 16 + (lane >> 2);
       const int m = m0 + row0 + row;
       const u32x4 v = *reinterpret_cast<const u32x4*>(wb + row * 64 + ((ch ^ (row & 3)) << 4));
-      if (m < p.M && col_ok) *reinterpret_cast<u32x4*>(p.out + (long long)m * p.ldo + n_out) = v;
+      if constexpr (EMIT) {
+        // the 4 lanes of a quad hold one row's 32 output columns = one MX block (from the bf16-rounded values)
+        const float f[8] = {bf16_lo(v[0]), bf16_hi(v[0]), bf16_lo(v[1]), bf16_hi(v[1]), bf16_lo(v[2]), bf16_hi(v[2]), bf16_lo(v[3]), bf16_hi(v[3])};
+        uint32_t sb;
+        const u32x2 q8 = mx8_quant_row8(f, sb);
+        if (m < p.M && col_ok) {
+          *reinterpret_cast<u32x2*>(p.q8_out + (long long)m * p.ld_q8 + n_out) = q8;
+          if (ch == 0) reinterpret_cast<uint8_t*>(p.q8_scale)[((long long)(n_out >> 7) * p.M + m) * 4 + ((n_out >> 5) & 3)] = (uint8_t)sb;
+          if (p.out) *reinterpret_cast<u32x4*>(p.out + (long long)m * p.ldo + n_out) = v;
+        }
+      } else {
+        if (m < p.M && col_ok) *reinterpret_cast<u32x4*>(p.out + (long long)m * p.ldo + n_out) = v;
+      }
     }
   } else {
     // ---- epilogue: accumulators -> this wave's fp32 rows in LDS (16-byte chunks XOR-swizzled by row & 7), in TM / TMB
@@ -422,6 +524,13 @@ __global__ void __launch_bounds__(NW * 64, 2) lgemm_kernel(const LParams p) {
       if (col_ok) {
         s0 = *reinterpret_cast<const f32x4*>(p.ln_s + n);
         s1 = *reinterpret_cast<const f32x4*>(p.ln_s + n + 4);
+      }
+    }
+    f32x4 w0 = {1.f, 1.f, 1.f, 1.f}, w1 = w0;              // FP8: the weight rows' scales
+    if constexpr (FP8) {
+      if (col_ok) {
+        w0 = *reinterpret_cast<const f32x4*>(p.colscale + n);
+        w1 = *reinterpret_cast<const f32x4*>(p.colscale + n + 4);
       }
     }
     float cs[8], cq[8];                                  // STATS: this lane's column sums over the rows it stores
@@ -471,6 +580,10 @@ __global__ void __launch_bounds__(NW * 64, 2) lgemm_kernel(const LParams p) {
           o[j] = v0[j];
           o[4 + j] = v1[j];
         }
+        if constexpr (FP8) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) o[j] *= w0[j], o[4 + j] *= w1[j];
+        }
         if constexpr (LN) {
           float mean, rstd;
           row_stats(prow0 + rr, mean, rstd);
@@ -502,9 +615,33 @@ __global__ void __launch_bounds__(NW * 64, 2) lgemm_kernel(const LParams p) {
             o[2 * j + 1] += bf16_hi(rv[i][j]);
           }
         }
+        if constexpr (EMIT) {
+          // the result again as an MX8 activation: the 4 lanes of an aligned quad hold one 32-column block of the row (every lane
+          // executes the cross-lane steps; N % 32 == 0 keeps a quad's lanes valid together)
+          uint32_t sb;
+          const u32x2 q8 = mx8_quant_row8(o, sb);
+          float ps = 0.f, pq = 0.f;
+          if (p.rowstat_out) {                            // partial row statistics over this wave's columns (CPR = 8 or 16 lanes)
+            static_assert(CPR == 8 || CPR == 16, "row statistics: 64- or 128-column wave blocks");
+#pragma unroll
+            for (int j = 0; j < 8; ++j) ps += o[j], pq += o[j] * o[j];
+            ps = dpp_add<0xB1>(ps); pq = dpp_add<0xB1>(pq);      // lane ^ 1
+            ps = dpp_add<0x4E>(ps); pq = dpp_add<0x4E>(pq);      // lane ^ 2
+            ps = dpp_add<0x141>(ps); pq = dpp_add<0x141>(pq);    // row_half_mirror: + the other quad of the 8 lanes
+            if constexpr (CPR == 16) { ps = dpp_add<0x140>(ps); pq = dpp_add<0x140>(pq); }   // row_mirror: + the other 8
+          }
+          if (ok) {
+            *reinterpret_cast<u32x2*>(p.q8_out + (long long)m * p.ld_q8 + n) = q8;
+            if ((c8 & 3) == 0) reinterpret_cast<uint8_t*>(p.q8_scale)[((long long)(n >> 7) * p.M + m) * 4 + ((n >> 5) & 3)] = (uint8_t)sb;
+            if (p.rowstat_out && c8 == 0) {
+              f32x2 st2 = {ps, pq};
+              reinterpret_cast<f32x2*>(p.rowstat_out)[(long long)((n0 + col0) / WCOLS) * p.M + m] = st2;
+            }
+          }
+        }
         if (ok) {
           u32x4 pk = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7])};
-          *reinterpret_cast<u32x4*>(p.out + (long long)m * p.ldo + n) = pk;
+          if (!EMIT || p.out) *reinterpret_cast<u32x4*>(p.out + (long long)m * p.ldo + n) = pk;
           if constexpr (STATS) {                         // statistics of the values as stored (bf16-rounded)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {

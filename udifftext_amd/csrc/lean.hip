@@ -40,6 +40,31 @@ hipError_t launch_lean(const lg::LParams& lp, int smem, int G, bool geglu, bool 
   return hipLaunchKernel(fn, dim3(G), dim3(NW * 64), args, smem, s);
 }
 
+// MX8 instances (lean.h FP8 / EMIT; BASELINE config #5): the 128 x 128 / two-workgroups-per-CU configuration.
+//   emit, bf16 operands : plain epilogue + the result again as an MX8 activation (proj_in -> q|k|v)
+//   fp8 operands        : plain (to_out / proj_out, optionally with column statistics), plain + emit (ff.net[2] -> proj_out),
+//                         LayerNorm-folded plain (q|k|v), LayerNorm-folded GEGLU + emit (ff.net[0] -> ff.net[2])
+template <bool GEGLU, bool LN, bool STATS, bool FP8, bool EMIT>
+hipError_t launch_lean_mx8_k(const lg::LParams& lp, int smem, int G, hipStream_t s) {
+  static AttrOnce once;
+  const void* fn = (const void*)lg::lgemm_kernel<4, 2, 2, 2, 2, 2, GEGLU, LN, 2, STATS, FP8, EMIT>;
+  hipError_t e = once.ensure(fn, smem);
+  if (e != hipSuccess) return e;
+  void* args[] = {const_cast<lg::LParams*>(&lp)};
+  return hipLaunchKernel(fn, dim3(G), dim3(256), args, smem, s);
+}
+hipError_t launch_lean_mx8(const lg::LParams& lp, int smem, int G, bool geglu, bool ln, bool fp8, bool emit, hipStream_t s) {
+  const bool stats = lp.colstats != nullptr;
+  if (!fp8) {
+    if (emit && !geglu && !ln && !stats) return launch_lean_mx8_k<false, false, false, false, true>(lp, smem, G, s);
+    return hipErrorInvalidValue;
+  }
+  if (geglu) return (ln && emit && !stats) ? launch_lean_mx8_k<true, true, false, true, true>(lp, smem, G, s) : hipErrorInvalidValue;
+  if (ln) return (!emit && !stats) ? launch_lean_mx8_k<false, true, false, true, false>(lp, smem, G, s) : hipErrorInvalidValue;
+  if (stats) return emit ? hipErrorInvalidValue : launch_lean_mx8_k<false, false, true, true, false>(lp, smem, G, s);
+  return emit ? launch_lean_mx8_k<false, false, false, true, true>(lp, smem, G, s) : launch_lean_mx8_k<false, false, false, true, false>(lp, smem, G, s);
+}
+
 template <int TW, int TH, bool UPS, bool STATS>
 hipError_t launch_lconv3s(const lg::C3Params& c3, hipStream_t s) {
   static AttrOnce once;
@@ -81,6 +106,8 @@ hipError_t launch_wconv3(const lg::C3Params& c3, hipStream_t s) {
 
 hipError_t udt_lean_launch_gemm(int cfg, const void* lparams, int smem, int G, int geglu, int ln, hipStream_t s) {
   const lg::LParams& lp = *static_cast<const lg::LParams*>(lparams);
+  const bool fp8 = lp.a_scale != nullptr, emit = lp.q8_out != nullptr;
+  if (fp8 || emit) return cfg == 1 ? launch_lean_mx8(lp, smem, G, geglu != 0, ln != 0, fp8, emit, s) : hipErrorInvalidValue;
   switch (cfg) {
     case 1: return launch_lean<4, 2, 2, 2, 2, 2>(lp, smem, G, geglu != 0, ln != 0, s);
     case 6: return launch_lean<8, 2, 4, 4, 2, 2, 1>(lp, smem, G, geglu != 0, ln != 0, s);

@@ -26,6 +26,15 @@ struct LParams {
   int* counters;           // split-K: [tiles] arrival tickets, zero between launches
   float* slabs;            // split-K: [tiles * splitk][BM * BN] fp32
   float* colstats;         // STATS kernels: fp32 [row slots][N][2] (sum, sum of squares) of the stored values, one slot per wave row block
+  // ---- MX8 (UDT_GEMM_MX8: `a` / `w` hold e4m3 bytes; lda / ldw / K count elements = bytes; a K tile is 128 elements) ----
+  const uint32_t* a_scale; // FP8 kernels: E8M0 block scales of A, uint32 [K / 128][M] (common.h "MX8 activations")
+  const float* colscale;   // FP8 kernels: fp32 [N] per-output-channel weight scales (multiply the accumulators)
+  const float* rowstat_in; // FP8 + LN kernels: fp32 [rowstat_in_parts][M][2] partial (sum, sum of squares) of the rows of A
+  int rowstat_in_parts;
+  uint8_t* q8_out;         // EMIT kernels: the result again as e4m3 [M][ld_q8] ...
+  uint32_t* q8_scale;      // ... with its block scales, uint32 [ceil(columns / 128)][M]
+  int ld_q8;
+  float* rowstat_out;      // EMIT kernels (optional): fp32 [N / wave columns][M][2] partial (sum, sum of squares) of the result's rows
 };
 
 struct C3Params {

@@ -20,6 +20,7 @@ GEMM_TRANSPOSED = 1 << 3
 GEMM_CONV = 1 << 4
 GEMM_SILU_OUT = 1 << 5
 GEMM_FP8 = 1 << 6
+GEMM_MX8 = 1 << 7
 
 PROF_CONV3X3, PROF_GEMM, PROF_ATTN, PROF_XATTN, PROF_NORM, PROF_ELEMENTWISE = range(6)
 
@@ -38,6 +39,8 @@ class GemmDesc(C.Structure):
         ("upsample", C.c_int32), ("rows_per_batch", C.c_int32), ("ld_rowvec", C.c_int32), ("flags", C.c_int32),
         ("alpha", C.c_float), ("colscale", C.c_void_p), ("in_scsh", C.c_void_p), ("in_act", C.c_int32), ("colstats", C.c_void_p),
         ("cu_share", C.c_int32), ("ln_colsum", C.c_void_p), ("ln_eps", C.c_float),
+        ("a_scale", C.c_void_p), ("q8_out", C.c_void_p), ("q8_scale", C.c_void_p), ("ld_q8", C.c_int32),
+        ("rowstat_out", C.c_void_p), ("rowstat_in", C.c_void_p), ("rowstat_in_parts", C.c_int32),
     ]
 
 
@@ -59,6 +62,7 @@ SYMBOLS = {
     "udt_check_async_error": (C.c_int, [_vp, C.c_size_t, _vp]),
     "udt_gemm_colstats_rows": (_i32, [C.POINTER(GemmDesc)]),
     "udt_gemm_colstats_slots": (_i32, [C.POINTER(GemmDesc)]),
+    "udt_gemm_rowstat_parts": (_i32, [C.POINTER(GemmDesc)]),
     "udt_gemm_in_scsh_ok": (_i32, [C.POINTER(GemmDesc)]),
     "udt_gn_silu_conv3x3_fwd": (C.c_int, [C.POINTER(GemmDesc), _vp, C.c_size_t, _vp]),
     "udt_ln_gemm_fwd": (C.c_int, [C.POINTER(GemmDesc), _vp, C.c_size_t, _vp]),

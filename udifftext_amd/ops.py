@@ -169,9 +169,48 @@ def _drop_stale_stats(out: Optional[torch.Tensor]) -> None:
         del out.gn_stats
 
 
+class Mx8Act(NamedTuple):
+    """an activation in the MX8 form the UDT_GEMM_MX8 consumers read (BASELINE config #5): OCP e4m3 elements + one E8M0 scale
+    per 32 consecutive columns of a row, written by the PRODUCING kernel's epilogue (udt_gemm_desc.q8_out, udt_tattn_fused_q8,
+    udt_attn_rowv_q8_fwd, udt_gn_apply_scsh_q8) — never by a pass of its own.
+      data  uint8 [M, K]            e4m3 bytes
+      scale int32 [K / 128, M]      byte j of dword (t, m) = scale of columns [128 t + 32 j, + 32) of row m
+      stats fp32 [P, M, 2] or None  partial (sum, sum of squares) of every row — for a LayerNorm-folded consumer"""
+    data: torch.Tensor
+    scale: torch.Tensor
+    stats: Optional[torch.Tensor] = None
+
+
+def mx8_of(t: Optional[torch.Tensor]) -> Optional[Mx8Act]:
+    """the MX8 twin a producer attached to its bf16 result (``out.mx8``), if any"""
+    return getattr(t, "mx8", None) if t is not None else None
+
+
+def _mx8_alloc(M: int, cols: int, device) -> Mx8Act:
+    return Mx8Act(torch.empty((M, cols), dtype=torch.uint8, device=device),
+                  torch.empty(((cols + 127) // 128, M), dtype=torch.int32, device=device))
+
+
+def _attach_q8(d: L.GemmDesc, M: int, cols: int, device, rowstats: bool) -> Optional[Mx8Act]:
+    """ask the library whether this launch can also emit its result as an MX8 activation (+ partial row statistics); if so
+    allocate the buffers and point the descriptor at them"""
+    q = _mx8_alloc(M, cols, device)
+    d.q8_out, d.q8_scale, d.ld_q8 = q.data.data_ptr(), q.scale.data_ptr(), cols
+    parts = L.load().udt_gemm_rowstat_parts(C.byref(d))
+    if parts <= 0 and not (d.flags & L.GEMM_GEGLU):
+        d.q8_out, d.q8_scale, d.ld_q8 = None, None, 0
+        return None
+    if rowstats:
+        st = torch.empty((parts, M, 2), dtype=torch.float32, device=device)
+        d.rowstat_out = st.data_ptr()
+        q = Mx8Act(q.data, q.scale, st)
+    return q
+
+
 def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, *, out: Optional[torch.Tensor] = None,
            residual: Optional[torch.Tensor] = None, rowvec: Optional[torch.Tensor] = None, rows_per_batch: int = 0,
-           flags: int = 0, alpha: float = 1.0, n_out: Optional[int] = None, colstats: bool = False) -> torch.Tensor:
+           flags: int = 0, alpha: float = 1.0, n_out: Optional[int] = None, colstats: bool = False,
+           emit_q8: bool = False, emit_rowstats: bool = False) -> torch.Tensor:
     """out[M, N] = epilogue(x[M, K] @ w[N, K]^T).  x may be a strided row view (last dim contiguous).
     colstats: also emit the per-column partial sums of the output (``out.gn_stats``, None when the plan cannot) —
     the GroupNorm statistics of the next layer; needs rows_per_batch (rows of one sample)."""
@@ -197,12 +236,70 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
                   alpha=alpha)
     if not (colstats and rows_per_batch > 0 and out.is_contiguous() and _attach_colstats(d, out, n_cols, rows_per_batch)):
         _drop_stale_stats(out)
+    q8 = None
+    if emit_q8 and not (flags & (L.GEMM_OUT_F32 | L.GEMM_TRANSPOSED | L.GEMM_GEGLU)) and d.colstats is None and rowvec is None:
+        q8 = _attach_q8(d, M, n_cols, x.device, emit_rowstats)      # (None: the plan has no emitting epilogue)
     run_gemm(d, x.device)
+    if getattr(out, "mx8", None) is not None:
+        del out.mx8
+    if q8 is not None:
+        out.mx8 = q8
     if WORK_COUNTER is not None:
         count_work("gemm", 2.0 * M * N * K)
         count_work("gemm_bytes", 2.0 * (M * K + N * K) + out.numel() * out.element_size()
                    + (2.0 * M * n_cols if residual is not None else 0.0))
         count_work("gemm_launches", 1.0)
+    return out
+
+
+def linear_mx8(x: Mx8Act, wq: torch.Tensor, colscale: torch.Tensor, bias: Optional[torch.Tensor] = None, *,
+               out: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None, rows_per_batch: int = 0,
+               flags: int = 0, n_out: Optional[int] = None, colstats: bool = False, emit_q8: bool = False,
+               emit_rowstats: bool = False, ln_c: Optional[torch.Tensor] = None, ln_s: Optional[torch.Tensor] = None,
+               eps: float = 1e-5, want_bf16: bool = True):
+    """out[M, N] (bf16) = epilogue(dequant(x) @ dequant(wq)^T) on the MX8 path (UDT_GEMM_MX8): x an Mx8Act, wq e4m3 [N, K]
+    with per-output-channel fp32 scales.  ln_c / ln_s: the GEMM is LayerNorm-folded (packing.pack_ln_linear_mx8; x.stats holds
+    the row statistics its producer emitted).  emit_q8: the result again as an Mx8Act (``out.mx8``; with GEGLU and
+    want_bf16=False ONLY that — the function then returns the Mx8Act)."""
+    xq = x.data
+    assert xq.dtype == torch.uint8 and wq.dtype == torch.uint8 and xq.is_contiguous() and wq.is_contiguous()
+    M, K = xq.shape
+    N = wq.shape[0] if n_out is None else n_out
+    assert wq.shape[1] == K and K % 128 == 0 and colscale.dtype == torch.float32 and colscale.numel() >= N
+    assert x.scale.dtype == torch.int32 and x.scale.shape == (K // 128, M) and x.scale.is_contiguous()
+    geglu = bool(flags & L.GEMM_GEGLU)
+    n_cols = N // 2 if geglu else N
+    only_q8 = geglu and emit_q8 and not want_bf16
+    if out is None and not only_q8:
+        out = torch.empty((M, n_cols), dtype=torch.bfloat16, device=xq.device)
+    d = gemm_desc(a=_ptr(xq), w=_ptr(wq), bias=_ptr(ln_c if ln_c is not None else bias), residual=_ptr(residual),
+                  out=_ptr(out), M=M, N=N, K=K, lda=K, ldo=(out.stride(0) if out is not None else 0),
+                  ldr=(residual.stride(0) if residual is not None else 0), rows_per_batch=rows_per_batch,
+                  flags=flags | L.GEMM_MX8, colscale=_ptr(colscale), a_scale=_ptr(x.scale))
+    if ln_s is not None:
+        if x.stats is None:
+            raise L.UdtError("linear_mx8: a LayerNorm-folded MX8 GEMM needs the row statistics of its input (Mx8Act.stats)")
+        assert x.stats.dtype == torch.float32 and x.stats.is_contiguous() and x.stats.shape[1:] == (M, 2)
+        d.ln_colsum, d.ln_eps = _ptr(ln_s), eps
+        d.rowstat_in, d.rowstat_in_parts = _ptr(x.stats), x.stats.shape[0]
+    if out is not None and not (colstats and rows_per_batch > 0 and out.is_contiguous()
+                                and _attach_colstats(d, out, n_cols, rows_per_batch)):
+        _drop_stale_stats(out)
+    q8 = None
+    if emit_q8:
+        q8 = _attach_q8(d, M, n_cols, xq.device, emit_rowstats and not geglu)
+        if q8 is None:
+            raise L.UdtError(f"udt_gemm has no MX8-emitting plan for M={M} N={N} K={K} flags={flags:#x}")
+    run_gemm(d, xq.device)
+    if out is not None and getattr(out, "mx8", None) is not None:
+        del out.mx8
+    if WORK_COUNTER is not None:
+        count_work("gemm_fp8", 2.0 * M * N * K)
+        count_work("gemm_fp8_launches", 1.0)
+    if only_q8:
+        return q8
+    if q8 is not None:
+        out.mx8 = q8
     return out
 
 

@@ -126,3 +126,20 @@ def pack_geglu_fp8(w: torch.Tensor, b: torch.Tensor):
     perm = geglu_permutation(inner).to(w.device)
     wq, cs = pack_linear_fp8(w[perm])
     return wq, cs, b[perm].float().contiguous()
+
+
+def pack_ln_linear_mx8(w: torch.Tensor, b, gamma: torch.Tensor, beta: torch.Tensor, geglu: bool = False):
+    """pack_ln_linear for the MX8 path (udt_gemm_desc UDT_GEMM_MX8 + ln_colsum): W' = W * gamma as e4m3 with per-output-channel
+    scales, s_n = sum_k of the DEQUANTISED W' (so that the mean term cancels what the fp8 MFMA accumulates), c_n = sum_k beta_k W_nk
+    + b_n.  Returns (W'q uint8 [N, Kpad128], colscale fp32 [N], c fp32 [N], s fp32 [N]); GEGLU rows permuted like pack_geglu."""
+    wf = w.float()
+    bf = torch.zeros((w.shape[0],), dtype=torch.float32, device=w.device) if b is None else b.float()
+    if geglu:
+        perm = geglu_permutation(w.shape[0] // 2).to(w.device)
+        wf, bf = wf[perm], bf[perm]
+    wq, cs = pack_linear_fp8(wf * gamma.float()[None, :])
+    s = (wq.view(torch.float8_e4m3fn).float() * cs[:, None]).sum(dim=1).contiguous()
+    c = pad_bias((wf @ beta.float() + bf).contiguous())
+    if c.shape[0] != wq.shape[0]:
+        raise ValueError(f"pack_ln_linear_mx8: {w.shape[0]} output rows are not a multiple of the bias padding")
+    return wq, cs, c, s
