@@ -221,6 +221,14 @@ int udt_attn_rowv_fwd(const void* q, const void* k, const void* v, void* o,
                       int32_t ldq, int32_t ldk, int32_t ldv, int32_t ldo,
                       int64_t q_bstride, int64_t k_bstride, int64_t v_bstride, int64_t o_bstride,
                       float scale, void* stream);
+/* The same launch that ALSO writes O as an MX8 activation (udt_gemm_desc "MX8 activations": q8_out e4m3 [batch * nq, ld_q8], column
+ * h * 64 + d; q8_scale uint32 [heads * 64 / 128][batch * nq]) for the e4m3 `to_out` GEMM of BASELINE config #5 (reference
+ * attention.py:246-262).  heads even, ld_q8 >= heads * 64, ld_q8 % 4 == 0, o_bstride == nq * ldo. */
+int udt_attn_rowv_q8_fwd(const void* q, const void* k, const void* v, void* o,
+                         int32_t batch, int32_t heads, int32_t nq, int32_t nk,
+                         int32_t ldq, int32_t ldk, int32_t ldv, int32_t ldo,
+                         int64_t q_bstride, int64_t k_bstride, int64_t v_bstride, int64_t o_bstride,
+                         float scale, void* q8_out, void* q8_scale, int32_t ld_q8, void* stream);
 
 /* Flash attention forward for ONE head of 512 dims: the AutoencoderKL mid-block attention (reference
  * sgm/modules/diffusionmodules/model.py:236-260, MemoryEfficientAttnBlock.attention: xformers.ops.memory_efficient_attention on
@@ -279,6 +287,14 @@ int udt_tattn_prepare(const void* kv, int32_t ldkv, const void* wq, int32_t ldwq
                       int32_t C, int32_t heads, float scale, void* stream);
 int udt_tattn_fused(const void* x, void* out, const void* A, const float* sc, const void* BmT, const float* bias,
                     int32_t B, int32_t n_tok, int32_t C, int32_t heads, int32_t zero_samples, float eps, void* stream);
+/* The same launch that ALSO writes its result as an MX8 activation (udt_gemm_desc "MX8 activations": q8_out e4m3 [B * n_tok, C],
+ * q8_scale uint32 [C / 128][B * n_tok]) and the partial row statistics (rowstat_out fp32 [udt_tattn_rowstat_parts][B * n_tok][2]) for
+ * the LayerNorm-folded GEGLU projection that consumes it on the e4m3 path (BASELINE config #5; reference attention.py:326-339:
+ * `x = t_attn(...) + x; x = ff(norm3(x)) + x`).  C = 640 / 1280.  udt_tattn_rowstat_parts: 0 = no such instance for the shape. */
+int32_t udt_tattn_rowstat_parts(int32_t B, int32_t n_tok, int32_t C);
+int udt_tattn_fused_q8(const void* x, void* out, const void* A, const float* sc, const void* BmT, const float* bias,
+                       int32_t B, int32_t n_tok, int32_t C, int32_t heads, int32_t zero_samples, float eps, void* q8_out,
+                       void* q8_scale, float* rowstat_out, void* stream);
 
 /* Row softmax of a bf16 [rows, cols] matrix in place (ld elements between rows), fp32 math. */
 int udt_softmax_rows(void* x, int64_t rows, int32_t cols, int32_t ld, void* stream);

@@ -177,3 +177,41 @@ def test_mx8_problems_outside_the_lean_family_are_refused(env, cuda):
     wq, cs = env.packing.pack_linear_fp8(w)
     with pytest.raises(ValueError):
         env.ops.linear_mx8(env.ops.Mx8Act(xq, xs), wq, cs, b)
+
+
+@pytest.mark.parametrize("B,N,heads,zero", [(8, 1024, 10, 4), (8, 256, 20, 4), (2, 64, 20, 1), (8, 1024, 10, 0)])
+def test_fused_text_attention_emits_mx8_twin_and_row_statistics(env, cuda, B, N, heads, zero):
+    """x + t_attn(LN(x)) in config #5: the fused launch also writes its result as MX8 + the row statistics of norm3 — for the live
+    samples and for the zero-context half, with and without the channel split (few token tiles)"""
+    from udifftext_amd import lib as L
+    O = env.ops
+    C, Lc = heads * 64, 9
+    g = torch.Generator(device="cpu").manual_seed(6)
+    x = (torch.randn((B, N, C), generator=g) * torch.logspace(-1, 1, C)[None, None, :]).to(cuda).bfloat16()
+    kv = torch.randn((B, Lc, 2 * C), generator=g).to(cuda).bfloat16()
+    wq = env.packing.pack_linear((torch.randn((C, C), generator=g) / math.sqrt(C)).to(cuda))
+    wo = env.packing.pack_linear((torch.randn((C, C), generator=g) / math.sqrt(C)).to(cuda))
+    gamma, beta = (1 + 0.1 * torch.randn((C,), generator=g)).to(cuda), (0.1 * torch.randn((C,), generator=g)).to(cuda)
+    bias = torch.randn((C,), generator=g).to(cuda)
+    tables = O.tattn_prepare(kv, wq, wo, gamma, beta, heads, 0.125)
+    plain = O.tattn_fused(x, tables, bias, heads, zero, 1e-5)
+    out = O.tattn_fused(x, tables, bias, heads, zero, 1e-5, emit_q8=True)
+    q8 = O.mx8_of(out)
+    assert q8 is not None and q8.stats is not None
+    assert q8.stats.shape[0] == L.load().udt_tattn_rowstat_parts(B, N, C)
+    assert torch.equal(out, plain)
+    _check_q8(q8, out.reshape(B * N, C))
+
+
+@pytest.mark.parametrize("B,N,heads", [(8, 1024, 10), (8, 256, 20), (3, 200, 10)])
+def test_flash_attention_emits_mx8_twin(env, cuda, B, N, heads):
+    """attn1's flash kernel in config #5: O also as an MX8 activation for the e4m3 to_out"""
+    O = env.ops
+    C = heads * 64
+    g = torch.Generator(device="cpu").manual_seed(7)
+    qkv = torch.randn((B, N, 3 * C), generator=g).to(cuda).bfloat16()
+    plain = O.attention_rowv(qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:], heads, 0.125)
+    out = O.attention_rowv(qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:], heads, 0.125, emit_q8=True)
+    q8 = O.mx8_of(out)
+    assert q8 is not None and torch.equal(out, plain)
+    _check_q8(q8, out.reshape(B * N, C), stats=False)

@@ -37,6 +37,11 @@ struct AttnParams {
   int ldq, ldk, ldvt, ldo;
   long long sq, sk, svt, so;
   float scale_log2e;
+  // attn_d64_v2_kernel only (udt_attn_rowv_q8_fwd, BASELINE config #5): O again as an MX8 activation (common.h) for the e4m3 to_out GEMM
+  uint8_t* q8_out;         // [batch * nq, ld_q8] e4m3, columns h * 64 + d
+  uint32_t* q8_scale;      // [heads * 64 / 128][batch * nq]
+  int ld_q8;
+  long long q8_rows;       // batch * nq
 };
 
 constexpr int KV_TILE = 64;
@@ -442,6 +447,24 @@ __global__ void __launch_bounds__(256, 3) attn_d64_v2_kernel(const AttnParams p)
                     pack_bf16x2(o_acc[dt][qd * 4 + 2] * inv, o_acc[dt][qd * 4 + 3] * inv)};
         *reinterpret_cast<u32x2*>(O + (long long)qi * p.ldo + d) = pk;
       }
+  }
+  if (p.q8_out) {
+    // a query's 32 dims of tile dt are one MX block: 16 of them in this lane, 16 in lane ^ 32 (every lane runs the exchange)
+    const long long m = (long long)b * p.nq + qi;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) {
+      float v[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) v[r] = o_acc[dt][r] * inv;
+      uint32_t q[4], sb;
+      mx8_quant_acc16(v, q, sb);
+      if (qok) {
+        const int blk = h * 2 + dt;
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) *reinterpret_cast<uint32_t*>(p.q8_out + m * p.ld_q8 + blk * 32 + qd * 8 + hi * 4) = q[qd];
+        if (hi == 0) reinterpret_cast<uint8_t*>(p.q8_scale)[((long long)(blk >> 2) * p.q8_rows + m) * 4 + (blk & 3)] = (uint8_t)sb;
+      }
+    }
   }
 }
 
@@ -888,8 +911,9 @@ __global__ void __launch_bounds__(256) softmax_rows_kernel(uint16_t* x, int cols
 static int attn_fwd_impl(bool vrow, const void* q, const void* k, const void* vt, void* o, int32_t batch, int32_t heads,
                          int32_t nq, int32_t nk, int32_t ldq, int32_t ldk, int32_t ldvt, int32_t ldo,
                          int64_t q_bstride, int64_t k_bstride, int64_t vt_bstride, int64_t o_bstride,
-                         float scale, void* stream) {
+                         float scale, void* stream, void* q8_out = nullptr, void* q8_scale = nullptr, int32_t ld_q8 = 0) {
   if (!q || !k || !vt || !o) return UDT_ERR_BAD_ARG;
+  if (q8_out && (!vrow || !q8_scale || ld_q8 < heads * 64 || ld_q8 % 4 != 0 || heads % 2 != 0)) return UDT_ERR_BAD_ARG;
   if (batch <= 0 || heads <= 0 || nq <= 0 || nk <= 0) return UDT_ERR_BAD_SHAPE;
   if (nk % 8 != 0 || ldq % 8 != 0 || ldk % 8 != 0 || ldvt % 8 != 0 || ldo % 4 != 0) return UDT_ERR_BAD_SHAPE;
   AttnParams p;
@@ -903,11 +927,13 @@ static int attn_fwd_impl(bool vrow, const void* q, const void* k, const void* vt
   p.ldq = ldq; p.ldk = ldk; p.ldvt = ldvt; p.ldo = ldo;
   p.sq = q_bstride; p.sk = k_bstride; p.svt = vt_bstride; p.so = o_bstride;
   p.scale_log2e = scale * 1.4426950408889634f;
+  p.q8_out = reinterpret_cast<uint8_t*>(q8_out); p.q8_scale = reinterpret_cast<uint32_t*>(q8_scale); p.ld_q8 = ld_q8;
+  p.q8_rows = (long long)batch * nq;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   UdtProfScope prof(2, s);
   if (prof.rec) {
     char tag[96];
-    snprintf(tag, sizeof(tag), "attn B=%d H=%d nq=%d nk=%d", batch, heads, nq, nk);
+    snprintf(tag, sizeof(tag), "attn%s B=%d H=%d nq=%d nk=%d", q8_out ? "+q8" : "", batch, heads, nq, nk);
     udt_prof_tag(prof.rec, tag);
   }
   dim3 grid((nq + 127) / 128, batch * heads);
@@ -943,6 +969,17 @@ extern "C" int udt_attn_rowv_fwd(const void* q, const void* k, const void* v, vo
                                  float scale, void* stream) {
   return attn_fwd_impl(true, q, k, v, o, batch, heads, nq, nk, ldq, ldk, ldv, ldo, q_bstride, k_bstride, v_bstride,
                        o_bstride, scale, stream);
+}
+
+extern "C" int udt_attn_rowv_q8_fwd(const void* q, const void* k, const void* v, void* o, int32_t batch, int32_t heads,
+                                    int32_t nq, int32_t nk, int32_t ldq, int32_t ldk, int32_t ldv, int32_t ldo,
+                                    int64_t q_bstride, int64_t k_bstride, int64_t v_bstride, int64_t o_bstride,
+                                    float scale, void* q8_out, void* q8_scale, int32_t ld_q8, void* stream) {
+  if (!q8_out) return UDT_ERR_BAD_ARG;
+  // (the MX8 twin is addressed as rows b * nq + i: the bf16 output must be that matrix too)
+  if (o_bstride != (int64_t)nq * ldo) return UDT_ERR_BAD_SHAPE;
+  return attn_fwd_impl(true, q, k, v, o, batch, heads, nq, nk, ldq, ldk, ldv, ldo, q_bstride, k_bstride, v_bstride,
+                       o_bstride, scale, stream, q8_out, q8_scale, ld_q8);
 }
 
 // key split plan: when the query tiles alone leave most CUs idle (a single image: 64 workgroups, each walking all 4096 keys

@@ -44,6 +44,11 @@ struct TattnParams {
   int M, C, hp, n_tok, zero_samples;
   int nsplit;              // workgroups per token tile: each recomputes the (cheap) scores and owns 1/nsplit of the output channels
   float eps;
+  // Q8 instances (udt_tattn_fused_q8, BASELINE config #5): the result again as an MX8 activation (common.h) for the LayerNorm-folded
+  // GEGLU projection that consumes it, + the partial row statistics of that LayerNorm, one part per channel split
+  uint8_t* q8_out;         // [M, C] e4m3
+  uint32_t* q8_scale;      // [C / 128][M]
+  float* rowstat_out;      // [nsplit][M][2]
 };
 
 UDT_DEVINL f32x16 zero16() {
@@ -54,7 +59,7 @@ UDT_DEVINL f32x16 zero16() {
 }
 
 // TT tokens per workgroup (64, or 32 for C = 1280 so that the x tile fits in LDS), 8 waves; NKT = C / 64, NKS = hp / 16
-template <int TT, int NKT, int NKS>
+template <int TT, int NKT, int NKS, bool Q8 = false>
 __global__ void __launch_bounds__(TA_THREADS) tattn_fused_kernel(const TattnParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int C = NKT * 64, hp = NKS * 16;
@@ -64,7 +69,6 @@ __global__ void __launch_bounds__(TA_THREADS) tattn_fused_kernel(const TattnPara
   float* const stats = reinterpret_cast<float*>(smem + (size_t)nkt * TT * 128);        // [TT][2]: mean, rstd
   const int prs = hp * 2 + 16;                              // padded row stride of the P tile (bytes)
   char* const pl = reinterpret_cast<char*>(stats + TT * 2);                            // [TT][prs]
-
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lane = tid & 63;
@@ -73,6 +77,23 @@ __global__ void __launch_bounds__(TA_THREADS) tattn_fused_kernel(const TattnPara
   const int b = (int)(tok0 / p.n_tok);
   const uint16_t* xg = p.x + tok0 * C;
   uint16_t* og = p.out + tok0 * C;
+  float* const rst = reinterpret_cast<float*>(pl + (size_t)TT * prs);                  // Q8: [TT][C / 32][2] per-block row sums
+  const int ct_lo = (int)blockIdx.y * (C >> 5) / p.nsplit, ct_hi = ((int)blockIdx.y + 1) * (C >> 5) / p.nsplit;   // this workgroup's 32-channel tiles
+  // Q8: per-row sums over this workgroup's channel tiles, in tile order (deterministic) -> part blockIdx.y of rowstat_out
+  auto q8_row_stats = [&]() {
+    __syncthreads();
+    if (tid < TT && tok0 + tid < p.M) {
+      float s = 0.f, q = 0.f;
+      for (int ct = ct_lo; ct < ct_hi; ++ct) {
+        const f32x2 v = *reinterpret_cast<const f32x2*>(rst + ((size_t)tid * (C >> 5) + ct) * 2);
+        s += v[0];
+        q += v[1];
+      }
+      f32x2 o = {s, q};
+      reinterpret_cast<f32x2*>(p.rowstat_out)[(long long)blockIdx.y * p.M + tok0 + tid] = o;
+    }
+  };
+
 
   // ---- the first score tile's A' fragments: independent of x, requested before anything is waited for -----------------
   const uint16_t* Ab = p.A + (long long)b * hp * C;
@@ -105,18 +126,41 @@ __global__ void __launch_bounds__(TA_THREADS) tattn_fused_kernel(const TattnPara
 
   // ---- the zero-context half: x + to_out.bias (reference: k = v = 0 -> attention output 0 -> to_out reduces to its bias)
   if (b < p.zero_samples) {
-    const int c8 = C >> 3;
-    const int ch_lo = (int)blockIdx.y * c8 / p.nsplit, ch_hi = ((int)blockIdx.y + 1) * c8 / p.nsplit;
-    for (int i = tid; i < TT * c8; i += TA_THREADS) {
-      const int row = i / c8, ch = i - row * c8;
-      if (tok0 + row >= p.M || ch < ch_lo || ch >= ch_hi) continue;
+    const int ch_lo = ct_lo * 4, ch_hi = ct_hi * 4;           // (whole 32-channel tiles: a quad of threads = one MX block)
+    const int nch = ch_hi - ch_lo;
+    for (int i0 = 0; i0 < TT * nch; i0 += TA_THREADS) {
+      const int i = i0 + tid;
+      const bool act = i < TT * nch;
+      const int row = act ? i / nch : 0, ch = ch_lo + (act ? i - row * nch : 0);
+      const bool ok = act && tok0 + row < p.M;
       const int kt = ch >> 3, s = ch & 7;
       const u32x4 v = *reinterpret_cast<const u32x4*>(xs + ((size_t)kt * TT + row) * 128 + ((s ^ ((row >> 1) & 7)) << 4));
       const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.bias + ch * 8), b1 = *reinterpret_cast<const f32x4*>(p.bias + ch * 8 + 4);
-      u32x4 o = {pack_bf16x2(bf16_lo(v[0]) + b0[0], bf16_hi(v[0]) + b0[1]), pack_bf16x2(bf16_lo(v[1]) + b0[2], bf16_hi(v[1]) + b0[3]),
-                 pack_bf16x2(bf16_lo(v[2]) + b1[0], bf16_hi(v[2]) + b1[1]), pack_bf16x2(bf16_lo(v[3]) + b1[2], bf16_hi(v[3]) + b1[3])};
-      *reinterpret_cast<u32x4*>(og + (long long)row * C + ch * 8) = o;
+      const float f[8] = {bf16_lo(v[0]) + b0[0], bf16_hi(v[0]) + b0[1], bf16_lo(v[1]) + b0[2], bf16_hi(v[1]) + b0[3],
+                          bf16_lo(v[2]) + b1[0], bf16_hi(v[2]) + b1[1], bf16_lo(v[3]) + b1[2], bf16_hi(v[3]) + b1[3]};
+      u32x4 o = {pack_bf16x2(f[0], f[1]), pack_bf16x2(f[2], f[3]), pack_bf16x2(f[4], f[5]), pack_bf16x2(f[6], f[7])};
+      if (ok) *reinterpret_cast<u32x4*>(og + (long long)row * C + ch * 8) = o;
+      if constexpr (Q8) {
+        // (nch % 4 == 0 and TA_THREADS % 4 == 0: the four threads of an aligned quad hold one row's 32-channel block)
+        uint32_t sb;
+        const u32x2 q8 = mx8_quant_row8(f, sb);
+        float ps = 0.f, pq = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ps += f[j], pq += f[j] * f[j];
+        ps = dpp_add<0xB1>(ps); pq = dpp_add<0xB1>(pq);
+        ps = dpp_add<0x4E>(ps); pq = dpp_add<0x4E>(pq);
+        if (ok) {
+          const long long m = tok0 + row;
+          *reinterpret_cast<u32x2*>(p.q8_out + m * C + ch * 8) = q8;
+          if ((ch & 3) == 0) {
+            reinterpret_cast<uint8_t*>(p.q8_scale)[((long long)(ch >> 4) * p.M + m) * 4 + ((ch >> 2) & 3)] = (uint8_t)sb;
+            f32x2 st2 = {ps, pq};
+            *reinterpret_cast<f32x2*>(rst + ((size_t)row * (C >> 5) + (ch >> 2)) * 2) = st2;
+          }
+        }
+      }
     }
+    if constexpr (Q8) q8_row_stats();
     return;
   }
 
@@ -223,7 +267,6 @@ __global__ void __launch_bounds__(TA_THREADS) tattn_fused_kernel(const TattnPara
 
   // ---- out^T = Bm^T P^T  (D rows = channels, D cols = tokens) + bias + residual -> store ---------------------------------
   const uint16_t* Bb = p.BmT + (long long)b * C * hp;
-  const int ct_lo = (int)blockIdx.y * (C >> 5) / p.nsplit, ct_hi = ((int)blockIdx.y + 1) * (C >> 5) / p.nsplit;
   const int tiles2 = (ct_hi - ct_lo) * (TT / 32);
   constexpr int nks = NKS;                                  // 16-wide k-steps over the score columns
   for (int t = wave; t < tiles2; t += TA_WAVES) {
@@ -240,20 +283,46 @@ __global__ void __launch_bounds__(TA_THREADS) tattn_fused_kernel(const TattnPara
       const bf16x8_t pf = *reinterpret_cast<const bf16x8_t*>(prow + ks * 32);
       acc = mfma32(bn[ks], pf, acc);
     }
-    if (tok0 + row < p.M) {
+    {
+      const bool rok = tok0 + row < p.M;                    // (rows past M stage the zero page: every lane runs the cross-lane steps)
       const int swz = (row >> 1) & 7;
+      float v[16];
 #pragma unroll
       for (int r4 = 0; r4 < 4; ++r4) {
         const int c = ct * 32 + 8 * r4 + 4 * hi;            // 4 consecutive channels
         const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + c);
         const int kt = c >> 6, sl = (c & 63) >> 3;
         const u32x2 xr = *reinterpret_cast<const u32x2*>(xs + ((size_t)kt * TT + row) * 128 + ((sl ^ swz) << 4) + (c & 7) * 2);
-        u32x2 pk = {pack_bf16x2(acc[r4 * 4 + 0] + bv[0] + bf16_lo(xr[0]), acc[r4 * 4 + 1] + bv[1] + bf16_hi(xr[0])),
-                    pack_bf16x2(acc[r4 * 4 + 2] + bv[2] + bf16_lo(xr[1]), acc[r4 * 4 + 3] + bv[3] + bf16_hi(xr[1]))};
-        *reinterpret_cast<u32x2*>(og + (long long)row * C + c) = pk;
+        v[r4 * 4 + 0] = acc[r4 * 4 + 0] + bv[0] + bf16_lo(xr[0]);
+        v[r4 * 4 + 1] = acc[r4 * 4 + 1] + bv[1] + bf16_hi(xr[0]);
+        v[r4 * 4 + 2] = acc[r4 * 4 + 2] + bv[2] + bf16_lo(xr[1]);
+        v[r4 * 4 + 3] = acc[r4 * 4 + 3] + bv[3] + bf16_hi(xr[1]);
+        u32x2 pk = {pack_bf16x2(v[r4 * 4 + 0], v[r4 * 4 + 1]), pack_bf16x2(v[r4 * 4 + 2], v[r4 * 4 + 3])};
+        if (rok) *reinterpret_cast<u32x2*>(og + (long long)row * C + c) = pk;
+      }
+      if constexpr (Q8) {
+        // this 32-channel tile of the row is one MX block: 16 of its values here, 16 in lane ^ 32
+        uint32_t q[4], sb;
+        mx8_quant_acc16(v, q, sb);
+        float ps = 0.f, pq = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ps += v[r], pq += v[r] * v[r];
+        ps = xor32_sum(ps);
+        pq = xor32_sum(pq);
+        if (rok) {
+          const long long m = tok0 + row;
+#pragma unroll
+          for (int r4 = 0; r4 < 4; ++r4) *reinterpret_cast<uint32_t*>(p.q8_out + m * C + ct * 32 + 8 * r4 + 4 * hi) = q[r4];
+          if (hi == 0) {
+            reinterpret_cast<uint8_t*>(p.q8_scale)[((long long)(ct >> 2) * p.M + m) * 4 + (ct & 3)] = (uint8_t)sb;
+            f32x2 st2 = {ps, pq};
+            *reinterpret_cast<f32x2*>(rst + ((size_t)row * (C >> 5) + ct) * 2) = st2;
+          }
+        }
       }
     }
   }
+  if constexpr (Q8) q8_row_stats();
 }
 
 // ---- once per batch: fold the context into the per-sample tables ------------------------------------------------------
@@ -347,44 +416,54 @@ extern "C" int udt_tattn_prepare(const void* kv, int32_t ldkv, const void* wq, i
   return UDT_OK;
 }
 
-extern "C" int udt_tattn_fused(const void* x, void* out, const void* A, const float* sc, const void* BmT, const float* bias,
-                               int32_t B, int32_t n_tok, int32_t C, int32_t heads, int32_t zero_samples, float eps, void* stream) {
+namespace {
+// workgroups per token tile (channel splits): few token tiles (the 16x16 / 8x8 levels) split the output channels over up to 8
+// workgroups per tile so that the launch covers the chip; every split recomputes the statistics and scores of its tile
+// (round 3: a full chip of workgroups — the launch is a chain of L2-latency-bound steps, so idle CUs are the one thing that is free)
+int tattn_nsplit(int M, int TT) {
+  const unsigned grid = (unsigned)(M / TT);
+  constexpr unsigned target = 256u;
+  int nsplit = 1;
+  while (nsplit < 8 && grid * nsplit < target) nsplit *= 2;
+  return nsplit;
+}
+
+int tattn_launch(const void* x, void* out, const void* A, const float* sc, const void* BmT, const float* bias, int32_t B, int32_t n_tok,
+                 int32_t C, int32_t heads, int32_t zero_samples, float eps, void* q8_out, void* q8_scale, float* rowstat_out, void* stream) {
   if (!x || !out || !bias || (zero_samples < B && (!A || !sc || !BmT))) return UDT_ERR_BAD_ARG;
   if (B <= 0 || n_tok <= 0 || heads <= 0 || C != heads * 64 || C > 1280 || zero_samples < 0 || zero_samples > B) return UDT_ERR_BAD_SHAPE;
   const int TT = (C > 640) ? 32 : 64;
   if (n_tok % TT != 0) return UDT_ERR_BAD_SHAPE;             // a token tile lies in one sample
+  const bool q8 = q8_out != nullptr;
+  if (q8 && (!q8_scale || !rowstat_out || C % 128 != 0)) return UDT_ERR_BAD_ARG;
   TattnParams p;
   p.x = reinterpret_cast<const uint16_t*>(x); p.out = reinterpret_cast<uint16_t*>(out);
   p.A = reinterpret_cast<const uint16_t*>(A); p.sc = sc; p.BmT = reinterpret_cast<const uint16_t*>(BmT); p.bias = bias;
   p.zero = udt_zero_page();
   if (!p.zero) return UDT_ERR_HIP;
   p.M = B * n_tok; p.C = C; p.hp = udt_tattn_hp(heads); p.n_tok = n_tok; p.zero_samples = zero_samples; p.eps = eps;
-  const size_t smem = (size_t)TT * C * 2 + (size_t)TT * 2 * sizeof(float) + (size_t)TT * (p.hp * 2 + 16);
+  p.q8_out = reinterpret_cast<uint8_t*>(q8_out); p.q8_scale = reinterpret_cast<uint32_t*>(q8_scale); p.rowstat_out = rowstat_out;
+  const size_t smem = (size_t)TT * C * 2 + (size_t)TT * 2 * sizeof(float) + (size_t)TT * (p.hp * 2 + 16) + (q8 ? (size_t)TT * (C / 32) * 8 : 0);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   UdtProfScope prof(3, s);
   if (prof.rec) {
     char tag[96];
-    snprintf(tag, sizeof(tag), "tattn_fused B=%d n=%d C=%d zero=%d", B, n_tok, C, zero_samples);
+    snprintf(tag, sizeof(tag), "tattn_fused%s B=%d n=%d C=%d zero=%d", q8 ? "+q8" : "", B, n_tok, C, zero_samples);
     udt_prof_tag(prof.rec, tag);
   }
-  static bool attr_done[3] = {false, false, false};          // (max dynamic LDS; set once per process — one device per process)
+  static bool attr_done[5] = {false, false, false, false, false};   // (max dynamic LDS; set once per process — one device per process)
   const unsigned grid = (unsigned)(p.M / TT);
-  // few token tiles (the 16x16 / 8x8 levels): split the output channels over up to 4 workgroups per tile so that the
-  // launch covers >= ~128 CUs; every split recomputes the statistics and scores of its tile (a third of the work)
-  // (round 3: up to 8 splits and a full chip of workgroups — the launch is a chain of L2-latency-bound steps, so idle CUs
-  //  are the one thing that is free)
-  constexpr unsigned target = 256u;
-  p.nsplit = 1;
-  while (p.nsplit < 8 && grid * p.nsplit < target) p.nsplit *= 2;
-  // instances: the UNet's three widths (C = 320 / 640 / 1280 with 5 / 10 / 20 heads: hp = 80 -> padded 96, 160, 320)
+  p.nsplit = tattn_nsplit(p.M, TT);
+  // instances: the UNet's three widths (C = 320 / 640 / 1280 with 5 / 10 / 20 heads: hp = 80 -> padded 96, 160, 320); the MX8-emitting
+  // form for the two widths whose linears run on e4m3 operands in config #5
   const void* fn = nullptr;
   int which = -1;
-  if (C == 320 && p.hp == 96) { fn = reinterpret_cast<const void*>(tattn_fused_kernel<64, 5, 6>); which = 0; }
-  else if (C == 640 && p.hp == 160) { fn = reinterpret_cast<const void*>(tattn_fused_kernel<64, 10, 10>); which = 1; }
-  else if (C == 1280 && p.hp == 320) { fn = reinterpret_cast<const void*>(tattn_fused_kernel<32, 20, 20>); which = 2; }
+  if (C == 320 && p.hp == 96 && !q8) { fn = reinterpret_cast<const void*>(tattn_fused_kernel<64, 5, 6>); which = 0; }
+  else if (C == 640 && p.hp == 160) { fn = q8 ? reinterpret_cast<const void*>(tattn_fused_kernel<64, 10, 10, true>) : reinterpret_cast<const void*>(tattn_fused_kernel<64, 10, 10>); which = q8 ? 3 : 1; }
+  else if (C == 1280 && p.hp == 320) { fn = q8 ? reinterpret_cast<const void*>(tattn_fused_kernel<32, 20, 20, true>) : reinterpret_cast<const void*>(tattn_fused_kernel<32, 20, 20>); which = q8 ? 4 : 2; }
   else return UDT_ERR_BAD_SHAPE;
   if (!attr_done[which]) {
-    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024);
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
     if (e != hipSuccess) return udt_set_hip_error(e);
     attr_done[which] = true;
   }
@@ -393,4 +472,24 @@ extern "C" int udt_tattn_fused(const void* x, void* out, const void* A, const fl
   if (el != hipSuccess) return udt_set_hip_error(el);
   UDT_CHECK_LAUNCH();
   return UDT_OK;
+}
+}  // namespace
+
+extern "C" int udt_tattn_fused(const void* x, void* out, const void* A, const float* sc, const void* BmT, const float* bias,
+                               int32_t B, int32_t n_tok, int32_t C, int32_t heads, int32_t zero_samples, float eps, void* stream) {
+  return tattn_launch(x, out, A, sc, BmT, bias, B, n_tok, C, heads, zero_samples, eps, nullptr, nullptr, nullptr, stream);
+}
+
+extern "C" int32_t udt_tattn_rowstat_parts(int32_t B, int32_t n_tok, int32_t C) {
+  if (B <= 0 || n_tok <= 0 || (C != 640 && C != 1280)) return 0;
+  const int TT = (C > 640) ? 32 : 64;
+  if (n_tok % TT != 0) return 0;
+  return tattn_nsplit(B * n_tok, TT);
+}
+
+extern "C" int udt_tattn_fused_q8(const void* x, void* out, const void* A, const float* sc, const void* BmT, const float* bias,
+                                  int32_t B, int32_t n_tok, int32_t C, int32_t heads, int32_t zero_samples, float eps, void* q8_out,
+                                  void* q8_scale, float* rowstat_out, void* stream) {
+  if (!q8_out) return UDT_ERR_BAD_ARG;
+  return tattn_launch(x, out, A, sc, BmT, bias, B, n_tok, C, heads, zero_samples, eps, q8_out, q8_scale, rowstat_out, stream);
 }

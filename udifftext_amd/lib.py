@@ -73,6 +73,8 @@ SYMBOLS = {
                                _i64, _i64, _i64, _i64, _f32, _vp]),
     "udt_attn_rowv_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32,
                                     _i64, _i64, _i64, _i64, _f32, _vp]),
+    "udt_attn_rowv_q8_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32,
+                                       _i64, _i64, _i64, _i64, _f32, _vp, _vp, _i32, _vp]),
     "udt_attn512_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i64, _i64, _i64, _i64, _f32, _vp]),
     "udt_attn512_workspace_bytes": (C.c_size_t, [_i32, _i32, _i32]),
     "udt_attn512_split_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i64, _i64, _i64, _i64, _f32,
@@ -84,6 +86,8 @@ SYMBOLS = {
     "udt_tattn_hp": (_i32, [_i32]),
     "udt_tattn_prepare": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _i32, _fp, _fp, _vp, _fp, _vp, _i32, _i32, _i32, _i32, _f32, _vp]),
     "udt_tattn_fused": (C.c_int, [_vp, _vp, _vp, _fp, _vp, _fp, _i32, _i32, _i32, _i32, _i32, _f32, _vp]),
+    "udt_tattn_rowstat_parts": (_i32, [_i32, _i32, _i32]),
+    "udt_tattn_fused_q8": (C.c_int, [_vp, _vp, _vp, _fp, _vp, _fp, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _vp, _fp, _vp]),
     "udt_gn_nchunks": (_i32, [_i64, _i32]),
     "udt_gn_stats": (C.c_int, [_vp, _vp, _fp, _i32, _i64, _i32, _i32, _i32, _vp]),
     "udt_gn_apply": (C.c_int, [_vp, _vp, _vp, _fp, _fp, _fp, _i32, _i64, _i32, _i32, _i32, _f32, _i32, _vp]),

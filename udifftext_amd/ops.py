@@ -438,19 +438,30 @@ def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, heads: int, sc
 
 
 def attention_rowv(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, scale: float,
-                   out: Optional[torch.Tensor] = None) -> torch.Tensor:
+                   out: Optional[torch.Tensor] = None, emit_q8: bool = False) -> torch.Tensor:
     """flash attention with V row-major like K: q, k, v [B, N, *] row views (e.g. the column ranges of one q|k|v
-    projection) whose first heads*64 columns are the head-major projections.  Returns o [B, Nq, heads*64]."""
+    projection) whose first heads*64 columns are the head-major projections.  Returns o [B, Nq, heads*64].
+    emit_q8: o ALSO as an MX8 activation (``out.mx8``) for an e4m3 ``to_out`` (heads even)."""
     _bf16(q); _bf16(k); _bf16(v)
     B, Nq = q.shape[0], q.shape[1]
     Nk = k.shape[1]
     assert q.stride(2) == 1 and k.stride(2) == 1 and v.stride(2) == 1 and v.shape[1] == Nk
     if out is None:
         out = torch.empty((B, Nq, heads * 64), dtype=torch.bfloat16, device=q.device)
-    L.check(L.load().udt_attn_rowv_fwd(_ptr(q), _ptr(k), _ptr(v), _ptr(out), B, heads, Nq, Nk,
-                                       q.stride(1), k.stride(1), v.stride(1), out.stride(1),
-                                       q.stride(0), k.stride(0), v.stride(0), out.stride(0), scale, _stream()),
-            "udt_attn_rowv_fwd")
+    if getattr(out, "mx8", None) is not None:
+        del out.mx8
+    if emit_q8 and heads % 2 == 0 and out.is_contiguous():
+        q8 = _mx8_alloc(B * Nq, heads * 64, q.device)
+        L.check(L.load().udt_attn_rowv_q8_fwd(_ptr(q), _ptr(k), _ptr(v), _ptr(out), B, heads, Nq, Nk,
+                                              q.stride(1), k.stride(1), v.stride(1), out.stride(1),
+                                              q.stride(0), k.stride(0), v.stride(0), out.stride(0), scale,
+                                              _ptr(q8.data), _ptr(q8.scale), heads * 64, _stream()), "udt_attn_rowv_q8_fwd")
+        out.mx8 = q8
+    else:
+        L.check(L.load().udt_attn_rowv_fwd(_ptr(q), _ptr(k), _ptr(v), _ptr(out), B, heads, Nq, Nk,
+                                           q.stride(1), k.stride(1), v.stride(1), out.stride(1),
+                                           q.stride(0), k.stride(0), v.stride(0), out.stride(0), scale, _stream()),
+                "udt_attn_rowv_fwd")
     if WORK_COUNTER is not None:
         count_work("attn", 4.0 * B * heads * Nq * Nk * 64)
         count_work("attn_bytes", 2.0 * B * heads * 64 * (2 * Nq + 2 * Nk))
@@ -563,8 +574,9 @@ def tattn_prepare(kv: torch.Tensor, wq: torch.Tensor, wo: torch.Tensor, gamma: t
 
 
 def tattn_fused(x: torch.Tensor, tables: Optional[TattnTables], bias: torch.Tensor, heads: int, zero_samples: int, eps: float,
-                out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """x bf16 [B, N, C] -> x + t_attn(LayerNorm(x)) (+ bias); the first zero_samples samples see a zero context"""
+                out: Optional[torch.Tensor] = None, emit_q8: bool = False) -> torch.Tensor:
+    """x bf16 [B, N, C] -> x + t_attn(LayerNorm(x)) (+ bias); the first zero_samples samples see a zero context.
+    emit_q8: the result ALSO as an MX8 activation with partial row statistics (``out.mx8``) where the library has the instance."""
     _bf16(x)
     assert x.is_contiguous()
     B, N, Cc = x.shape
@@ -573,6 +585,17 @@ def tattn_fused(x: torch.Tensor, tables: Optional[TattnTables], bias: torch.Tens
     assert out.is_contiguous()
     if tables is not None:
         assert tables.A.is_contiguous() and tables.sc.is_contiguous() and tables.BmT.is_contiguous() and tables.A.shape[0] == B
+    if getattr(out, "mx8", None) is not None:
+        del out.mx8
+    parts = L.load().udt_tattn_rowstat_parts(B, N, Cc) if emit_q8 else 0
+    if parts > 0:
+        q = _mx8_alloc(B * N, Cc, x.device)
+        q = Mx8Act(q.data, q.scale, torch.empty((parts, B * N, 2), dtype=torch.float32, device=x.device))
+        L.check(L.load().udt_tattn_fused_q8(_ptr(x), _ptr(out), _ptr(tables.A) if tables else None, _ptr(tables.sc) if tables else None,
+                                            _ptr(tables.BmT) if tables else None, _ptr(bias), B, N, Cc, heads, zero_samples, eps,
+                                            _ptr(q.data), _ptr(q.scale), _ptr(q.stats), _stream()), "udt_tattn_fused_q8")
+        out.mx8 = q
+        return out
     L.check(L.load().udt_tattn_fused(_ptr(x), _ptr(out), _ptr(tables.A) if tables else None, _ptr(tables.sc) if tables else None,
                                      _ptr(tables.BmT) if tables else None, _ptr(bias), B, N, Cc, heads, zero_samples, eps, _stream()),
             "udt_tattn_fused")

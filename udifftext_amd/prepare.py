@@ -52,7 +52,7 @@ def prepare(engine, free_masters: bool = False, dedup_vae: bool = True) -> Dict[
         # where the LayerNorm-folded layouts serve the forward pass (BasicTransformerBlock: fold = LN_GEMM and not fp8), the plain
         # q|k|v and GEGLU layouts of the UNet's blocks are never read: not packed (~270 MB of bf16 for the SD-2 UNet)
         from sgm.modules.attention import BasicTransformerBlock as _BTB
-        fold_on = H.LN_GEMM and not H.FP8_LINEARS
+        fold_on = H.LN_GEMM
         ln_only = set()
         if fold_on:
             for m in unet.modules():
@@ -73,23 +73,15 @@ def prepare(engine, free_masters: bool = False, dedup_vae: bool = True) -> Dict[
         report["packed_bytes"] += w.numel() * w.element_size() + b.numel() * b.element_size()
         # ---- LayerNorm-folded layouts of the q|k|v and GEGLU projections (udt_ln_gemm_fwd)
         from sgm.modules.attention import BasicTransformerBlock
-        if H.LN_GEMM and not H.FP8_LINEARS:
+        # (in config #5 — UDT_FP8=1 — prepare_ln / prepare_mx8 also build, and freeze, the e4m3 layouts of the blocks whose linears
+        #  run on MX8 operands: ahead of the release of the masters)
+        if H.LN_GEMM:
+            from sgm.modules.attention import SpatialTransformer
             for m in unet.modules():
                 if isinstance(m, BasicTransformerBlock):
                     report["packed_bytes"] += m.prepare_ln(freeze=free_masters)
-        # ---- e4m3 layouts (UDT_FP8=1): built and frozen here, ahead of the release of the masters
-        if H.FP8_LINEARS:
-            for m in engine.modules():
-                if isinstance(m, H._Packed) and (id(m) in seen):
-                    try:
-                        pk8 = m.packed_fp8()
-                    except NotImplementedError:
-                        continue
-                    m._pk8_frozen = bool(free_masters)
-                    for t in (pk8 if isinstance(pk8, (tuple, list)) else (pk8,)):
-                        for u in (t if isinstance(t, (tuple, list)) else (t,)):
-                            if isinstance(u, torch.Tensor):
-                                report["packed_bytes"] += u.numel() * u.element_size()
+                elif isinstance(m, SpatialTransformer):
+                    report["packed_bytes"] += m.prepare_mx8(freeze=free_masters)
         # ---- release the masters
         if free_masters:
             victims = []

@@ -43,20 +43,22 @@ class GEGLU(H._Packed):
     def _pack(self):
         return packing.pack_geglu(self.proj.weight, self.proj.bias)
 
-    def _pack_fp8(self):
-        return packing.pack_geglu_fp8(self.proj.weight, self.proj.bias)
-
     def _pack_ln(self, gamma, beta):
         return packing.pack_ln_linear(self.proj.weight, self.proj.bias, gamma, beta, geglu=True)
 
-    def forward(self, x, ln=None):
-        """ln: the LayerNorm in front of this projection, folded into the GEMM (x is then the RAW activation)"""
+    def _pack_ln_mx8(self, gamma, beta):
+        return packing.pack_ln_linear_mx8(self.proj.weight, self.proj.bias, gamma, beta, geglu=True)
+
+    def forward(self, x, ln=None, x8=None):
+        """ln: the LayerNorm in front of this projection, folded into the GEMM (x is then the RAW activation).
+        x8 (with ln): the raw activation as an MX8 activation with row statistics -> the e4m3 GEMM; the hidden activation is then
+        returned as an ops.Mx8Act ONLY (config #5: its one consumer is the e4m3 ff.net[2])"""
+        if ln is not None and x8 is not None:
+            wq, cs, c, s = self.packed_ln_mx8(ln)
+            return ops.linear_mx8(x8, wq, cs, ln_c=c, ln_s=s, eps=ln.eps, flags=H.GEMM_GEGLU, emit_q8=True, want_bf16=False)
         if ln is not None:
             wf, c, s = self.packed_ln(ln)
             return ops.ln_linear(x, wf, c, s, eps=ln.eps, flags=H.GEMM_GEGLU)
-        if isinstance(x, ops.Fp8Act):
-            wq, cs, b = self.packed_fp8()
-            return ops.linear_fp8(x, wq, cs, b, flags=H.GEMM_GEGLU)
         w, b = self.packed()
         return ops.linear(x, w, b, flags=H.GEMM_GEGLU)
 
@@ -69,8 +71,11 @@ class FeedForward(nn.Module):
         inner = int(dim * mult)
         self.net = nn.Sequential(GEGLU(dim, inner), nn.Identity(), H.Linear(inner, dim_out or dim))
 
-    def forward(self, x, residual=None, ln=None):
-        return self.net[2](self.net[0](x, ln=ln), residual=residual)
+    def forward(self, x, residual=None, ln=None, x8=None, emit_q8: bool = False, emit_rowstats: bool = False):
+        h = self.net[0](x, ln=ln, x8=x8)
+        if isinstance(h, ops.Mx8Act):                       # (config #5: e4m3 hidden activation -> e4m3 ff.net[2])
+            return self.net[2](None, residual=residual, x8=h, emit_q8=emit_q8, emit_rowstats=emit_rowstats)
+        return self.net[2](h, residual=residual)
 
 
 class CrossAttention(H._Packed):
@@ -103,14 +108,10 @@ class CrossAttention(H._Packed):
         return ops.linear(context_bf16.reshape(B * Lc, Dc), self.packed()).reshape(B, Lc, -1)
 
     def forward(self, x, context=None, kv=None, residual=None, emit_map: bool = False, out=None):
-        """x: bf16 [B, N, C], or an ops.Fp8Act of the [B * N, C] rows (then B, N come from the residual)"""
+        """x: bf16 [B, N, C]"""
         inner = self.heads * self.dim_head
-        if isinstance(x, ops.Fp8Act):
-            B, N = residual.shape[0], residual.shape[1]
-            q = self.to_q(x).reshape(B, N, inner)
-        else:
-            B, N, _ = x.shape
-            q = self.to_q(x.reshape(B * N, -1)).reshape(B, N, inner)
+        B, N, _ = x.shape
+        q = self.to_q(x.reshape(B * N, -1)).reshape(B, N, inner)
         if kv is None:
             kv = self.project_context(context)
         probs = None
@@ -169,35 +170,34 @@ class MemoryEfficientCrossAttention(H._Packed):
         # one q|k|v projection; the flash kernel transposes V tiles out of LDS itself
         return H.fuse_rows(self.to_q.weight, self.to_k.weight, self.to_v.weight), None
 
-    def _pack_fp8(self):
-        return packing.pack_linear_fp8(torch.cat([self.to_q.weight, self.to_k.weight, self.to_v.weight], 0)), None
-
     def _pack_ln(self, gamma, beta):
         return packing.pack_ln_linear(torch.cat([self.to_q.weight, self.to_k.weight, self.to_v.weight], 0), None, gamma, beta)
 
-    def forward(self, x, context=None, mask=None, residual=None, ln=None):
-        """ln: the LayerNorm in front of the q|k|v projection, folded into that GEMM (x is then the RAW activation)"""
+    def _pack_ln_mx8(self, gamma, beta):
+        return packing.pack_ln_linear_mx8(torch.cat([self.to_q.weight, self.to_k.weight, self.to_v.weight], 0), None, gamma, beta)
+
+    def forward(self, x, context=None, mask=None, residual=None, ln=None, x8=None):
+        """ln: the LayerNorm in front of the q|k|v projection, folded into that GEMM (x is then the RAW activation).
+        x8 (with ln; config #5): x as an MX8 activation with row statistics -> e4m3 q|k|v GEMM; the flash kernel then writes its
+        output as MX8 too and to_out runs on e4m3 operands"""
         if context is not None or mask is not None:
             raise NotImplementedError("attn1 is pure self-attention on this path (reference attention.py:251-252)")
         inner = self.heads * self.dim_head
-        fp8 = isinstance(x, ops.Fp8Act)                   # LayerNorm output quantised for the fp8 linears
-        if fp8:
-            B, N = residual.shape[0], residual.shape[1]
-        else:
-            B, N, C = x.shape
-            x2 = x.reshape(B * N, C)
-        if fp8:
-            (wqkv, sqkv), _ = self.packed_fp8()
-            qkv = ops.linear_fp8(x, wqkv, sqkv).reshape(B, N, 3 * inner)
+        B, N, C = x.shape
+        x2 = x.reshape(B * N, C)
+        mx = ln is not None and x8 is not None
+        if mx:
+            wq, cs, c, sv = self.packed_ln_mx8(ln)
+            qkv = ops.linear_mx8(x8, wq, cs, ln_c=c, ln_s=sv, eps=ln.eps).reshape(B, N, 3 * inner)
         elif ln is not None:
             wf, c, sv = self.packed_ln(ln)
             qkv = ops.ln_linear(x2, wf, c, sv, eps=ln.eps).reshape(B, N, 3 * inner)
         else:
             qkv = ops.linear(x2, self.packed()[0]).reshape(B, N, 3 * inner)
         o = ops.attention_rowv(qkv[..., :inner], qkv[..., inner:2 * inner], qkv[..., 2 * inner:], self.heads,
-                               self.dim_head ** -0.5)
+                               self.dim_head ** -0.5, emit_q8=mx)
         res = residual.reshape(B * N, -1) if residual is not None else None
-        return self.to_out[0](o.reshape(B * N, inner), residual=res).reshape(B, N, -1)
+        return self.to_out[0](o.reshape(B * N, inner), residual=res, x8=ops.mx8_of(o) if mx else None).reshape(B, N, -1)
 
 
 class BasicTransformerBlock(nn.Module):
@@ -219,42 +219,60 @@ class BasicTransformerBlock(nn.Module):
                 and n_tokens % (32 if C > 640 else 64) == 0)
 
     def forward(self, x, t_context=None, v_context=None, t_kv=None, emit_map: bool = False, zero_ctx_rows: int = 0,
-                t_fused=None):
+                t_fused=None, x8=None, emit_rowstats: bool = False):
         """zero_ctx_rows: the first n samples of the batch attend to an all-zero text context (the unconditional
         half of a CFG pair under force_uc_zero_embeddings) — their t_attn branch is x + to_out.bias, no GEMMs.
-        t_fused: the block's folded context tables (ops.TattnTables for the samples of x) -> one fused launch."""
-        fp8 = H.FP8_LINEARS
-        fold = H.LN_GEMM and not fp8                            # LayerNorm inside the consuming GEMM (udt_ln_gemm_fwd)
-        ln = (lambda norm, t: norm.forward_fp8(t.reshape(-1, t.shape[-1]))) if fp8 else (lambda norm, t: norm(t))
-        x = self.attn1(x, residual=x, ln=self.norm1) if fold else self.attn1(ln(self.norm1, x), residual=x)
+        t_fused: the block's folded context tables (ops.TattnTables for the samples of x) -> one fused launch.
+        x8 (config #5): x as an MX8 activation with row statistics (written by the producer of x) -> the block's linears run on
+        e4m3 operands and the result carries its own MX8 twin (``.mx8``; with row statistics if emit_rowstats: the next consumer
+        is another block's LayerNorm-folded q|k|v)"""
+        fold = H.LN_GEMM                                        # LayerNorm inside the consuming GEMM (udt_ln_gemm_fwd)
+        mx = fold and x8 is not None and H.mx8_width(x.shape[-1])
+        x = self.attn1(x, residual=x, ln=self.norm1, x8=x8 if mx else None) if fold else self.attn1(self.norm1(x), residual=x)
         if hasattr(self, "t_attn"):
             n0 = 0 if emit_map else min(int(zero_ctx_rows), x.shape[0])
             if t_fused is not None and not emit_map and n0 < x.shape[0] and self.fused_tattn_ok(x.shape[1]):
                 _, bo = self.t_attn.to_out[0].packed()
-                x = ops.tattn_fused(x, t_fused, bo, self.t_attn.heads, n0, self.t_norm.eps)
+                x = ops.tattn_fused(x, t_fused, bo, self.t_attn.heads, n0, self.t_norm.eps, emit_q8=mx)
             elif n0 > 0 and t_kv is not None:
                 y = torch.empty_like(x)
                 self.t_attn.zero_context_residual(x[:n0], y[:n0])
                 if n0 < x.shape[0]:
                     xc = x[n0:]
-                    self.t_attn(ln(self.t_norm, xc), kv=t_kv[n0:], residual=xc, out=y[n0:])
+                    self.t_attn(self.t_norm(xc), kv=t_kv[n0:], residual=xc, out=y[n0:])
                 x = y
             else:
-                x = self.t_attn(ln(self.t_norm, x), context=t_context, kv=t_kv, residual=x, emit_map=emit_map)
+                x = self.t_attn(self.t_norm(x), context=t_context, kv=t_kv, residual=x, emit_map=emit_map)
         B, N, C = x.shape
         x2 = x.reshape(B * N, C)
         if fold:
-            return self.ff(x2, residual=x2, ln=self.norm3).reshape(B, N, C)
-        return self.ff(ln(self.norm3, x2), residual=x2).reshape(B, N, C)
+            x8b = ops.mx8_of(x) if mx else None               # (None: the unfused text cross-attention ran — bf16 feed-forward)
+            out = self.ff(x2, residual=x2, ln=self.norm3, x8=x8b, emit_q8=x8b is not None, emit_rowstats=emit_rowstats)
+            return H.carry_mx8(out.reshape(B, N, C), out)
+        return self.ff(self.norm3(x2), residual=x2).reshape(B, N, C)
 
     def prepare_ln(self, freeze: bool = False) -> int:
-        """build (and optionally freeze) the LayerNorm-folded layouts; returns their bytes"""
+        """build (and optionally freeze) the LayerNorm-folded layouts — and, in config #5, the e4m3 layouts of the block's linears
+        (the bf16 ones stay: calls that must return attention maps take the unfused text cross-attention and a bf16 feed-forward);
+        returns their bytes"""
         n = 0
         for mod, norm in ((self.attn1, self.norm1), (self.ff.net[0], self.norm3)):
             for t in mod.packed_ln(norm):
                 n += t.numel() * t.element_size()
             if freeze:
                 mod._pkln_frozen = True
+        if H.mx8_width(self.norm1.dim):
+            for mod, norm in ((self.attn1, self.norm1), (self.ff.net[0], self.norm3)):
+                for t in mod.packed_ln_mx8(norm):
+                    n += t.numel() * t.element_size()
+                if freeze:
+                    mod._pkln8_frozen = True
+            for lin in (self.attn1.to_out[0], self.ff.net[2]):
+                for t in lin.packed_fp8():
+                    if t is not None:
+                        n += t.numel() * t.element_size()
+                if freeze:
+                    lin._pk8_frozen = True
         return n
 
 
@@ -287,10 +305,27 @@ class SpatialTransformer(nn.Module):
         """x: bf16 NHWC [B, H, W, C]"""
         B, Hh, Ww, C = x.shape
         N = Hh * Ww
-        t = self.proj_in(self.norm(x).reshape(B * N, C)).reshape(B, N, -1)
+        # config #5: proj_in's epilogue also writes its result as an MX8 activation + the row statistics of norm1 (hipnn.FP8_LINEARS)
+        mx = H.mx8_width(self.proj_in.out_features)
+        t2 = self.proj_in(self.norm(x).reshape(B * N, C), emit_q8=mx, emit_rowstats=mx)
+        t = H.carry_mx8(t2.reshape(B, N, -1), t2)
+        nb = len(self.transformer_blocks)
         for i, blk in enumerate(self.transformer_blocks):
             t = blk(t, t_context=t_context, t_kv=(t_kv[i] if t_kv is not None else None), emit_map=emit_map,
-                    zero_ctx_rows=zero_ctx_rows, t_fused=(t_fused[i] if t_fused is not None else None))
+                    zero_ctx_rows=zero_ctx_rows, t_fused=(t_fused[i] if t_fused is not None else None),
+                    x8=ops.mx8_of(t) if mx else None, emit_rowstats=(i + 1 < nb))
         # the output feeds a ResBlock's GroupNorm (and maybe a skip concat): statistics from the GEMM epilogue
-        out = self.proj_out(t.reshape(B * N, -1), residual=x.reshape(B * N, C), rows_per_batch=N, colstats=True)
+        out = self.proj_out(t.reshape(B * N, -1), residual=x.reshape(B * N, C), rows_per_batch=N, colstats=True,
+                            x8=ops.mx8_of(t) if mx else None)
         return H.carry_stats(out.reshape(B, Hh, Ww, C), out)
+
+    def prepare_mx8(self, freeze: bool = False) -> int:
+        """config #5: the e4m3 layout of proj_out (proj_in stays a bf16 GEMM: its input is a GroupNorm output); bytes"""
+        n = 0
+        if H.mx8_width(self.proj_in.out_features):
+            for t in self.proj_out.packed_fp8():
+                if t is not None:
+                    n += t.numel() * t.element_size()
+            if freeze:
+                self.proj_out._pk8_frozen = True
+        return n

@@ -48,11 +48,21 @@ def want_stats(B: int, HW: int, C: int) -> bool:
     return FUSE_GN or (GN_EPI and C % 8 == 0)
 
 
-# UDT_FP8=1 (BASELINE config #5): the LayerNorm-fed linears of every transformer block (q|k, v, t_attn.to_q, GEGLU — 60 % of
-# the linear FLOPs) run on the fp8 MFMA path: e4m3 weights with per-output-channel scales, e4m3 activations quantised
-# inside the LayerNorm kernel with a static per-tensor scale, fp32 accumulation, bf16 results.  Everything else (residual
-# stream, attention, convolutions, norm statistics, softmax) is unchanged.
+# UDT_FP8=1 (BASELINE config #5, second generation — round 5): every linear of the transformer blocks whose width is a multiple of
+# 128 (the 640- and 1280-channel levels: q|k|v, to_out, GEGLU, ff.net[2], proj_out — and proj_in's OUTPUT) runs on MX8 operands:
+# e4m3 weights with per-output-channel scales, e4m3 activations with one E8M0 scale per 32 channels (csrc/common.h "MX8
+# activations") that the PRODUCING kernel's epilogue writes next to its bf16 result (lean GEMM, fused text cross-attention, flash
+# attention) — no quantisation pass, no normalised copy: the LayerNorms stay folded into the consuming GEMMs, their row statistics
+# come out of the producers' epilogues too.  fp32 accumulation, bf16 residual stream.  The 320-channel level (K = 320: five
+# K-tiles, epilogue-bound — e4m3 operands buy nothing there, tools/bench_mx8.py), attention scores, convolutions, norm statistics,
+# softmax and the sampler are unchanged.  (Round 2's first generation — a LayerNorm -> e4m3 kernel with a static per-tensor scale in
+# front of the 8-wave fp8 GEMM, LayerNorm-fed linears only — measured SLOWER than the LayerNorm-folded bf16 GEMMs and is gone.)
 FP8_LINEARS = os.environ.get("UDT_FP8", "0") != "0"
+
+
+def mx8_width(c: int) -> bool:
+    """does a transformer block of this width run its linears on MX8 operands in config #5?"""
+    return FP8_LINEARS and LN_GEMM and c % 128 == 0
 
 # LayerNorm folded into the GEMM that consumes it (udt_ln_gemm_fwd, csrc/lean.h): `attn1(norm1(x))` and `ff(norm3(x))` of
 # every transformer block (reference attention.py:310-339) run as ONE launch on the raw residual stream — the normalised
@@ -66,6 +76,14 @@ def carry_stats(dst: torch.Tensor, src: torch.Tensor) -> torch.Tensor:
     st = ops.gn_stats_of(src)
     if st is not None:
         dst.gn_stats = st
+    return dst
+
+
+def carry_mx8(dst: torch.Tensor, src: torch.Tensor) -> torch.Tensor:
+    """the same for the MX8 twin a producer attached to its result (``out.mx8``)"""
+    q = ops.mx8_of(src)
+    if q is not None:
+        dst.mx8 = q
     return dst
 
 
@@ -141,6 +159,24 @@ class _Packed(nn.Module):
     def _pack_ln(self, gamma, beta):
         raise NotImplementedError(f"{type(self).__name__} has no LayerNorm-folded layout")
 
+    def packed_ln_mx8(self, norm):
+        """the LayerNorm-folded layout on e4m3 weights (packing.pack_ln_linear_mx8) for UDT_GEMM_MX8 + ln_colsum: (gamma o W as
+        e4m3, per-channel scales, c, s); cached and frozen like ``packed_ln()``"""
+        if getattr(self, "_pkln8_frozen", False):
+            return self._pkln8
+        if getattr(self, "_pk_frozen", False) and getattr(self, "_pkln8_key", None) is None:
+            raise L.UdtError(f"{type(self).__name__}: the fp32 masters were released by prepare(free_masters=True) before the MX8 "
+                             "layout was built — call prepare() with UDT_FP8=1 set, or reload the checkpoint")
+        key = (self._key(), norm.weight.data_ptr(), norm.weight._version, norm.bias.data_ptr(), norm.bias._version)
+        if getattr(self, "_pkln8_key", None) != key:
+            with torch.no_grad():
+                self._pkln8 = self._pack_ln_mx8(norm.weight, norm.bias)
+            self._pkln8_key = key
+        return self._pkln8
+
+    def _pack_ln_mx8(self, gamma, beta):
+        raise NotImplementedError(f"{type(self).__name__} has no LayerNorm-folded MX8 layout")
+
 
 class Linear(_Packed):
     def __init__(self, in_features: int, out_features: int, bias: bool = True):
@@ -162,16 +198,23 @@ class Linear(_Packed):
         return wq, cs, packing.pad_bias(self.bias)
 
     def forward(self, x, residual=None, flags: int = 0, out=None, rowvec=None, rows_per_batch: int = 0,
-                colstats: bool = False):
-        if isinstance(x, ops.Fp8Act):
+                colstats: bool = False, x8=None, emit_q8: bool = False, emit_rowstats: bool = False):
+        """x8: the input as an MX8 activation (ops.Mx8Act, written by its producer's epilogue) -> the e4m3 GEMM (config #5; x may then
+        be None).  emit_q8 (+ emit_rowstats): the result ALSO as an MX8 activation (``out.mx8``) for the next e4m3 GEMM."""
+        if x8 is not None:
             wq, cs, b = self.packed_fp8()
-            return ops.linear_fp8(x, wq, cs, b, residual=residual, flags=flags, out=out, rows_per_batch=rows_per_batch)
+            M = x8.data.shape[0]
+            if colstats:
+                rpb = rows_per_batch if rows_per_batch > 0 else M
+                colstats = want_stats(M // rpb, rpb, wq.shape[0])
+            return ops.linear_mx8(x8, wq, cs, b, residual=residual, flags=flags, out=out, rows_per_batch=rows_per_batch,
+                                  colstats=bool(colstats), emit_q8=emit_q8, emit_rowstats=emit_rowstats)
         w, b = self.packed()
         if colstats:
             rpb = rows_per_batch if rows_per_batch > 0 else x.shape[0]
             colstats = want_stats(x.shape[0] // rpb, rpb, w.shape[0])
         return ops.linear(x, w, b, residual=residual, flags=flags, out=out, rowvec=rowvec, rows_per_batch=rows_per_batch,
-                          colstats=bool(colstats))
+                          colstats=bool(colstats), emit_q8=emit_q8, emit_rowstats=emit_rowstats)
 
 
 class Conv2d(_Packed):
@@ -281,20 +324,6 @@ class LayerNorm(nn.Module):
 
     def forward(self, x):
         return ops.layer_norm(x, self.weight, self.bias, self.eps)
-
-    def fp8_scale(self) -> float:
-        """static per-tensor activation scale of this norm's output: |LN(x)| <= 12 |gamma|_max + |beta|_max covers every
-        value but > 12-sigma outliers (those saturate at the e4m3 maximum); data independent, one host sync per weight set"""
-        key = (self.weight.data_ptr(), self.weight._version, self.bias.data_ptr(), self.bias._version)
-        if getattr(self, "_fp8_key", None) != key:
-            with torch.no_grad():
-                bound = 12.0 * float(self.weight.abs().max()) + float(self.bias.abs().max())
-            self._fp8_scale, self._fp8_key = packing.FP8_MAX / max(bound, 1e-6), key
-        return self._fp8_scale
-
-    def forward_fp8(self, x):
-        """LayerNorm -> e4m3 (ops.Fp8Act) for an fp8 linear"""
-        return ops.layer_norm_fp8(x, self.weight, self.bias, self.eps, self.fp8_scale())
 
 
 def fuse_rows(*weights: torch.Tensor) -> torch.Tensor:
