@@ -64,6 +64,8 @@ def parse():
     ap.add_argument("--sampler-steps", type=int, default=50)
     ap.add_argument("--chars", type=int, default=9)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-config1", action="store_true", help="the CPU baseline also runs BASELINE config #1 in full (256x256, 10 steps: "
+                    "minutes of host time; off by default so that the bench command stays a few minutes long)")
     ap.add_argument("--no-mode-table", action="store_true", help="skip the extra passes in the other launch modes")
     ap.add_argument("--in-flight", type=int, default=3, help="batches sampled concurrently per GPU, one launch stream each "
                     "(same-box on MI355X: 1 -> 5.7, 2 -> 7.13, 3 -> 7.67, 4 -> 6.0 images/s)")
@@ -95,38 +97,35 @@ def measured_traffic():
     return None, None
 
 
-def cpu_baseline(model, size: int, chars: int, sampler_steps: int) -> dict:
-    """time the CPU oracle on a bounded sample: BASELINE config #1 in full (256x256, 10 steps, 4 characters, batch 1)
-    + for the bench resolution 2 UNet calls on one CFG pair, LabelEncoder, 1 VAE encode, 1 VAE decode, extrapolated to
-    sampler_steps UNet calls per image (every step costs the same)"""
-    from oracle import nets, sampling, spec
-    from udifftext_amd import synth
-    cfg = spec.EngineConfig()
-    sd = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
-    cores = torch.get_num_threads()
-    batch = synth.synthetic_batch(1, size, size, chars, seed=0)
-    h = size // 8
-    with torch.no_grad():
-        torch.manual_seed(0)
-        t0 = time.time(); sampling.predict(sd, cfg, synth.synthetic_batch(1, 256, 256, 4, seed=0), steps=10, scale=5.0); t_c1 = time.time() - t0
-        t0 = time.time(); ctx = nets.label_encoder(sd, batch["label"], cfg.label); t_label = time.time() - t0
-        t0 = time.time(); nets.vae_encode_moments(sd, batch["masked"], cfg.vae, "conditioner.embedders.2.model."); t_enc = time.time() - t0
-        xin = torch.randn(2, 9, h, h)
-        tctx = torch.cat([torch.zeros_like(ctx), ctx])
-        ts = torch.tensor([999, 999])
-        nets.unet_forward(sd, xin, ts, tctx, cfg.unet)                      # warm
-        t0 = time.time()
-        for _ in range(2):
-            nets.unet_forward(sd, xin, ts, tctx, cfg.unet)
-        t_unet = (time.time() - t0) / 2
-        t0 = time.time(); nets.vae_decode(sd, torch.randn(1, 4, h, h), cfg.vae); t_dec = time.time() - t0
-    per_image = sampler_steps * t_unet + t_enc + t_dec + t_label
-    return {"value": 1.0 / per_image, "unit": "images/s", "cores": cores, "kind": "port",
-            "config1_full_run_s": t_c1, "config1_images_per_s": 1.0 / t_c1,
-            "sample": f"oracle (fp32 torch CPU): BASELINE config #1 in full (256x256, 10 steps, batch 1: {t_c1:.2f} s); at "
-                      f"{size}x{size}: 2 warm UNet calls on one CFG pair ({t_unet:.2f} s each), 1 VAE encode ({t_enc:.2f} s), "
-                      f"1 VAE decode ({t_dec:.2f} s), LabelEncoder ({t_label:.2f} s); extrapolated to {sampler_steps} UNet "
-                      "calls per image"}
+def physical_cores() -> int:
+    try:
+        import psutil
+        n = psutil.cpu_count(logical=False)
+        if n:
+            return int(n)
+    except Exception:
+        pass
+    return max(1, (os.cpu_count() or 2) // 2)
+
+
+def cpu_baseline(size: int, chars: int, sampler_steps: int, config1: bool = False) -> dict:
+    """time the CPU oracle on a bounded sample IN ITS OWN PROCESS (oracle/cpu_bench.py): one thread per physical core, bound
+    (OMP_PROC_BIND=close, OMP_PLACES=cores — set before the child's OpenMP runtime starts), nothing else in the process, warm runs
+    in front of every timed item, the UNet call timed in two rounds that are both reported.  At the bench resolution: 2 x 2 UNet
+    calls on one CFG pair, LabelEncoder, 1 VAE encode, 1 VAE decode, extrapolated to sampler_steps UNet calls per image (every
+    step costs the same); --cpu-config1 adds BASELINE config #1 in full (minutes)."""
+    import subprocess
+    n = physical_cores()
+    env = dict(os.environ)
+    env.update({"OMP_NUM_THREADS": str(n), "MKL_NUM_THREADS": str(n), "OMP_PROC_BIND": "close", "OMP_PLACES": "cores",
+                "HIP_VISIBLE_DEVICES": "", "CUDA_VISIBLE_DEVICES": ""})
+    cmd = [sys.executable, os.path.join(ROOT, "oracle", "cpu_bench.py"), "--size", str(size), "--chars", str(chars),
+           "--sampler-steps", str(sampler_steps), "--threads", str(n)] + (["--config1"] if config1 else [])
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, cwd=ROOT)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    if r.returncode != 0 or not lines:
+        return {"value": None, "unit": "images/s", "cores": n, "kind": "port", "sample": "oracle/cpu_bench.py failed: " + r.stderr[-300:]}
+    return json.loads(lines[-1])
 
 
 def self_launch(args) -> int:
@@ -485,7 +484,7 @@ def main():
                 "attention": cls("flash attention: attn_d64_v2_kernel (UNet self-attention, head_dim 64) + attn_d512_q64_kernel (VAE mid block, one head of 512)", attn_flops, attn_bytes, attn_ms, attn_launches)},
         }
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(model, args.size, args.chars, args.sampler_steps)
+            line["cpu_baseline"] = cpu_baseline(args.size, args.chars, args.sampler_steps, config1=args.cpu_config1)
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()

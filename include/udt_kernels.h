@@ -164,6 +164,9 @@ typedef struct {
  * the kernels' slab flags + error word: zero them once when the buffer is allocated (they are zero again after
  * every successful launch) and give concurrent streams separate workspaces. */
 size_t udt_gemm_workspace_bytes(const udt_gemm_desc* d);
+/* Limits: the MFMA kernels address one operand (one batch element) through 31-bit byte offsets — an A or W operand of 2 GiB or more
+ * is only served for outputs of <= 64 columns (the first-generation 256 x 64 kernel); wider problems of that size return
+ * UDT_ERR_BAD_SHAPE (udt_gemm_workspace_bytes answers 0 for them: nothing to plan).  No shape of the UNet / VAE comes near. */
 int udt_gemm(const udt_gemm_desc* d, void* workspace, size_t workspace_bytes, void* stream);
 /* Column-statistics geometry of udt_gemm for this problem: rows of the output covered by one slot of `colstats`
  * (32 or 64; slot s covers rows [s*rows, (s+1)*rows) of M for plain GEMMs / gathered convolutions and the same number of

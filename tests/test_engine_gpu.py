@@ -869,7 +869,10 @@ def test_predict_sharded_under_nccl_world1(engine, cuda, monkeypatch, n_images, 
 def test_unet_call_with_each_switch_in_its_non_default_position(engine, cuda, monkeypatch, switch):
     """every surviving launch-path switch (the environment variables are read once at import / first use,
     so the test sets what they set) gives the same UNet call as the default path up to the other kernel family's rounding:
-    8 samples at 32x32 latents (all four levels incl. 4x4 maps) — rel RMS <= 1.5e-2 between the two paths, each finite.
+    8 samples at 32x32 latents (all four levels incl. 4x4 maps; 64x64 latents for UDT_WIDE_CONV — the wide kernel is only selected
+    where its 256-pixel tiles fill the chip) through the call path of the sampling loop (fused text cross-attention, zero-context
+    rows) — rel RMS <= 1.5e-2 between the two paths, each finite, and NOT bit-identical: the kernels are deterministic, so equal bits
+    would mean the switch changed nothing on this call (round 4's versions of two cases were vacuous that way).
     UDT_GRAPHS, UDT_FP8, UDT_FUSE_GN, UDT_ATTN512 and UDT_NOISE_BATCH have tests of their own above."""
     import sgm.modules.attention as A
     import sgm.modules.diffusionmodules.sampling as S
@@ -881,10 +884,11 @@ def test_unet_call_with_each_switch_in_its_non_default_position(engine, cuda, mo
     le = engine.conditioner.embedders[0]
     ctx = le(synth.synthetic_batch(B, 256, 256, 6, seed=8)["label"])
     tctx = torch.cat([torch.zeros_like(ctx), ctx])
-    x = torch.randn((2 * B, 9, 32, 32), device=cuda)
+    hw = 64 if switch.startswith("UDT_WIDE_CONV") else 32
+    x = torch.randn((2 * B, 9, hw, hw), device=cuda)
     ts = torch.full((2 * B,), 333, device=cuda)
     unet = engine.model.diffusion_model
-    ref = unet(x, timesteps=ts, t_context=tctx).float()
+    ref = _sampler_call(unet, x, ts, tctx, B).float()
     keys = []
     try:
         if switch.startswith("UDT_LEAN=") or switch.startswith("UDT_LEAN_CONV=") or switch.startswith("UDT_WIDE_CONV=") or switch.startswith("UDT_LEAN_SPLITK="):
@@ -915,11 +919,40 @@ def test_unet_call_with_each_switch_in_its_non_default_position(engine, cuda, mo
                 st.check()
                 outs.append(z.clone())
             got, ref = outs[1], outs[0]
+        elif switch == "fused text cross-attention off":
+            # (prepare_fused_tattn returns no tables with the module switch off: the call takes the layernorm -> to_q -> xattn -> to_out chain)
+            from udifftext_amd import ops
+            from sgm.modules.diffusionmodules.openaimodel import CPAD
+            t_kv = unet.project_context(tctx)
+            assert all(tb is None for lst in unet.prepare_fused_tattn(t_kv) for tb in lst)
+            eps = unet.forward_nhwc(ops.nchw_to_nhwc(x.float().contiguous(), CPAD), unet.time_embedding_rows(ts), t_kv, emit_maps=False,
+                                    zero_ctx_rows=B, t_fused=None)
+            got = ops.nhwc_to_nchw(eps, unet.out_channels).float()
         else:
-            got = unet(x, timesteps=ts, t_context=tctx).float()
+            got = _sampler_call(unet, x, ts, tctx, B).float()
         torch.cuda.synchronize()
     finally:
         for k in keys:
             L.check(lib.udt_debug_set(k.encode(), -1), "udt_debug_set")
     assert torch.isfinite(got).all()
+    if switch != "UDT_DUAL_STREAM=1":       # (a scheduling switch: the same kernels on two streams may well agree bit for bit)
+        assert not torch.equal(got, ref), f"{switch}: bit-identical to the default path — the switch did not change the launch path of this call"
     _check(f"UNet call with {switch} vs the default path", got.cpu(), ref.cpu(), 1.5e-2)
+
+
+def test_conditioner_notices_a_touched_unconditional_batch(engine, cuda):
+    """pipeline.prepare_batch marks its unconditional batch as a clone of the conditional one (the masked-image encoder pass is then
+    shared without a device-side comparison).  The marker records identity + version counter of every tensor: a caller that writes to
+    the unconditional batch afterwards (a different masked image for uc) must get that image encoded, not the conditional one's."""
+    from udifftext_amd import pipeline, synth
+    emb = engine.conditioner
+    torch.manual_seed(5)
+    b, buc = pipeline.prepare_batch(synth.synthetic_batch(1, 256, 256, 4, seed=3), cuda)
+    c0, uc0 = emb.get_unconditional_conditioning(b, batch_uc=buc, force_uc_zero_embeddings=["label"])
+    torch.manual_seed(5)
+    b, buc = pipeline.prepare_batch(synth.synthetic_batch(1, 256, 256, 4, seed=3), cuda)
+    buc["masked"].mul_(-1.0)                                   # in place: same tensor object, bumped version counter
+    c1, uc1 = emb.get_unconditional_conditioning(b, batch_uc=buc, force_uc_zero_embeddings=["label"])
+    assert torch.equal(c1["concat"], c0["concat"])
+    r, _ = _metrics(uc1["concat"][:, 1:].cpu(), uc0["concat"][:, 1:].cpu())
+    assert r > 0.1, f"the unconditional masked latent did not change ({r}): the stale clone marker was trusted"

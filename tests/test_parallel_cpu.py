@@ -184,12 +184,14 @@ def test_single_process_is_identity():
 
 
 # ---- lane assignment of pipeline.predict_many (host logic, stub engine) -------------------------------------------
-@pytest.mark.parametrize("n_batches,in_flight,fuse,expect", [(4, 3, 1, [(0, 3), (1, 3), (2, 3), (0, 3)]), (5, 3, 1, [(0, 3), (1, 3), (2, 3), (0, 3), (1, 3)]),
+@pytest.mark.parametrize("n_batches,in_flight,fuse,expect", [(4, 3, 1, [(0, 2), (1, 2), (0, 2), (1, 2)]), (5, 3, 1, [(0, 3), (1, 3), (2, 3), (0, 3), (1, 3)]),
+                                                             (7, 3, 1, [(0, 3), (1, 3), (2, 3), (0, 3), (1, 3), (2, 3), (0, 3)]),
                                                              (2, 3, 1, [(0, 2), (1, 2)]), (3, 1, 1, [(0, 1), (0, 1), (0, 1)]),
                                                              (5, 2, 2, [(0, 2), (1, 2), (0, 2)])])
 def test_predict_many_free_running_lanes(n_batches, in_flight, fuse, expect):
-    """sampling batch u runs on lane u % lanes, every lane planned for 1 / lanes of the CUs (never more lanes than sampling
-    batches); results keep the input order and the per-batch CPU draw order whatever the lane count"""
+    """sampling batch u runs on lane u % lanes, every lane planned for 1 / lanes of the CUs; the lane count is the smallest that
+    keeps the number of rounds (4 batches with 3 lanes allowed: 2 + 2 on two lanes, not 2 + 1 + 1); results keep the input order and
+    the per-batch CPU draw order whatever the lane count"""
     from udifftext_amd import config as C, pipeline
 
     class Rec(_StubSampler):

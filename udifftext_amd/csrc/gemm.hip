@@ -938,6 +938,20 @@ int wide_conv_mode() {
 std::atomic<int> g_lconv_dbg{0};   // cost attribution of the lean convolution's loop (C3Params.dbg): wrong results
 #endif
 
+// channel-chunk slices per tile of the lean / wide convolution (ticket split-K): ONE rule for the plan and for the wide kernel's
+// eligibility test (which used to predict chunks / 5 and ignore the forced knob while the plan cut chunks / 4)
+int conv_chunk_slices(long long tiles, int slots, int chunks, int knob) {
+  long long sk = 1;
+  if (tiles <= 1023) {
+    if (knob > 1) { sk = knob; if (sk > chunks) sk = chunks; }              // forced (tests / A-B): any cut the chunks allow
+    // (slices of >= 4 chunks = 36 taps; round 4: was >= 5 — 8 x 8 maps, 1280 -> 1280 on 8 samples: 5 slices 29.2 us, 4 slices 32.1 us,
+    //  profiles/r04_pair_conv_rejected.txt)
+    else if (knob < 0 && tiles * 2 <= slots && chunks >= 10) { sk = slots / tiles; if (sk > chunks / 4) sk = chunks / 4; }
+    if (sk < 1) sk = 1;
+  }
+  return (int)sk;
+}
+
 bool lean_conv_plan(const udt_gemm_desc* d, lg::C3Params& c, bool want_stats) {
   int on = g_lean_conv.load(std::memory_order_relaxed);
   if (on < 0) {
@@ -969,9 +983,7 @@ bool lean_conv_plan(const udt_gemm_desc* d, lg::C3Params& c, bool want_stats) {
       const int cus = device_cus(), share = d->cu_share > 1 ? d->cu_share : 1;
       wide_slots = cus / share > 0 ? cus / share : 1;
       const long long wt = (long long)(d->M / 256) * (d->N / 160);
-      const int ch = d->C1 / 64;
-      long long sk = 1;
-      if (wt * 2 <= wide_slots && ch >= 10) { sk = wide_slots / wt; if (sk > ch / 5) sk = ch / 5; }
+      const long long sk = conv_chunk_slices(wt, wide_slots, d->C1 / 64, lean_splitk_knob());
       const long long units = wt * sk;
       const long long rounds = (units + cus - 1) / cus;
       const double eff = units > cus ? (double)units / (double)(rounds * cus) : ((double)units * share >= cus ? 1.0 : (double)units * share / cus);
@@ -1001,16 +1013,8 @@ bool lean_conv_plan(const udt_gemm_desc* d, lg::C3Params& c, bool want_stats) {
   c.tiles = c.tiles_m * c.tiles_n;
   c.chunks = c.C / 64;
   const int slots = c.geo == 3 ? wide_slots : 2 * device_cus();
-  int sk = 1;
-  const int knob = lean_splitk_knob();
-  if (c.tiles <= 1023) {
-    if (knob > 1) { sk = knob; if (sk > c.chunks) sk = c.chunks; }          // forced (tests / A-B): any cut the chunks allow
-    // (slices of >= 4 chunks = 36 taps; round 4: was >= 5 — 8 x 8 maps, 1280 -> 1280 on 8 samples: 5 slices 29.2 us, 4 slices 32.1 us,
-    //  profiles/r04_pair_conv_rejected.txt)
-    else if (knob < 0 && c.tiles * 2 <= slots && c.chunks >= 10) { sk = slots / c.tiles; if (sk > c.chunks / 4) sk = c.chunks / 4; }
-    while (sk > 1 && (long long)c.tiles * sk * c.tw * c.th * c.bn * 4 > (64LL << 20)) --sk;
-    if (sk < 1) sk = 1;
-  }
+  int sk = conv_chunk_slices(c.tiles, slots, c.chunks, lean_splitk_knob());
+  while (sk > 1 && (long long)c.tiles * sk * c.tw * c.th * c.bn * 4 > (64LL << 20)) --sk;       // slabs stay inside the workspace
   c.ch_per = (c.chunks + sk - 1) / sk;
   c.splitk = (c.chunks + c.ch_per - 1) / c.ch_per;
   c.G = round_workgroups(c.tiles * c.splitk);
@@ -1150,7 +1154,9 @@ extern "C" size_t udt_gemm_workspace_bytes(const udt_gemm_desc* d) {
     return G8_HEADER_BYTES + (size_t)t8.G * t8.bm * t8.bn * sizeof(float);
   }
   TilePlan t = plan_tiles(d);
-  if (!t.fixup) return 0;
+  // (the first-generation kernel survives in its 256 x 64 geometry only: a problem it would have taken on 128 x 128 tiles — one the
+  //  newer kernels decline, e.g. operands of 2 GiB and more — is refused by udt_gemm with UDT_ERR_BAD_SHAPE; no workspace to plan)
+  if (t.bm != 256 || !t.fixup) return 0;
   // the first G8_HEADER_BYTES of the workspace hold the 8-wave kernels' flags and are never used for slabs
   return G8_HEADER_BYTES + (size_t)t.G * 2 * SLAB_FLOATS * sizeof(float);
 }

@@ -71,8 +71,12 @@ def prepare_batch(batch: dict, device: torch.device) -> Tuple[dict, dict]:
         buc["label"] = ["" for _ in batch["label"]]
     # host-side knowledge for the conditioner: every tensor of buc is a clone of batch's (it then shares the masked-image
     # encoder pass between c and uc without comparing the two tensors on the device)
+    # The marker is only as good as the tensors it was made for: it records (identity, version counter) of both sides per key, and
+    # the conditioner falls back to comparing the tensors when either was replaced or written to since (e.g. a caller that gives the
+    # unconditional batch a different masked image between prepare_batch and get_unconditional_conditioning).
     buc["_udt_clone_of"] = batch
     buc["_udt_changed"] = ("txt", "label")
+    buc["_udt_clone_state"] = {k: (id(buc[k]), buc[k]._version, id(v), v._version) for k, v in batch.items() if isinstance(v, torch.Tensor)}
     return batch, buc
 
 
@@ -153,7 +157,10 @@ def predict_many(cfgs, model, sampler, batches, device: Optional[torch.device] =
     # had no sampling running, and a slow lane held the others.)
     lane_sampler = getattr(sampler, "sample_lane", None)
     units = [list(range(i, min(i + f, len(batches)))) for i in range(0, len(batches), f)]
-    n_used = min(n, len(units)) if units else 1
+    # lanes in use: as few as keep every lane equally loaded — 4 sampling batches on 3 lanes run as 2 + 2 on TWO lanes (each planned
+    # for half of the CUs), not as 2 + 1 + 1 with the 4th batch alone on a lane planned for a third of the chip while two lanes idle
+    rounds = -(-len(units) // n) if units else 1
+    n_used = max(1, -(-len(units) // rounds)) if units else 1
     for lane in lanes[:n_used]:
         after(lane, main)
     for u, idx in enumerate(units):
@@ -191,5 +198,7 @@ def predict_many(cfgs, model, sampler, batches, device: Optional[torch.device] =
         chk()
     if gpu:
         ops.check_async_errors()
+    if hasattr(sampler, "release_retired"):             # (the checks above synchronised every lane: evicted graph runners may go)
+        sampler.release_retired()
     del keep
     return out

@@ -464,15 +464,21 @@ class EulerEDMSampler(EDMSampler):
         cache = self.__dict__.setdefault("_in_flight", {})
         fp = weights_fingerprint(model)
         key = (slot, n_lanes, id(model), tuple(x.shape), len(sig), float(self.guider.scale), tuple(sig[:2]), x.device.index)
+        # a runner that leaves the cache may still have graph replays queued on a lane stream (nothing here synchronises the host):
+        # it is parked in ``_retired`` — its graphs and private memory pool stay alive — until the caller has synchronised
+        # (pipeline.predict_many -> release_retired); runners of the current call's lanes are never evicted
+        retired = self.__dict__.setdefault("_retired", [])
         gs = cache.get(key)
         if gs is not None and gs.fingerprint != fp:            # weights changed: the captured pointers are stale
-            cache.pop(key)
+            retired.append(cache.pop(key))
             gs = None
         if gs is None or not gs.rebind(cond, uc):
             gs = _GraphedSteps(model, cond, uc, x.shape[0], x.shape[2:], self.guider.scale, sig, cu_share=n_lanes)
-            cache.pop(key, None)
-            while len(cache) >= 8:                              # every runner owns a memory pool: keep the newest few
-                cache.pop(next(iter(cache)))
+            if key in cache:
+                retired.append(cache.pop(key))
+            victims = [k for k in cache if not (k[1] == n_lanes and k[2] == id(model) and k[3] == tuple(x.shape))]
+            while len(cache) >= 8 and victims:                  # every runner owns a memory pool: keep the newest few
+                retired.append(cache.pop(victims.pop(0)))
             cache[key] = gs
         lane = torch.cuda.current_stream()
         missing = [i for i in steps if i not in gs.graphs]
@@ -493,6 +499,10 @@ class EulerEDMSampler(EDMSampler):
         else:
             gs.st.check()
         return out
+
+    def release_retired(self) -> None:
+        """drop the runners sample_lane took out of its cache — call after the lanes' streams have been synchronised"""
+        self.__dict__.get("_retired", []).clear()
 
     def _run_graphed(self, model, x, cond, uc, sig, init_step):
         """replay (capturing on first use) the hipGraphs of this sampling configuration; None -> eager launches"""

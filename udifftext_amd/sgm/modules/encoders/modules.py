@@ -114,7 +114,10 @@ class GeneralConditioner(nn.Module):
                 k = e.input_key
                 # (pipeline.prepare_batch marks its unconditional batch as a clone of the conditional one: no device-side
                 #  comparison — a host sync that would stall the launch thread while other batches are in flight)
-                same = (buc[k] is batch_c[k]) or (buc.get("_udt_clone_of") is batch_c and k not in buc.get("_udt_changed", ())) \
+                st = buc.get("_udt_clone_state", {}).get(k) if isinstance(buc, dict) else None
+                marked = (buc.get("_udt_clone_of") is batch_c and k not in buc.get("_udt_changed", ()) and st is not None
+                          and st == (id(buc[k]), buc[k]._version, id(batch_c[k]), batch_c[k]._version))   # neither side touched since
+                same = (buc[k] is batch_c[k]) or marked \
                     or (buc[k].shape == batch_c[k].shape and bool(torch.equal(buc[k], batch_c[k])))
                 e.share_between_calls(same)
         try:
