@@ -117,6 +117,10 @@ class MemoryEfficientAttnBlock(H._Packed):
             # one q|k|v projection, then the head_dim-512 flash kernel (udt_attn512_fwd): the score tile never leaves the CU
             qkv = ops.linear(hn, wqkv, bqkv).reshape(B, N, 3 * C)
             o = ops.attention_d512(qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:], C ** -0.5)
+        elif C == 64:
+            # one head of 64 dims (not a width of the UDiffText autoencoder; the reference-module goldens use it): the UNet's flash kernel
+            qkv = ops.linear(hn, wqkv, bqkv).reshape(B, N, 3 * C)
+            o = ops.attention_rowv(qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:], 1, C ** -0.5)
         else:
             qk = ops.linear(hn, wqkv[:2 * C], bqkv[:2 * C]).reshape(B, N, 2 * C)
             vt = ops.linear(hn, wv, bv, flags=H.GEMM_TRANSPOSED, rows_per_batch=N)       # [B, C, N]
