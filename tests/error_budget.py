@@ -1,0 +1,168 @@
+"""Per-rounding error budget of one UNet call (CPU, the oracle): which bf16 rounding of the HIP path owns how much of the ~1.2e-2
+rel RMS the GPU tests measure against the fp32 reference?  Not a test — a script (``python tests/error_budget.py``) that re-runs
+oracle.nets.unet_forward on the G7 golden's inputs with bf16 roundings injected at the places where the kernels round:
+
+  W     weights of every conv / linear -> bf16                                   (packing.pack_linear / pack_conv)
+  A     the activation operand of every conv / linear -> bf16                    (MFMA operands are bf16)
+  O     the OUTPUT of every conv / linear (after bias, + time embedding, + residual where the epilogue adds it) -> bf16
+        = the residual stream and every intermediate tensor is stored as bf16
+  N     the output of every GroupNorm(+SiLU) / LayerNorm -> bf16                 (gn_apply writes bf16; folded LayerNorms never exist
+        in memory — N_ln off reproduces that)
+  P     attention: q, k, v as bf16 (O of their GEMM), probabilities -> bf16 before P V, output -> bf16
+  R32   like O, but the residual stream stays fp32: the sums x + h of ResBlock / attention / feed-forward / SpatialTransformer are
+        not rounded (what an fp32 residual stream would buy)
+
+Each variant's eps is compared with the fp32 run (rel RMS).  Uses the synthetic weights and the G7 inputs (32x32 latents, CFG pair).
+Test infrastructure (imports oracle/): never part of the product path.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import nets, sampling, spec          # noqa: E402
+from udifftext_amd import synth                  # noqa: E402
+
+bf = lambda t: t.to(torch.bfloat16).float()
+FLAGS = dict(W=False, A=False, O=False, N=False, N_ln=True, P=False, R32=False)
+
+
+def _q(flag, t):
+    return bf(t) if FLAGS[flag] else t
+
+
+# ---- oracle building blocks with the roundings injected (same arithmetic as oracle/nets.py otherwise) -------------------------
+def _gn(sd, p, x, eps):
+    return F.group_norm(x.float(), 32, sd[p + "weight"], sd[p + "bias"], eps)
+
+
+def _conv(sd, p, x, stride=1, padding=1, add=None):
+    y = F.conv2d(_q("A", x), _q("W", sd[p + "weight"]), sd[p + "bias"], stride=stride, padding=padding)
+    if add is not None:
+        y = y + add
+    return _q("O", y)
+
+
+def _lin(sd, p, x, bias=True, add=None, keep32=False):
+    y = F.linear(_q("A", x), _q("W", sd[p + "weight"]), sd[p + "bias"] if bias else None)
+    if add is not None:
+        y = y + add
+    return y if keep32 else _q("O", y)
+
+
+def _resblock(sd, p, x, emb):
+    e = F.linear(F.silu(emb), sd[p + "emb_layers.1.weight"], sd[p + "emb_layers.1.bias"])[:, :, None, None]   # fp32 rows on the GPU too
+    h = _conv(sd, p + "in_layers.2.", _q("N", F.silu(_gn(sd, p + "in_layers.0.", x, 1e-5))), add=e)
+    skip = _conv(sd, p + "skip_connection.", x, padding=0) if (p + "skip_connection.weight") in sd else x
+    n2 = _q("N", F.silu(_gn(sd, p + "out_layers.0.", h, 1e-5)))
+    if FLAGS["R32"]:                                              # fp32 residual stream: the sum is not rounded
+        y = F.conv2d(_q("A", n2), _q("W", sd[p + "out_layers.3.weight"]), sd[p + "out_layers.3.bias"], padding=1)
+        return skip + y
+    return _conv(sd, p + "out_layers.3.", n2, add=skip)
+
+
+def _self_attention(sd, p, x, heads, res):
+    q, k, v = (nets._split_heads(_lin(sd, p + n, x, bias=False), heads) for n in ("to_q.", "to_k.", "to_v."))
+    d = q.shape[-1]
+    attn = torch.softmax(q @ k.transpose(-1, -2) * d ** -0.5, dim=-1)
+    o = _q("P", nets._merge_heads(_q("P", attn) @ v))
+    return _lin(sd, p + "to_out.0.", o, add=res, keep32=FLAGS["R32"])
+
+
+def _text_cross_attention(sd, p, x, ctx, heads, res):
+    q = nets._split_heads(_lin(sd, p + "to_q.", x, bias=False), heads)
+    k = nets._split_heads(_lin(sd, p + "to_k.", ctx, bias=False), heads)
+    v = nets._split_heads(_lin(sd, p + "to_v.", ctx, bias=False), heads)
+    sim = (q @ k.transpose(-1, -2) * q.shape[-1] ** -0.5).softmax(dim=-1)
+    return _lin(sd, p + "to_out.0.", nets._merge_heads(sim @ v), add=res, keep32=FLAGS["R32"])
+
+
+def _transformer_block(sd, p, x, ctx, heads):
+    c = x.shape[-1]
+    ln = lambda n, t: _q("N" if not FLAGS["N_ln"] else "N_off", F.layer_norm(t, (c,), sd[p + n + ".weight"], sd[p + n + ".bias"], 1e-5))
+    x = _self_attention(sd, p + "attn1.", ln("norm1", x), heads, x)
+    x = _text_cross_attention(sd, p + "t_attn.", ln("t_norm", x), ctx, heads, x)
+    val, gate = _lin(sd, p + "ff.net.0.proj.", ln("norm3", x), keep32=True).chunk(2, dim=-1)      # GEGLU in the epilogue: one rounding
+    return _lin(sd, p + "ff.net.2.", _q("O", val * F.gelu(gate)), add=x, keep32=FLAGS["R32"])
+
+
+def _spatial_transformer(sd, p, x, ctx, heads):
+    b, c, h, w = x.shape
+    t = _q("N", _gn(sd, p + "norm.", x, 1e-6)).permute(0, 2, 3, 1).reshape(b, h * w, c)
+    t = _lin(sd, p + "proj_in.", t)
+    t = _transformer_block(sd, p + "transformer_blocks.0.", t, ctx, heads)
+    y = F.linear(_q("A", t), _q("W", sd[p + "proj_out.weight"]), sd[p + "proj_out.bias"]).reshape(b, h, w, c).permute(0, 3, 1, 2) + x
+    return y if FLAGS["R32"] else _q("O", y)
+
+
+def unet(sd, x, ts, ctx, cfg):
+    FLAGS["N_off"] = False
+    p = "model.diffusion_model."
+    emb = nets.timestep_embedding(ts, cfg.model_channels)
+    emb = F.linear(F.silu(F.linear(emb, sd[p + "time_embed.0.weight"], sd[p + "time_embed.0.bias"])), sd[p + "time_embed.2.weight"], sd[p + "time_embed.2.bias"])
+    inp, mid, outp = spec.unet_schedule(cfg)
+
+    def run(rel, layers, h):
+        for j, layer in enumerate(layers):
+            q = f"{p}{rel}{j}."
+            kind = layer[0]
+            if kind == "conv":
+                h = _conv(sd, q, h)
+            elif kind == "res":
+                h = _resblock(sd, q, h, emb)
+            elif kind == "st":
+                h = _spatial_transformer(sd, q, h, ctx, layer[2])
+            elif kind == "down":
+                h = _conv(sd, q + "op.", h, stride=2)
+            elif kind == "up":
+                h = _conv(sd, q + "conv.", F.interpolate(h, scale_factor=2, mode="nearest"))
+        return h
+    hs = []
+    h = _q("A", x)
+    for i, layers in enumerate(inp):
+        h = run(f"input_blocks.{i}.", layers, h)
+        hs.append(h)
+    h = run("middle_block.", mid, h)
+    for i, layers in enumerate(outp):
+        h = run(f"output_blocks.{i}.", layers, torch.cat([h, hs.pop()], dim=1))
+    h = _q("N", F.silu(_gn(sd, p + "out.0.", h, 1e-5)))
+    return F.conv2d(_q("A", h), _q("W", sd[p + "out.2.weight"]), sd[p + "out.2.bias"], padding=1)
+
+
+def main():
+    torch.set_grad_enabled(False)
+    cfg = spec.EngineConfig()
+    eg = np.load(os.path.join(ROOT, "tests", "golden", "engine_golden.npz"))
+    sd = synth.synthetic_state_dict([(k, s) for k, s in spec.engine_param_shapes(cfg) if k.startswith("model.") or k.startswith("conditioner.embedders.0.")])
+    sd["conditioner.embedders.0.pos_embedding.pe"] = nets.positional_encoding(12, 2048)
+    x7 = torch.from_numpy(eg["g7_x"])
+    xin = torch.cat([torch.cat([x7, x7]), torch.cat([torch.from_numpy(eg["g6_uc_concat"]), torch.from_numpy(eg["g6_c_concat"])])], dim=1)
+    ctx = nets.label_encoder(sd, ["TEXT"], cfg.label)
+    tctx = torch.cat([torch.zeros_like(ctx), ctx])
+    ts = torch.tensor([999, 999])
+    rel = lambda a, b: ((a - b).pow(2).mean().sqrt() / b.pow(2).mean().sqrt()).item()
+    base = dict(W=False, A=False, O=False, N=False, N_ln=True, P=False, R32=False)
+    FLAGS.update(base)
+    ref = unet(sd, xin, ts, tctx, cfg.unet)
+    print(f"injected-rounding harness vs oracle.nets.unet_forward (must be ~0): {rel(ref, nets.unet_forward(sd, xin, ts, tctx, cfg.unet)):.2e}")
+    print(f"fp32 harness vs the reference golden g7_eps: {rel(ref, torch.from_numpy(eg['g7_eps'])):.2e}")
+    rows = [("W   weights -> bf16", dict(W=True)), ("A   conv / linear activation operands -> bf16", dict(A=True)),
+            ("O   conv / linear outputs (residual stream, intermediates) -> bf16", dict(O=True)),
+            ("N   GroupNorm(+SiLU) outputs -> bf16", dict(N=True)), ("P   attention probabilities / output -> bf16", dict(P=True)),
+            ("W+A (what the MFMA sees)", dict(W=True, A=True)), ("O+N (what is stored)", dict(O=True, N=True)),
+            ("all = the HIP path's roundings (LayerNorms folded: never stored)", dict(W=True, A=True, O=True, N=True, P=True)),
+            ("all, LayerNorm outputs ALSO stored as bf16 (UDT_LN_GEMM=0)", dict(W=True, A=True, O=True, N=True, P=True, N_ln=False)),
+            ("all, fp32 residual stream (R32)", dict(W=True, A=True, O=True, N=True, P=True, R32=True))]
+    for name, fl in rows:
+        FLAGS.update(base)
+        FLAGS.update(fl)
+        got = unet(sd, xin, ts, tctx, cfg.unet)
+        print(f"{name:70s} rel RMS vs fp32 {rel(got, ref):.2e}")
+
+
+if __name__ == "__main__":
+    main()
