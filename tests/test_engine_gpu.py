@@ -956,3 +956,39 @@ def test_conditioner_notices_a_touched_unconditional_batch(engine, cuda):
     assert torch.equal(c1["concat"], c0["concat"])
     r, _ = _metrics(uc1["concat"][:, 1:].cpu(), uc0["concat"][:, 1:].cpu())
     assert r > 0.1, f"the unconditional masked latent did not change ({r}): the stale clone marker was trusted"
+
+
+def test_detailed_dumps_attention_and_segment_maps(engine, cuda, tmp_path, monkeypatch):
+    """configs/test.yaml `detailed: True` (reference sampling.py:384,344-346; openaimodel.py:559-591; sampling.py:254-262): at the
+    middle step the text cross-attention probabilities of save_attn_layers (output_blocks.6.1) are averaged over heads, plotted,
+    and the label's per-character maps saved as temp/seg_map/seg_<name>.npy; the latent is the plain sampler's up to the two
+    text-attention forms' rounding on that one step."""
+    from udifftext_amd import config as C, pipeline, synth
+    monkeypatch.chdir(tmp_path)
+    steps = 6
+    batch = synth.synthetic_batch(1, 256, 256, 4, seed=9)
+    label = batch["label"][0]
+    sampler = pipeline.init_sampling(steps, 5.0, cuda)
+    torch.manual_seed(11)
+    s0, z0 = pipeline.predict(C.default_runtime_config(steps=steps, batch_size=1, noise_iters=0),
+                              engine, sampler, {k: (v.clone() if isinstance(v, torch.Tensor) else list(v)) for k, v in batch.items()})
+    torch.manual_seed(11)
+    s1, z1 = pipeline.predict(C.default_runtime_config(steps=steps, batch_size=1, noise_iters=0, detailed=True),
+                              engine, sampler, {k: (v.clone() if isinstance(v, torch.Tensor) else list(v)) for k, v in batch.items()})
+    _check("detailed=True latent vs the plain sampler", z1.cpu(), z0.cpu(), 1.5e-2)
+    name = batch["name"][0]
+    seg = np.load(tmp_path / "temp" / "seg_map" / f"seg_{name}.npy")
+    assert seg.shape == (len(label), 16, 16) and np.isfinite(seg).all()        # (output_blocks.6.1: the 2x-downsampled level of a 32x32 latent)
+    assert (tmp_path / "temp" / "attn_map" / f"attn_map_{name}.png").stat().st_size > 1000
+    # the maps are softmax probabilities over the 12 context tokens averaged over heads and layers: every pixel's 12 maps sum to 1,
+    # so the label's first characters carry a positive share everywhere
+    unet = engine.model.diffusion_model
+    full = unet.save_attn_map(save_name="again", tokens=label, out_dir=str(tmp_path / "again"))
+    assert full.shape == (12, 16, 16)
+    np.testing.assert_allclose(full.sum(axis=0), 1.0, atol=2e-3)
+    np.testing.assert_array_equal(full[:len(label)], seg)
+    # against the cached probabilities of the configured layer themselves
+    items = [it for it in unet.attn_map_cache if it["name"].startswith("output_blocks.6.1") and it["name"].endswith("t_attn")]
+    assert len(items) == 1 and items[0]["size"] == 16
+    m = items[0]["attn_map"].float().reshape(-1, items[0]["heads"], 256, 12).mean(dim=1)[-1].t().reshape(12, 16, 16).cpu().numpy()
+    np.testing.assert_allclose(full, m, atol=1e-6)

@@ -55,5 +55,10 @@ jstamp $O/bench_config4_768.json $O/bench_fp8.json
 (cd $R && python tools/bench_rowres.py 2>/dev/null | grep " x \|shape" > $O/rowres_bench.txt)
 (cd $R && python tools/bench_tattn.py 2>/dev/null | grep tattn > $O/tattn_bench.txt)
 (cd $R && python tools/bench_reference_default.py 2>/dev/null | tail -1 > $O/reference_default.txt)
+# 9. config #5 (round 5): the MX8 linears per layer against the bf16 launches they replace, one eager step traced in fp8 mode, and the
+#    MFMA utilisation of the fp8 step
+(cd $R && python tools/bench_mx8.py 2>/dev/null > $O/mx8_layers.txt)
+(cd $R && UDT_FP8=1 UDT_DUAL_STREAM=0 python tools/trace_step.py 2>/dev/null > $O/trace_step_fp8.txt)
+stamp $O/mx8_layers.txt $O/trace_step_fp8.txt
 stamp $O/in_flight_sweep.txt $O/phase_times.txt $O/gemm_shapes.txt $O/wide_conv.txt $O/trace_step.txt $O/bench_ops.txt $O/attn512.txt $O/rowres_bench.txt $O/tattn_bench.txt $O/reference_default.txt
 ls -la $O; cut -c1-400 $O/bench.json; cat $O/traffic.json | head -40; head -30 $O/mfma_util.json

@@ -14,6 +14,8 @@ Internally activations are bf16 channel-last and every op is a launch into libud
 """
 from __future__ import annotations
 
+import os
+
 from typing import List, Optional
 
 import torch
@@ -212,9 +214,45 @@ class UnifiedUNetModel(nn.Module):
         for item in self.attn_map_cache:
             item["attn_map"] = None
 
-    def save_attn_map(self, attn_type="t_attn", save_name="temp", tokens=""):
-        raise NotImplementedError("attention heat-map plotting (reference openaimodel.py:559-591) is a "
-                                  "visualisation side path, out of scope (DESIGN.md)")
+    def save_attn_map(self, attn_type="t_attn", save_name="temp", tokens="", out_dir="temp/attn_map"):
+        """reference openaimodel.py:559-591: the cached ``attn_type`` probabilities of the layers named by ``save_attn_layers``
+        (configs: output_blocks.6.1), averaged over layers and heads -> per-token heat maps [L, h, w] of the LAST sample of the
+        batch; a 3 x 4 grid of the first 12 is written to ``out_dir``/attn_map_<save_name>.png (matplotlib's imshow where the
+        reference draws seaborn heatmaps — the returned array is what the sampler passes on to save_segment_map).  Host-side only:
+        the maps are whatever the last map-emitting UNet call cached."""
+        maps, heads = [], 1
+        for item in self.attn_map_cache:
+            name = item["name"]
+            if any(name.startswith(block) for block in self.attn_layers) and name.endswith(attn_type):
+                if item["attn_map"] is None:
+                    raise RuntimeError(f"save_attn_map: no cached map for {name} — run a map-emitting UNet call first")
+                heads = item["heads"]
+                maps.append(item["attn_map"].detach().float().cpu())
+        if not maps:
+            raise RuntimeError("save_attn_map: save_attn_layers / save_attn_type select no attention layer")
+        attn_map = torch.stack(maps, dim=0).mean(dim=0)                     # [b * heads, n, l]
+        bh, n, l = attn_map.shape
+        attn_map = attn_map.reshape(-1, heads, n, l).mean(dim=1)             # [b, n, l]
+        b = attn_map.shape[0]
+        h = w = int(n ** 0.5)
+        attn_map_i = attn_map.permute(0, 2, 1).reshape(b, l, h, w).numpy()[-1]
+        try:
+            import matplotlib
+            matplotlib.use("Agg")
+            import matplotlib.pyplot as plt
+            os.makedirs(out_dir, exist_ok=True)
+            fig = plt.figure(figsize=(12, 8), dpi=100)
+            for j in range(min(12, attn_map_i.shape[0])):
+                ax = fig.add_subplot(3, 4, j + 1)
+                ax.imshow(attn_map_i[j])
+                ax.set_xticks([]); ax.set_yticks([])
+                if j < len(tokens):
+                    ax.set_title(tokens[j])
+            fig.savefig(os.path.join(out_dir, f"attn_map_{save_name}.png"))
+            plt.close(fig)
+        except ImportError:                                                  # (no plotting backend: the array is still returned)
+            pass
+        return attn_map_i
 
     def _emb_pack(self):
         if getattr(self, "_emb_frozen", False):

@@ -345,8 +345,8 @@ class EulerEDMSampler(EDMSampler):
                      thres=None, update=False, name=None, save_loss=False, save_attn=False, save_inter=False):
         """reference-shaped single step on tensors (sigma / next_sigma are [B] tensors); returns
         (x_next, denoised_decode, local_loss).  Generic formulation via denoiser + guider."""
-        if gamma > 0 or update or save_attn:
-            raise NotImplementedError("churn / attend-and-excite / attention plots are out of scope (DESIGN.md)")
+        if gamma > 0 or update:
+            raise NotImplementedError("churn / attend-and-excite are out of scope (DESIGN.md)")
         denoised = self.denoise(x, model, sigma, cond, uc)
         inter = model.decode_first_stage(denoised) if save_inter else None
         if save_loss:
@@ -354,9 +354,20 @@ class EulerEDMSampler(EDMSampler):
             ll = ll[ll.shape[0] // 2:]
         else:
             ll = torch.zeros(1)
+        if save_attn:                                                      # reference sampling.py:344-346
+            attn_map = model.model.diffusion_model.save_attn_map(save_name=name, tokens=batch["label"][0])
+            self.save_segment_map(attn_map, tokens=batch["label"][0], save_name=name)
         d = to_d(x, sigma, denoised)
         dt = (next_sigma - sigma)[(...,) + (None,) * (x.ndim - 1)]
         return self.euler_step(x, d, dt), inter, ll
+
+    def save_segment_map(self, attn_maps, tokens=None, save_name=None, out_dir="./temp/seg_map"):
+        """reference sampling.py:254-262: the per-token heat maps of save_attn_map for the label's characters -> one .npy"""
+        import numpy as np
+        section = np.stack([attn_maps[i] for i in range(len(tokens))])
+        os.makedirs(out_dir, exist_ok=True)
+        np.save(os.path.join(out_dir, f"seg_{save_name}.npy"), section)
+        return section
 
     # --------------------------------------------------------------------------------------------- loop
     def __call__(self, model, x, cond, batch=None, uc=None, num_steps=None, init_step=0, name=None, aae_enabled=False,
@@ -364,14 +375,27 @@ class EulerEDMSampler(EDMSampler):
         if aae_enabled:
             raise NotImplementedError("attend-and-excite needs a backward pass through the UNet — out of scope "
                                       "(SURVEY.md §8f rank 4)")
-        if detailed:
-            raise NotImplementedError("attention-map / segment-map dumps are a visualisation side path (out of scope)")
         self._check_fast_path()
         require_gpu(x, "EulerEDMSampler")
         uc = default(uc, cond)
         sig = self._host_sigmas(num_steps)
         x = x.float().contiguous()
         x *= (1.0 + sig[0] ** 2.0) ** 0.5                                  # in place, like the reference :54
+        if detailed:
+            # reference sampling.py:384,344-346: at the middle step the text cross-attention maps of the configured layers are
+            # plotted and the label's per-character maps saved.  That one step runs with map emission (eager launches, the xattn
+            # chain); every other step is the fast step — the loop is the same Euler loop, so the latent equals the plain call's
+            # up to the two text-attention forms' rounding
+            name = name if name is not None else (batch["name"][0] if batch is not None and "name" in batch else "sample")
+            stepper = _Stepper(model, cond, uc, x.shape[0], x.shape[2:], self.guider.scale)
+            mid = (len(sig) - 1) // 2
+            for i in self.get_sigma_gen(len(sig), init_step=init_step):
+                stepper.step(x, sig[i], sig[i + 1], emit_maps=(i == mid))
+                if i == mid:
+                    attn_map = stepper.unet.save_attn_map(save_name=name, tokens=batch["label"][0])
+                    self.save_segment_map(attn_map, tokens=batch["label"][0], save_name=name)
+            stepper.check()
+            return x
         if self.use_graphs:
             out = self._run_graphed(model, x, cond, uc, sig, init_step)
             if out is not None:
