@@ -258,6 +258,14 @@ __global__ void __launch_bounds__(256, 4) attn_d64_kernel(const AttnParams p) {
 // 48 KiB of LDS -> three workgroups per CU.
 constexpr int A2_STAGE = 2 * TILE_BYTES;     // K tile + V tile
 constexpr int A2_NST = 3;
+// cost attribution (measurement builds only: -DUDT_MEASURE -DA2_HALF_MFMA; WRONG results): HALF of the QK^T and P V MFMAs and of the
+// K / V fragment reads that feed them — what e4m3 K / V / P operands (v_mfma_scale_f32_32x32x64_f8f6f4: half the matrix-pipe time and
+// half the LDS bytes per tile) could save at most, with the softmax arithmetic unchanged (profiles/r05_attn_fp8_bound.txt)
+#if defined(UDT_MEASURE) && defined(A2_HALF_MFMA)
+constexpr int A2_KS = 2, A2_DT = 1;
+#else
+constexpr int A2_KS = 4, A2_DT = 2;
+#endif
 constexpr float A2_DEFER = 8.0f;
 
 __global__ void __launch_bounds__(256, 3) attn_d64_v2_kernel(const AttnParams p) {
@@ -355,12 +363,12 @@ __global__ void __launch_bounds__(256, 3) attn_d64_v2_kernel(const AttnParams p)
       for (int r = 0; r < 16; ++r) s[t][r] = 0.f;
     bf16x8_t kf[4][2];
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks)
+    for (int ks = 0; ks < A2_KS; ++ks)
 #pragma unroll
       for (int t = 0; t < 2; ++t) kf[ks][t] = lds_read_frag(buf + koff_l[ks] + t * 32 * 128);
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks)
+    for (int ks = 0; ks < A2_KS; ++ks)
 #pragma unroll
       for (int t = 0; t < 2; ++t) s[t] = mfma32(kf[ks][t], qf[ks], s[t]);
     __builtin_amdgcn_s_setprio(0);
@@ -421,7 +429,7 @@ __global__ void __launch_bounds__(256, 3) attn_d64_v2_kernel(const AttnParams p)
       const bf16x8_t pf = __builtin_bit_cast(bf16x8_t, pk);
       u32x4 vv[2];
 #pragma unroll
-      for (int dt = 0; dt < 2; ++dt) {
+      for (int dt = 0; dt < A2_DT; ++dt) {
         const v4s a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s)(buf + s4 * 2048 + voff_a[dt]));
         const v4s b8 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s)(buf + s4 * 2048 + voff_b[dt]));
         const u32x2 lo = __builtin_bit_cast(u32x2, a), hh = __builtin_bit_cast(u32x2, b8);
@@ -430,7 +438,7 @@ __global__ void __launch_bounds__(256, 3) attn_d64_v2_kernel(const AttnParams p)
       }
       __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-      for (int dt = 0; dt < 2; ++dt) o_acc[dt] = mfma32(__builtin_bit_cast(bf16x8_t, vv[dt]), pf, o_acc[dt]);
+      for (int dt = 0; dt < A2_DT; ++dt) o_acc[dt] = mfma32(__builtin_bit_cast(bf16x8_t, vv[dt]), pf, o_acc[dt]);
       __builtin_amdgcn_s_setprio(0);
     }
     st = st + 1 == A2_NST ? 0 : st + 1;
