@@ -420,6 +420,9 @@ namespace {
 // workgroups per token tile (channel splits): few token tiles (the 16x16 / 8x8 levels) split the output channels over up to 8
 // workgroups per tile so that the launch covers the chip; every split recomputes the statistics and scores of its tile
 // (round 3: a full chip of workgroups — the launch is a chain of L2-latency-bound steps, so idle CUs are the one thing that is free)
+// tokens per workgroup: 32 for C = 1280 (the x tile must fit in LDS) and, since round 5, for C = 640 (two workgroups per CU: 17.6 ->
+// 15.1 us on 8 x 1024 tokens; C = 320 measured the same either way, 15.5 / 15.8 us, and keeps 64)
+int tattn_tt(int C) { return C >= 640 ? 32 : 64; }
 int tattn_nsplit(int M, int TT) {
   const unsigned grid = (unsigned)(M / TT);
   constexpr unsigned target = 256u;
@@ -432,7 +435,7 @@ int tattn_launch(const void* x, void* out, const void* A, const float* sc, const
                  int32_t C, int32_t heads, int32_t zero_samples, float eps, void* q8_out, void* q8_scale, float* rowstat_out, void* stream) {
   if (!x || !out || !bias || (zero_samples < B && (!A || !sc || !BmT))) return UDT_ERR_BAD_ARG;
   if (B <= 0 || n_tok <= 0 || heads <= 0 || C != heads * 64 || C > 1280 || zero_samples < 0 || zero_samples > B) return UDT_ERR_BAD_SHAPE;
-  const int TT = (C > 640) ? 32 : 64;
+  const int TT = tattn_tt(C);
   if (n_tok % TT != 0) return UDT_ERR_BAD_SHAPE;             // a token tile lies in one sample
   const bool q8 = q8_out != nullptr;
   if (q8 && (!q8_scale || !rowstat_out || C % 128 != 0)) return UDT_ERR_BAD_ARG;
@@ -459,7 +462,7 @@ int tattn_launch(const void* x, void* out, const void* A, const float* sc, const
   const void* fn = nullptr;
   int which = -1;
   if (C == 320 && p.hp == 96 && !q8) { fn = reinterpret_cast<const void*>(tattn_fused_kernel<64, 5, 6>); which = 0; }
-  else if (C == 640 && p.hp == 160) { fn = q8 ? reinterpret_cast<const void*>(tattn_fused_kernel<64, 10, 10, true>) : reinterpret_cast<const void*>(tattn_fused_kernel<64, 10, 10>); which = q8 ? 3 : 1; }
+  else if (C == 640 && p.hp == 160) { fn = q8 ? reinterpret_cast<const void*>(tattn_fused_kernel<32, 10, 10, true>) : reinterpret_cast<const void*>(tattn_fused_kernel<32, 10, 10>); which = q8 ? 3 : 1; }
   else if (C == 1280 && p.hp == 320) { fn = q8 ? reinterpret_cast<const void*>(tattn_fused_kernel<32, 20, 20, true>) : reinterpret_cast<const void*>(tattn_fused_kernel<32, 20, 20>); which = q8 ? 4 : 2; }
   else return UDT_ERR_BAD_SHAPE;
   if (!attr_done[which]) {
@@ -482,7 +485,7 @@ extern "C" int udt_tattn_fused(const void* x, void* out, const void* A, const fl
 
 extern "C" int32_t udt_tattn_rowstat_parts(int32_t B, int32_t n_tok, int32_t C) {
   if (B <= 0 || n_tok <= 0 || (C != 640 && C != 1280)) return 0;
-  const int TT = (C > 640) ? 32 : 64;
+  const int TT = tattn_tt(C);
   if (n_tok % TT != 0) return 0;
   return tattn_nsplit(B * n_tok, TT);
 }

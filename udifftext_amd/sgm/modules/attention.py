@@ -216,7 +216,7 @@ class BasicTransformerBlock(nn.Module):
     def fused_tattn_ok(self, n_tokens: int) -> bool:
         C = self.t_attn.heads * self.t_attn.dim_head
         return (TATTN_FUSED and self.t_attn.dim_head == 64 and C in (320, 640, 1280) and self.t_attn.heads * 64 == C
-                and n_tokens % (32 if C > 640 else 64) == 0)
+                and n_tokens % (32 if C >= 640 else 64) == 0)       # (the kernel's token tile: csrc/tattn.hip tattn_tt)
 
     def forward(self, x, t_context=None, v_context=None, t_kv=None, emit_map: bool = False, zero_ctx_rows: int = 0,
                 t_fused=None, x8=None, emit_rowstats: bool = False):
