@@ -69,8 +69,8 @@ def parse():
     ap.add_argument("--no-mode-table", action="store_true", help="skip the extra passes in the other launch modes")
     ap.add_argument("--in-flight", type=int, default=3, help="batches sampled concurrently per GPU, one launch stream each "
                     "(same-box on MI355X: 1 -> 5.7, 2 -> 7.13, 3 -> 7.67, 4 -> 6.0 images/s)")
-    ap.add_argument("--fp8", action="store_true", help="BASELINE config #5 arithmetic: the transformer blocks' LayerNorm-fed "
-                    "linears on the fp8 (e4m3) MFMA path")
+    ap.add_argument("--fp8", action="store_true", help="BASELINE config #5 arithmetic: every linear of the 640- / 1280-channel "
+                    "transformer blocks on MX8 operands (e4m3 + E8M0 block scales written by the producers' epilogues)")
     ap.add_argument("--noise-iters", type=int, default=10, help="noise search iterations of the reference-default measurement "
                     "(configs/test.yaml:14 noise_iters: 10, batch_size 1): reported as images_per_s_reference_default")
     ap.add_argument("--no-reference-default", action="store_true", help="skip the reference-default (B = 1, noise search) pass")
@@ -454,9 +454,11 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak" if weak else "strong",
             "vs_baseline": None, "data": "synthetic",
             "dtype": "fp8" if args.fp8 else "bf16",
-            "dtype_note": ("e4m3 MFMA (v_mfma_scale_f32_32x32x64_f8f6f4) for the LayerNorm-fed linears of the transformer blocks "
-                           "(q|k, v, t_attn.to_q, GEGLU: 60 % of the linear FLOPs); bf16 MFMA everywhere else; fp32 accumulation, "
-                           "statistics, softmax and sampler state") if args.fp8 else
+            "dtype_note": ("MX8 MFMA (v_mfma_scale_f32_32x32x64_f8f6f4: e4m3 elements, one E8M0 scale per 32 K-elements of an activation "
+                           "row written by the PRODUCING kernel's epilogue, per-output-channel weight scales) for every linear of the "
+                           "640- / 1280-channel transformer blocks (q|k|v, to_out, GEGLU, ff.net[2], proj_out: 69 % of the linear "
+                           "FLOPs; the 320-channel level's K = 320 projections are epilogue-bound and stay bf16, as do the attention "
+                           "scores and the convolutions); fp32 accumulation, statistics, softmax and sampler state") if args.fp8 else
                           "bf16 storage + MFMA, fp32 accumulation / statistics / softmax / sampler state",
             "value_one_batch": (value if (args.in_flight == 1 and args.fuse == 1) else other_modes.get("one_batch_at_a_time")),
             "value_one_batch_note": "the same K steps with ONE batch of --batch images on the GPU at a time (no batches in "

@@ -84,14 +84,9 @@ typedef enum {
 #define UDT_GEMM_TRANSPOSED  (1 << 3)  /* out is [batch_of_row][N][rows_per_batch] (V^T for attn)  */
 #define UDT_GEMM_CONV        (1 << 4)  /* implicit-GEMM convolution, A gathered from NHWC sources   */
 #define UDT_GEMM_SILU_OUT    (1 << 5)  /* out = silu(acc...) (time_embed MLP)                      */
-#define UDT_GEMM_FP8         (1 << 6)  /* a and w are OCP fp8 e4m3 (1 byte / element; K, lda, ldw in
-                                          elements, K % 128 == 0): BASELINE config #5's "fp8 MFMA
-                                          linear path" (v_mfma_scale_f32_32x32x64_f8f6f4, fp32
-                                          accumulation).  out = acc * alpha * colscale[n] (+ epilogue):
-                                          alpha = 1 / activation scale, colscale = per-channel weight
-                                          scale.  Linears only (plain / GEGLU / transposed), N > 64.   */
-
-#define UDT_GEMM_MX8         (1 << 7)  /* config #5, second generation: a is an MX8 activation — OCP e4m3
+/* (1 << 6) was UDT_GEMM_FP8 — round 2's first-generation fp8 path (unit block scales, a per-tensor activation scale written by a
+   quantising LayerNorm kernel): slower than the LayerNorm-folded bf16 GEMMs, retired in round 5 in favour of UDT_GEMM_MX8. */
+#define UDT_GEMM_MX8         (1 << 7)  /* BASELINE config #5: a is an MX8 activation — OCP e4m3
                                           bytes [M, lda] + one E8M0 block scale per 32 K-elements of a
                                           row (a_scale) — and w is e4m3 [N, ldw] + per-channel fp32 scales
                                           (colscale); K % 128 == 0, lda / ldw % 16 == 0.  Plain, LayerNorm-
@@ -125,7 +120,7 @@ typedef struct {
   float alpha;          /* acc * alpha before bias (softmax scale for QK^T GEMMs); 1.0 default    */
   /* fused GroupNorm (north star: "3x3 conv + GroupNorm + SiLU fused blocks"; reference chain
      openaimodel.py:183-187,218-231, util.py:258-275, model.py:128-148)                                             */
-  const float* colscale;/* UDT_GEMM_FP8 only: fp32 [N] per-output-channel weight scales (in packed row order), or NULL */
+  const float* colscale;/* UDT_GEMM_MX8 only: fp32 [N] per-output-channel weight scales (in packed row order), or NULL */
   const float* in_scsh; /* 3x3 / stride 1 / pad 1 convolutions only (see udt_gn_silu_conv3x3_fwd): per-(sample,
                            channel) scale / shift from udt_gn_finalize, applied — with in_act — to the input patch
                            as it is staged in LDS: y = act(x * scale + shift); zero padding stays zero.  NULL = off */
@@ -187,7 +182,7 @@ int udt_gn_silu_conv3x3_fwd(const udt_gemm_desc* d, void* workspace, size_t work
 /* LayerNorm -> linear in one launch (SURVEY.md §8b `udt_ln_gemm_fwd`; reference attention.py:310-339: `attn1(norm1(x))`,
  * `ff(norm3(x))`, LayerNorm over the last dimension = the GEMM's K).  Descriptor as for udt_gemm with the ln_colsum /
  * ln_eps fields set (see udt_gemm_desc); plain or GEGLU epilogue, optional residual.  UDT_ERR_BAD_SHAPE when the
- * problem is outside the lean GEMM family (N <= 64, fp32 / transposed outputs, batched, fp8). */
+ * problem is outside the lean GEMM family (N <= 64, fp32 / transposed outputs, batched). */
 int udt_ln_gemm_fwd(const udt_gemm_desc* d, void* workspace, size_t workspace_bytes, void* stream);
 /* Synchronises `stream` and reports (UDT_ERR_ASYNC) whether any udt_gemm launch that used `workspace` gave up waiting
  * for a partner workgroup since the last check; in that case the header is re-zeroed so the workspace stays usable.
@@ -350,14 +345,6 @@ int udt_gn_strip_stats(const void* x, const void* x2, void* y, const float* stat
 /* LayerNorm over the last dim of bf16 [rows, C] (C % 8 == 0, C <= 4096). */
 int udt_layernorm(const void* x, void* y, const float* gamma, const float* beta,
                   int64_t rows, int32_t C, float eps, void* stream);
-/* The same with an fp8 (OCP e4m3) result for an UDT_GEMM_FP8 consumer: y[r][c] = sat_e4m3(LN(x)[r][c] * scale), rows of
- * ldy >= C bytes (ldy % 16 == 0), columns [C, ldy) zero-filled (K padding of the consumer GEMM).  scale is the static
- * per-tensor activation scale; the consumer's alpha is 1 / scale. */
-int udt_layernorm_fp8(const void* x, void* y, const float* gamma, const float* beta, int64_t rows, int32_t C, int32_t ldy,
-                      float eps, float scale, void* stream);
-/* y = sat_e4m3(x * scale): bf16 [rows, C] -> e4m3 [rows, ldy] (columns [C, ldy) zero-filled); C % 8 == 0, ldy % 16 == 0 */
-int udt_quantize_fp8(const void* x, void* y, int64_t rows, int32_t C, int32_t ldy, float scale, void* stream);
-
 /* ---- sampler / boundary elementwise ------------------------------------------------------------ */
 /* UNet input for one CFG step: x fp32 NCHW [B,4,h,w] -> xin bf16 NHWC [2B, h*w, cpad]; channels 0..3 of
  * both halves = x * c_in; the other channels (mask / masked latent / zero pad) are left untouched. */

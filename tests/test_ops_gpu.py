@@ -363,73 +363,6 @@ def test_fused_gn_matches_unfused_resblock(ops, cuda):
     assert (epi.float() - plain.float()).abs().mean().item() < 4e-3
 
 
-def _deq(q_u8):
-    return q_u8.view(torch.float8_e4m3fn).float()
-
-
-@pytest.mark.parametrize("M,N,K,mode", [(512, 640, 640, "plain"), (2048, 320, 320, "plain160"), (1000, 1280, 1280, "residual"),
-                                        (1024, 320, 320, "trans"), (768, 2560, 320, "geglu"), (256, 128, 2048, "deepk")])
-def test_linear_fp8(ops, cuda, M, N, K, mode):
-    """UDT_GEMM_FP8 (v_mfma_scale_f32_32x32x64_f8f6f4, unit block scales): e4m3 activations (per-tensor scale) x e4m3 weights
-    (per-channel scales), fp32 accumulation.  The reference multiplies the SAME quantised operands in fp32, so the
-    tolerance only covers accumulation order and the bf16 rounding of the result."""
-    from udifftext_amd import lib as L, packing
-    x = (_rand((M, K), cuda, 1.3, seed=1) + 0.2).bfloat16()
-    w = _rand((N, K), cuda, 1.0 / math.sqrt(K), seed=2) * (1.0 + 3.0 * torch.arange(N, device=cuda)[:, None] / N)   # row-dependent scales
-    b = _rand((N,), cuda, seed=3)
-    act_scale = 448.0 / 8.0
-    xq = ops.quantize_fp8(x, act_scale)
-    Kp = xq.data.shape[1]
-    assert Kp % 128 == 0 and int(xq.data[:, K:].abs().sum()) == 0
-    xd = _deq(xq.data)[:, :K] / act_scale
-    # the quantiser itself: within half an e4m3 step (2^-4 relative) of the bf16 input, saturating at 448
-    assert ((xd - x.float().clamp(-8, 8)).abs() <= 0.0625 * x.float().abs().clamp(max=8) + 2e-3).all()
-    if mode == "geglu":
-        wq, cs, bp = packing.pack_geglu_fp8(w, b)
-        wd = _deq(wq)[:, :K] * cs[:, None]
-        out = ops.linear_fp8(xq, wq, cs, bp, flags=L.GEMM_GEGLU)
-        full = xd @ wd.t() + bp
-        blocks = full.reshape(M, N // 64, 2, 32)
-        ref = (blocks[:, :, 0] * F.gelu(blocks[:, :, 1])).reshape(M, N // 2)
-    else:
-        wq, cs = packing.pack_linear_fp8(w)
-        wd = _deq(wq)[:, :K] * cs[:, None]
-        if mode == "trans":
-            rpb = 256
-            out = ops.linear_fp8(xq, wq, cs, None, flags=L.GEMM_TRANSPOSED, rows_per_batch=rpb)
-            ref = (xd @ wd.t()).reshape(M // rpb, rpb, N).permute(0, 2, 1)
-        elif mode == "residual":
-            res = _rand((M, N), cuda, seed=5).bfloat16()
-            out = ops.linear_fp8(xq, wq, cs, packing.pad_bias(b), residual=res)
-            ref = xd @ wd.t() + b + res.float()
-        else:
-            out = ops.linear_fp8(xq, wq, cs, packing.pad_bias(b))
-            ref = xd @ wd.t() + b
-    _close(out, ref, what=f"fp8 linear {mode} {M}x{N}x{K}")
-    # and against the unquantised product: e4m3 x e4m3 keeps ~3 % relative error of the result's scale (stated)
-    if mode in ("plain", "plain160", "deepk"):
-        exact = x.float() @ w.t() + b
-        rel = ((out.float() - exact).pow(2).mean().sqrt() / exact.pow(2).mean().sqrt()).item()
-        assert rel < 6e-2, rel
-
-
-def test_layer_norm_fp8(ops, cuda):
-    rows, Cc = 1000, 320
-    x = (_rand((rows, Cc), cuda, 2.0, seed=1) + 0.3).bfloat16()
-    g = _rand((Cc,), cuda, seed=2) * 0.2 + 1.0
-    b = _rand((Cc,), cuda, seed=3) * 0.2
-    scale = 448.0 / 14.0
-    q = ops.layer_norm_fp8(x, g, b, 1e-5, scale)
-    assert q.data.shape == (rows, 384) and int(q.data[:, Cc:].abs().sum()) == 0
-    ref = F.layer_norm(x.float(), (Cc,), g, b, 1e-5)
-    got = _deq(q.data)[:, :Cc] / scale
-    assert ((got - ref).abs() <= 0.0625 * ref.abs() + 4e-3).all()
-    # identical to quantising the bf16 LayerNorm output up to one e4m3 step (the fused kernel skips the bf16 rounding)
-    two = ops.quantize_fp8(ops.layer_norm(x, g, b, 1e-5), scale)
-    a, bq = _deq(two.data), _deq(q.data)
-    assert ((a - bq).abs() <= 0.126 * torch.maximum(a.abs(), bq.abs()) + 1e-2).all()
-
-
 def test_conv_epilogue(ops, cuda):
     from udifftext_amd import packing
     B, H, W, Cc, N = 2, 16, 16, 320, 320

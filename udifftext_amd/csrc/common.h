@@ -103,18 +103,14 @@ UDT_DEVINL f32x16 mfma32(bf16x8_t a, bf16x8_t b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
 
-// fp8 (OCP e4m3) operands: 32 bytes per lane = 64 K-elements per instruction, unit E8M0 block scales (127 = 2^0).
-// The only large-K fp8 MFMA on gfx950 is the block-scaled form (cdna_hip_programming.md §3); layout verified by
-// tools/probes/fp8_mfma_layout.cpp: row = lane % 32, the two half-waves hold the two halves of K.
+// fp8 (OCP e4m3) operands: 32 bytes per lane = 64 K-elements per instruction.  The only large-K fp8 MFMA on gfx950 is the
+// block-scaled form (cdna_hip_programming.md §3).
 typedef __attribute__((ext_vector_type(8))) int i32x8_t;
 UDT_DEVINL i32x8_t lds_read_frag32(const char* p0, const char* p1) {
   const u32x4 a = *reinterpret_cast<const u32x4*>(p0);
   const u32x4 b = *reinterpret_cast<const u32x4*>(p1);
   i32x8_t r = {(int)a[0], (int)a[1], (int)a[2], (int)a[3], (int)b[0], (int)b[1], (int)b[2], (int)b[3]};
   return r;
-}
-UDT_DEVINL f32x16 mfma32_fp8(i32x8_t a, i32x8_t b, f32x16 c) {
-  return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 0, 0, 0, 127, 0, 127);
 }
 
 // MX (microscaling) form of the same instruction.  The 64 k of one instruction are TWO scale blocks, k in [0, 32) and [32, 64);

@@ -569,9 +569,9 @@ std::atomic<int> g_dbg_bits{0};  // cost-attribution modes that switch parts of 
 #endif
 constexpr int INTERNAL_DIRECT_EPI = 1 << 30;   // kernel-side flag bit, never part of the public flag set
 constexpr int PUBLIC_FLAGS = UDT_GEMM_OUT_F32 | UDT_GEMM_GEGLU | UDT_GEMM_RELU | UDT_GEMM_TRANSPOSED | UDT_GEMM_CONV |
-                             UDT_GEMM_SILU_OUT | UDT_GEMM_FP8 | UDT_GEMM_MX8;
-inline int k_tile(const udt_gemm_desc* d) { return (d->flags & (UDT_GEMM_FP8 | UDT_GEMM_MX8)) ? 128 : BK; }   // K elements per 128-byte row
-inline int elem_bytes(const udt_gemm_desc* d) { return (d->flags & (UDT_GEMM_FP8 | UDT_GEMM_MX8)) ? 1 : 2; }
+                             UDT_GEMM_SILU_OUT | UDT_GEMM_MX8;
+inline int k_tile(const udt_gemm_desc* d) { return (d->flags & UDT_GEMM_MX8) ? 128 : BK; }   // K elements per 128-byte row
+inline int elem_bytes(const udt_gemm_desc* d) { return (d->flags & UDT_GEMM_MX8) ? 1 : 2; }
 
 // the 8-wave kernels serve everything the lean family declines, except outputs of <= 64 columns (the UNet's 4-channel output
 // convolution): those keep the first-generation 4-wave kernel with its 256 x 64 tile
@@ -628,13 +628,13 @@ TilePlan plan_tiles8(const udt_gemm_desc* d) {
   return t;
 }
 
-template <int WGM, int WGN, int TM, int TN, bool CONV, bool TRANS, bool STATS = false, bool FP8 = false>
+template <int WGM, int WGN, int TM, int TN, bool CONV, bool TRANS, bool STATS = false>
 hipError_t launch8(const g8::Params& pp, const TilePlan& t, hipStream_t s) {
   constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
   // the 256x128 configuration transposes its output through LDS: stage 2 plus 16 KiB above the ring (160 KiB total)
   constexpr int smem = (TM == 2 && TN == 2 && !TRANS) ? 160 * 1024 : g8::NSTAGE * (BM + BN) * ROW_BYTES;
   static AttrOnce once;
-  auto kern = g8::gemm8_kernel<WGM, WGN, TM, TN, CONV, TRANS, STATS, FP8>;
+  auto kern = g8::gemm8_kernel<WGM, WGN, TM, TN, CONV, TRANS, STATS>;
   hipError_t e = once.ensure(reinterpret_cast<const void*>(kern), smem);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(kern, dim3(t.G), dim3(g8::NTHREADS), smem, s, pp);
@@ -786,7 +786,7 @@ bool rowres_on() { return g_rowres.load(std::memory_order_relaxed) != 0; }
 bool lean_plan(const udt_gemm_desc* d, LeanPlan& t, bool want_stats) {
   const int mode = lean_mode();
   if (mode == 0) return false;
-  constexpr int unsupported = UDT_GEMM_OUT_F32 | UDT_GEMM_RELU | UDT_GEMM_TRANSPOSED | UDT_GEMM_SILU_OUT | UDT_GEMM_FP8;
+  constexpr int unsupported = UDT_GEMM_OUT_F32 | UDT_GEMM_RELU | UDT_GEMM_TRANSPOSED | UDT_GEMM_SILU_OUT;
   if (d->flags & unsupported) return false;
   // 1x1 / stride-1 convolutions are plain GEMMs over the pixels; two NHWC sources (the UNet's skip concat in front of a
   // ResBlock's skip_connection, reference openaimodel.py:218-231,620) = two A sources along K
@@ -1166,19 +1166,13 @@ extern "C" int udt_gemm(const udt_gemm_desc* d, void* workspace, size_t workspac
   if (d->M <= 0 || d->N <= 0 || d->K <= 0) return UDT_ERR_BAD_SHAPE;
   if (d->K % k_tile(d) != 0) return UDT_ERR_BAD_SHAPE;
   if (d->N % 4 != 0) return UDT_ERR_BAD_SHAPE;
-  const bool fp8 = (d->flags & UDT_GEMM_FP8) != 0;
   const bool mx8 = (d->flags & UDT_GEMM_MX8) != 0;
   if (mx8 || d->q8_out || d->rowstat_out || d->rowstat_in) {
     // MX8 operands / the MX8-emitting epilogues exist on the lean 128 x 128 kernels only (lean_plan): say so instead of falling
     // through to a kernel that would read e4m3 bytes as bf16
     LeanPlan lt8;
-    if (fp8 || !lean_plan(d, lt8, d->colstats != nullptr)) return UDT_ERR_BAD_ARG;
-  }
-  if (fp8) {
-    // e4m3 operands: plain / GEGLU / transposed linears on the 8-wave kernel only
-    if ((d->flags & (UDT_GEMM_CONV | UDT_GEMM_OUT_F32)) || d->colstats || d->in_scsh || !use_gemm8(d)) return UDT_ERR_BAD_ARG;
-    if (d->lda % 16 != 0 || (d->ldw > 0 && d->ldw % 16 != 0)) return UDT_ERR_BAD_SHAPE;
-  } else if (d->colscale && !mx8) {
+    if (!lean_plan(d, lt8, d->colstats != nullptr)) return UDT_ERR_BAD_ARG;
+  } else if (d->colscale) {
     return UDT_ERR_BAD_ARG;
   }
   const bool conv = (d->flags & UDT_GEMM_CONV) != 0;
@@ -1412,11 +1406,7 @@ extern "C" int udt_gemm(const udt_gemm_desc* d, void* workspace, size_t workspac
     }
     hipError_t e8;
     const bool st = d->colstats != nullptr;         // statistics-emitting epilogues are separate kernels
-    if (fp8) {
-      if (t8.bn == 160) e8 = launch8<8, 1, 1, 5, false, false, false, true>(pp, t8, s);
-      else if (trans) e8 = launch8<4, 2, 2, 2, false, true, false, true>(pp, t8, s);
-      else e8 = launch8<4, 2, 2, 2, false, false, false, true>(pp, t8, s);
-    } else if (t8.bn == 160) {
+    if (t8.bn == 160) {
       if (st) e8 = conv ? launch8<8, 1, 1, 5, true, false, true>(pp, t8, s) : launch8<8, 1, 1, 5, false, false, true>(pp, t8, s);
       else e8 = conv ? launch8<8, 1, 1, 5, true, false>(pp, t8, s) : launch8<8, 1, 1, 5, false, false>(pp, t8, s);
     } else if (trans) {

@@ -723,17 +723,11 @@ UDT_DEVINL void raw_barrier() {
 // WGM x WGN waves, each TM x TN MFMA tiles of 32x32
 // STATS: the row-coalesced epilogues also emit the output's column statistics (udt_gemm_desc.colstats) — a separate
 // kernel, so that the plain one keeps its instruction stream and register allocation
-//
-// FP8: A and W are OCP e4m3 bytes (UDT_GEMM_FP8; K, lda, ldw count elements = bytes).  The LDS image is the same
-// 128-byte rows — now 128 K-elements per tile — and a K-tile is two v_mfma_scale_f32_32x32x64_f8f6f4 steps (unit
-// block scales): each lane feeds 32 bytes of its row per step, the SAME two 16-byte slots for both operands, so the
-// instruction's internal k order never matters.  Twice the FLOPs per staged byte and per MFMA cycle; per-output-channel
-// weight scales (udt_gemm_desc.colscale) and the per-tensor activation scale (alpha) are applied to the fp32
-// accumulators ahead of the epilogues.
-template <int WGM, int WGN, int TM, int TN, bool CONV, bool TRANS, bool STATS, bool FP8 = false>
+// (round 5: the e4m3 instance of this kernel — round 2's first-generation fp8 path, unit block scales + a per-tensor activation
+// scale — is gone: config #5 runs on the lean family's MX8 instances, lean.h)
+template <int WGM, int WGN, int TM, int TN, bool CONV, bool TRANS, bool STATS>
 __global__ void __launch_bounds__(NTHREADS) gemm8_kernel(const Params pp) {
-  static_assert(!(FP8 && CONV), "the fp8 path covers linears");
-  constexpr int EB = FP8 ? 1 : 2;                  // bytes per operand element
+  constexpr int EB = 2;                            // bytes per operand element
   static_assert(WGM * WGN == 8, "8 waves per workgroup");
   constexpr int BM = WGM * TM * 32;
   constexpr int BN = WGN * TN * 32;
@@ -912,29 +906,7 @@ __global__ void __launch_bounds__(NTHREADS) gemm8_kernel(const Params pp) {
       if (kt + 2 < kt1) stage(st2, kt + 2);
       const char* abuf = smem + st * STAGE_BYTES;
       const char* bbuf = abuf + A_BYTES;
-      if constexpr (FP8) {
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {                 // 64 K-elements per step: 16-byte slots 4*ks + 2*hi + {0, 1}
-          const int slot0 = ((ks * 4 + hi * 2) ^ swz) << 4;
-          const int slot1 = ((ks * 4 + hi * 2 + 1) ^ swz) << 4;
-          i32x8_t xf[TM], wf[TN];
-#pragma unroll
-          for (int t = 0; t < TM; ++t)
-            xf[t] = lds_read_frag32(abuf + a_frag_row + t * 32 * ROW_BYTES + slot0, abuf + a_frag_row + t * 32 * ROW_BYTES + slot1);
-#pragma unroll
-          for (int t = 0; t < TN; ++t)
-            wf[t] = lds_read_frag32(bbuf + b_frag_row + t * 32 * ROW_BYTES + slot0, bbuf + b_frag_row + t * 32 * ROW_BYTES + slot1);
-#pragma unroll
-          for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-            for (int tn = 0; tn < TN; ++tn) {
-              if constexpr (TRANS)
-                acc[tm][tn] = mfma32_fp8(xf[tm], wf[tn], acc[tm][tn]);
-              else
-                acc[tm][tn] = mfma32_fp8(wf[tn], xf[tm], acc[tm][tn]);
-            }
-        }
-      } else {
+      {
       // all fragment reads of the K-tile are issued ahead of its MFMAs (sched_group_barrier pins that order: left
       // alone, the scheduler keeps three fragment registers and drains lgkmcnt to 0 twice per 16-wide step, exposing
       // the LDS latency eight times per K-tile); the compiler's counted lgkmcnt waits then release the MFMAs as
@@ -1067,34 +1039,6 @@ __global__ void __launch_bounds__(NTHREADS) gemm8_kernel(const Params pp) {
         if (tid == 0 && partners_ok)
           for (int pg = g + 1; pg <= g_last; ++pg)
             __hip_atomic_store(pp.flags + pg, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-      if constexpr (FP8) {
-        if (p.colscale) {                 // per-output-channel weight scale, applied to the fp32 accumulators
-          if constexpr (TRANS) {
-#pragma unroll
-            for (int tn = 0; tn < TN; ++tn) {
-              const int n = cur_n0 + col0 + tn * 32 + l31;
-              const float cs = (n < p.N) ? p.colscale[n] : 0.f;
-#pragma unroll
-              for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[tm][tn][r] *= cs;
-            }
-          } else {
-#pragma unroll
-            for (int tn = 0; tn < TN; ++tn)
-#pragma unroll
-              for (int q = 0; q < 4; ++q) {
-                const int n = cur_n0 + col0 + tn * 32 + q * 8 + hi * 4;
-                f32x4 cs = {0.f, 0.f, 0.f, 0.f};
-                if (n < p.N) cs = *reinterpret_cast<const f32x4*>(p.colscale + n);
-#pragma unroll
-                for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-                  for (int r = 0; r < 4; ++r) acc[tm][tn][q * 4 + r] *= cs[r];
-              }
-          }
-        }
       }
       if constexpr (ROWS16_EPI) {
         if (!(p.flags & (UDT_GEMM_OUT_F32 | UDT_GEMM_GEGLU | (1 << 30)))) {

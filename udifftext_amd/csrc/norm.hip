@@ -430,114 +430,6 @@ int gn_strip_groups(long long HW, int C1, int C2, int G) {
   return gw;
 }
 
-// ---- fp8 (OCP e4m3) activations for UDT_GEMM_FP8 consumers ---------------------------------------------------------
-// 8 fp32 -> 8 saturated e4m3 bytes (v_cvt_pk_fp8_f32 converts to the OCP format on gfx950; values are clamped to the
-// largest finite e4m3, 448, first: the conversion itself does not saturate)
-UDT_DEVINL u32x2 pack_fp8x8(const float (&v)[8]) {
-  float c[8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) c[j] = fminf(fmaxf(v[j], -448.f), 448.f);
-  int lo = 0, hi = 0;
-  lo = __builtin_amdgcn_cvt_pk_fp8_f32(c[0], c[1], lo, false);
-  lo = __builtin_amdgcn_cvt_pk_fp8_f32(c[2], c[3], lo, true);
-  hi = __builtin_amdgcn_cvt_pk_fp8_f32(c[4], c[5], hi, false);
-  hi = __builtin_amdgcn_cvt_pk_fp8_f32(c[6], c[7], hi, true);
-  u32x2 r = {(uint32_t)lo, (uint32_t)hi};
-  return r;
-}
-
-// LayerNorm with an fp8 result (one wave per row, as layernorm_kernel); the K padding [C, ldy) is written as zeros
-template <int NCH>
-__global__ void __launch_bounds__(256) layernorm_fp8_kernel(const uint16_t* __restrict__ x, uint8_t* __restrict__ y,
-                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                            long long rows, int C, int ldy, float eps, float scale) {
-  const int lane = threadIdx.x & 63;
-  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= rows) return;
-  const int c8 = C >> 3;
-  const uint16_t* xr = x + row * C;
-  float v[NCH][8];
-  float s = 0.f;
-#pragma unroll
-  for (int i = 0; i < NCH; ++i) {
-    const int ch = lane + i * 64;
-    if (ch < c8) {
-      const u32x4 u = *reinterpret_cast<const u32x4*>(xr + ch * 8);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        v[i][2 * j] = bf16_lo(u[j]);
-        v[i][2 * j + 1] = bf16_hi(u[j]);
-      }
-    } else {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) v[i][j] = 0.f;
-    }
-#pragma unroll
-    for (int j = 0; j < 8; ++j) s += v[i][j];
-  }
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
-  const float mean = s / (float)C;
-  float q = 0.f;
-#pragma unroll
-  for (int i = 0; i < NCH; ++i) {
-    const int ch = lane + i * 64;
-    if (ch < c8) {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const float d = v[i][j] - mean;
-        q += d * d;
-      }
-    }
-  }
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) q += __shfl_xor(q, off);
-  const float rstd = rsqrtf(q / (float)C + eps);
-  uint8_t* yr = y + row * ldy;
-  const int y8 = ldy >> 3;
-#pragma unroll
-  for (int i = 0; i < NCH + 1; ++i) {
-    const int ch = lane + i * 64;
-    if (ch < c8 && i < NCH) {
-      const f32x4 g0 = *reinterpret_cast<const f32x4*>(gamma + ch * 8);
-      const f32x4 g1 = *reinterpret_cast<const f32x4*>(gamma + ch * 8 + 4);
-      const f32x4 b0 = *reinterpret_cast<const f32x4*>(beta + ch * 8);
-      const f32x4 b1 = *reinterpret_cast<const f32x4*>(beta + ch * 8 + 4);
-      float o[8];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        o[j] = ((v[i < NCH ? i : 0][j] - mean) * rstd * g0[j] + b0[j]) * scale;
-        o[4 + j] = ((v[i < NCH ? i : 0][4 + j] - mean) * rstd * g1[j] + b1[j]) * scale;
-      }
-      *reinterpret_cast<u32x2*>(yr + ch * 8) = pack_fp8x8(o);
-    } else if (ch >= c8 && ch < y8) {
-      u32x2 z = {0u, 0u};
-      *reinterpret_cast<u32x2*>(yr + ch * 8) = z;
-    }
-  }
-}
-
-// y = sat_e4m3(x * scale), 8 elements per thread
-__global__ void __launch_bounds__(256) quantize_fp8_kernel(const uint16_t* __restrict__ x, uint8_t* __restrict__ y, long long rows,
-                                                           int C, int ldy, float scale) {
-  const int y8 = ldy >> 3;
-  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= rows * y8) return;
-  const long long row = i / y8;
-  const int ch = (int)(i - row * y8);
-  u32x2 o = {0u, 0u};
-  if (ch * 8 < C) {
-    const u32x4 u = *reinterpret_cast<const u32x4*>(x + row * C + ch * 8);
-    float v[8];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      v[2 * j] = bf16_lo(u[j]) * scale;
-      v[2 * j + 1] = bf16_hi(u[j]) * scale;
-    }
-    o = pack_fp8x8(v);
-  }
-  *reinterpret_cast<u32x2*>(y + row * ldy + ch * 8) = o;
-}
 
 // ---- GroupNorm statistics from producer epilogues -------------------------------------------------------------
 // grid (G, B): one workgroup per (sample, group).  Thread t = (slot lane t / cpg, channel t % cpg): the slot lanes share
@@ -758,44 +650,7 @@ extern "C" int udt_gn_apply_scsh(const void* x, const void* x2, void* y, const f
   return UDT_OK;
 }
 
-extern "C" int udt_layernorm_fp8(const void* x, void* y, const float* gamma, const float* beta, int64_t rows, int32_t C,
-                                 int32_t ldy, float eps, float scale, void* stream) {
-  if (!x || !y || !gamma || !beta) return UDT_ERR_BAD_ARG;
-  if (rows <= 0 || C <= 0 || C % 8 != 0 || C > 4096 || ldy < C || ldy % 16 != 0 || ldy > 4096 + 512) return UDT_ERR_BAD_SHAPE;
-  if (!(scale > 0.f)) return UDT_ERR_BAD_ARG;
-  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  const int nch = (C + 511) / 512;
-  if ((ldy >> 3) > (nch + 1) * 64) return UDT_ERR_BAD_SHAPE;        // the padding must fit one more 64-lane sweep
-  const unsigned blocks = (unsigned)((rows + 3) / 4);
-  const uint16_t* xp = reinterpret_cast<const uint16_t*>(x);
-  uint8_t* yp = reinterpret_cast<uint8_t*>(y);
-  UdtProfScope prof(4, s);
-#define UDT_LNQ_CASE(N)                                                                                          \
-  case N:                                                                                                        \
-    hipLaunchKernelGGL(layernorm_fp8_kernel<N>, dim3(blocks), dim3(256), 0, s, xp, yp, gamma, beta, (long long)rows, \
-                       C, ldy, eps, scale);                                                                      \
-    break;
-  switch (nch) {
-    UDT_LNQ_CASE(1) UDT_LNQ_CASE(2) UDT_LNQ_CASE(3) UDT_LNQ_CASE(4) UDT_LNQ_CASE(5) UDT_LNQ_CASE(6) UDT_LNQ_CASE(7)
-    UDT_LNQ_CASE(8)
-    default: return UDT_ERR_BAD_SHAPE;
-  }
-#undef UDT_LNQ_CASE
-  UDT_CHECK_LAUNCH();
-  return UDT_OK;
-}
 
-extern "C" int udt_quantize_fp8(const void* x, void* y, int64_t rows, int32_t C, int32_t ldy, float scale, void* stream) {
-  if (!x || !y) return UDT_ERR_BAD_ARG;
-  if (rows <= 0 || C <= 0 || C % 8 != 0 || ldy < C || ldy % 16 != 0 || !(scale > 0.f)) return UDT_ERR_BAD_SHAPE;
-  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  UdtProfScope prof(5, s);
-  const long long n = (long long)rows * (ldy / 8);
-  hipLaunchKernelGGL(quantize_fp8_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s,
-                     reinterpret_cast<const uint16_t*>(x), reinterpret_cast<uint8_t*>(y), (long long)rows, C, ldy, scale);
-  UDT_CHECK_LAUNCH();
-  return UDT_OK;
-}
 
 extern "C" int udt_layernorm(const void* x, void* y, const float* gamma, const float* beta, int64_t rows, int32_t C,
                              float eps, void* stream) {

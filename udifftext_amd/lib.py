@@ -19,7 +19,6 @@ GEMM_RELU = 1 << 2
 GEMM_TRANSPOSED = 1 << 3
 GEMM_CONV = 1 << 4
 GEMM_SILU_OUT = 1 << 5
-GEMM_FP8 = 1 << 6
 GEMM_MX8 = 1 << 7
 
 PROF_CONV3X3, PROF_GEMM, PROF_ATTN, PROF_XATTN, PROF_NORM, PROF_ELEMENTWISE = range(6)
@@ -94,8 +93,6 @@ SYMBOLS = {
     "udt_gn_strip_ok": (_i32, [_i32, _i64, _i32, _i32, _i32]),
     "udt_gn_strip": (C.c_int, [_vp, _vp, _vp, _fp, _fp, _i32, _i64, _i32, _i32, _i32, _f32, _i32, _vp]),
     "udt_layernorm": (C.c_int, [_vp, _vp, _fp, _fp, _i64, _i32, _f32, _vp]),
-    "udt_layernorm_fp8": (C.c_int, [_vp, _vp, _fp, _fp, _i64, _i32, _i32, _f32, _f32, _vp]),
-    "udt_quantize_fp8": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _f32, _vp]),
     "udt_unet_input": (C.c_int, [_fp, _vp, _i32, _i32, _i32, _f32, _vp]),
     "udt_cfg_euler_step": (C.c_int, [_fp, _fp, _fp, _i32, _i32, _i32, _f32, _f32, _f32, _f32, _vp]),
     "udt_sampler_step": (C.c_int, [_fp, _fp, _fp, _i32, _i32, _i32, _f32, _f32, _f32, _f32, _vp]),

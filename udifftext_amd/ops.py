@@ -684,63 +684,6 @@ def group_norm_from_stats(x: torch.Tensor, st1: GnStats, gamma: torch.Tensor, be
     return out
 
 
-class Fp8Act(NamedTuple):
-    """an activation quantised for an UDT_GEMM_FP8 consumer: e4m3 bytes [rows, Kpad128] (uint8) = sat(value * scale)"""
-    data: torch.Tensor
-    scale: float
-
-
-def layer_norm_fp8(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float, scale: float) -> Fp8Act:
-    """LayerNorm with the fp8 quantisation fused (udt_layernorm_fp8); x bf16 [rows, C]"""
-    _bf16(x)
-    assert x.is_contiguous()
-    Cc = x.shape[-1]
-    rows = x.numel() // Cc
-    kp = (Cc + 127) // 128 * 128
-    y = torch.empty((rows, kp), dtype=torch.uint8, device=x.device)
-    L.check(L.load().udt_layernorm_fp8(_ptr(x), _ptr(y), _ptr(gamma), _ptr(beta), rows, Cc, kp, eps, scale, _stream()),
-            "udt_layernorm_fp8")
-    return Fp8Act(y, scale)
-
-
-def quantize_fp8(x: torch.Tensor, scale: float) -> Fp8Act:
-    _bf16(x)
-    assert x.is_contiguous()
-    Cc = x.shape[-1]
-    rows = x.numel() // Cc
-    kp = (Cc + 127) // 128 * 128
-    y = torch.empty((rows, kp), dtype=torch.uint8, device=x.device)
-    L.check(L.load().udt_quantize_fp8(_ptr(x), _ptr(y), rows, Cc, kp, scale, _stream()), "udt_quantize_fp8")
-    return Fp8Act(y, scale)
-
-
-def linear_fp8(x: Fp8Act, wq: torch.Tensor, colscale: torch.Tensor, bias: Optional[torch.Tensor] = None, *,
-               out: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None, rows_per_batch: int = 0,
-               flags: int = 0, n_out: Optional[int] = None) -> torch.Tensor:
-    """out[M, N] (bf16) = epilogue((xq @ wq^T) / x.scale * colscale[n]) on the fp8 MFMA path (UDT_GEMM_FP8)."""
-    xq = x.data
-    assert xq.dtype == torch.uint8 and wq.dtype == torch.uint8 and xq.is_contiguous() and wq.is_contiguous()
-    M, K = xq.shape
-    N = wq.shape[0] if n_out is None else n_out
-    assert wq.shape[1] == K and K % 128 == 0 and colscale.dtype == torch.float32 and colscale.numel() >= N
-    n_cols = N // 2 if (flags & L.GEMM_GEGLU) else N
-    if out is None:
-        if flags & L.GEMM_TRANSPOSED:
-            assert rows_per_batch > 0
-            out = torch.empty((M // rows_per_batch, N, rows_per_batch), dtype=torch.bfloat16, device=xq.device)
-        else:
-            out = torch.empty((M, n_cols), dtype=torch.bfloat16, device=xq.device)
-    ldo = out.stride(0) if not (flags & L.GEMM_TRANSPOSED) else 0
-    d = gemm_desc(a=_ptr(xq), w=_ptr(wq), bias=_ptr(bias), residual=_ptr(residual), out=_ptr(out), M=M, N=N, K=K, lda=K,
-                  ldo=ldo, ldr=(residual.stride(0) if residual is not None else 0), rows_per_batch=rows_per_batch,
-                  flags=flags | L.GEMM_FP8, alpha=1.0 / x.scale, colscale=_ptr(colscale))
-    run_gemm(d, xq.device)
-    if WORK_COUNTER is not None:
-        count_work("gemm_fp8", 2.0 * M * N * K)
-        count_work("gemm_fp8_launches", 1.0)
-    return out
-
-
 def layer_norm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-5,
                out: Optional[torch.Tensor] = None) -> torch.Tensor:
     _bf16(x)

@@ -106,7 +106,8 @@ FP8_MAX = 448.0         # largest finite OCP e4m3 value
 
 def pack_linear_fp8(w: torch.Tensor, n_pad_to: int = 4):
     """[N, K] fp32 -> (e4m3 bytes [Npad, Kpad128] as uint8, per-output-channel scale fp32 [Npad]):
-    w[n, k] ~= q[n, k] * scale[n] with scale[n] = max_k |w[n, k]| / 448 (per-channel weight scales, udt_gemm colscale)."""
+    w[n, k] ~= q[n, k] * scale[n] with scale[n] = max_k |w[n, k]| / 448 (per-channel weight scales, udt_gemm colscale) —
+    the weight side of an UDT_GEMM_MX8 launch (the activation side carries E8M0 block scales written by its producer)."""
     N, K = w.shape
     Np, Kp = _round_up(N, n_pad_to), _round_up(K, FP8_KPAD)
     wf = w.float()
@@ -118,14 +119,6 @@ def pack_linear_fp8(w: torch.Tensor, n_pad_to: int = 4):
     cs = torch.ones((Np,), dtype=torch.float32, device=w.device)
     cs[:N] = scale
     return out.contiguous(), cs
-
-
-def pack_geglu_fp8(w: torch.Tensor, b: torch.Tensor):
-    """GEGLU.proj [2*inner, C] -> permuted e4m3 weight, permuted per-channel scales, permuted fp32 bias"""
-    inner = w.shape[0] // 2
-    perm = geglu_permutation(inner).to(w.device)
-    wq, cs = pack_linear_fp8(w[perm])
-    return wq, cs, b[perm].float().contiguous()
 
 
 def pack_ln_linear_mx8(w: torch.Tensor, b, gamma: torch.Tensor, beta: torch.Tensor, geglu: bool = False):

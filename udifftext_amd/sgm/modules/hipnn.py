@@ -66,8 +66,8 @@ def mx8_width(c: int) -> bool:
 
 # LayerNorm folded into the GEMM that consumes it (udt_ln_gemm_fwd, csrc/lean.h): `attn1(norm1(x))` and `ff(norm3(x))` of
 # every transformer block (reference attention.py:310-339) run as ONE launch on the raw residual stream — the normalised
-# activation never exists in memory.  UDT_LN_GEMM=0 restores layernorm kernel + GEMM (A/B measurements); the fp8 path
-# keeps its own LayerNorm -> e4m3 kernel.
+# activation never exists in memory.  UDT_LN_GEMM=0 restores layernorm kernel + GEMM (A/B measurements; config #5's MX8 linears
+# need the folded form and are off with it).
 LN_GEMM = os.environ.get("UDT_LN_GEMM", "1") != "0" and os.environ.get("UDT_LEAN", "") != "0"
 
 
