@@ -739,7 +739,9 @@ def test_predict_many_in_flight_with_noise_search(engine, cuda):
 def test_checkpoint_load_prepare_free_masters_matches_goldens(engine, cond256, eg, cuda, tmp_path):
     """SURVEY §8f-3 on the GPU: write the engine's 1330 keys as .safetensors, build a FRESH engine, init_from_ckpt,
     prepare(free_masters=True, dedup_vae=True) — packed layouts only, fp32 masters released — and re-run the reference
-    golden checks (VAE G5, UNet call G7, 10-step trajectory G9)"""
+    golden checks (VAE G5, UNet call G7, 10-step trajectory G9).  prepare() runs with UDT_FP8 on: the e4m3 layouts of config #5
+    are built and frozen next to the bf16 ones, and the packed-only engine serves BOTH arithmetics."""
+    import sgm.modules.hipnn as H
     from safetensors.torch import save_file
     from udifftext_amd import config as C, ops, pipeline
     path = os.path.join(str(tmp_path), "engine.safetensors")
@@ -751,7 +753,12 @@ def test_checkpoint_load_prepare_free_masters_matches_goldens(engine, cond256, e
     fresh.freeze()
     missing, unexpected = fresh.init_from_ckpt(path)
     assert not missing and not unexpected
-    rep = fresh.prepare(free_masters=True, dedup_vae=True)
+    prev_fp8 = H.FP8_LINEARS
+    H.FP8_LINEARS = True
+    try:
+        rep = fresh.prepare(free_masters=True, dedup_vae=True)
+    finally:
+        H.FP8_LINEARS = prev_fp8
     # (the name-keyed synthetic recipe gives the twin autoencoders DIFFERENT weights, so nothing is deduplicated here; the
     #  dedup itself is covered by tests/test_dropin_cpu.py)
     assert rep["vae_deduplicated"] == 0 and rep["freed_bytes"] > 4e9
@@ -771,6 +778,16 @@ def test_checkpoint_load_prepare_free_masters_matches_goldens(engine, cond256, e
     xin = torch.cat([torch.cat([x7, x7]), torch.cat([ucc, cc])], dim=1)
     eps = fresh.model.diffusion_model(xin, timesteps=torch.tensor([999, 999], device=cuda), t_context=tctx)
     _check("ckpt -> prepare(free_masters): UNet eps vs reference", eps.cpu(), eg["g7_eps"], 2e-2, 8e-2)
+    H.FP8_LINEARS = True
+    try:
+        ops.WORK_COUNTER = {}
+        eps8 = _sampler_call(fresh.model.diffusion_model, xin, torch.tensor([999, 999], device=cuda), tctx, 1)
+        n8 = ops.WORK_COUNTER.get("gemm_fp8_launches", 0)
+    finally:
+        H.FP8_LINEARS = prev_fp8
+        ops.WORK_COUNTER = None
+    assert n8 == 52
+    _check("ckpt -> prepare(free_masters): UNet eps with MX8 linears vs reference", eps8.cpu(), eg["g7_eps"], 8e-2)
     sampler = pipeline.init_sampling(10, 5.0, cuda)
     cfgs = C.default_runtime_config(steps=10, batch_size=1, noise_iters=0)
     torch.manual_seed(99)
