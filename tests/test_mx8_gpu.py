@@ -215,3 +215,18 @@ def test_flash_attention_emits_mx8_twin(env, cuda, B, N, heads):
     q8 = O.mx8_of(out)
     assert q8 is not None and torch.equal(out, plain)
     _check_q8(q8, out.reshape(B * N, C), stats=False)
+
+
+def test_mx8_launches_are_bit_reproducible(env, cuda):
+    """the MX8 GEMM with a ticket split-K (2048 x 1280 x 5120: three K slices summed in slice order), the emitting epilogue and the
+    fused text attention's MX8 twin give the same bits on every run — no atomics, no arrival-order sums"""
+    x, xd, xq, xs, w, b, g = _mx8_operands(env, cuda, 2048, 1280, 5120, seed=8)
+    wq, cs = env.packing.pack_linear_fp8(w)
+    r = torch.randn((2048, 1280), generator=g).to(cuda).bfloat16()
+    act = env.ops.Mx8Act(xq, xs)
+    outs = [env.ops.linear_mx8(act, wq, cs, b, residual=r, emit_q8=True, emit_rowstats=True) for _ in range(3)]
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0])
+        assert torch.equal(env.ops.mx8_of(o).data, env.ops.mx8_of(outs[0]).data)
+        assert torch.equal(env.ops.mx8_of(o).scale, env.ops.mx8_of(outs[0]).scale)
+        assert torch.equal(env.ops.mx8_of(o).stats, env.ops.mx8_of(outs[0]).stats)
