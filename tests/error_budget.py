@@ -28,7 +28,25 @@ from oracle import nets, sampling, spec          # noqa: E402
 from udifftext_amd import synth                  # noqa: E402
 
 bf = lambda t: t.to(torch.bfloat16).float()
-FLAGS = dict(W=False, A=False, O=False, N=False, N_ln=True, P=False, R32=False)
+FLAGS = dict(W=False, A=False, O=False, N=False, N_ln=True, P=False, R32=False, A8=False)
+
+
+def _e4m3(t, scale):
+    """fixed-scale e4m3 round trip"""
+    return (t * scale).clamp(-448.0, 448.0).to(torch.float8_e4m3fn).float() / scale
+
+
+def _mx8_lastdim(t):
+    """MX8 round trip with 32-element blocks along the last dimension (tests/mx8_ref.py: the kernels' scale rule)"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import mx8_ref
+    shp = t.shape
+    flat = t.reshape(-1, shp[-1])
+    pad = (-flat.shape[1]) % 128
+    if pad:
+        flat = F.pad(flat, (0, pad))
+    q, sc = mx8_ref.encode(flat)
+    return mx8_ref.decode(q, sc)[:, :shp[-1]].reshape(shp)
 
 
 def _q(flag, t):
@@ -68,6 +86,17 @@ def _resblock(sd, p, x, emb):
 def _self_attention(sd, p, x, heads, res):
     q, k, v = (nets._split_heads(_lin(sd, p + n, x, bias=False), heads) for n in ("to_q.", "to_k.", "to_v."))
     d = q.shape[-1]
+    if FLAGS["A8"]:
+        # an e4m3 attention kernel as sketched in DESIGN.md section 10: q and k with MX blocks along d (two per head), v with one
+        # power-of-two scale, the un-normalised probabilities (<= 2^8 under the deferred rescale) as e4m3
+        q, k = _mx8_lastdim(q), _mx8_lastdim(k)
+        v = _e4m3(v, 2.0 ** float(torch.floor(torch.log2(448.0 / v.abs().max()))))
+        sc = q @ k.transpose(-1, -2) * d ** -0.5
+        pr = torch.exp(sc - sc.amax(dim=-1, keepdim=True))
+        pr8 = _e4m3(pr, 256.0)
+        attn_v = (pr8 @ v) / pr.sum(dim=-1, keepdim=True)
+        o = _q("P", nets._merge_heads(attn_v))
+        return _lin(sd, p + "to_out.0.", o, add=res, keep32=FLAGS["R32"])
     attn = torch.softmax(q @ k.transpose(-1, -2) * d ** -0.5, dim=-1)
     o = _q("P", nets._merge_heads(_q("P", attn) @ v))
     return _lin(sd, p + "to_out.0.", o, add=res, keep32=FLAGS["R32"])
@@ -145,7 +174,7 @@ def main():
     tctx = torch.cat([torch.zeros_like(ctx), ctx])
     ts = torch.tensor([999, 999])
     rel = lambda a, b: ((a - b).pow(2).mean().sqrt() / b.pow(2).mean().sqrt()).item()
-    base = dict(W=False, A=False, O=False, N=False, N_ln=True, P=False, R32=False)
+    base = dict(W=False, A=False, O=False, N=False, N_ln=True, P=False, R32=False, A8=False)
     FLAGS.update(base)
     ref = unet(sd, xin, ts, tctx, cfg.unet)
     print(f"injected-rounding harness vs oracle.nets.unet_forward (must be ~0): {rel(ref, nets.unet_forward(sd, xin, ts, tctx, cfg.unet)):.2e}")
@@ -156,7 +185,9 @@ def main():
             ("W+A (what the MFMA sees)", dict(W=True, A=True)), ("O+N (what is stored)", dict(O=True, N=True)),
             ("all = the HIP path's roundings (LayerNorms folded: never stored)", dict(W=True, A=True, O=True, N=True, P=True)),
             ("all, LayerNorm outputs ALSO stored as bf16 (UDT_LN_GEMM=0)", dict(W=True, A=True, O=True, N=True, P=True, N_ln=False)),
-            ("all, fp32 residual stream (R32)", dict(W=True, A=True, O=True, N=True, P=True, R32=True))]
+            ("all, fp32 residual stream (R32)", dict(W=True, A=True, O=True, N=True, P=True, R32=True)),
+            ("A8  an e4m3 self-attention alone (q, k MX8 along d; v, P fixed-scale e4m3), everything else fp32", dict(A8=True)),
+            ("all + A8", dict(W=True, A=True, O=True, N=True, P=True, A8=True))]
     for name, fl in rows:
         FLAGS.update(base)
         FLAGS.update(fl)
