@@ -144,10 +144,14 @@ typedef struct {
      value = e4m3 * 2^(scale - 127)).                                                                                   */
   const void* a_scale;     /* UDT_GEMM_MX8: the block scales of `a`                                                     */
   void* q8_out;            /* optional second output: the result (after bias / residual / GEGLU, as rounded for `out`) again
-                              as an MX8 activation for the next GEMM; with UDT_GEMM_GEGLU `out` may then be NULL.  Lean
+                              as an MX8 activation for the next GEMM; `out` may then be NULL.  Lean
                               128 x 128 plans only (udt_gemm_rowstat_parts > 0), N % 32 == 0 (GEGLU: N % 64 == 0)         */
   void* q8_scale;          /* its block scales (see above)                                                               */
   int32_t ld_q8;           /* bytes between rows of q8_out (% 8 == 0)                                                    */
+  int32_t q8_fixed_col;    /* 0 = off; else result columns >= q8_fixed_col (a multiple of 32) are written as e4m3(value * q8_fixed_mul),
+                              clamped to +-448, with the unit scale byte 127 instead of block scales: the v third of a q|k|v
+                              projection feeding udt_attn_mx8_fwd, whose P V product contracts over keys                        */
+  float q8_fixed_mul;
   float* rowstat_out;      /* optional, with q8_out (not GEGLU): fp32 [udt_gemm_rowstat_parts(d)][M][2] partial (sum, sum of
                               squares) of every result row — the LayerNorm statistics of a LayerNorm-folded MX8 consumer  */
   const float* rowstat_in; /* UDT_GEMM_MX8 with ln_colsum: the partial row statistics of `a` its producer emitted,
@@ -172,6 +176,8 @@ int32_t udt_gemm_colstats_rows(const udt_gemm_desc* d);
 /* Parts of the partial row statistics (rowstat_out) udt_gemm would emit for this problem = N / (columns per wave of the plan);
  * 0 = the plan has no MX8-emitting epilogue (q8_out / rowstat_out must then be NULL). */
 int32_t udt_gemm_rowstat_parts(const udt_gemm_desc* d);
+/* 1 if udt_gemm would take this descriptor WITH its q8_out / q8_scale (an MX8-emitting epilogue exists for the plan), else 0. */
+int32_t udt_gemm_q8_ok(const udt_gemm_desc* d);
 int32_t udt_gemm_colstats_slots(const udt_gemm_desc* d);
 /* 1 if udt_gemm accepts `in_scsh` for this problem (patch-staged 3x3 convolution geometry; one or two NHWC sources). */
 int32_t udt_gemm_in_scsh_ok(const udt_gemm_desc* d);
@@ -227,6 +233,17 @@ int udt_attn_rowv_q8_fwd(const void* q, const void* k, const void* v, void* o,
                          int32_t ldq, int32_t ldk, int32_t ldv, int32_t ldo,
                          int64_t q_bstride, int64_t k_bstride, int64_t v_bstride, int64_t o_bstride,
                          float scale, void* q8_out, void* q8_scale, int32_t ld_q8, void* stream);
+
+/* BASELINE config #5's "fp8 attention": the same self-attention on e4m3 operands (v_mfma_scale_f32_32x32x64_f8f6f4 for Q K^T and
+ * P V; fp32 softmax).  q, k, v are column ranges of ONE MX8 activation qkv8 [batch * n, ld8] — q at column h * 64, k at C + h * 64,
+ * v at 2 C + h * 64, C = heads * 64 — written by the q|k|v projection's emitting epilogue (udt_gemm_desc.q8_out) with
+ * q8_fixed_col = 2 C: q and k carry block scales along the head dimension (qkv_scale, uint32 [ld8 / 128 rounded up][batch * n]),
+ * v was multiplied by q8_fixed_mul; v_inv = 1 / q8_fixed_mul.  o: bf16 rows b * n + i of ldo elements; q8_out / q8_scale / ld_q8
+ * (optional): O again as an MX8 activation, as udt_attn_rowv_q8_fwd (heads even for it).  n % 4 == 0, ld8 % 16 == 0, qkv8 16-byte aligned.
+ * Reference: sgm/modules/attention.py:236-248. */
+int udt_attn_mx8_fwd(const void* qkv8, const void* qkv_scale, void* o, int32_t batch, int32_t heads, int32_t n,
+                     int32_t ld8, int32_t ldo, float scale, float v_inv, void* q8_out, void* q8_scale, int32_t ld_q8,
+                     void* stream);
 
 /* Flash attention forward for ONE head of 512 dims: the AutoencoderKL mid-block attention (reference
  * sgm/modules/diffusionmodules/model.py:236-260, MemoryEfficientAttnBlock.attention: xformers.ops.memory_efficient_attention on

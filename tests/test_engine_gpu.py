@@ -607,6 +607,18 @@ def test_benchmarked_call_path_vs_oracle_bf16_and_fp8(engine, cuda):
         H.FP8_LINEARS = prev
         ops.WORK_COUNTER = None
     assert n8 == 11 * 5, f"{n8} MX8 GEMM launches"
+    # ... and with attn1's Q K^T / P V on e4m3 operands too (hipnn.FP8_ATTENTION): all 16 blocks, the 320-channel level included
+    H.FP8_LINEARS, prev_a8 = True, H.FP8_ATTENTION
+    H.FP8_ATTENTION = True
+    try:
+        ops.WORK_COUNTER = {}
+        eps_a8 = _sampler_call(unet, x, ts, tctx, B)
+        na8, n8b = ops.WORK_COUNTER.get("attn_fp8_launches", 0), ops.WORK_COUNTER.get("gemm_fp8_launches", 0)
+        assert ops.WORK_COUNTER.get("attn_launches", 0) == 0
+    finally:
+        H.FP8_LINEARS, H.FP8_ATTENTION = prev, prev_a8
+        ops.WORK_COUNTER = None
+    assert na8 == 16 and n8b == 11 * 5, (na8, n8b)
     pick = [0, 3, 4, 7]
     sd = {k: v.detach().float().cpu() for k, v in engine.state_dict().items() if k.startswith("model.")}
     with torch.no_grad():
@@ -614,9 +626,12 @@ def test_benchmarked_call_path_vs_oracle_bf16_and_fp8(engine, cuda):
     _check("benchmarked call path (fused t_attn, zero-context rows) bf16 vs oracle", ref_bf16[pick].cpu(), ref, 2e-2, 8e-2)
     _check("benchmarked call path with MX8 linears vs oracle", eps[pick].cpu(), ref, 8e-2)
     _check("benchmarked call path with MX8 linears vs the bf16 path", eps.cpu(), ref_bf16.cpu(), 8e-2)
+    _check("benchmarked call path with MX8 linears + e4m3 attention vs oracle", eps_a8[pick].cpu(), ref, 8e-2)
+    _check("benchmarked call path with MX8 linears + e4m3 attention vs the bf16 path", eps_a8.cpu(), ref_bf16.cpu(), 8e-2)
 
 
-def test_config2_512_fifty_steps_with_fp8_linears_vs_reference_golden(engine, cuda, monkeypatch):
+@pytest.mark.parametrize("attn8", [False, True])
+def test_config2_512_fifty_steps_with_fp8_linears_vs_reference_golden(engine, cuda, monkeypatch, attn8):
     """config #5's arithmetic over a whole trajectory: BASELINE config #2's image (512x512, 9 characters, CFG 5) through 50 Euler
     steps with the MX8 linears, against the REAL reference's latents after 10 / 25 / 50 steps (engine_golden_512.npz).  Stated
     tolerance: rel_rms <= 8e-2 at every horizon (bf16: 3e-2 stated / 1.2e-2 measured) — the e4m3 error of one call must not grow
@@ -629,6 +644,8 @@ def test_config2_512_fifty_steps_with_fp8_linears_vs_reference_golden(engine, cu
     batch, buc = pipeline.prepare_batch(batch, cuda)
     c, uc = engine.conditioner.get_unconditional_conditioning(batch, batch_uc=buc, force_uc_zero_embeddings=["label"])
     monkeypatch.setattr(H, "FP8_LINEARS", True)
+    monkeypatch.setattr(H, "FP8_ATTENTION", attn8)            # (True: attn1's Q K^T and P V on e4m3 operands as well)
+    tag = " + e4m3 attention" if attn8 else ""
     cfgs = C.default_runtime_config(steps=50, batch_size=1, noise_iters=0)
     from sgm.modules.diffusionmodules.sampling import _Stepper
     sampler = pipeline.init_sampling(50, 5.0, cuda)
@@ -641,13 +658,13 @@ def test_config2_512_fifty_steps_with_fp8_linears_vs_reference_golden(engine, cu
     for i in range(50):
         st.step(z, sig[i], sig[i + 1])
         if i + 1 in (10, 25, 50):
-            _check(f"512x512 with MX8 linears: latent after {i + 1} steps vs reference", z.cpu(), g12[f"g12_latent_{i + 1}"], 8e-2)
+            _check(f"512x512 with MX8 linears{tag}: latent after {i + 1} steps vs reference", z.cpu(), g12[f"g12_latent_{i + 1}"], 8e-2)
     st.check()
     # (the sampler's own entry point, hipGraph replay included, must give the same trajectory)
     z2 = sampler(engine, x0.clone(), cond=c, batch=batch, uc=uc)
-    _check("512x512 with MX8 linears: graph-replayed sampler vs eager steps", z2.cpu(), z.cpu(), 1e-6)
+    _check(f"512x512 with MX8 linears{tag}: graph-replayed sampler vs eager steps", z2.cpu(), z.cpu(), 1e-6)
     dec = engine.decode_first_stage(z)
-    _check("512x512 with MX8 linears: decoded image of the 50-step latent vs reference", dec[:, :, ::8, ::8].cpu(), g12["g12_decoded_sub"], 8e-2)
+    _check(f"512x512 with MX8 linears{tag}: decoded image of the 50-step latent vs reference", dec[:, :, ::8, ::8].cpu(), g12["g12_decoded_sub"], 8e-2)
 
 
 def test_noise_search_at_benchmarked_latent_size_vs_oracle(engine, cuda):

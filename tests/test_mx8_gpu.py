@@ -230,3 +230,126 @@ def test_mx8_launches_are_bit_reproducible(env, cuda):
         assert torch.equal(env.ops.mx8_of(o).data, env.ops.mx8_of(outs[0]).data)
         assert torch.equal(env.ops.mx8_of(o).scale, env.ops.mx8_of(outs[0]).scale)
         assert torch.equal(env.ops.mx8_of(o).stats, env.ops.mx8_of(outs[0]).stats)
+
+
+# ------------------------------------------------------------------------------------------- e4m3 self-attention (config #5)
+#   the e4m3 attention vs fp32 torch on the same dequantised q, k, v: P is rounded to e4m3 inside the kernel — a relative error of up
+#   to 2^-4 per probability, rms 2.6e-2.  With ZERO-MEAN random v the output is itself a cancelling sum (|O| ~ |v| / sqrt(keys that
+#   carry weight)), so nothing averages down and the output's relative error IS that rms; with v of one sign it averages down
+REL_ATTN8 = 3.5e-2
+REL_ATTN8_ONE_SIGN = 1.2e-2
+V_MUL = 32.0
+
+
+def _check_qkv8(q8, ref_bf16, C, v_mul):
+    """the q|k|v projection's MX8 form: q and k thirds block-scaled, the v third e4m3(v * v_mul) with saturation"""
+    M = ref_bf16.shape[0]
+    qk = type(q8)(q8.data[:, :2 * C].contiguous(), q8.scale[: 2 * C // 128].contiguous())
+    _check_q8(qk, ref_bf16[:, :2 * C], stats=False)
+    v = ref_bf16[:, 2 * C:3 * C].float()
+    got = q8.data[:, 2 * C:3 * C].contiguous().view(torch.float8_e4m3fn).float() / v_mul
+    want = (v * v_mul).clamp(-448.0, 448.0)
+    assert bool(((got * v_mul - want).abs() <= want.abs() * 2.0 ** -4 + 2.0 ** -10 + v.abs() * v_mul * 2.0 ** -7).all())
+    assert _rel(got, v.clamp(-448.0 / v_mul, 448.0 / v_mul)) < REL_Q8
+
+
+@pytest.mark.parametrize("M,C", [(8192, 320), (520, 320)])
+def test_qkv_projection_of_the_row_resident_kernel_emits_mx8_with_a_fixed_scale_v(env, cuda, M, C):
+    """attn1's q|k|v at the 320-channel level in config #5: the bf16 LayerNorm-folded K = 320 kernel writes ONLY the MX8 form"""
+    g = torch.Generator(device="cpu").manual_seed(11)
+    x = (torch.randn((M, C), generator=g).to(cuda) * torch.logspace(-1, 1, M, device=cuda)[:, None] + 0.3).bfloat16()
+    w = (torch.randn((3 * C, C), generator=g) / math.sqrt(C)).to(cuda)
+    w[2 * C:] *= 0.25
+    gamma = (1.0 + 0.2 * torch.randn((C,), generator=g)).to(cuda)
+    beta = (0.1 * torch.randn((C,), generator=g)).to(cuda)
+    wp, c, s = env.packing.pack_ln_linear(w, None, gamma, beta)
+    plain = env.ops.ln_linear(x, wp, c, s)
+    q8 = env.ops.ln_linear(x, wp, c, s, emit_q8=True, want_bf16=False, q8_fixed=(2 * C, V_MUL))
+    assert isinstance(q8, env.ops.Mx8Act)
+    _check_qkv8(q8, plain, C, V_MUL)
+    both = env.ops.ln_linear(x, wp, c, s, emit_q8=True, q8_fixed=(2 * C, V_MUL))
+    # (below a chip-filling row count the plain launch runs on the tiled kernel, the emitting one always on the row-resident one)
+    assert _rel(both, plain) < 4e-3
+    q8b = env.ops.mx8_of(both)
+    assert torch.equal(q8b.data, q8.data) and torch.equal(q8b.scale[: 2 * C // 128], q8.scale[: 2 * C // 128])
+
+
+@pytest.mark.parametrize("M,C", [(2048, 640), (520, 1280), (2048, 1280)])
+def test_mx8_layernorm_folded_qkv_projection_emits_mx8_with_a_fixed_scale_v(env, cuda, M, C):
+    """the same at the 640 / 1280-channel levels: MX8 in (the block's producer), MX8 out (for the e4m3 attention)"""
+    x, xd, xq, xs, w, _, g = _mx8_operands(env, cuda, M, 3 * C, C, seed=12, ln=True)
+    w[2 * C:] *= 0.25
+    gamma = (1.0 + 0.2 * torch.randn((C,), generator=g)).to(cuda)
+    beta = (0.1 * torch.randn((C,), generator=g)).to(cuda)
+    wq, cs, c, s = env.packing.pack_ln_linear_mx8(w, None, gamma, beta)
+    P = C // 64
+    parts = torch.stack([x.reshape(M, P, 64).sum(dim=2).t(), x.reshape(M, P, 64).pow(2).sum(dim=2).t()], dim=2).contiguous()
+    act = env.ops.Mx8Act(xq, xs, parts)
+    plain = env.ops.linear_mx8(act, wq, cs, ln_c=c, ln_s=s, eps=1e-5)
+    q8 = env.ops.linear_mx8(act, wq, cs, ln_c=c, ln_s=s, eps=1e-5, emit_q8=True, want_bf16=False, q8_fixed=(2 * C, V_MUL))
+    assert isinstance(q8, env.ops.Mx8Act)
+    _check_qkv8(q8, plain, C, V_MUL)
+
+
+def _qkv8(dev, B, N, heads, seed, sharp=1.0, one_sign=False):
+    C = heads * 64
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    qkv = torch.randn((B * N, 3 * C), generator=g).to(dev)
+    qkv[:, :C] *= sharp * (0.5 + torch.rand((B * N, 1), generator=g).to(dev) * 2.0)       # rows of different magnitude
+    qkv[:, 2 * C:] *= 0.3
+    if one_sign:
+        qkv[:, 2 * C:] += 1.0
+    Cp = -(-2 * C // 128) * 128
+    qk = F.pad(qkv[:, :2 * C], (0, Cp - 2 * C))
+    qk8, qks = mx8_ref.encode(qk)
+    v8 = (qkv[:, 2 * C:] * V_MUL).clamp(-448, 448).to(torch.float8_e4m3fn)
+    data = torch.cat([qk8[:, :2 * C], v8.view(torch.uint8)], dim=1).contiguous()
+    nt = (3 * C + 127) // 128
+    scale = torch.zeros((nt, B * N), dtype=torch.int32, device=dev)
+    scale[: qks.shape[0]] = qks
+    qkd = mx8_ref.decode(qk8, qks)[:, :2 * C]
+    return data, scale, qkd[:, :C], qkd[:, C:], v8.float() / V_MUL
+
+
+@pytest.mark.parametrize("B,N,heads,sharp", [(2, 4096, 5, 1.0), (2, 1024, 10, 1.0), (4, 256, 20, 1.0), (3, 200, 10, 1.0),
+                                             (2, 1024, 10, 6.0), (1, 64, 2, 1.0), (2, 4, 20, 1.0)])
+def test_mx8_self_attention_vs_torch_on_the_same_quantised_operands(env, cuda, B, N, heads, sharp):
+    """attn1 in config #5 with e4m3 Q K^T and P V (udt_attn_mx8_fwd); ragged key counts, one-tile and sub-tile sequences,
+    peaked softmaxes (sharp)"""
+    O = env.ops
+    C = heads * 64
+    data, scale, qd, kd, vd = _qkv8(cuda, B, N, heads, seed=13, sharp=sharp)
+    out = O.attention_mx8(O.Mx8Act(data, scale), B, heads, 0.125, V_MUL, emit_q8=(heads % 2 == 0))
+
+    def split(t):
+        return t.reshape(B, N, heads, 64).permute(0, 2, 1, 3)
+    p = torch.softmax(split(qd) @ split(kd).transpose(-1, -2) * 0.125, dim=-1)
+    ref = (p @ split(vd)).permute(0, 2, 1, 3).reshape(B, N, C)
+    err = _rel(out, ref)
+    print(f"mx8 attention B={B} N={N} heads={heads} sharp={sharp}: vs same-operand fp32 {err:.2e}")
+    assert err < REL_ATTN8
+    q8 = O.mx8_of(out)
+    if heads % 2 == 0:
+        _check_q8(q8, out.reshape(B * N, C), stats=False)
+    again = O.attention_mx8(O.Mx8Act(data, scale), B, heads, 0.125, V_MUL)
+    assert torch.equal(again, out)
+    # v of one sign: the rounding of P averages down over the keys
+    data, scale, qd, kd, vd = _qkv8(cuda, B, N, heads, seed=15, sharp=sharp, one_sign=True)
+    out = O.attention_mx8(O.Mx8Act(data, scale), B, heads, 0.125, V_MUL)
+    p = torch.softmax(split(qd) @ split(kd).transpose(-1, -2) * 0.125, dim=-1)
+    ref = (p @ split(vd)).permute(0, 2, 1, 3).reshape(B, N, C)
+    print(f"    v of one sign: {_rel(out, ref):.2e}")
+    assert _rel(out, ref) < REL_ATTN8_ONE_SIGN
+
+
+def test_mx8_self_attention_refuses_what_it_cannot_run(env, cuda):
+    """status codes of the C entry, no launch: a row pitch below 3 C, an unaligned pitch, a missing scale array, v_inv <= 0"""
+    data, scale, *_ = _qkv8(cuda, 1, 64, 2, seed=14)
+    out = torch.empty((1, 64, 128), dtype=torch.bfloat16, device=cuda)
+    lib = env.lib_mod.load()
+
+    def call(ld8=384, sc=scale.data_ptr(), v_inv=1.0 / V_MUL, n=64):
+        return lib.udt_attn_mx8_fwd(data.data_ptr(), sc, out.data_ptr(), 1, 2, n, ld8, 128, 0.125, v_inv, None, None, 0, None)
+    assert call() == 0
+    assert call(ld8=368) == -1 and call(ld8=392) == -1 and call(n=0) == -1
+    assert call(sc=None) == -2 and call(v_inv=0.0) == -2

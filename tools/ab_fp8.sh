@@ -6,14 +6,15 @@ mkdir -p $O
 cd $R
 python bench.py --no-cpu-baseline --no-reference-default "$@" 2>/dev/null | tail -1 > $O/bench_bf16.json
 python bench.py --fp8 --no-cpu-baseline --no-reference-default "$@" 2>/dev/null | tail -1 > $O/bench_fp8.json
+UDT_FP8_ATTN=1 python bench.py --fp8 --no-cpu-baseline --no-reference-default "$@" 2>/dev/null | tail -1 > $O/bench_fp8a.json
 python - "$O" <<'PY'
 import json, sys
 o = sys.argv[1]
 v = {}
-for n in ("bf16", "fp8"):
+for n in ("bf16", "fp8", "fp8a"):
     d = json.load(open(f"{o}/bench_{n}.json"))
     v[n] = d["value"]
     cls = {k: round(x["frac"], 3) for k, x in (d.get("roofline_classes") or {}).items() if isinstance(x, dict) and "frac" in x}
     print(f"{n:5s} {d['value']:.3f} images/s  {d['ms_per_step']:.1f} ms per batch  roofline {round(d['roofline']['frac'], 3)} classes {cls}  modes {d.get('images_per_s_by_launch_mode')}  unet ms {d.get('unet_ms_per_step')}")
-print(f"fp8 / bf16 = {v['fp8'] / v['bf16']:.4f}")
+print(f"fp8 / bf16 = {v['fp8'] / v['bf16']:.4f}   fp8 + e4m3 attention / bf16 = {v['fp8a'] / v['bf16']:.4f}")
 PY

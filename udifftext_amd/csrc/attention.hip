@@ -476,6 +476,217 @@ __global__ void __launch_bounds__(256, 3) attn_d64_v2_kernel(const AttnParams p)
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// attn_d64_mx8_kernel (round 5, BASELINE config #5's "fp8 attention"): the self-attention of attn_d64_v2_kernel on e4m3 operands.
+// q, k, v are column ranges of ONE MX8 activation (the q|k|v projection's emitting epilogue, udt_gemm_desc.q8_out): q and k carry an
+// E8M0 scale per (token, 32 head dims), v was written with one fixed multiplier (q8_fixed_col / q8_fixed_mul) because P V contracts
+// over KEYS.  Per 64-key tile and wave (32 queries):
+//   S^T = K Q^T   : 2 x v_mfma_scale_f32_32x32x64_f8f6f4 (one per 32 keys; the 64 head dims are the instruction's two scale blocks)
+//   softmax       : as attn_d64_v2_kernel (fp32, deferred rescale: P <= 2^8)
+//   O^T += V^T P^T: 2 x the same instruction with unit scales (one per 32 output dims; the 64 keys of the tile are its K)
+// i.e. 4 matrix instructions of 64 cycles instead of 16 of 32, half the LDS bytes per fragment and per staged tile.
+// Two layout tricks make the operands fall into place (layouts measured by tools/probes/mx_*.cpp and tr_read_b8.cpp):
+//   * the K rows of a 32-key fragment are PERMUTED (fragment lane i holds key 16 ((i >> 2) & 1) + 4 (i >> 3) + (i & 3)), so that the
+//     16 scores a half-wave ends up with per 32-key tile are 16 CONSECUTIVE keys, in register order;
+//   * the instruction wants, per lane (d, h), 16 key bytes of block 0 and 16 of block 1: with the permutation these are keys
+//     16 h .. 16 h + 15 of the two 32-key halves of the tile — two ds_read_b64_tr_b8 each out of the row-major V tile (a 16-lane
+//     group turns an 8-key x 16-dim byte block into 16 dims x 8 keys), and P's bytes are the lane's own scores in register order.
+struct AttnMx8Params {
+  const uint8_t* x8;       // [batch * n, ld8] e4m3: q at column h * 64, k at C + h * 64, v at 2 C + h * 64
+  const uint32_t* sc;      // [ld8 / 128 (rounded up)][batch * n] block scales (bytes of the v third: unused)
+  uint16_t* o;             // bf16 [batch * n, ldo], column h * 64 + d
+  int heads, n, ld8, ldo, C;
+  long long rows;          // batch * n
+  float scale_log2e, v_inv;
+  uint8_t* q8_out;         // optional: O again as an MX8 activation (as attn_d64_v2_kernel)
+  uint32_t* q8_scale;
+  int ld_q8;
+};
+constexpr int A8_TILE = 64 * 64;                 // 64 keys x 64 bytes
+constexpr int A8_STAGE = 2 * A8_TILE + 256;      // K tile + V tile + the K tile's scale dwords
+constexpr int A8_NST = 3;
+
+__global__ void __launch_bounds__(256, 3) attn_d64_mx8_kernel(const AttnMx8Params p) {
+  extern __shared__ __attribute__((aligned(16))) char smem8[];
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = tid & 63;
+  const int l31 = lane & 31;
+  const int hi = lane >> 5;
+  const int bh = blockIdx.y;
+  const int b = bh / p.heads;
+  const int h = bh - b * p.heads;
+  const long long row0 = (long long)b * p.n;
+  const uint8_t* __restrict__ X = p.x8 + row0 * p.ld8;
+  const int qi = blockIdx.x * 128 + wave * 32 + l31;
+  const bool qok = qi < p.n;
+  // ---- Q fragment (the B operand of S^T = K Q^T) and its block scale: block 2 h + hi of the row
+  i32x8_t qf;
+  int qsc;
+  {
+    const long long qr = qok ? qi : 0;
+    const uint8_t* g = X + qr * p.ld8 + h * 64;
+    const u32x4 a = *reinterpret_cast<const u32x4*>(g + 16 * hi), bb = *reinterpret_cast<const u32x4*>(g + 32 + 16 * hi);
+    i32x8_t t = {(int)a[0], (int)a[1], (int)a[2], (int)a[3], (int)bb[0], (int)bb[1], (int)bb[2], (int)bb[3]};
+    qf = t;
+    const int bq = 2 * h + hi;
+    qsc = (int)(p.sc[(long long)(bq >> 2) * p.rows + row0 + qr] >> (8 * (bq & 3)));
+  }
+  // ---- staging: per wave and tile one K piece, one V piece (16 keys x 64 B each) and the tile's 64 scale dwords (every wave
+  // writes the same 256 bytes: a uniform count of three loads per stage and wave)
+  const int kb0 = p.C / 32 + 2 * h;               // k's first block of this head: even -> both of its scales sit in one dword
+  const unsigned kvbytes = (unsigned)((long long)(p.n - 1) * p.ld8 + 64);
+  const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(X + p.C + h * 64), 0, kvbytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(X + 2 * p.C + h * 64), 0, kvbytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(p.sc + (long long)(kb0 >> 2) * p.rows + row0), 0,
+                                                                       (unsigned)(p.n * 4), 0x00020000);
+  const unsigned kv_voff = (unsigned)((long long)(wave * 16 + (lane >> 2)) * p.ld8 + (lane & 3) * 16);
+  const int tile_step = 64 * p.ld8;
+  auto stage = [&](int st, int kt) {
+    char* kbuf = smem8 + st * A8_STAGE;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, (__attribute__((address_space(3))) void*)(kbuf + wave * 1024), 16, kv_voff, kt * tile_step, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (__attribute__((address_space(3))) void*)(kbuf + A8_TILE + wave * 1024), 16, kv_voff, kt * tile_step, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(kbuf + 2 * A8_TILE), 4, (unsigned)(lane * 4), kt * 256, 0, 0);
+  };
+  // ---- per-lane LDS offsets
+  const int kperm = 16 * ((l31 >> 2) & 1) + 4 * (l31 >> 3) + (l31 & 3);       // the key (of a 32-key half) this fragment lane holds
+  const int k_off = kperm * 64 + 16 * hi;                                       // + 32: the second scale block; + 2048: the second half
+  const int s_off = 2 * A8_TILE + kperm * 4;
+  const int s_shift = 8 * ((kb0 & 3) + hi);
+  const int tr_i = lane & 15;
+  const int v_off = A8_TILE + (16 * hi + (tr_i >> 1)) * 64 + 16 * ((lane >> 4) & 1) + 8 * (tr_i & 1);   // + 512 g + 2048 t + 32 dt
+
+  f32x16 o_acc[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o_acc[i][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+  const int ntiles = (p.n + 63) / 64;
+  const float c = p.scale_log2e;
+  stage(0, 0);
+  if (ntiles > 1) stage(1, 1);
+  int st = 0;
+  typedef int v2i __attribute__((ext_vector_type(2)));
+  typedef __attribute__((address_space(3))) v2i* lds_v2i;
+  for (int kt = 0; kt < ntiles; ++kt) {
+    if (kt + 1 < ntiles) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");       // the tile after this one stays in flight
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (kt + 2 < ntiles) {
+      int s2 = st + 2;
+      if (s2 >= A8_NST) s2 -= A8_NST;
+      stage(s2, kt + 2);
+    }
+    const char* buf = smem8 + st * A8_STAGE;
+    f32x16 s[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const char* kr = buf + t * 2048 + k_off;
+      const i32x8_t kf = lds_read_frag32(kr, kr + 32);
+      const int ksc = (int)(*reinterpret_cast<const uint32_t*>(buf + s_off + t * 128) >> s_shift);
+      f32x16 z;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) z[r] = 0.f;
+      s[t] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(kf, qf, z, 0, 0, 0, ksc, 0, qsc);
+    }
+    if (kt * 64 + 64 > p.n) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = kt * 64 + t * 32 + 16 * hi + r;              // (the permuted fragment rows: register r = key 16 hi + r)
+          if (key >= p.n) s[t][r] = -INFINITY;
+        }
+    }
+    float mx = s[0][0];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[t][r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float mxs = mx * c;
+    if (!__all(mxs - m_run <= A2_DEFER)) {                  // wave-uniform: some query's maximum grew by more than 2^8
+      const float m_new = fmaxf(m_run, mxs);
+      const float alpha = fast_exp2(m_run - m_new);
+      m_run = m_new;
+      l_run *= alpha;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o_acc[i][r] *= alpha;
+    }
+    typedef float f32x2v __attribute__((ext_vector_type(2)));
+    const f32x2v c2 = {c, c}, m2 = {m_run, m_run};
+    f32x2v ps2 = {0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        f32x2v e = {s[t][r], s[t][r + 1]};
+        e = __builtin_elementwise_fma(e, c2, -m2);
+        f32x2v pv = {fast_exp2(e[0]), fast_exp2(e[1])};
+        s[t][r] = pv[0];
+        s[t][r + 1] = pv[1];
+        ps2 += pv;
+      }
+    l_run += ps2[0] + ps2[1];
+    // P as e4m3 with the unit scale (0 < P <= 2^8 under the deferred rescale): bytes = the lane's own scores in register order
+    i32x8_t pf;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int q4 = 0; q4 < 4; ++q4) pf[t * 4 + q4] = (int)mx8_pack4(s[t][q4 * 4], s[t][q4 * 4 + 1], s[t][q4 * 4 + 2], s[t][q4 * 4 + 3]);
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) {
+      i32x8_t vf;
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+          const v2i w = __builtin_amdgcn_ds_read_tr8_b64_v2i32((lds_v2i)(buf + v_off + t * 2048 + g * 512 + dt * 32));
+          vf[t * 4 + g * 2] = w[0];
+          vf[t * 4 + g * 2 + 1] = w[1];
+        }
+      o_acc[dt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(vf, pf, o_acc[dt], 0, 0, 0, 127, 0, 127);
+    }
+    st = st + 1 == A8_NST ? 0 : st + 1;
+  }
+  const float l_tot = l_run + __shfl_xor(l_run, 32);
+  const float inv = p.v_inv / l_tot;
+  const long long m = row0 + qi;
+  if (qok) {
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) {
+        const int d = dt * 32 + qd * 8 + hi * 4;
+        u32x2 pk = {pack_bf16x2(o_acc[dt][qd * 4 + 0] * inv, o_acc[dt][qd * 4 + 1] * inv),
+                    pack_bf16x2(o_acc[dt][qd * 4 + 2] * inv, o_acc[dt][qd * 4 + 3] * inv)};
+        *reinterpret_cast<u32x2*>(p.o + m * p.ldo + h * 64 + d) = pk;
+      }
+  }
+  if (p.q8_out) {
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) {
+      float v[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) v[r] = o_acc[dt][r] * inv;
+      uint32_t q[4], sb;
+      mx8_quant_acc16(v, q, sb);
+      if (qok) {
+        const int blk = h * 2 + dt;
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) *reinterpret_cast<uint32_t*>(p.q8_out + m * p.ld_q8 + blk * 32 + qd * 8 + hi * 4) = q[qd];
+        if (hi == 0) reinterpret_cast<uint8_t*>(p.q8_scale)[((long long)(blk >> 2) * p.rows + m) * 4 + (blk & 3)] = (uint8_t)sb;
+      }
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // head_dim 512, one head (the AutoencoderKL mid-block attention, reference sgm/modules/diffusionmodules/model.py:236-260:
 // xformers.ops.memory_efficient_attention on [B, H*W, 512]).  512 dims do not fit one wave's registers (O alone would be
@@ -988,6 +1199,35 @@ extern "C" int udt_attn_rowv_q8_fwd(const void* q, const void* k, const void* v,
   if (o_bstride != (int64_t)nq * ldo) return UDT_ERR_BAD_SHAPE;
   return attn_fwd_impl(true, q, k, v, o, batch, heads, nq, nk, ldq, ldk, ldv, ldo, q_bstride, k_bstride, v_bstride,
                        o_bstride, scale, stream, q8_out, q8_scale, ld_q8);
+}
+
+extern "C" int udt_attn_mx8_fwd(const void* qkv8, const void* qkv_scale, void* o, int32_t batch, int32_t heads, int32_t n,
+                                int32_t ld8, int32_t ldo, float scale, float v_inv, void* q8_out, void* q8_scale, int32_t ld_q8,
+                                void* stream) {
+  if (!qkv8 || !qkv_scale || !o) return UDT_ERR_BAD_ARG;
+  if (batch <= 0 || heads <= 0 || n <= 0 || n % 4 != 0) return UDT_ERR_BAD_SHAPE;
+  const int C = heads * 64;
+  // (16-byte fragment loads and LDS-DMA pieces; k's two block scales of a head share a dword when C / 32 is even; 31-bit offsets)
+  if (ld8 < 3 * C || ld8 % 16 != 0 || ldo % 4 != 0 || (C / 32) % 2 != 0 || (long long)n * ld8 >= (1LL << 31)) return UDT_ERR_BAD_SHAPE;
+  if ((reinterpret_cast<uintptr_t>(qkv8) & 15) || !(v_inv > 0.f)) return UDT_ERR_BAD_ARG;
+  if (q8_out && (!q8_scale || ld_q8 < C || ld_q8 % 4 != 0)) return UDT_ERR_BAD_ARG;
+  AttnMx8Params p;
+  p.x8 = reinterpret_cast<const uint8_t*>(qkv8); p.sc = reinterpret_cast<const uint32_t*>(qkv_scale);
+  p.o = reinterpret_cast<uint16_t*>(o);
+  p.heads = heads; p.n = n; p.ld8 = ld8; p.ldo = ldo; p.C = C; p.rows = (long long)batch * n;
+  p.scale_log2e = scale * 1.4426950408889634f; p.v_inv = v_inv;
+  p.q8_out = reinterpret_cast<uint8_t*>(q8_out); p.q8_scale = reinterpret_cast<uint32_t*>(q8_scale); p.ld_q8 = ld_q8;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  UdtProfScope prof(2, s);
+  if (prof.rec) {
+    char tag[96];
+    snprintf(tag, sizeof(tag), "attn-mx8%s B=%d H=%d nq=%d nk=%d", q8_out ? "+q8" : "", batch, heads, n, n);
+    udt_prof_tag(prof.rec, tag);
+  }
+  constexpr int smem = A8_NST * A8_STAGE;
+  hipLaunchKernelGGL(attn_d64_mx8_kernel, dim3((n + 127) / 128, batch * heads), dim3(256), smem, s, p);
+  UDT_CHECK_LAUNCH();
+  return UDT_OK;
 }
 
 // key split plan: when the query tiles alone leave most CUs idle (a single image: 64 workgroups, each walking all 4096 keys

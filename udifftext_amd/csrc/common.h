@@ -159,6 +159,14 @@ UDT_DEVINL u32x2 mx8_quant_row8(const float (&o)[8], uint32_t& sbyte) {
   u32x2 r = {mx8_pack4(o[0] * m, o[1] * m, o[2] * m, o[3] * m), mx8_pack4(o[4] * m, o[5] * m, o[6] * m, o[7] * m)};
   return r;
 }
+// The same 8 values with a FIXED multiplier (no block scale: unit E8M0), clamped to the e4m3 range — the conversion does not saturate
+UDT_DEVINL u32x2 e4m3_fixed_row8(const float (&o)[8], float m) {
+  float c[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) c[j] = fminf(fmaxf(o[j] * m, -448.f), 448.f);
+  u32x2 r = {mx8_pack4(c[0], c[1], c[2], c[3]), mx8_pack4(c[4], c[5], c[6], c[7])};
+  return r;
+}
 // Accumulator layout of a 32 x 32 MFMA tile whose D rows are the CHANNELS (lane = (row l31, half hi) holds channels
 // 8 q + 4 hi + e, q = 0..3, e = 0..3, of its row's 32-channel block; the other 16 sit in lane ^ 32): quantise the block;
 // out[q] = the 4 bytes of channels 8 q + 4 hi .. + 3

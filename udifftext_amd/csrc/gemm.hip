@@ -806,9 +806,9 @@ bool lean_plan(const udt_gemm_desc* d, LeanPlan& t, bool want_stats) {
     if (conv1 || d->rowvec || mode == 0 || (mode > 0 && mode != 1)) return false;
     if (mx8 && (!d->a_scale || d->K % 128 != 0 || d->lda % 16 != 0 || (d->ldw > 0 && d->ldw % 16 != 0))) return false;
     if (mx8 && ln && (!d->rowstat_in || d->rowstat_in_parts <= 0)) return false;
-    if (!mx8 && (geglu || ln)) return false;
-    if (mx8 && geglu != (ln && emit)) return false;
-    if (mx8 && ln && !geglu && emit) return false;
+    if (!mx8 && geglu) return false;
+    if (mx8 && geglu && !(ln && emit)) return false;
+    if (mx8 && !geglu && ln && emit && d->rowstat_out) return false;
     if (emit && (want_stats || !d->q8_scale || d->ld_q8 % 8 != 0 || d->N % (geglu ? 64 : 32) != 0)) return false;
     if (d->rowstat_out && (!emit || geglu)) return false;
     if ((reinterpret_cast<uintptr_t>(d->q8_out) | reinterpret_cast<uintptr_t>(d->colscale)) & 15) return false;
@@ -831,9 +831,12 @@ bool lean_plan(const udt_gemm_desc* d, LeanPlan& t, bool want_stats) {
   if (mode > 0 && mode != 1 && mode != 6 && mode != 7) return false;
   // 7 = rowres.h: the LayerNorm-folded projections with K = 320 and enough rows to give every CU a 256-row block: the rows'
   // A fragments stay in registers, the weights stream through LDS in 64-row chunks; automatic where it applies
-  if (!mx8 && !emit && (mode == 7 || (mode < 0 && rowres_on()))) {
+  if (!mx8 && (!emit || (ln && !geglu && !d->rowstat_out)) && (mode == 7 || (mode < 0 && rowres_on()))) {
     // (its A fragments are 16-byte vector loads straight from global memory: a 16-byte aligned base; lda % 8 == 0 is checked above)
-    if (ln && !want_stats && d->K == 320 && d->N % 64 == 0 && !d->residual && !d->rowvec && !conv1 &&
+    // (its emitting epilogue addresses through 32-bit buffer offsets and switches to the fixed multiplier per 64-column chunk)
+    const bool emit_fits = !emit || ((d->q8_fixed_col <= 0 || d->q8_fixed_col % 64 == 0) && (long long)d->M * d->ld_q8 < (1LL << 31) &&
+                                     (long long)d->M * (d->out ? d->ldo : 0) * 2 < (1LL << 31) && (long long)((d->N + 127) / 128) * d->M * 4 < (1LL << 31));
+    if (ln && !want_stats && d->K == 320 && d->N % 64 == 0 && !d->residual && !d->rowvec && !conv1 && emit_fits &&
         (reinterpret_cast<uintptr_t>(d->a) & 15) == 0) {
       const int tiles_m = (d->M + 255) / 256, chunks = d->N / 64;
       int ns = (device_cus() + tiles_m - 1) / tiles_m;           // column splits: one workgroup per CU ...
@@ -845,7 +848,8 @@ bool lean_plan(const udt_gemm_desc* d, LeanPlan& t, bool want_stats) {
       // (16384 rows: 48 vs 59 us; 32768: 90 vs 103 us), the plain epilogue only with every CU busy (32768 x 960: 36.6 vs 38.2 us;
       // 16384 rows: slower)
       const long long wgs = (long long)tiles_m * ns;
-      if (ns >= 1 && (mode == 7 || (geglu ? wgs * 4 >= 3LL * device_cus() : wgs >= device_cus()))) {
+      // (the bf16 LayerNorm-folded emitting epilogue exists on this kernel only: taken at any size)
+      if (ns >= 1 && (mode == 7 || emit || (geglu ? wgs * 4 >= 3LL * device_cus() : wgs >= device_cus()))) {
         t.cfg = 7; t.stats_rows = 0; t.nw = 4; t.bm = 256; t.bn = 64; t.smem = 0;
         t.tiles_m = tiles_m; t.kt_per = (chunks + ns - 1) / ns; t.tiles_n = (chunks + t.kt_per - 1) / t.kt_per;
         t.tiles = t.tiles_m * t.tiles_n; t.nkt = d->K / BK; t.splitk = 1; t.n_block = 1;
@@ -853,7 +857,7 @@ bool lean_plan(const udt_gemm_desc* d, LeanPlan& t, bool want_stats) {
         return true;
       }
     }
-    if (mode == 7) return false;
+    if (mode == 7 || (emit && ln)) return false;
   }
   t.cfg = (mode > 0) ? mode : 1;
   if (!mx8 && !emit) {
@@ -1103,6 +1107,12 @@ extern "C" int udt_check_async_error(void* workspace, size_t workspace_bytes, vo
 
 extern "C" int32_t udt_gemm_colstats_rows(const udt_gemm_desc* d) { return d ? colstats_rows(d) : 0; }
 extern "C" int32_t udt_gemm_colstats_slots(const udt_gemm_desc* d) { return d ? colstats_slots(d) : 0; }
+extern "C" int32_t udt_gemm_q8_ok(const udt_gemm_desc* d) {
+  if (!d || !d->q8_out || d->M <= 0 || d->N <= 0 || d->K <= 0) return 0;
+  LeanPlan lt;
+  return lean_plan(d, lt, d->colstats != nullptr) ? 1 : 0;
+}
+
 extern "C" int32_t udt_gemm_rowstat_parts(const udt_gemm_desc* d) {
   if (!d || d->M <= 0 || d->N <= 0 || d->K <= 0) return 0;
   // the MX8-emitting epilogues live on the 128 x 128 lean configuration: two wave columns of 64 -> one part per 64 output columns
@@ -1189,7 +1199,7 @@ extern "C" int udt_gemm(const udt_gemm_desc* d, void* workspace, size_t workspac
   } else {
     if (d->lda < d->K || d->lda % 8 != 0) return UDT_ERR_BAD_SHAPE;
   }
-  if (!d->out && !(d->q8_out && (d->flags & UDT_GEMM_GEGLU))) return UDT_ERR_BAD_ARG;
+  if (!d->out && !d->q8_out) return UDT_ERR_BAD_ARG;
   if (trans) {
     if (d->rows_per_batch <= 0 || d->rows_per_batch % 4 != 0 || d->M % d->rows_per_batch != 0)
       return UDT_ERR_BAD_SHAPE;
@@ -1267,6 +1277,8 @@ extern "C" int udt_gemm(const udt_gemm_desc* d, void* workspace, size_t workspac
       lp.rowstat_in = d->rowstat_in; lp.rowstat_in_parts = d->rowstat_in_parts;
       lp.q8_out = reinterpret_cast<uint8_t*>(d->q8_out); lp.q8_scale = reinterpret_cast<uint32_t*>(d->q8_scale); lp.ld_q8 = d->ld_q8;
       lp.rowstat_out = d->rowstat_out;
+      lp.q8_fixed_col = d->q8_fixed_col > 0 ? d->q8_fixed_col : 0x7fffffff;
+      lp.q8_fixed_mul = d->q8_fixed_mul;
       lp.G = lt.G;
       lp.counters = nullptr; lp.slabs = nullptr;
       if (lt.splitk > 1) {

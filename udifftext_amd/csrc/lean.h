@@ -619,7 +619,11 @@ __global__ void __launch_bounds__(NW * 64, 2) lgemm_kernel(const LParams p) {
           // the result again as an MX8 activation: the 4 lanes of an aligned quad hold one 32-column block of the row (every lane
           // executes the cross-lane steps; N % 32 == 0 keeps a quad's lanes valid together)
           uint32_t sb;
-          const u32x2 q8 = mx8_quant_row8(o, sb);
+          u32x2 q8 = mx8_quant_row8(o, sb);
+          if (n >= p.q8_fixed_col) {                      // (the v third of a q|k|v projection: one scale for the whole tensor)
+            q8 = e4m3_fixed_row8(o, p.q8_fixed_mul);
+            sb = 127u;
+          }
           float ps = 0.f, pq = 0.f;
           if (p.rowstat_out) {                            // partial row statistics over this wave's columns (CPR = 8 or 16 lanes)
             static_assert(CPR == 8 || CPR == 16, "row statistics: 64- or 128-column wave blocks");

@@ -60,7 +60,9 @@ hipError_t launch_lean_mx8(const lg::LParams& lp, int smem, int G, bool geglu, b
     return hipErrorInvalidValue;
   }
   if (geglu) return (ln && emit && !stats) ? launch_lean_mx8_k<true, true, false, true, true>(lp, smem, G, s) : hipErrorInvalidValue;
-  if (ln) return (!emit && !stats) ? launch_lean_mx8_k<false, true, false, true, false>(lp, smem, G, s) : hipErrorInvalidValue;
+  if (ln) return stats ? hipErrorInvalidValue
+                 : emit ? launch_lean_mx8_k<false, true, false, true, true>(lp, smem, G, s)      // q|k|v whose consumer is the e4m3 attention
+                        : launch_lean_mx8_k<false, true, false, true, false>(lp, smem, G, s);
   if (stats) return emit ? hipErrorInvalidValue : launch_lean_mx8_k<false, false, true, true, false>(lp, smem, G, s);
   return emit ? launch_lean_mx8_k<false, false, false, true, true>(lp, smem, G, s) : launch_lean_mx8_k<false, false, false, true, false>(lp, smem, G, s);
 }
@@ -88,13 +90,13 @@ hipError_t launch_wconv3s(const lg::C3Params& c3, hipStream_t s) {
   hipLaunchKernelGGL((wd::wconv3_kernel<STATS>), dim3(c3.G), dim3(256), smem, s, c3);
   return hipGetLastError();
 }
-template <int KT, bool GEGLU>
+template <int KT, bool GEGLU, bool EMIT = false>
 hipError_t launch_rowres(const lg::LParams& lp, int G, hipStream_t s) {
   static AttrOnce once;
   constexpr int smem = rr::RGeo<KT, GEGLU>::SMEM;
-  hipError_t e = once.ensure(reinterpret_cast<const void*>(rr::rgemm_kernel<KT, GEGLU>), smem);
+  hipError_t e = once.ensure(reinterpret_cast<const void*>(rr::rgemm_kernel<KT, GEGLU, EMIT>), smem);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL((rr::rgemm_kernel<KT, GEGLU>), dim3(G), dim3(256), smem, s, lp);
+  hipLaunchKernelGGL((rr::rgemm_kernel<KT, GEGLU, EMIT>), dim3(G), dim3(256), smem, s, lp);
   return hipGetLastError();
 }
 
@@ -107,6 +109,7 @@ hipError_t launch_wconv3(const lg::C3Params& c3, hipStream_t s) {
 hipError_t udt_lean_launch_gemm(int cfg, const void* lparams, int smem, int G, int geglu, int ln, hipStream_t s) {
   const lg::LParams& lp = *static_cast<const lg::LParams*>(lparams);
   const bool fp8 = lp.a_scale != nullptr, emit = lp.q8_out != nullptr;
+  if (cfg == 7 && emit && !fp8 && !geglu && ln && lp.K == 320) return launch_rowres<5, false, true>(lp, G, s);
   if (fp8 || emit) return cfg == 1 ? launch_lean_mx8(lp, smem, G, geglu != 0, ln != 0, fp8, emit, s) : hipErrorInvalidValue;
   switch (cfg) {
     case 1: return launch_lean<4, 2, 2, 2, 2, 2>(lp, smem, G, geglu != 0, ln != 0, s);

@@ -34,6 +34,8 @@ struct LParams {
   uint8_t* q8_out;         // EMIT kernels: the result again as e4m3 [M][ld_q8] ...
   uint32_t* q8_scale;      // ... with its block scales, uint32 [ceil(columns / 128)][M]
   int ld_q8;
+  int q8_fixed_col;        // EMIT kernels: result columns >= this are quantised with the FIXED multiplier below (clamped to +-448, scale byte
+  float q8_fixed_mul;      //   127) instead of per-block scales — the v third of a q|k|v projection, whose P V contraction runs over keys
   float* rowstat_out;      // EMIT kernels (optional): fp32 [N / wave columns][M][2] partial (sum, sum of squares) of the result's rows
 };
 

@@ -45,8 +45,12 @@ struct RGeo {
   static_assert(SMEM <= 160 * 1024, "one workgroup per CU");
 };
 
-template <int KT, bool GEGLU>
+// EMIT (plain epilogue only, round 5): the result ALSO as an MX8 activation (common.h) — q and k of a q|k|v projection with block
+// scales along the head dimension, the v third (columns >= q8_fixed_col) with the fixed multiplier — for the e4m3 self-attention of
+// BASELINE config #5 at the 64 x 64 level; `out` may then be null
+template <int KT, bool GEGLU, bool EMIT = false>
 __global__ void __launch_bounds__(256, 1) rgemm_kernel(const lg::LParams p) {
+  static_assert(!(GEGLU && EMIT), "the emitting epilogue is the plain one");
   using Geo = RGeo<KT, GEGLU>;
   constexpr int KS = KT * 4;                             // 16-element K steps
   constexpr int CH_BYTES = Geo::CH_BYTES;
@@ -93,6 +97,18 @@ __global__ void __launch_bounds__(256, 1) rgemm_kernel(const lg::LParams p) {
   };
   stage(c0);
   if (c0 + 1 < c1) stage(c0 + 1);
+
+  // ---- EMIT: descriptors and lane offsets of the epilogue's buffer stores (see epilogue_store)
+  __amdgpu_buffer_rsrc_t rs_q, rs_s, rs_o;
+  int vq = 0, vs = 0, vo = 0;
+  if constexpr (EMIT) {
+    rs_q = __builtin_amdgcn_make_buffer_rsrc(p.q8_out, 0, (unsigned)(p.M * p.ld_q8), 0x00020000);
+    rs_s = __builtin_amdgcn_make_buffer_rsrc(p.q8_scale, 0, (unsigned)(((p.N + 127) >> 7) * p.M * 4), 0x00020000);
+    rs_o = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, p.out ? (unsigned)(p.M * p.ldo * 2) : 0u, 0x00020000);
+    vq = (lane >> 3) * p.ld_q8 + (lane & 7) * 8;
+    vs = (lane >> 3) * 4 + ((lane & 7) >> 2);
+    vo = ((lane >> 3) * p.ldo + (lane & 7) * 8) * 2;
+  }
 
   // ---- column constants of this workgroup's range -> LDS ([chunk][0: bias | 1: s][64])
   {
@@ -203,7 +219,9 @@ __global__ void __launch_bounds__(256, 1) rgemm_kernel(const lg::LParams p) {
     }
   };
   // staged bf16 rows -> global, 16 bytes per lane (a wave's LDS operations execute in order: no barrier around its own block)
-  auto epilogue_store = [&](int c) {
+  // (always_inline: with the emitting body hipcc left this lambda as a CALL — its closure, the kernel arguments included, then lives
+  // in scratch and every field is reloaded through the vmcnt queue)
+  auto epilogue_store = [&](int c) __attribute__((always_inline)) {
     if constexpr (GEGLU) {
       const int ch = lane & 3;
       uint16_t* const ob = p.out + c * 32 + ch * 8;
@@ -216,13 +234,36 @@ __global__ void __launch_bounds__(256, 1) rgemm_kernel(const lg::LParams p) {
       }
     } else {
       const int c8 = lane & 7;
-      uint16_t* const ob = p.out + c * 64 + c8 * 8;
+      if constexpr (EMIT) {
+        // Buffer stores: the descriptors sit in SGPRs, the lane part of every address in ONE VGPR each (e4m3 bytes, scale bytes,
+        // bf16 result), the row / chunk part in an SGPR — 64-bit per-row pointers hoisted out of the chunk loop do not fit next
+        // to the resident A fragments (they landed in scratch and their reloads in the vmcnt queue: 107 us instead of 41).
+        // The 4 lanes of an aligned quad (c8 = 0..3 / 4..7) hold one row's 32-column block; a chunk is either block-scaled or,
+        // from q8_fixed_col on (a multiple of 64), written with the fixed multiplier.
+        const bool fixed = c * 64 >= p.q8_fixed_col;
+        const int sq0 = m0 * p.ld_q8 + c * 64, ss0 = (((c >> 1) * p.M + m0) << 2) + ((2 * c) & 3), so0 = (m0 * p.ldo + c * 64) * 2;
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int row = i * 8 + (lane >> 3);
-        const int m = m0 + row;
-        const u32x4 v = *reinterpret_cast<const u32x4*>(stg + row * 128 + ((c8 ^ (row & 7)) << 4));
-        if (m < p.M && !RR_DBG(4)) *reinterpret_cast<u32x4*>(ob + (long long)m * p.ldo) = v;
+        for (int i = 0; i < 8; ++i) {
+          const int row = i * 8 + (lane >> 3);
+          const u32x4 v = *reinterpret_cast<const u32x4*>(stg + row * 128 + ((c8 ^ (row & 7)) << 4));
+          const float f[8] = {bf16_lo(v[0]), bf16_hi(v[0]), bf16_lo(v[1]), bf16_hi(v[1]), bf16_lo(v[2]), bf16_hi(v[2]), bf16_lo(v[3]), bf16_hi(v[3])};
+          uint32_t sb = 127u;
+          const u32x2 q8 = fixed ? e4m3_fixed_row8(f, p.q8_fixed_mul) : mx8_quant_row8(f, sb);
+          if (m0 + row < p.M) {
+            __builtin_amdgcn_raw_buffer_store_b64(q8, rs_q, vq, sq0 + i * 8 * p.ld_q8, 0);
+            if ((c8 & 3) == 0) __builtin_amdgcn_raw_buffer_store_b8((uint8_t)sb, rs_s, vs, ss0 + i * 32, 0);
+            if (p.out) __builtin_amdgcn_raw_buffer_store_b128(v, rs_o, vo, so0 + i * 16 * p.ldo, 0);
+          }
+        }
+      } else {
+        uint16_t* const ob = p.out + c * 64 + c8 * 8;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int row = i * 8 + (lane >> 3);
+          const int m = m0 + row;
+          const u32x4 v = *reinterpret_cast<const u32x4*>(stg + row * 128 + ((c8 ^ (row & 7)) << 4));
+          if (m < p.M && !RR_DBG(4)) *reinterpret_cast<u32x4*>(ob + (long long)m * p.ldo) = v;
+        }
       }
     }
   };
@@ -319,7 +360,9 @@ __global__ void __launch_bounds__(256, 1) rgemm_kernel(const lg::LParams p) {
   auto top = [&](int cj) {
     // chunk cj landed: behind it at most the DMA of chunk cj + 1 and the (<= 8) stores of the last epilogue are in flight; waiting
     // for all but the PPW youngest operations covers it (vmcnt retires in order and counts stores too)
-    if (cj + 1 < c1) wait_vm<PPW>(); else wait_vm<0>();
+    // (EMIT: an epilogue issues 16 stores — 8 of e4m3 bytes, 8 of scale bytes — or 24 with the bf16 result: with the plain count the
+    // wait would reach into the stores issued a moment ago and expose their latency at every chunk)
+    if (cj + 1 < c1) wait_vm<PPW + (EMIT ? 16 : 0)>(); else wait_vm<0>();
     lg::raw_barrier();                                   // every wave is past chunk cj - 1: its ring slot takes chunk cj + 2
     if (cj + 2 < c1 && !RR_DBG(0)) stage(cj + 2);
   };

@@ -39,6 +39,7 @@ class GemmDesc(C.Structure):
         ("alpha", C.c_float), ("colscale", C.c_void_p), ("in_scsh", C.c_void_p), ("in_act", C.c_int32), ("colstats", C.c_void_p),
         ("cu_share", C.c_int32), ("ln_colsum", C.c_void_p), ("ln_eps", C.c_float),
         ("a_scale", C.c_void_p), ("q8_out", C.c_void_p), ("q8_scale", C.c_void_p), ("ld_q8", C.c_int32),
+        ("q8_fixed_col", C.c_int32), ("q8_fixed_mul", C.c_float),
         ("rowstat_out", C.c_void_p), ("rowstat_in", C.c_void_p), ("rowstat_in_parts", C.c_int32),
     ]
 
@@ -62,6 +63,7 @@ SYMBOLS = {
     "udt_gemm_colstats_rows": (_i32, [C.POINTER(GemmDesc)]),
     "udt_gemm_colstats_slots": (_i32, [C.POINTER(GemmDesc)]),
     "udt_gemm_rowstat_parts": (_i32, [C.POINTER(GemmDesc)]),
+    "udt_gemm_q8_ok": (_i32, [C.POINTER(GemmDesc)]),
     "udt_gemm_in_scsh_ok": (_i32, [C.POINTER(GemmDesc)]),
     "udt_gn_silu_conv3x3_fwd": (C.c_int, [C.POINTER(GemmDesc), _vp, C.c_size_t, _vp]),
     "udt_ln_gemm_fwd": (C.c_int, [C.POINTER(GemmDesc), _vp, C.c_size_t, _vp]),
@@ -74,6 +76,7 @@ SYMBOLS = {
                                     _i64, _i64, _i64, _i64, _f32, _vp]),
     "udt_attn_rowv_q8_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32,
                                        _i64, _i64, _i64, _i64, _f32, _vp, _vp, _i32, _vp]),
+    "udt_attn_mx8_fwd": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _f32, _vp, _vp, _i32, _vp]),
     "udt_attn512_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i64, _i64, _i64, _i64, _f32, _vp]),
     "udt_attn512_workspace_bytes": (C.c_size_t, [_i32, _i32, _i32]),
     "udt_attn512_split_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i64, _i64, _i64, _i64, _f32,

@@ -191,14 +191,18 @@ def _mx8_alloc(M: int, cols: int, device) -> Mx8Act:
                   torch.empty(((cols + 127) // 128, M), dtype=torch.int32, device=device))
 
 
-def _attach_q8(d: L.GemmDesc, M: int, cols: int, device, rowstats: bool) -> Optional[Mx8Act]:
+def _attach_q8(d: L.GemmDesc, M: int, cols: int, device, rowstats: bool, fixed: Optional[tuple] = None) -> Optional[Mx8Act]:
     """ask the library whether this launch can also emit its result as an MX8 activation (+ partial row statistics); if so
-    allocate the buffers and point the descriptor at them"""
+    allocate the buffers and point the descriptor at them.  fixed = (first column, multiplier): columns from there on are written
+    with that fixed scale instead of block scales (udt_gemm_desc.q8_fixed_col)"""
     q = _mx8_alloc(M, cols, device)
     d.q8_out, d.q8_scale, d.ld_q8 = q.data.data_ptr(), q.scale.data_ptr(), cols
-    parts = L.load().udt_gemm_rowstat_parts(C.byref(d))
-    if parts <= 0 and not (d.flags & L.GEMM_GEGLU):
-        d.q8_out, d.q8_scale, d.ld_q8 = None, None, 0
+    if fixed is not None:
+        d.q8_fixed_col, d.q8_fixed_mul = int(fixed[0]), float(fixed[1])
+    lib = L.load()
+    parts = lib.udt_gemm_rowstat_parts(C.byref(d)) if rowstats else 0
+    if not lib.udt_gemm_q8_ok(C.byref(d)) or (rowstats and parts <= 0):
+        d.q8_out, d.q8_scale, d.ld_q8, d.q8_fixed_col = None, None, 0, 0
         return None
     if rowstats:
         st = torch.empty((parts, M, 2), dtype=torch.float32, device=device)
@@ -256,7 +260,7 @@ def linear_mx8(x: Mx8Act, wq: torch.Tensor, colscale: torch.Tensor, bias: Option
                out: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None, rows_per_batch: int = 0,
                flags: int = 0, n_out: Optional[int] = None, colstats: bool = False, emit_q8: bool = False,
                emit_rowstats: bool = False, ln_c: Optional[torch.Tensor] = None, ln_s: Optional[torch.Tensor] = None,
-               eps: float = 1e-5, want_bf16: bool = True):
+               eps: float = 1e-5, want_bf16: bool = True, q8_fixed: Optional[tuple] = None):
     """out[M, N] (bf16) = epilogue(dequant(x) @ dequant(wq)^T) on the MX8 path (UDT_GEMM_MX8): x an Mx8Act, wq e4m3 [N, K]
     with per-output-channel fp32 scales.  ln_c / ln_s: the GEMM is LayerNorm-folded (packing.pack_ln_linear_mx8; x.stats holds
     the row statistics its producer emitted).  emit_q8: the result again as an Mx8Act (``out.mx8``; with GEGLU and
@@ -269,7 +273,7 @@ def linear_mx8(x: Mx8Act, wq: torch.Tensor, colscale: torch.Tensor, bias: Option
     assert x.scale.dtype == torch.int32 and x.scale.shape == (K // 128, M) and x.scale.is_contiguous()
     geglu = bool(flags & L.GEMM_GEGLU)
     n_cols = N // 2 if geglu else N
-    only_q8 = geglu and emit_q8 and not want_bf16
+    only_q8 = emit_q8 and not want_bf16
     if out is None and not only_q8:
         out = torch.empty((M, n_cols), dtype=torch.bfloat16, device=xq.device)
     d = gemm_desc(a=_ptr(xq), w=_ptr(wq), bias=_ptr(ln_c if ln_c is not None else bias), residual=_ptr(residual),
@@ -287,7 +291,7 @@ def linear_mx8(x: Mx8Act, wq: torch.Tensor, colscale: torch.Tensor, bias: Option
         _drop_stale_stats(out)
     q8 = None
     if emit_q8:
-        q8 = _attach_q8(d, M, n_cols, xq.device, emit_rowstats and not geglu)
+        q8 = _attach_q8(d, M, n_cols, xq.device, emit_rowstats and not geglu, fixed=q8_fixed)
         if q8 is None:
             raise L.UdtError(f"udt_gemm has no MX8-emitting plan for M={M} N={N} K={K} flags={flags:#x}")
     run_gemm(d, xq.device)
@@ -305,7 +309,7 @@ def linear_mx8(x: Mx8Act, wq: torch.Tensor, colscale: torch.Tensor, bias: Option
 
 def ln_linear(x: torch.Tensor, w_folded: torch.Tensor, c: torch.Tensor, s: torch.Tensor, *, eps: float = 1e-5,
               out: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None, flags: int = 0,
-              n_out: Optional[int] = None) -> torch.Tensor:
+              n_out: Optional[int] = None, emit_q8: bool = False, want_bf16: bool = True, q8_fixed: Optional[tuple] = None):
     """out = epilogue(LayerNorm(x) @ W^T + b) in ONE launch (udt_ln_gemm_fwd): x holds the raw rows, (w_folded, c, s) come
     from packing.pack_ln_linear; the row statistics are taken inside the GEMM (reference attention.py:310-339)."""
     _bf16(x); _bf16(w_folded)
@@ -315,11 +319,18 @@ def ln_linear(x: torch.Tensor, w_folded: torch.Tensor, c: torch.Tensor, s: torch
     M = x2.shape[0]
     N = w_folded.shape[0] if n_out is None else n_out
     n_cols = N // 2 if (flags & L.GEMM_GEGLU) else N
-    if out is None:
+    only_q8 = emit_q8 and not want_bf16
+    if out is None and not only_q8:
         out = torch.empty((M, n_cols), dtype=torch.bfloat16, device=x.device)
     d = gemm_desc(a=_ptr(x2), w=_ptr(w_folded), bias=_ptr(c), residual=_ptr(residual), out=_ptr(out), M=M, N=N, K=K,
-                  lda=x2.stride(0), ldo=out.stride(0), ldr=(residual.stride(0) if residual is not None else 0), flags=flags,
-                  ln_colsum=_ptr(s), ln_eps=eps)
+                  lda=x2.stride(0), ldo=(out.stride(0) if out is not None else 0),
+                  ldr=(residual.stride(0) if residual is not None else 0), flags=flags, ln_colsum=_ptr(s), ln_eps=eps)
+    q8 = None
+    if emit_q8:
+        # (the row-resident K = 320 kernel's emitting epilogue: q|k|v for the e4m3 self-attention of config #5 at the 64x64 level)
+        q8 = _attach_q8(d, M, n_cols, x.device, False, fixed=q8_fixed)
+        if q8 is None:
+            raise L.UdtError(f"udt_ln_gemm_fwd has no MX8-emitting plan for M={M} N={N} K={K}")
     lib = L.load()
     need = lib.udt_gemm_workspace_bytes(C.byref(d))
     ws_ptr, ws_bytes = None, 0
@@ -337,9 +348,13 @@ def ln_linear(x: torch.Tensor, w_folded: torch.Tensor, c: torch.Tensor, s: torch
     L.check(rc, "udt_ln_gemm_fwd")
     if WORK_COUNTER is not None:
         count_work("gemm", 2.0 * M * N * K)
-        count_work("gemm_bytes", 2.0 * (M * K + N * K) + out.numel() * out.element_size()
-                   + (2.0 * M * n_cols if residual is not None else 0.0))
+        count_work("gemm_bytes", 2.0 * (M * K + N * K) + (2.0 if out is not None else 0.0) * M * n_cols
+                   + (1.0 * M * n_cols if q8 is not None else 0.0) + (2.0 * M * n_cols if residual is not None else 0.0))
         count_work("gemm_launches", 1.0)
+    if only_q8:
+        return q8
+    if q8 is not None:
+        out.mx8 = q8
     return out
 
 
@@ -466,6 +481,33 @@ def attention_rowv(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int
         count_work("attn", 4.0 * B * heads * Nq * Nk * 64)
         count_work("attn_bytes", 2.0 * B * heads * 64 * (2 * Nq + 2 * Nk))
         count_work("attn_launches", 1.0)
+    return out
+
+
+def attention_mx8(qkv: Mx8Act, batch: int, heads: int, scale: float, v_mul: float, out: Optional[torch.Tensor] = None,
+                  emit_q8: bool = False) -> torch.Tensor:
+    """the same self-attention on e4m3 operands (BASELINE config #5's "fp8 attention", udt_attn_mx8_fwd): qkv is the MX8 form of
+    one q|k|v projection [B * N, 3 C] whose emitting epilogue wrote the v third with the fixed multiplier v_mul
+    (q8_fixed = (2 C, v_mul)).  Returns o [B, N, C] bf16 (``out.mx8``: o again as an MX8 activation, emit_q8)."""
+    C_ = heads * 64
+    M, ld8 = qkv.data.shape
+    assert qkv.data.dtype == torch.uint8 and qkv.data.is_contiguous() and ld8 >= 3 * C_ and M % batch == 0
+    assert qkv.scale.dtype == torch.int32 and qkv.scale.is_contiguous() and qkv.scale.shape == ((ld8 + 127) // 128, M)
+    N = M // batch
+    if out is None:
+        out = torch.empty((batch, N, C_), dtype=torch.bfloat16, device=qkv.data.device)
+    assert out.is_contiguous()
+    if getattr(out, "mx8", None) is not None:
+        del out.mx8
+    q8 = _mx8_alloc(M, C_, qkv.data.device) if emit_q8 else None
+    L.check(L.load().udt_attn_mx8_fwd(_ptr(qkv.data), _ptr(qkv.scale), _ptr(out), batch, heads, N, ld8, out.stride(1), scale,
+                                      1.0 / v_mul, _ptr(q8.data) if q8 else None, _ptr(q8.scale) if q8 else None, C_, _stream()),
+            "udt_attn_mx8_fwd")
+    if q8 is not None:
+        out.mx8 = q8
+    if WORK_COUNTER is not None:
+        count_work("attn_fp8", 4.0 * batch * heads * N * N * 64)
+        count_work("attn_fp8_launches", 1.0)
     return out
 
 

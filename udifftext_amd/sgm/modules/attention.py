@@ -171,31 +171,51 @@ class MemoryEfficientCrossAttention(H._Packed):
         return H.fuse_rows(self.to_q.weight, self.to_k.weight, self.to_v.weight), None
 
     def _pack_ln(self, gamma, beta):
-        return packing.pack_ln_linear(torch.cat([self.to_q.weight, self.to_k.weight, self.to_v.weight], 0), None, gamma, beta)
+        pk = packing.pack_ln_linear(torch.cat([self.to_q.weight, self.to_k.weight, self.to_v.weight], 0), None, gamma, beta)
+        inner = self.heads * self.dim_head
+        self.v_mul = H.v_fixed_mul(pk[0][2 * inner:3 * inner], pk[1][2 * inner:3 * inner])     # (for the e4m3 attention)
+        return pk
 
     def _pack_ln_mx8(self, gamma, beta):
-        return packing.pack_ln_linear_mx8(torch.cat([self.to_q.weight, self.to_k.weight, self.to_v.weight], 0), None, gamma, beta)
+        pk = packing.pack_ln_linear_mx8(torch.cat([self.to_q.weight, self.to_k.weight, self.to_v.weight], 0), None, gamma, beta)
+        inner = self.heads * self.dim_head
+        wv = pk[0][2 * inner:3 * inner].view(torch.float8_e4m3fn).float() * pk[1][2 * inner:3 * inner, None]
+        self.v_mul8 = H.v_fixed_mul(wv, pk[2][2 * inner:3 * inner])
+        return pk
 
     def forward(self, x, context=None, mask=None, residual=None, ln=None, x8=None):
         """ln: the LayerNorm in front of the q|k|v projection, folded into that GEMM (x is then the RAW activation).
         x8 (with ln; config #5): x as an MX8 activation with row statistics -> e4m3 q|k|v GEMM; the flash kernel then writes its
-        output as MX8 too and to_out runs on e4m3 operands"""
+        output as MX8 too and to_out runs on e4m3 operands.  With hipnn.FP8_ATTENTION the projection writes q|k|v as MX8 ONLY and
+        the attention itself runs on e4m3 operands (ops.attention_mx8)."""
         if context is not None or mask is not None:
             raise NotImplementedError("attn1 is pure self-attention on this path (reference attention.py:251-252)")
         inner = self.heads * self.dim_head
         B, N, C = x.shape
         x2 = x.reshape(B * N, C)
         mx = ln is not None and x8 is not None
+        a8 = ln is not None and H.fp8_attention() and N % 4 == 0
+        scale = self.dim_head ** -0.5
+        o = None
         if mx:
             wq, cs, c, sv = self.packed_ln_mx8(ln)
-            qkv = ops.linear_mx8(x8, wq, cs, ln_c=c, ln_s=sv, eps=ln.eps).reshape(B, N, 3 * inner)
+            if a8:
+                qkv8 = ops.linear_mx8(x8, wq, cs, ln_c=c, ln_s=sv, eps=ln.eps, emit_q8=True, want_bf16=False,
+                                      q8_fixed=(2 * inner, self.v_mul8))
+                o = ops.attention_mx8(qkv8, B, self.heads, scale, self.v_mul8, emit_q8=True)
+            else:
+                qkv = ops.linear_mx8(x8, wq, cs, ln_c=c, ln_s=sv, eps=ln.eps).reshape(B, N, 3 * inner)
         elif ln is not None:
             wf, c, sv = self.packed_ln(ln)
-            qkv = ops.ln_linear(x2, wf, c, sv, eps=ln.eps).reshape(B, N, 3 * inner)
+            if a8 and C == 320:                  # (the row-resident K = 320 kernel has the emitting epilogue)
+                qkv8 = ops.ln_linear(x2, wf, c, sv, eps=ln.eps, emit_q8=True, want_bf16=False, q8_fixed=(2 * inner, self.v_mul))
+                o = ops.attention_mx8(qkv8, B, self.heads, scale, self.v_mul)
+            else:
+                qkv = ops.ln_linear(x2, wf, c, sv, eps=ln.eps).reshape(B, N, 3 * inner)
         else:
             qkv = ops.linear(x2, self.packed()[0]).reshape(B, N, 3 * inner)
-        o = ops.attention_rowv(qkv[..., :inner], qkv[..., inner:2 * inner], qkv[..., 2 * inner:], self.heads,
-                               self.dim_head ** -0.5, emit_q8=mx)
+        if o is None:
+            o = ops.attention_rowv(qkv[..., :inner], qkv[..., inner:2 * inner], qkv[..., 2 * inner:], self.heads, scale, emit_q8=mx)
         res = residual.reshape(B * N, -1) if residual is not None else None
         return self.to_out[0](o.reshape(B * N, inner), residual=res, x8=ops.mx8_of(o) if mx else None).reshape(B, N, -1)
 

@@ -60,6 +60,25 @@ def want_stats(B: int, HW: int, C: int) -> bool:
 FP8_LINEARS = os.environ.get("UDT_FP8", "0") != "0"
 
 
+# UDT_FP8_ATTN=1 (with UDT_FP8=1; config #5's "fp8 attention"): attn1's Q K^T and P V run on e4m3 operands too
+# (udt_attn_mx8_fwd, v_mfma_scale_f32_32x32x64_f8f6f4): the q|k|v projection writes ONLY the MX8 form of its result — q and k with
+# block scales along the head dimension, v with one fixed power-of-two multiplier per layer (P V contracts over keys) — at all three
+# widths (the 320-channel level through the row-resident kernel's emitting epilogue); softmax stays fp32.
+FP8_ATTENTION = os.environ.get("UDT_FP8_ATTN", "0") != "0"
+
+
+def fp8_attention() -> bool:
+    return FP8_LINEARS and LN_GEMM and FP8_ATTENTION
+
+
+def v_fixed_mul(w_v: torch.Tensor, c_v: torch.Tensor) -> float:
+    """the fixed e4m3 multiplier of a layer's v projection behind a LayerNorm: v_j = sum_k n_k w_jk + c_j with n a normalised row
+    (mean 0, variance 1), so |v_j| is of the order of ||w_j||_2; 448 (the largest e4m3 value; the emitting epilogue saturates) is put
+    at 12 ||w_j||_2 + |c_j| of the widest row, rounded down to a power of two (exact to undo).  Data-free, computed once at packing."""
+    bound = 12.0 * float(w_v.float().norm(dim=1).max()) + float(c_v.float().abs().max())
+    return float(2.0 ** math.floor(math.log2(448.0 / max(bound, 1e-20))))
+
+
 def mx8_width(c: int) -> bool:
     """does a transformer block of this width run its linears on MX8 operands in config #5?"""
     return FP8_LINEARS and LN_GEMM and c % 128 == 0
