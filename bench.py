@@ -70,7 +70,8 @@ def parse():
     ap.add_argument("--in-flight", type=int, default=3, help="batches sampled concurrently per GPU, one launch stream each "
                     "(same-box on MI355X: 1 -> 5.7, 2 -> 7.13, 3 -> 7.67, 4 -> 6.0 images/s)")
     ap.add_argument("--fp8", action="store_true", help="BASELINE config #5 arithmetic: every linear of the 640- / 1280-channel "
-                    "transformer blocks on MX8 operands (e4m3 + E8M0 block scales written by the producers' epilogues)")
+                    "transformer blocks on MX8 operands (e4m3 + E8M0 block scales written by the producers' epilogues) and the "
+                    "self-attention's Q K^T / P V on e4m3 operands (UDT_FP8_ATTN=0: bf16 attention)")
     ap.add_argument("--noise-iters", type=int, default=10, help="noise search iterations of the reference-default measurement "
                     "(configs/test.yaml:14 noise_iters: 10, batch_size 1): reported as images_per_s_reference_default")
     ap.add_argument("--no-reference-default", action="store_true", help="skip the reference-default (B = 1, noise search) pass")
@@ -240,9 +241,10 @@ def main():
     import udifftext_amd  # noqa: F401
     from udifftext_amd import config as C, lib as L, ops, parallel, pipeline, synth
 
+    import sgm.modules.hipnn as Hnn
     if args.fp8:
-        import sgm.modules.hipnn as Hnn
         Hnn.FP8_LINEARS = True
+    Hnn_fp8_attention = Hnn.fp8_attention
     torch.set_grad_enabled(False)
     with contextlib.redirect_stdout(sys.stderr):          # the conditioner announces its embedders like the reference does;
         model = pipeline.build_engine(dev)                # stdout carries the ONE JSON line only
@@ -319,7 +321,7 @@ def main():
     c3p_bytes, c3p_launches = W.get("conv3p_bytes", 0.0), W.get("conv3p_launches", 0.0)
     gemm_flops = W.get("gemm", 0.0) + W.get("conv1x1", 0.0) + W.get("gemm_fp8", 0.0)
     gemm_bytes = W.get("gemm_bytes", 0.0) + W.get("conv1x1_bytes", 0.0)
-    attn_flops, attn_bytes = W.get("attn", 0.0), W.get("attn_bytes", 0.0)
+    attn_flops, attn_bytes = W.get("attn", 0.0) + W.get("attn_fp8", 0.0), W.get("attn_bytes", 0.0) + W.get("attn_fp8_bytes", 0.0)
 
     # ---- the same K steps in the other launch modes, for reference next to `value` (same barriers / max over ranks)
     def timed_mode(in_flight, fuse):
@@ -457,8 +459,10 @@ def main():
             "dtype_note": ("MX8 MFMA (v_mfma_scale_f32_32x32x64_f8f6f4: e4m3 elements, one E8M0 scale per 32 K-elements of an activation "
                            "row written by the PRODUCING kernel's epilogue, per-output-channel weight scales) for every linear of the "
                            "640- / 1280-channel transformer blocks (q|k|v, to_out, GEGLU, ff.net[2], proj_out: 69 % of the linear "
-                           "FLOPs; the 320-channel level's K = 320 projections are epilogue-bound and stay bf16, as do the attention "
-                           "scores and the convolutions); fp32 accumulation, statistics, softmax and sampler state") if args.fp8 else
+                           "FLOPs; the 320-channel level's K = 320 projections are epilogue-bound and stay bf16, as do the "
+                           "convolutions) and for the self-attention's Q K^T and P V at all three levels (q, k block-scaled along the "
+                           "head dimension, v fixed-scale, probabilities as e4m3; text cross-attention bf16); fp32 accumulation, "
+                           "statistics, softmax maxima / normalisation and sampler state") if args.fp8 else
                           "bf16 storage + MFMA, fp32 accumulation / statistics / softmax / sampler state",
             "value_one_batch": (value if (args.in_flight == 1 and args.fuse == 1) else other_modes.get("one_batch_at_a_time")),
             "value_one_batch_note": "the same K steps with ONE batch of --batch images on the GPU at a time (no batches in "
@@ -483,7 +487,9 @@ def main():
                 "gemm": cls("linears + 1x1 convolutions: lg::lgemm_kernel (lean co-resident family; plain / GEGLU / LayerNorm-folded) "
                             "+ g8::gemm8_kernel (two-source 1x1, transposed, fp32 outputs)", gemm_flops,
                             gemm_bytes, gemm_ms, gemm_launches),
-                "attention": cls("flash attention: attn_d64_v2_kernel (UNet self-attention, head_dim 64) + attn_d512_q64_kernel (VAE mid block, one head of 512)", attn_flops, attn_bytes, attn_ms, attn_launches)},
+                "attention": cls("flash attention: " + ("attn_d64_mx8_kernel (UNet self-attention on e4m3 operands, head_dim 64; priced against the bf16 peak like the class)"
+                                                 if args.fp8 and Hnn_fp8_attention() else "attn_d64_v2_kernel (UNet self-attention, head_dim 64)")
+                                 + " + attn_d512_q64_kernel (VAE mid block, one head of 512)", attn_flops, attn_bytes, attn_ms, attn_launches)},
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.size, args.chars, args.sampler_steps, config1=args.cpu_config1)

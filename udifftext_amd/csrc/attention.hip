@@ -42,6 +42,8 @@ struct AttnParams {
   uint32_t* q8_scale;      // [heads * 64 / 128][batch * nq]
   int ld_q8;
   long long q8_rows;       // batch * nq
+  // attn_d64_v2_kernel: 1-D grid of G = units rounded up to 8 workgroups; unit = (batch * heads + head) * qtiles + query tile
+  int qtiles, units, G;
 };
 
 constexpr int KV_TILE = 64;
@@ -176,7 +178,7 @@ __global__ void __launch_bounds__(256, 4) attn_d64_kernel(const AttnParams p) {
     for (int t = 0; t < 2; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[t][r]);
-    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    mx = half_swap_max(mx);
     const float m_new = fmaxf(m_run, mx * c);
     const float alpha = fast_exp2(m_run - m_new);
     m_run = m_new;
@@ -210,14 +212,11 @@ __global__ void __launch_bounds__(256, 4) attn_d64_kernel(const AttnParams p) {
       for (int dt = 0; dt < 2; ++dt) {
         u32x2 lo, hh;
         if constexpr (VROW) {
-          typedef short v4s __attribute__((ext_vector_type(4)));
-          typedef __attribute__((address_space(3))) v4s* lds_v4s;
-          const char* blk = vbuf + s4 * 2048 + tr_base;
+          const unsigned blk = lds_offset(vbuf) + tr_base;
           const int c = dt * 4 + tr_chunk;
-          const v4s a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s)(blk + ((c ^ tr_swz) << 4)));
-          const v4s b8 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s)(blk + 1024 + ((c ^ tr_swz ^ 4) << 4)));
-          lo = __builtin_bit_cast(u32x2, a);
-          hh = __builtin_bit_cast(u32x2, b8);
+          lo = lds_tr16_b64(blk + ((c ^ tr_swz) << 4), s4 * 2048);
+          hh = lds_tr16_b64(blk + ((c ^ tr_swz ^ 4) << 4), s4 * 2048 + 1024);
+          lds_tr_wait(lo, hh);
         } else {
           const char* row = vbuf + (dt * 32 + l31) * 128;
           lo = *reinterpret_cast<const u32x2*>(row + (((2 * s4) ^ swz) << 4) + 8 * hi);
@@ -230,7 +229,7 @@ __global__ void __launch_bounds__(256, 4) attn_d64_kernel(const AttnParams p) {
   }
 
   // ---- epilogue: O[q][d] = O^T / l ------------------------------------------------------------------------
-  const float l_tot = l_run + __shfl_xor(l_run, 32);
+  const float l_tot = half_swap_sum(l_run);
   const float inv = 1.0f / l_tot;
   if (qok) {
 #pragma unroll
@@ -275,14 +274,21 @@ __global__ void __launch_bounds__(256, 3) attn_d64_v2_kernel(const AttnParams p)
   const int lane = tid & 63;
   const int l31 = lane & 31;
   const int hi = lane >> 5;
-  const int bh = blockIdx.y;
+  // XCD-aware unit order: the hardware deals consecutive workgroups round-robin to the 8 XCDs, each with an L2 of its own.  With a
+  // (query tile, batch * heads) grid every XCD works on every (batch, head) at once and the K / V of ~32 of them (0.5 MiB each at
+  // 4096 keys) compete for its 4 MiB; range_index gives XCD x the contiguous unit range [x G / 8, (x + 1) G / 8): the query tiles of ONE
+  // (batch, head) run together on ONE XCD and stream its K / V out of that L2.
+  const int unit = range_index(blockIdx.x, p.G);
+  if (unit >= p.units) return;
+  const int bh = unit / p.qtiles;
+  const int qt = unit - bh * p.qtiles;
   const int b = bh / p.heads;
   const int h = bh - b * p.heads;
   const uint16_t* __restrict__ Q = p.q + (long long)b * p.sq + h * 64;
   const uint16_t* __restrict__ K = p.k + (long long)b * p.sk + h * 64;
   const uint16_t* __restrict__ V = p.vt + (long long)b * p.svt + h * 64;
   uint16_t* __restrict__ O = p.o + (long long)b * p.so + h * 64;
-  const int qi = blockIdx.x * 128 + wave * 32 + l31;
+  const int qi = qt * 128 + wave * 32 + l31;
   const bool qok = qi < p.nq;
   bf16x8_t qf[4];
 #pragma unroll
@@ -356,6 +362,12 @@ __global__ void __launch_bounds__(256, 3) attn_d64_v2_kernel(const AttnParams p)
       stage(s2, kt + 2);
     }
     const char* buf = smem2 + st * A2_STAGE;
+    unsigned tra[2], trb[2];                               // this tile's transposed-read addresses (lds_tr16_b64)
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) {
+      tra[dt] = lds_offset(buf) + voff_a[dt];
+      trb[dt] = lds_offset(buf) + voff_b[dt];
+    }
     f32x16 s[2];
 #pragma unroll
     for (int t = 0; t < 2; ++t)
@@ -386,7 +398,7 @@ __global__ void __launch_bounds__(256, 3) attn_d64_v2_kernel(const AttnParams p)
     for (int t = 0; t < 2; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[t][r]);
-    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    mx = half_swap_max(mx);
     const float mxs = mx * c;
     if (!__all(mxs - m_run <= A2_DEFER)) {                  // wave-uniform: some query's maximum grew by more than 2^8
       const float m_new = fmaxf(m_run, mxs);
@@ -416,8 +428,6 @@ __global__ void __launch_bounds__(256, 3) attn_d64_v2_kernel(const AttnParams p)
         ps2 += pv;
       }
     l_run += ps2[0] + ps2[1];
-    typedef short v4s __attribute__((ext_vector_type(4)));
-    typedef __attribute__((address_space(3))) v4s* lds_v4s;
 #pragma unroll
     for (int s4 = 0; s4 < 4; ++s4) {
       const int t = s4 >> 1, half = s4 & 1;
@@ -428,13 +438,16 @@ __global__ void __launch_bounds__(256, 3) attn_d64_v2_kernel(const AttnParams p)
       pk[3] = pack_bf16x2(s[t][half * 8 + 6], s[t][half * 8 + 7]);
       const bf16x8_t pf = __builtin_bit_cast(bf16x8_t, pk);
       u32x4 vv[2];
+      {
+        u32x2 lo[2], hh[2];
 #pragma unroll
-      for (int dt = 0; dt < A2_DT; ++dt) {
-        const v4s a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s)(buf + s4 * 2048 + voff_a[dt]));
-        const v4s b8 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s)(buf + s4 * 2048 + voff_b[dt]));
-        const u32x2 lo = __builtin_bit_cast(u32x2, a), hh = __builtin_bit_cast(u32x2, b8);
-        u32x4 w = {lo[0], lo[1], hh[0], hh[1]};
-        vv[dt] = w;
+        for (int dt = 0; dt < A2_DT; ++dt) {
+          lo[dt] = lds_tr16_b64(tra[dt], s4 * 2048);
+          hh[dt] = lds_tr16_b64(trb[dt], s4 * 2048);
+        }
+        if constexpr (A2_DT == 2) lds_tr_wait(lo[0], hh[0], lo[1], hh[1]); else lds_tr_wait(lo[0], hh[0]);
+#pragma unroll
+        for (int dt = 0; dt < A2_DT; ++dt) vv[dt] = u32x4{lo[dt][0], lo[dt][1], hh[dt][0], hh[dt][1]};
       }
       __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -443,7 +456,7 @@ __global__ void __launch_bounds__(256, 3) attn_d64_v2_kernel(const AttnParams p)
     }
     st = st + 1 == A2_NST ? 0 : st + 1;
   }
-  const float l_tot = l_run + __shfl_xor(l_run, 32);
+  const float l_tot = half_swap_sum(l_run);
   const float inv = 1.0f / l_tot;
   if (qok) {
 #pragma unroll
@@ -502,11 +515,32 @@ struct AttnMx8Params {
   uint8_t* q8_out;         // optional: O again as an MX8 activation (as attn_d64_v2_kernel)
   uint32_t* q8_scale;
   int ld_q8;
+  int qtiles, units, G;    // 1-D grid as attn_d64_v2_kernel
 };
 constexpr int A8_TILE = 64 * 64;                 // 64 keys x 64 bytes
 constexpr int A8_STAGE = 2 * A8_TILE + 256;      // K tile + V tile + the K tile's scale dwords
 constexpr int A8_NST = 3;
+// The softmax numerators are produced as e4m3 BYTES without an exponential: an e4m3 bit pattern read as an integer is a
+// piecewise-linear log2 scale (byte = 8 (log2 p + 7) + the mantissa's 8 (2^f - 1) ~ 8 f), so
+//     byte(p) = rne(8 (s c - m_run) + 8 (A8_OFF + 7) + A8_ADJ)          — one (packed) FMA + one v_cvt_pk_u8_f32 per score
+// (the conversion rounds to nearest even and saturates at 0 / 255; -inf and NaN give 0) instead of FMA + v_exp_f32 + add (row sum) +
+// v_cvt_pk_fp8_f32 — measured issue cost per wave64 instruction relative to v_fma_f32: v_exp_f32 1.7, v_cvt_pk_fp8_f32 1.8 (two
+// scores), v_cvt_pk_u8_f32 1.1, v_max3_f32 1.1 (profiles/r05_probe_cvt_pk_u8.txt).
+// The row sum comes out of the matrix pipe (one more MFMA against an all-ones fragment), i.e. the denominator is the sum of exactly
+// the quantised numerators.  Error of the log-linear mantissa + the rounding: 3.1 % rms per probability against 2.65 % for
+// round-to-nearest e4m3 of the exact exponential (a constant factor of 1.045 cancels in the ratio); tools/probes/cvt_pk_u8.cpp.
+// The running maximum is updated when a row's maximum grows by more than 2^A8_TAU; the bytes encode p 2^A8_OFF so that
+// p = 2^A8_TAU is the top binade of e4m3 (byte 120 = 2^8) and p = 2^-12 its smallest normal; the B-side block scale 127 - A8_OFF
+// of the two MFMAs undoes the shift.
+constexpr float A8_TAU = 2.0f;
+constexpr int A8_OFF = 6;
+constexpr float A8_ADJ = 0.05f;                  // minimises the rms error of the log-linear map
 
+// Measured and not adopted (8 x 4096 x 5 heads, 120 us as built here; tools/attn_tail.py, profiles/r05_attn_mx8_study.txt): two 64-key
+// tiles per ring stage (half the workgroup barriers) 126 us; a software pipeline over the tiles (S of tile kt + 1 and the V^T reads
+// of tile kt issued ahead of tile kt's softmax, scores double-buffered, ring of four) 159 us at 3 waves per SIMD (the Q fragment
+// spills and its reload drains vmcnt) and 134 us at 2.  Knock-outs of that build: barrier + fragment reads + S MFMAs alone are half of
+// the time — every wave reads the whole K and V tile out of LDS for its 32 queries; 64 queries per wave is the next step.
 __global__ void __launch_bounds__(256, 3) attn_d64_mx8_kernel(const AttnMx8Params p) {
   extern __shared__ __attribute__((aligned(16))) char smem8[];
   const int tid = threadIdx.x;
@@ -514,12 +548,15 @@ __global__ void __launch_bounds__(256, 3) attn_d64_mx8_kernel(const AttnMx8Param
   const int lane = tid & 63;
   const int l31 = lane & 31;
   const int hi = lane >> 5;
-  const int bh = blockIdx.y;
+  const int unit = range_index(blockIdx.x, p.G);           // (XCD-aware unit order: see attn_d64_v2_kernel)
+  if (unit >= p.units) return;
+  const int bh = unit / p.qtiles;
+  const int qt = unit - bh * p.qtiles;
   const int b = bh / p.heads;
   const int h = bh - b * p.heads;
   const long long row0 = (long long)b * p.n;
   const uint8_t* __restrict__ X = p.x8 + row0 * p.ld8;
-  const int qi = blockIdx.x * 128 + wave * 32 + l31;
+  const int qi = qt * 128 + wave * 32 + l31;
   const bool qok = qi < p.n;
   // ---- Q fragment (the B operand of S^T = K Q^T) and its block scale: block 2 h + hi of the row
   i32x8_t qf;
@@ -534,42 +571,51 @@ __global__ void __launch_bounds__(256, 3) attn_d64_mx8_kernel(const AttnMx8Param
     qsc = (int)(p.sc[(long long)(bq >> 2) * p.rows + row0 + qr] >> (8 * (bq & 3)));
   }
   // ---- staging: per wave and tile one K piece, one V piece (16 keys x 64 B each) and the tile's 64 scale dwords (every wave
-  // writes the same 256 bytes: a uniform count of three loads per stage and wave)
+  // writes the same 256 bytes: a uniform count of three loads per stage and wave).  The LDS-DMA writes lane-contiguous 16-byte
+  // slots, so the bank swizzle is applied on the SOURCE side: LDS slot j of key row r holds head dims 16 (j ^ g(r)) .. + 15 with
+  //   K: g(r) = ((r >> 2) & 1) | (((r >> 4) & 1) << 1)   (the 16 lanes of a ds_read_b128 phase read rows {0..3, 16..19, 4..7, 20..23} + c)
+  //   V: g(r) = (r >> 2) & 1                              (the 16 lanes of a ds_read_b64_tr_b8 read rows r0 .. r0 + 7, 16 bytes each)
   const int kb0 = p.C / 32 + 2 * h;               // k's first block of this head: even -> both of its scales sit in one dword
   const unsigned kvbytes = (unsigned)((long long)(p.n - 1) * p.ld8 + 64);
   const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(X + p.C + h * 64), 0, kvbytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(X + 2 * p.C + h * 64), 0, kvbytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(p.sc + (long long)(kb0 >> 2) * p.rows + row0), 0,
                                                                        (unsigned)(p.n * 4), 0x00020000);
-  const unsigned kv_voff = (unsigned)((long long)(wave * 16 + (lane >> 2)) * p.ld8 + (lane & 3) * 16);
+  const unsigned row_voff = (unsigned)((long long)(wave * 16 + (lane >> 2)) * p.ld8);
+  const unsigned k_voff = row_voff + (((lane & 3) ^ (((lane >> 4) & 1) | ((wave & 1) << 1))) << 4);
+  const unsigned v_voff = row_voff + (((lane & 3) ^ ((lane >> 4) & 1)) << 4);
   const int tile_step = 64 * p.ld8;
-  auto stage = [&](int st, int kt) {
+  auto stage = [&](int st, int kt) __attribute__((always_inline)) {
     char* kbuf = smem8 + st * A8_STAGE;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, (__attribute__((address_space(3))) void*)(kbuf + wave * 1024), 16, kv_voff, kt * tile_step, 0, 0);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (__attribute__((address_space(3))) void*)(kbuf + A8_TILE + wave * 1024), 16, kv_voff, kt * tile_step, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, (__attribute__((address_space(3))) void*)(kbuf + wave * 1024), 16, k_voff, kt * tile_step, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (__attribute__((address_space(3))) void*)(kbuf + A8_TILE + wave * 1024), 16, v_voff, kt * tile_step, 0, 0);
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(kbuf + 2 * A8_TILE), 4, (unsigned)(lane * 4), kt * 256, 0, 0);
   };
   // ---- per-lane LDS offsets
   const int kperm = 16 * ((l31 >> 2) & 1) + 4 * (l31 >> 3) + (l31 & 3);       // the key (of a 32-key half) this fragment lane holds
-  const int k_off = kperm * 64 + 16 * hi;                                       // + 32: the second scale block; + 2048: the second half
+  const int kg = ((kperm >> 2) & 1) | (((kperm >> 4) & 1) << 1);
+  const int k_off0 = kperm * 64 + ((hi ^ kg) << 4);                             // head dims 16 hi .. + 15 (scale block 0)
+  const int k_off1 = kperm * 64 + (((2 + hi) ^ kg) << 4);                       // head dims 32 + 16 hi .. (scale block 1); + 2048: keys + 32
   const int s_off = 2 * A8_TILE + kperm * 4;
   const int s_shift = 8 * ((kb0 & 3) + hi);
   const int tr_i = lane & 15;
-  const int v_off = A8_TILE + (16 * hi + (tr_i >> 1)) * 64 + 16 * ((lane >> 4) & 1) + 8 * (tr_i & 1);   // + 512 g + 2048 t + 32 dt
+  // V^T: key row 16 hi + (i >> 1) (+ 8 g + 32 t), head dims 32 dt + 16 ((lane >> 4) & 1) + 8 (i & 1) .. + 7; (row >> 2) & 1 = i >> 3
+  const int v_row = A8_TILE + (16 * hi + (tr_i >> 1)) * 64 + 8 * (tr_i & 1);
+  const int v_off0 = v_row + (((0 + ((lane >> 4) & 1)) ^ (tr_i >> 3)) << 4);   // dt = 0
+  const int v_off1 = v_row + (((2 + ((lane >> 4) & 1)) ^ (tr_i >> 3)) << 4);   // dt = 1; + 512 g + 2048 t
 
-  f32x16 o_acc[2];
+  f32x16 o_acc[2], l_acc;
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) o_acc[i][r] = 0.f;
-  float m_run = -INFINITY, l_run = 0.f;
+  for (int r = 0; r < 16; ++r) o_acc[0][r] = o_acc[1][r] = l_acc[r] = 0.f;
+  i32x8_t ones = {0x38383838, 0x38383838, 0x38383838, 0x38383838, 0x38383838, 0x38383838, 0x38383838, 0x38383838};   // e4m3 1.0
+  asm volatile("" : "+v"(ones));                            // (kept in eight registers: left alone hipcc rebuilds the fragment every tile)
+  float m_run = -INFINITY;
   const int ntiles = (p.n + 63) / 64;
   const float c = p.scale_log2e;
+  typedef float f32x2v __attribute__((ext_vector_type(2)));
   stage(0, 0);
   if (ntiles > 1) stage(1, 1);
   int st = 0;
-  typedef int v2i __attribute__((ext_vector_type(2)));
-  typedef __attribute__((address_space(3))) v2i* lds_v2i;
   for (int kt = 0; kt < ntiles; ++kt) {
     if (kt + 1 < ntiles) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");       // the tile after this one stays in flight
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -585,8 +631,7 @@ __global__ void __launch_bounds__(256, 3) attn_d64_mx8_kernel(const AttnMx8Param
     f32x16 s[2];
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-      const char* kr = buf + t * 2048 + k_off;
-      const i32x8_t kf = lds_read_frag32(kr, kr + 32);
+      const i32x8_t kf = lds_read_frag32(buf + t * 2048 + k_off0, buf + t * 2048 + k_off1);
       const int ksc = (int)(*reinterpret_cast<const uint32_t*>(buf + s_off + t * 128) >> s_shift);
       f32x16 z;
 #pragma unroll
@@ -602,61 +647,53 @@ __global__ void __launch_bounds__(256, 3) attn_d64_mx8_kernel(const AttnMx8Param
           if (key >= p.n) s[t][r] = -INFINITY;
         }
     }
-    float mx = s[0][0];
+    float mx = fmaxf(s[0][0], s[1][0]);
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[t][r]);
-    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    for (int r = 1; r < 16; ++r) mx = fmaxf(fmaxf(mx, s[0][r]), s[1][r]);     // (v_max3_f32)
+    mx = half_swap_max(mx);
     const float mxs = mx * c;
-    if (!__all(mxs - m_run <= A2_DEFER)) {                  // wave-uniform: some query's maximum grew by more than 2^8
+    if (!__all(mxs - m_run <= A8_TAU)) {                    // wave-uniform: some query's maximum grew by more than 2^A8_TAU
       const float m_new = fmaxf(m_run, mxs);
       const float alpha = fast_exp2(m_run - m_new);
       m_run = m_new;
-      l_run *= alpha;
+      l_acc[0] *= alpha;                                     // (every row of the ones product holds the same sums: row 0 is the one kept)
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) o_acc[i][r] *= alpha;
     }
-    typedef float f32x2v __attribute__((ext_vector_type(2)));
-    const f32x2v c2 = {c, c}, m2 = {m_run, m_run};
-    f32x2v ps2 = {0.f, 0.f};
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int r = 0; r < 16; r += 2) {
-        f32x2v e = {s[t][r], s[t][r + 1]};
-        e = __builtin_elementwise_fma(e, c2, -m2);
-        f32x2v pv = {fast_exp2(e[0]), fast_exp2(e[1])};
-        s[t][r] = pv[0];
-        s[t][r + 1] = pv[1];
-        ps2 += pv;
-      }
-    l_run += ps2[0] + ps2[1];
-    // P as e4m3 with the unit scale (0 < P <= 2^8 under the deferred rescale): bytes = the lane's own scores in register order
+    // ---- P as e4m3 bytes: the lane's own scores in register order (registers 0..3 = keys 16 hi + r of the first 32, 4..7 of the second)
+    const float c8 = 8.0f * c, k8 = 8.0f * (A8_OFF + 7) + A8_ADJ - 8.0f * m_run;
+    const f32x2v c2 = {c8, c8}, k2 = {k8, k8};
     i32x8_t pf;
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
-      for (int q4 = 0; q4 < 4; ++q4) pf[t * 4 + q4] = (int)mx8_pack4(s[t][q4 * 4], s[t][q4 * 4 + 1], s[t][q4 * 4 + 2], s[t][q4 * 4 + 3]);
+      for (int q4 = 0; q4 < 4; ++q4) {
+        const f32x2v e0 = __builtin_elementwise_fma(f32x2v{s[t][q4 * 4], s[t][q4 * 4 + 1]}, c2, k2);
+        const f32x2v e1 = __builtin_elementwise_fma(f32x2v{s[t][q4 * 4 + 2], s[t][q4 * 4 + 3]}, c2, k2);
+        unsigned w = __builtin_amdgcn_cvt_pk_u8_f32(e0[0], 0u, 0u);
+        w = __builtin_amdgcn_cvt_pk_u8_f32(e0[1], 1u, w);
+        w = __builtin_amdgcn_cvt_pk_u8_f32(e1[0], 2u, w);
+        w = __builtin_amdgcn_cvt_pk_u8_f32(e1[1], 3u, w);
+        pf[t * 4 + q4] = (int)w;
+      }
+    l_acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(ones, pf, l_acc, 0, 0, 0, 127, 0, 127 - A8_OFF);
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt) {
-      i32x8_t vf;
+      const unsigned vb = lds_offset(buf) + (dt ? v_off1 : v_off0);
+      u32x2 w[4];
 #pragma unroll
       for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int g = 0; g < 2; ++g) {
-          const v2i w = __builtin_amdgcn_ds_read_tr8_b64_v2i32((lds_v2i)(buf + v_off + t * 2048 + g * 512 + dt * 32));
-          vf[t * 4 + g * 2] = w[0];
-          vf[t * 4 + g * 2 + 1] = w[1];
-        }
-      o_acc[dt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(vf, pf, o_acc[dt], 0, 0, 0, 127, 0, 127);
+        for (int g = 0; g < 2; ++g) w[t * 2 + g] = lds_tr8_b64(vb, t * 2048 + g * 512);
+      lds_tr_wait(w[0], w[1], w[2], w[3]);
+      const i32x8_t vf = {(int)w[0][0], (int)w[0][1], (int)w[1][0], (int)w[1][1], (int)w[2][0], (int)w[2][1], (int)w[3][0], (int)w[3][1]};
+      o_acc[dt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(vf, pf, o_acc[dt], 0, 0, 0, 127, 0, 127 - A8_OFF);
     }
     st = st + 1 == A8_NST ? 0 : st + 1;
   }
-  const float l_tot = l_run + __shfl_xor(l_run, 32);
-  const float inv = p.v_inv / l_tot;
+  const float inv = p.v_inv / l_acc[0];
   const long long m = row0 + qi;
   if (qok) {
 #pragma unroll
@@ -882,7 +919,7 @@ UDT_DEVINL void attn_d512_body(const Attn512Params& p) {
     float mx = s[0];
 #pragma unroll
     for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
-    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    mx = half_swap_max(mx);
     const float m_new = fmaxf(m_run, mx * c);
     if (!__all(m_new == m_run)) {                          // (wave-uniform: skip the 64 multiplies when no maximum moved)
       const float alpha = fast_exp2(m_run - m_new);
@@ -901,8 +938,6 @@ UDT_DEVINL void attn_d512_body(const Attn512Params& p) {
       psum += pv;
     }
     l_run += psum;
-    typedef short v4s __attribute__((ext_vector_type(4)));
-    typedef __attribute__((address_space(3))) v4s* lds_v4s;
 #pragma unroll
     for (int s4 = 0; s4 < 2; ++s4) {                       // two 16-key steps
       u32x4 pk;
@@ -912,22 +947,25 @@ UDT_DEVINL void attn_d512_body(const Attn512Params& p) {
       pk[3] = pack_bf16x2(s[s4 * 8 + 6], s[s4 * 8 + 7]);
       const bf16x8_t pf = __builtin_bit_cast(bf16x8_t, pk);
       u32x4 vv[4];
+      u32x2 tl[4], th[4];
 #pragma unroll
       for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) {
-          const char* sb = vbuf + (sub0 + j) * A5_SUB + s4 * 2048;
-          const v4s a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s)(sb + voff_a[dt]));
-          const v4s b8 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s)(sb + voff_b[dt]));
-          const u32x2 lo = __builtin_bit_cast(u32x2, a), hh = __builtin_bit_cast(u32x2, b8);
-          const u32x4 w = {lo[0], lo[1], hh[0], hh[1]};
-          vv[j * 2 + dt] = w;
+          const unsigned sb = lds_offset(vbuf) + (sub0 + j) * A5_SUB;
+          u32x2 lo = lds_tr16_b64(sb + voff_a[dt], s4 * 2048), hh = lds_tr16_b64(sb + voff_b[dt], s4 * 2048);
+          tl[j * 2 + dt] = lo;
+          th[j * 2 + dt] = hh;
         }
+      lds_tr_wait(tl[0], th[0], tl[1], th[1]);
+      lds_tr_wait(tl[2], th[2], tl[3], th[3]);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) vv[t] = u32x4{tl[t][0], tl[t][1], th[t][0], th[t][1]};
 #pragma unroll
       for (int t = 0; t < 4; ++t) o_acc[t] = mfma32(__builtin_bit_cast(bf16x8_t, vv[t]), pf, o_acc[t]);
     }
   }
-  const float l_tot = l_run + __shfl_xor(l_run, 32);
+  const float l_tot = half_swap_sum(l_run);
   if (p.ksplit > 1) {
     // park the slice: unnormalised O (fp32, this wave's 128 dims of its 32 queries) and, once per query, (m, l)
     if (qok) {
@@ -1166,7 +1204,10 @@ static int attn_fwd_impl(bool vrow, const void* q, const void* k, const void* vt
       if (e != hipSuccess) return udt_set_hip_error(e);
       attr_done.store(1);
     }
-    hipLaunchKernelGGL(attn_d64_v2_kernel, grid, dim3(256), smem, s, p);
+    p.qtiles = (nq + 127) / 128;
+    p.units = p.qtiles * batch * heads;
+    p.G = (p.units + 7) / 8 * 8;
+    hipLaunchKernelGGL(attn_d64_v2_kernel, dim3(p.G), dim3(256), smem, s, p);
   } else {
     hipLaunchKernelGGL(attn_d64_kernel<false>, grid, dim3(256), 0, s, p);      // V^T operand (udt_attn_fwd)
   }
@@ -1224,8 +1265,10 @@ extern "C" int udt_attn_mx8_fwd(const void* qkv8, const void* qkv_scale, void* o
     snprintf(tag, sizeof(tag), "attn-mx8%s B=%d H=%d nq=%d nk=%d", q8_out ? "+q8" : "", batch, heads, n, n);
     udt_prof_tag(prof.rec, tag);
   }
-  constexpr int smem = A8_NST * A8_STAGE;
-  hipLaunchKernelGGL(attn_d64_mx8_kernel, dim3((n + 127) / 128, batch * heads), dim3(256), smem, s, p);
+  p.qtiles = (n + 127) / 128;
+  p.units = p.qtiles * batch * heads;
+  p.G = (p.units + 7) / 8 * 8;
+  hipLaunchKernelGGL(attn_d64_mx8_kernel, dim3(p.G), dim3(256), A8_NST * A8_STAGE, s, p);
   UDT_CHECK_LAUNCH();
   return UDT_OK;
 }

@@ -182,6 +182,46 @@ UDT_DEVINL void mx8_quant_acc16(const float (&v)[16], uint32_t (&out)[4], uint32
   for (int q = 0; q < 4; ++q) out[q] = mx8_pack4(v[q * 4] * m, v[q * 4 + 1] * m, v[q * 4 + 2] * m, v[q * 4 + 3] * m);
 }
 
+// workgroup -> iteration-range index.  Blocks are dispatched round-robin over the 8 XCDs (block b -> XCD b % 8,
+// speed heuristic only); give every XCD a contiguous slice of the iteration space so that its private L2 sees
+// neighbouring tiles (which share the weight column tile).
+UDT_DEVINL int range_index(int g, int G) {
+  if ((G & 7) != 0) return g;
+  return (g & 7) * (G >> 3) + (g >> 3);
+}
+
+// ---- transposed LDS reads (ds_read_b64_tr_b16 / _b8) through inline assembly -----------------------------------------------
+// hipcc's waitcnt insertion treats the __builtin_amdgcn_ds_read_tr* intrinsics as LDS reads that may alias ANY LDS-DMA load in
+// flight and puts `s_waitcnt vmcnt(0)` in front of the first one: in a ring of DMA-staged tiles that drains the loads issued for the
+// tile two steps ahead in the middle of every step (found in all three flash attention kernels, round 5).  An asm statement is
+// opaque to that pass: the kernel's own vmcnt(N) + barrier at the top of a step order the DMA against these reads.  The result
+// registers must pass through lds_tr_wait() before use (the pass does not count the asm's LDS operation either).
+UDT_DEVINL unsigned lds_offset(const void* p) { return (unsigned)(uintptr_t)p; }       // (the low half of a flat LDS address)
+// (off: a value that is a compile-time constant once the surrounding loops are unrolled — it becomes the instruction's offset field)
+UDT_DEVINL u32x2 lds_tr16_b64(unsigned addr, int off) {
+  u32x2 r;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "i"(off) : "memory");
+  return r;
+}
+UDT_DEVINL u32x2 lds_tr8_b64(unsigned addr, int off) {
+  u32x2 r;
+  asm volatile("ds_read_b64_tr_b8 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "i"(off) : "memory");
+  return r;
+}
+UDT_DEVINL void lds_tr_wait(u32x2& a, u32x2& b) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b) : : "memory"); }
+UDT_DEVINL void lds_tr_wait(u32x2& a, u32x2& b, u32x2& c, u32x2& d) {
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : : "memory");
+}
+// max of a value with its partner lane ^ 32 in the VALU (v_permlane32_swap; __shfl_xor(v, 32) is a ds_bpermute round trip)
+UDT_DEVINL float half_swap_max(float v) {
+  const auto sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, v), __builtin_bit_cast(unsigned, v), false, false);
+  return fmaxf(__builtin_bit_cast(float, (unsigned)sw[0]), __builtin_bit_cast(float, (unsigned)sw[1]));
+}
+UDT_DEVINL float half_swap_sum(float v) {
+  const auto sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, v), __builtin_bit_cast(unsigned, v), false, false);
+  return __builtin_bit_cast(float, (unsigned)sw[0]) + __builtin_bit_cast(float, (unsigned)sw[1]);
+}
+
 // ---- cross-lane sums without LDS traffic ---------------------------------------------------------------------------
 // DPP row operations (quad_perm / row_ror inside a row of 16 lanes) and the gfx950 row / half swaps add a value over
 // lane groups in the VALU — no ds_bpermute round trips (measured: a __shfl_xor butterfly over the 32 row lanes of an

@@ -5,13 +5,6 @@
 constexpr int BK = 64;          // K elements per tile (128 bytes per row)
 constexpr int ROW_BYTES = 128;
 
-// workgroup -> iteration-range index.  Blocks are dispatched round-robin over the 8 XCDs (block b -> XCD b % 8,
-// speed heuristic only); give every XCD a contiguous slice of the iteration space so that its private L2 sees
-// neighbouring tiles (which share the weight column tile).
-UDT_DEVINL int range_index(int g, int G) {
-  if ((G & 7) != 0) return g;
-  return (g & 7) * (G >> 3) + (g >> 3);
-}
 
 
 namespace g8 {

@@ -507,6 +507,7 @@ def attention_mx8(qkv: Mx8Act, batch: int, heads: int, scale: float, v_mul: floa
         out.mx8 = q8
     if WORK_COUNTER is not None:
         count_work("attn_fp8", 4.0 * batch * heads * N * N * 64)
+        count_work("attn_fp8_bytes", 1.0 * batch * heads * 64 * 3 * N + 2.0 * batch * heads * 64 * N)
         count_work("attn_fp8_launches", 1.0)
     return out
 

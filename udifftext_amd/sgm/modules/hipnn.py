@@ -54,17 +54,18 @@ def want_stats(B: int, HW: int, C: int) -> bool:
 # activations") that the PRODUCING kernel's epilogue writes next to its bf16 result (lean GEMM, fused text cross-attention, flash
 # attention) — no quantisation pass, no normalised copy: the LayerNorms stay folded into the consuming GEMMs, their row statistics
 # come out of the producers' epilogues too.  fp32 accumulation, bf16 residual stream.  The 320-channel level (K = 320: five
-# K-tiles, epilogue-bound — e4m3 operands buy nothing there, tools/bench_mx8.py), attention scores, convolutions, norm statistics,
-# softmax and the sampler are unchanged.  (Round 2's first generation — a LayerNorm -> e4m3 kernel with a static per-tensor scale in
+# K-tiles, epilogue-bound — e4m3 operands buy nothing there, tools/bench_mx8.py), the text cross-attention, convolutions, norm
+# statistics and the sampler are unchanged.  (Round 2's first generation — a LayerNorm -> e4m3 kernel with a static per-tensor scale in
 # front of the 8-wave fp8 GEMM, LayerNorm-fed linears only — measured SLOWER than the LayerNorm-folded bf16 GEMMs and is gone.)
 FP8_LINEARS = os.environ.get("UDT_FP8", "0") != "0"
 
 
-# UDT_FP8_ATTN=1 (with UDT_FP8=1; config #5's "fp8 attention"): attn1's Q K^T and P V run on e4m3 operands too
-# (udt_attn_mx8_fwd, v_mfma_scale_f32_32x32x64_f8f6f4): the q|k|v projection writes ONLY the MX8 form of its result — q and k with
-# block scales along the head dimension, v with one fixed power-of-two multiplier per layer (P V contracts over keys) — at all three
-# widths (the 320-channel level through the row-resident kernel's emitting epilogue); softmax stays fp32.
-FP8_ATTENTION = os.environ.get("UDT_FP8_ATTN", "0") != "0"
+# ... and attn1's Q K^T and P V (config #5's "fp8 attention"; UDT_FP8_ATTN=0 keeps the bf16 flash kernel for A/B measurements):
+# udt_attn_mx8_fwd on v_mfma_scale_f32_32x32x64_f8f6f4.  The q|k|v projection then writes ONLY the MX8 form of its result — q and k
+# with block scales along the head dimension, v with one fixed power-of-two multiplier per layer (P V contracts over keys) — at all
+# three widths (the 320-channel level through the row-resident kernel's emitting epilogue); the softmax numerators are produced
+# directly as e4m3 bytes (csrc/attention.hip), the maxima and the normalisation stay fp32.
+FP8_ATTENTION = os.environ.get("UDT_FP8_ATTN", "1") != "0"
 
 
 def fp8_attention() -> bool:
