@@ -630,6 +630,42 @@ def test_benchmarked_call_path_vs_oracle_bf16_and_fp8(engine, cuda):
     _check("benchmarked call path with MX8 linears + e4m3 attention vs the bf16 path", eps_a8.cpu(), ref_bf16.cpu(), 8e-2)
 
 
+def test_fixed_scale_of_v_in_the_e4m3_attention_neither_saturates_nor_wastes_its_range(engine, cuda, monkeypatch):
+    """config #5's e4m3 attention writes v with ONE data-free multiplier per layer (hipnn.v_fixed_mul: 448 at 12 ||w_j||_2 + |c_j| of the
+    widest output row; the emitting epilogue saturates).  On the benchmarked call path, for every one of the 16 attn1 layers: no
+    element of v sits on the saturation value, and the largest |v| of the layer uses at least the format's upper 8 binades (an e4m3
+    normal has 14) — so the coarse steps of the subnormal range are >= 6 binades below the layer's maximum."""
+    import sgm.modules.hipnn as H
+    from udifftext_amd import ops, synth
+    torch.manual_seed(33)
+    B = 2
+    le = engine.conditioner.embedders[0]
+    ctx = le(synth.synthetic_batch(B, 512, 512, 9, seed=8)["label"])
+    tctx = torch.cat([torch.zeros_like(ctx), ctx])
+    x = torch.randn((2 * B, 9, 64, 64), device=cuda)
+    ts = torch.full((2 * B,), 300, device=cuda)
+    seen = []
+    real = ops.attention_mx8
+
+    def spy(qkv, batch, heads, scale, v_mul, **kw):
+        C = heads * 64
+        v = qkv.data[:, 2 * C:3 * C]
+        mag = (v & 0x7F).to(torch.int32)
+        seen.append((C, v_mul, float((mag >= 0x7E).float().mean()), int(mag.max())))
+        return real(qkv, batch, heads, scale, v_mul, **kw)
+    monkeypatch.setattr(H, "FP8_LINEARS", True)
+    monkeypatch.setattr(H, "FP8_ATTENTION", True)
+    monkeypatch.setattr(ops, "attention_mx8", spy)
+    _sampler_call(engine.model.diffusion_model, x, ts, tctx, B)
+    assert len(seen) == 16
+    for C, v_mul, sat, top in seen:
+        assert sat == 0.0, f"width {C}: {sat:.2e} of v saturated at multiplier {v_mul}"
+        assert top >= (7 << 3), f"width {C}: largest |v| byte {top:#x} — the multiplier {v_mul} leaves the upper half of the range unused"
+    os.makedirs(os.path.dirname(REPORT), exist_ok=True)
+    with open(REPORT, "a") as f:
+        f.write("fixed-scale v of the e4m3 attention: (width, multiplier, largest byte) " + " ".join(f"({c},{m:g},{t:#x})" for c, m, _, t in seen) + "\n")
+
+
 @pytest.mark.parametrize("attn8", [False, True])
 def test_config2_512_fifty_steps_with_fp8_linears_vs_reference_golden(engine, cuda, monkeypatch, attn8):
     """config #5's arithmetic over a whole trajectory: BASELINE config #2's image (512x512, 9 characters, CFG 5) through 50 Euler
