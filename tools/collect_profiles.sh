@@ -59,6 +59,12 @@ jstamp $O/bench_config4_768.json $O/bench_fp8.json
 #    MFMA utilisation of the fp8 step
 (cd $R && python tools/bench_mx8.py 2>/dev/null > $O/mx8_layers.txt)
 (cd $R && UDT_FP8=1 UDT_DUAL_STREAM=0 python tools/trace_step.py 2>/dev/null > $O/trace_step_fp8.txt)
-stamp $O/mx8_layers.txt $O/trace_step_fp8.txt
+#    ... the e4m3 self-attention next to the bf16 flash kernel (q|k|v projection + attention per level; time against the workgroup count)
+#    and the bench line of config #5 with the bf16 attention kept (UDT_FP8_ATTN=0: the MX8 linears alone)
+(cd $R && python tools/bench_attn8.py 2>/dev/null | grep -v amdgpu.ids > $O/attn_mx8_layers.txt)
+(cd $R && python tools/attn_tail.py 2>/dev/null | grep "workgroups" > $O/attn_vs_workgroups.txt)
+(cd $R && UDT_FP8_ATTN=0 python bench.py --fp8 --no-cpu-baseline --no-reference-default 2>/dev/null | tail -1 > $O/bench_fp8_linears_only.json)
+jstamp $O/bench_fp8_linears_only.json
+stamp $O/mx8_layers.txt $O/trace_step_fp8.txt $O/attn_mx8_layers.txt $O/attn_vs_workgroups.txt
 stamp $O/in_flight_sweep.txt $O/phase_times.txt $O/gemm_shapes.txt $O/wide_conv.txt $O/trace_step.txt $O/bench_ops.txt $O/attn512.txt $O/rowres_bench.txt $O/tattn_bench.txt $O/reference_default.txt
 ls -la $O; cut -c1-400 $O/bench.json; cat $O/traffic.json | head -40; head -30 $O/mfma_util.json
