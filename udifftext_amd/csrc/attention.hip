@@ -496,9 +496,9 @@ __global__ void __launch_bounds__(256, 3) attn_d64_v2_kernel(const AttnParams p)
 // E8M0 scale per (token, 32 head dims), v was written with one fixed multiplier (q8_fixed_col / q8_fixed_mul) because P V contracts
 // over KEYS.  Per 64-key tile and wave (32 queries):
 //   S^T = K Q^T   : 2 x v_mfma_scale_f32_32x32x64_f8f6f4 (one per 32 keys; the 64 head dims are the instruction's two scale blocks)
-//   softmax       : as attn_d64_v2_kernel (fp32, deferred rescale: P <= 2^8)
-//   O^T += V^T P^T: 2 x the same instruction with unit scales (one per 32 output dims; the 64 keys of the tile are its K)
-// i.e. 4 matrix instructions of 64 cycles instead of 16 of 32, half the LDS bytes per fragment and per staged tile.
+//   softmax       : maxima in fp32 with the deferred rescale of attn_d64_v2_kernel; the numerators straight to e4m3 bytes (below)
+//   O^T += V^T P^T: 2 x the same instruction (one per 32 output dims; the 64 keys of the tile are its K) + 1 for the row sums
+// i.e. 5 matrix instructions of 64 cycles instead of 16 of 32, half the LDS bytes per fragment and per staged tile.
 // Two layout tricks make the operands fall into place (layouts measured by tools/probes/mx_*.cpp and tr_read_b8.cpp):
 //   * the K rows of a 32-key fragment are PERMUTED (fragment lane i holds key 16 ((i >> 2) & 1) + 4 (i >> 3) + (i & 3)), so that the
 //     16 scores a half-wave ends up with per 32-key tile are 16 CONSECUTIVE keys, in register order;
