@@ -255,8 +255,12 @@ __global__ void __launch_bounds__(256, 4) attn_d64_kernel(const AttnParams p) {
 //     P then stays <= 256, exact in fp32 and harmless for the bf16 P fragments — the normaliser l sees the same P);
 //   * MFMA groups run at raised wave priority (the other waves of the SIMD are in their softmax / read phases).
 // 48 KiB of LDS -> three workgroups per CU.
-constexpr int A2_STAGE = 2 * TILE_BYTES;     // K tile + V tile
-constexpr int A2_NST = 3;
+// LDS: a ring of THREE K tiles and a ring of TWO V tiles (40 KiB -> four workgroups per CU; round 5 — it was three stages of K | V
+// = 48 KiB and three workgroups): K is requested two tiles ahead, V one tile ahead (a V tile is not needed before the second half of
+// its step, and a step is longer than the DMA round trip).
+constexpr int A2_KRING = 3, A2_VRING = 2;
+constexpr int A2_VBASE = A2_KRING * TILE_BYTES;
+constexpr int A2_SMEM = (A2_KRING + A2_VRING) * TILE_BYTES;
 // cost attribution (measurement builds only: -DUDT_MEASURE -DA2_HALF_MFMA; WRONG results): HALF of the QK^T and P V MFMAs and of the
 // K / V fragment reads that feed them — what e4m3 K / V / P operands (v_mfma_scale_f32_32x32x64_f8f6f4: half the matrix-pipe time and
 // half the LDS bytes per tile) could save at most, with the softmax arithmetic unchanged (profiles/r05_attn_fp8_bound.txt)
@@ -267,7 +271,7 @@ constexpr int A2_KS = 4, A2_DT = 2;
 #endif
 constexpr float A2_DEFER = 8.0f;
 
-__global__ void __launch_bounds__(256, 3) attn_d64_v2_kernel(const AttnParams p) {
+__global__ void __launch_bounds__(256, 4) attn_d64_v2_kernel(const AttnParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem2[];
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -311,12 +315,14 @@ __global__ void __launch_bounds__(256, 3) attn_d64_v2_kernel(const AttnParams p)
     vvo[i] = (unsigned)(((long long)row * p.ldvt + koff) * 2);
   }
   const int kstep = KV_TILE * p.ldk * 2, vstep = KV_TILE * p.ldvt * 2;        // bytes per 64-key tile
-  auto stage = [&](int st, int kt) {
-    char* kbuf = smem2 + st * A2_STAGE;
-    char* vbuf = kbuf + TILE_BYTES;
+  auto stage_k = [&](int kt) __attribute__((always_inline)) {
+    char* kbuf = smem2 + (kt % A2_KRING) * TILE_BYTES;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, (__attribute__((address_space(3))) void*)(kbuf + (wave * 2 + i) * 1024), 16, kvo[i], kt * kstep, 0, 0);
+  };
+  auto stage_v = [&](int kt) __attribute__((always_inline)) {
+    char* vbuf = smem2 + A2_VBASE + (kt % A2_VRING) * TILE_BYTES;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (__attribute__((address_space(3))) void*)(vbuf + (wave * 2 + i) * 1024), 16, vvo[i], kt * vstep, 0, 0);
@@ -335,8 +341,8 @@ __global__ void __launch_bounds__(256, 3) attn_d64_v2_kernel(const AttnParams p)
 #pragma unroll
   for (int dt = 0; dt < 2; ++dt) {
     const int c = dt * 4 + tr_chunk;
-    voff_a[dt] = TILE_BYTES + tr_base + ((c ^ tr_swz) << 4);
-    voff_b[dt] = TILE_BYTES + tr_base + 1024 + ((c ^ tr_swz ^ 4) << 4);
+    voff_a[dt] = tr_base + ((c ^ tr_swz) << 4);                 // (relative to the V tile)
+    voff_b[dt] = tr_base + 1024 + ((c ^ tr_swz ^ 4) << 4);
   }
 
   f32x16 o_acc[2];
@@ -347,26 +353,26 @@ __global__ void __launch_bounds__(256, 3) attn_d64_v2_kernel(const AttnParams p)
   float m_run = -INFINITY, l_run = 0.f;
   const int ntiles = (p.nk + KV_TILE - 1) / KV_TILE;
   const float c = p.scale_log2e;
-  stage(0, 0);
-  if (ntiles > 1) stage(1, 1);
-  int st = 0;
+  // request order: K(0), V(0), K(1) | step kt: V(kt + 1), K(kt + 2) — at the top of step kt everything but the two youngest loads
+  // (K(kt + 1)) has to be there
+  stage_k(0);
+  stage_v(0);
+  if (ntiles > 1) stage_k(1);
+  int ks3 = 0;                                             // kt % 3
   for (int kt = 0; kt < ntiles; ++kt) {
-    if (kt + 1 < ntiles) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");       // the tile after this one stays in flight
+    if (kt + 1 < ntiles) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");       // K(kt + 1) stays in flight
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_s_barrier();                                               // every wave is past step kt - 1: its K and V tiles are free
     asm volatile("" ::: "memory");
-    if (kt + 2 < ntiles) {
-      int s2 = st + 2;
-      if (s2 >= A2_NST) s2 -= A2_NST;
-      stage(s2, kt + 2);
-    }
-    const char* buf = smem2 + st * A2_STAGE;
+    if (kt + 1 < ntiles) stage_v(kt + 1);
+    if (kt + 2 < ntiles) stage_k(kt + 2);
+    const char* buf = smem2 + ks3 * TILE_BYTES;            // this step's K tile
     unsigned tra[2], trb[2];                               // this tile's transposed-read addresses (lds_tr16_b64)
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt) {
-      tra[dt] = lds_offset(buf) + voff_a[dt];
-      trb[dt] = lds_offset(buf) + voff_b[dt];
+      tra[dt] = lds_offset(smem2) + A2_VBASE + (kt & 1) * TILE_BYTES + voff_a[dt];
+      trb[dt] = lds_offset(smem2) + A2_VBASE + (kt & 1) * TILE_BYTES + voff_b[dt];
     }
     f32x16 s[2];
 #pragma unroll
@@ -454,7 +460,7 @@ __global__ void __launch_bounds__(256, 3) attn_d64_v2_kernel(const AttnParams p)
       for (int dt = 0; dt < A2_DT; ++dt) o_acc[dt] = mfma32(__builtin_bit_cast(bf16x8_t, vv[dt]), pf, o_acc[dt]);
       __builtin_amdgcn_s_setprio(0);
     }
-    st = st + 1 == A2_NST ? 0 : st + 1;
+    ks3 = ks3 + 1 == A2_KRING ? 0 : ks3 + 1;
   }
   const float l_tot = half_swap_sum(l_run);
   const float inv = 1.0f / l_tot;
@@ -1198,7 +1204,7 @@ static int attn_fwd_impl(bool vrow, const void* q, const void* k, const void* vt
     // row-major V: the three-stage kernel; it addresses K / V through 31-bit buffer offsets
     if ((long long)nk * ldk * 2 >= (1LL << 31) || (long long)nk * ldvt * 2 >= (1LL << 31)) return UDT_ERR_BAD_SHAPE;
     static std::atomic<int> attr_done{0};
-    constexpr int smem = A2_NST * A2_STAGE;
+    constexpr int smem = A2_SMEM;
     if (!attr_done.load()) {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_d64_v2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
       if (e != hipSuccess) return udt_set_hip_error(e);
