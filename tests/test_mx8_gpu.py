@@ -342,6 +342,27 @@ def test_mx8_self_attention_vs_torch_on_the_same_quantised_operands(env, cuda, B
     assert _rel(out, ref) < REL_ATTN8_ONE_SIGN
 
 
+def test_fixed_scale_columns_must_be_whole_blocks(env, cuda):
+    """udt_gemm_q8_ok: a fixed-scale range that starts inside a 32-column block, a non-positive multiplier, or one on a launch that
+    does not emit, has no plan (the MX8 GEMM refuses it instead of writing a half-scaled block)"""
+    O, L = env.ops, env.lib_mod
+    import ctypes as C
+    M, K, N = 256, 128, 256
+    q, sc = mx8_ref.encode(torch.randn((M, K), device=cuda))
+    w = torch.randn((N, K), device=cuda) / math.sqrt(K)
+    wq, cs = env.packing.pack_linear_fp8(w)
+    out = torch.empty((M, N), dtype=torch.bfloat16, device=cuda)
+    q8 = O._mx8_alloc(M, N, cuda)
+
+    def ok(col, mul):
+        d = O.gemm_desc(a=q.data_ptr(), w=wq.data_ptr(), out=out.data_ptr(), M=M, N=N, K=K, lda=K, ldo=N, flags=L.GEMM_MX8,
+                        colscale=cs.data_ptr(), a_scale=sc.data_ptr(), q8_out=q8.data.data_ptr(), q8_scale=q8.scale.data_ptr(), ld_q8=N,
+                        q8_fixed_col=col, q8_fixed_mul=mul)
+        return bool(L.load().udt_gemm_q8_ok(C.byref(d)))
+    assert ok(0, 0.0) and ok(128, 32.0) and ok(160, 0.5)
+    assert not ok(136, 32.0) and not ok(128, 0.0) and not ok(128, -1.0)
+
+
 def test_mx8_self_attention_refuses_what_it_cannot_run(env, cuda):
     """status codes of the C entry, no launch: a row pitch below 3 C, an unaligned pitch, a missing scale array, v_inv <= 0"""
     data, scale, *_ = _qkv8(cuda, 1, 64, 2, seed=14)

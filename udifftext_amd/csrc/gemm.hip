@@ -811,6 +811,8 @@ bool lean_plan(const udt_gemm_desc* d, LeanPlan& t, bool want_stats) {
     if (mx8 && !geglu && ln && emit && d->rowstat_out) return false;
     if (emit && (want_stats || !d->q8_scale || d->ld_q8 % 8 != 0 || d->N % (geglu ? 64 : 32) != 0)) return false;
     if (d->rowstat_out && (!emit || geglu)) return false;
+    // (columns from q8_fixed_col on leave with a fixed multiplier and the unit scale byte: whole 32-column blocks, no GEGLU halves)
+    if (d->q8_fixed_col > 0 && (!emit || geglu || d->q8_fixed_col % 32 != 0 || !(d->q8_fixed_mul > 0.f))) return false;
     if ((reinterpret_cast<uintptr_t>(d->q8_out) | reinterpret_cast<uintptr_t>(d->colscale)) & 15) return false;
   } else if (d->rowstat_out || d->rowstat_in) {
     return false;
