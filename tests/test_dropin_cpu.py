@@ -269,3 +269,25 @@ def test_sd2_inpainting_key_map():
     assert all((".t_attn." in k or ".t_norm." in k) for k in missing if k.startswith("model.diffusion_model."))
     assert any(k.startswith("conditioner.embedders.0.") for k in missing)      # the LabelEncoder has its own checkpoint
     assert set(mapped) <= set(engine_keys)
+
+
+def test_config5_host_logic_fixed_v_multiplier_and_switches(monkeypatch):
+    """host side of BASELINE config #5 (no kernel runs): the data-free e4m3 multiplier of a layer's v projection is a power of two
+    that puts 448 at >= 12 sigma of the widest output row (+ its constant term) — and never above twice that; the e4m3 attention
+    is on only together with the MX8 linears and the LayerNorm-folded GEMMs."""
+    import math
+    import sgm.modules.hipnn as H
+    g = torch.Generator().manual_seed(5)
+    for scale, cmax in ((0.02, 0.0), (1.0, 0.3), (7.5, 40.0)):
+        w = torch.randn((192, 640), generator=g) * scale
+        c = (torch.rand((192,), generator=g) * 2 - 1) * cmax
+        m = H.v_fixed_mul(w, c)
+        bound = 12.0 * float(w.norm(dim=1).max()) + float(c.abs().max())
+        assert m == 2.0 ** round(math.log2(m)) and 224.0 < m * bound <= 448.0, (m, bound)
+    assert H.v_fixed_mul(torch.zeros((4, 8)), torch.zeros((4,))) > 0                      # (degenerate weights: finite, positive)
+    for fp8, ln, a8, want in ((True, True, True, True), (False, True, True, False), (True, False, True, False), (True, True, False, False)):
+        monkeypatch.setattr(H, "FP8_LINEARS", fp8)
+        monkeypatch.setattr(H, "LN_GEMM", ln)
+        monkeypatch.setattr(H, "FP8_ATTENTION", a8)
+        assert H.fp8_attention() is want
+        assert H.mx8_width(640) is (fp8 and ln) and H.mx8_width(320) is False
