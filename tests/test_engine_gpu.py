@@ -577,6 +577,47 @@ def test_predict_many_matches_predict(engine, cuda):
         _check(f"predict_many image of batch {i} vs predict", s_got.cpu(), s_ref.cpu(), 3e-2)
 
 
+@pytest.mark.parametrize("fp8", [False, True])
+def test_sample_alone_vs_inside_a_batch(engine, cuda, monkeypatch, fp8):
+    """What a sample's result owes to the batch it is computed in (bf16, and config #5: MX8 linears + e4m3 self-attention).  No value of
+    another sample enters it — GroupNorm / LayerNorm statistics, MX block scales and attention are per sample or per row, the e4m3 v
+    multiplier is per layer and data-free — and the same call twice is bit-identical.  But the batch size selects the launch PLANS:
+    8 x 4096 tokens run the row-resident LayerNorm-folded projections (their own GEGLU / fold arithmetic), 2 x 4096 the tiled
+    kernels; each is within the stated tolerance of the reference, and they differ from each other by a few 1e-4 per block, adding up
+    over the 35 blocks of a call to about the arithmetic's own distance from fp32 (tools/batch_dependence.py,
+    profiles/r05_batch_dependence.txt: the first convolution and ResBlock are bit-identical, the first transformer block brings 6e-4).
+    Stated: one call, a sample alone vs inside a batch of 4 (and of 2): bf16 2e-2 (measured 1.1e-2), config #5 6e-2 (3.1e-2)."""
+    import sgm.modules.hipnn as H
+    from udifftext_amd import synth
+    monkeypatch.setattr(H, "FP8_LINEARS", fp8)
+    monkeypatch.setattr(H, "FP8_ATTENTION", fp8)
+    torch.manual_seed(35)
+    B = 4
+    le = engine.conditioner.embedders[0]
+    ctx = le(synth.synthetic_batch(B, 512, 512, 9, seed=16)["label"])
+    x = torch.randn((B, 9, 64, 64), device=cuda)
+    unet = engine.model.diffusion_model
+
+    def call(idx):
+        n = len(idx)
+        xs = torch.cat([x[idx], x[idx]])
+        tc = torch.cat([torch.zeros_like(ctx[idx]), ctx[idx]])
+        return _sampler_call(unet, xs, torch.full((2 * n,), 441, device=cuda), tc, n)
+    tol = 6e-2 if fp8 else 2e-2
+    tag = "config #5" if fp8 else "bf16"
+    eps4, eps1 = call([0, 1, 2, 3]), call([2])
+    _check(f"{tag}: one sample alone vs inside a batch of 4 (one UNet call)", eps1.cpu(), eps4[[2, 6]].cpu(), tol)
+    assert torch.equal(call([2]), eps1), "the same call twice must be bit-identical"
+    eps2 = call([2, 3])
+    _check(f"{tag}: one sample alone vs inside a batch of 2 (one UNet call)", eps1.cpu(), eps2[[0, 2]].cpu(), tol)
+    # the other samples' VALUES do not matter: the batch of 4 with samples 0, 1, 3 replaced by noise gives sample 2 the same bits
+    keep = x.clone()
+    x[[0, 1, 3]] = torch.randn((3, 9, 64, 64), device=cuda)
+    eps4b = call([0, 1, 2, 3])
+    x.copy_(keep)
+    assert torch.equal(eps4b[[2, 6]], eps4[[2, 6]]), "a sample's result changed with the VALUES of its batch mates"
+
+
 def test_benchmarked_call_path_vs_oracle_bf16_and_fp8(engine, cuda):
     """EXACTLY the call the benchmark replays — sampling._Stepper.step's forward_nhwc: 64x64 latents, 8 samples (batch 4 with CFG),
     fused text cross-attention on folded tables, the unconditional half on the zero-context shortcut, no attention maps — against
