@@ -374,3 +374,43 @@ def test_mx8_self_attention_refuses_what_it_cannot_run(env, cuda):
     assert call() == 0
     assert call(ld8=368) == -1 and call(ld8=392) == -1 and call(n=0) == -1
     assert call(sc=None) == -2 and call(v_inv=0.0) == -2
+
+
+def test_mx8_self_attention_properties_at_full_size(env, cuda):
+    """size-independent properties at the benchmarked size (8 samples x 4096 tokens x 5 heads: no torch reference of 2.7 GB of scores):
+    (1) the denominator is the sum of exactly the numerators the P V product uses: with v CONSTANT along the keys (a different
+        e4m3-exact constant per head dim) every output row equals those constants to one bf16 rounding, whatever q and k are;
+    (2) attention does not care about the ORDER of the keys: k and v rows permuted together give the same output up to the rounding
+        steps that depend on tile order (deferred maximum -> the exponent of a probability's byte, fp32 summation order);
+    (3) samples are independent: sample 3 alone gives the same bits as inside the batch of 8."""
+    O = env.ops
+    B, N, heads = 8, 4096, 5
+    C = heads * 64
+    data, scale, *_ = _qkv8(cuda, B, N, heads, seed=21, sharp=2.0)
+    consts = ((torch.arange(C, device=cuda) % 8 + 1).float() / 4.0)                    # 0.25 .. 2.0: x 32 = 8 .. 64, exact in e4m3
+    vconst = (consts * V_MUL).to(torch.float8_e4m3fn).view(torch.uint8)
+    d1 = data.clone()
+    d1[:, 2 * C:] = vconst[None, :]
+    out = O.attention_mx8(O.Mx8Act(d1, scale), B, heads, 0.125, V_MUL)
+    err = (out.float() - consts[None, None, :]).abs() / consts[None, None, :]
+    assert float(err.max()) <= 2.0 ** -8, float(err.max())
+    # (2) (v of one sign: with zero-mean v the output is a cancelling sum that carries the probabilities' rounding noise in full, and a
+    #      different key order is a fresh realisation of it — REL_ATTN8 times sqrt 2)
+    data, scale, *_ = _qkv8(cuda, B, N, heads, seed=22, sharp=2.0, one_sign=True)
+    out0 = O.attention_mx8(O.Mx8Act(data, scale), B, heads, 0.125, V_MUL)
+    perm = torch.randperm(N, device=cuda)
+    rows = (torch.arange(B, device=cuda)[:, None] * N + perm[None, :]).reshape(-1)
+    d2 = data.clone()
+    d2[:, C:] = data[rows][:, C:]                                                     # k and v of every sample in permuted key order
+    s2 = scale.clone()
+    kb = C // 128                                                                      # dwords that hold k's scale bytes: blocks [C/32, 2C/32)
+    # a scale dword holds 4 blocks and q's / k's blocks may share one (C = 320: block 10 starts mid-dword): move k's BYTES
+    sb = scale.view(torch.uint8).reshape(scale.shape[0], B * N, 4).permute(1, 0, 2).reshape(B * N, -1).clone()      # [row, block]
+    sb2 = sb.clone()
+    sb2[:, C // 32:2 * C // 32] = sb[rows][:, C // 32:2 * C // 32]
+    s2 = sb2.reshape(B * N, scale.shape[0], 4).permute(1, 0, 2).contiguous().view(torch.int32).reshape(scale.shape)
+    out2 = O.attention_mx8(O.Mx8Act(d2, s2), B, heads, 0.125, V_MUL)
+    assert _rel(out2, out0) < 1.5 * REL_ATTN8_ONE_SIGN, _rel(out2, out0)
+    # (3)
+    one = O.attention_mx8(O.Mx8Act(data[3 * N:4 * N].contiguous(), scale[:, 3 * N:4 * N].contiguous()), 1, heads, 0.125, V_MUL)
+    assert torch.equal(one[0], out0[3])
