@@ -236,6 +236,7 @@ def main():
     if world > 1 or os.environ.get("UDT_BENCH_FORCE_DIST"):     # (the env switch exercises the RCCL path on a 1-GPU box)
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(args.master_port or 29541))     # (set by torchrun; the forced one-rank world has none)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     import udifftext_amd  # noqa: F401
