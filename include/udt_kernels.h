@@ -145,10 +145,11 @@ typedef struct {
   const void* a_scale;     /* UDT_GEMM_MX8: the block scales of `a`                                                     */
   void* q8_out;            /* optional second output: the result (after bias / residual / GEGLU, as rounded for `out`) again
                               as an MX8 activation for the next GEMM; `out` may then be NULL.  Lean
-                              128 x 128 plans only (udt_gemm_rowstat_parts > 0), N % 32 == 0 (GEGLU: N % 64 == 0)         */
+                              128 x 128 plans and the row-resident LayerNorm-folded K = 320 plan only (udt_gemm_q8_ok), N % 32 == 0
+                              (GEGLU: N % 64 == 0)                                                                         */
   void* q8_scale;          /* its block scales (see above)                                                               */
   int32_t ld_q8;           /* bytes between rows of q8_out (% 8 == 0)                                                    */
-  int32_t q8_fixed_col;    /* 0 = off; else result columns >= q8_fixed_col (a multiple of 32) are written as e4m3(value * q8_fixed_mul),
+  int32_t q8_fixed_col;    /* 0 = off; else result columns >= q8_fixed_col (a multiple of 32; 64 on the row-resident plan) are written as e4m3(value * q8_fixed_mul > 0),
                               clamped to +-448, with the unit scale byte 127 instead of block scales: the v third of a q|k|v
                               projection feeding udt_attn_mx8_fwd, whose P V product contracts over keys                        */
   float q8_fixed_mul;
