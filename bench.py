@@ -67,6 +67,8 @@ def parse():
     ap.add_argument("--cpu-config1", action="store_true", help="the CPU baseline also runs BASELINE config #1 in full (256x256, 10 steps: "
                     "minutes of host time; off by default so that the bench command stays a few minutes long)")
     ap.add_argument("--no-mode-table", action="store_true", help="skip the extra passes in the other launch modes")
+    ap.add_argument("--no-extra-configs", action="store_true", help="skip the short BASELINE config #5 (--fp8) and config #4 (768x768, "
+                    "batch 8, 12 characters) passes that the default single-GPU config-#2 run appends under `config5` / `config4`")
     ap.add_argument("--in-flight", type=int, default=3, help="batches sampled concurrently per GPU, one launch stream each "
                     "(same-box on MI355X: 1 -> 5.7, 2 -> 7.13, 3 -> 7.67, 4 -> 6.0 images/s)")
     ap.add_argument("--fp8", action="store_true", help="BASELINE config #5 arithmetic: every linear of the 640- / 1280-channel "
@@ -111,9 +113,9 @@ def physical_cores() -> int:
 
 def cpu_baseline(size: int, chars: int, sampler_steps: int, config1: bool = False) -> dict:
     """time the CPU oracle on a bounded sample IN ITS OWN PROCESS (oracle/cpu_bench.py): one thread per physical core, bound
-    (OMP_PROC_BIND=close, OMP_PLACES=cores — set before the child's OpenMP runtime starts), nothing else in the process, warm runs
-    in front of every timed item, the UNet call timed in two rounds that are both reported.  At the bench resolution: 2 x 2 UNet
-    calls on one CFG pair, LabelEncoder, 1 VAE encode, 1 VAE decode, extrapolated to sampler_steps UNet calls per image (every
+    (OMP_PROC_BIND=close, OMP_PLACES=cores — set before the child's OpenMP runtime starts), nothing else in the process, a warm run
+    in front of the UNet call and the LabelEncoder (the VAE passes, < 1 % of the per-image time, are timed cold), the UNet call timed
+    twice, both reported.  At the bench resolution: 1 + 2 UNet calls on one CFG pair, LabelEncoder, 1 VAE encode, 1 VAE decode, extrapolated to sampler_steps UNet calls per image (every
     step costs the same); --cpu-config1 adds BASELINE config #1 in full (minutes)."""
     import subprocess
     n = physical_cores()
@@ -127,6 +129,35 @@ def cpu_baseline(size: int, chars: int, sampler_steps: int, config1: bool = Fals
     if r.returncode != 0 or not lines:
         return {"value": None, "unit": "images/s", "cores": n, "kind": "port", "sample": "oracle/cpu_bench.py failed: " + r.stderr[-300:]}
     return json.loads(lines[-1])
+
+
+def extra_config(flags: list, steps: int, warmup: int, value_bf16: float | None = None) -> dict:
+    """one more BASELINE config on this box, right after the main line's timed region: THIS script in a process of its own (the same
+    code path as a direct `python bench.py <flags>` run: own engine, own hipGraphs, same barriers around exactly `steps` timed steps),
+    reduced to the keys that identify the workload and its numbers.  Reported beside `value`, never as it."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", str(steps), "--warmup", str(warmup), "--no-cpu-baseline",
+           "--no-reference-default", "--no-mode-table", "--no-extra-configs"] + flags
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "UDT_BENCH_FORCE_DIST")}
+    t0 = time.perf_counter()
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, cwd=ROOT)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    if r.returncode != 0 or not lines:
+        return {"value": None, "error": "bench.py " + " ".join(flags) + " failed: " + r.stderr[-300:]}
+    d = json.loads(lines[-1])
+    out = {k: d[k] for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "dtype", "unet_ms_per_sampler_step") if k in d}
+    out["workload"] = d["config"]["workload"]
+    out["flags"] = " ".join(flags)
+    out["roofline_classes"] = dict({"conv3x3": {k: d["roofline"][k] for k in ("achieved", "frac", "launches", "avg_launch_us")}},
+                                   **{n: {k: c[k] for k in ("achieved", "frac", "launches", "avg_launch_us")} for n, c in d["roofline_classes"].items()})
+    out["whole_path_frac_of_peak"] = d["roofline"]["whole_path_frac_of_peak"]
+    if d["roofline"].get("whole_path_frac_of_fp8_peak") is not None:
+        out["whole_path_frac_of_fp8_peak"] = d["roofline"]["whole_path_frac_of_fp8_peak"]
+    if value_bf16:
+        out["ratio_to_value"] = d["value"] / value_bf16
+        out["ratio_note"] = "this pass's images/s over the main line's bf16 `value`: same box, same steps / warm-up, back to back"
+    out["wall_s"] = time.perf_counter() - t0
+    return out
 
 
 def self_launch(args) -> int:
@@ -446,6 +477,8 @@ def main():
                      "whole_path_frac_of_fp8_peak": (value * fpi / (world * 2 * PEAK_BF16)) if args.fp8 else None})
         cfg_id = ("BASELINE.json configs[1]" if (args.size, args.batch, args.chars, args.sampler_steps, G, args.fp8) == (512, 4, 9, 50, 4 * world, False)
                   else "BASELINE.json configs[4]" if (args.fp8 and (args.size, args.sampler_steps, G, world) == (512, 50, 32, 8))
+                  else ("BASELINE.json configs[4] arithmetic (fp8 MFMA attention / linear path), per-GPU share: batches of 4 of the 32 images "
+                        "that config shards over 8 GPUs, on %d GPU(s)" % world) if (args.fp8 and (args.size, args.batch, args.sampler_steps) == (512, 4, 50))
                   else "BASELINE.json configs[2]" if (args.size, args.sampler_steps, G, world) == (512, 50, 64, 8)
                   else "BASELINE.json configs[3]" if (args.size, args.batch, args.chars, args.sampler_steps) == (768, 8, 12, 50)
                   else "non-baseline shape")
@@ -492,6 +525,11 @@ def main():
                                                  if args.fp8 and Hnn_fp8_attention() else "attn_d64_v2_kernel (UNet self-attention, head_dim 64)")
                                  + " + attn_d512_q64_kernel (VAE mid block, one head of 512)", attn_flops, attn_bytes, attn_ms, attn_launches)},
         }
+        if world == 1 and not args.no_extra_configs and cfg_id == "BASELINE.json configs[1]":
+            # the other single-GPU configurations of BASELINE.json on the same box, back to back with the line above (the GPU is idle
+            # here: this process only holds memory); `value` stays config #2
+            line["config5"] = extra_config(["--fp8"], args.steps, args.warmup, value)
+            line["config4"] = extra_config(["--size", "768", "--batch", "8", "--chars", "12"], 3, 1)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.size, args.chars, args.sampler_steps, config1=args.cpu_config1)
         print(json.dumps(line), flush=True)

@@ -3,11 +3,14 @@
 Round 4's baseline ran inside the benchmark process (HIP runtime helper threads alive, torch's default of one intra-op thread
 per LOGICAL core, unbound) and gave 52 s on one lease and 190 s on the driver's for the same work.  Here the parent sets
 OMP_NUM_THREADS to the physical cores, OMP_PROC_BIND=close / OMP_PLACES=cores before this interpreter starts, nothing else
-runs in the process, every timed item has a warm run in front of it, and the timed UNet call is repeated in two rounds whose
-times are both reported (``unet_call_s``): the same box should now give the same number twice.
+runs in the process, the UNet call (99.5 % of the per-image time) and the LabelEncoder have a warm run in front of them, and the
+timed UNet call is repeated in two rounds whose times are both reported (``unet_call_s``): the same box should now give the same
+number twice.  The VAE encode / decode are timed ONCE, cold (first-touch allocation and primitive creation included): together
+they are < 1 % of the extrapolated per-image time, a warm run of each would cost more host seconds than it corrects.
 
-Sample (bounded, ~10-30 s of CPU work on the GPU box's host): at the bench resolution — LabelEncoder, 1 VAE encode, 2 x 2 warm
-UNet calls on one CFG pair, 1 VAE decode; extrapolated to ``sampler_steps`` UNet calls per image (every step costs the same).
+Sample (bounded, ~10-30 s of CPU work on the GPU box's host): at the bench resolution — LabelEncoder, 1 VAE encode (cold), 1 warm-up
++ 2 timed UNet calls on one CFG pair (round 6: two rounds of ONE call, was two of two — the bench command also runs configs #5 / #4
+now), 1 VAE decode (cold); extrapolated to ``sampler_steps`` UNet calls per image (every step costs the same).
 ``--config1``: additionally BASELINE config #1 in full (256x256, 10 steps, 4 characters: ~1-3 minutes).
 
 Weights: the name-keyed synthetic recipe (udifftext_amd/synth.py) generated here from oracle.spec's shape list — the same
@@ -62,9 +65,8 @@ def main() -> None:
         rounds = []
         for _ in range(2):
             t0 = time.time()
-            for _ in range(2):
-                nets.unet_forward(sd, xin, ts, tctx, cfg.unet)
-            rounds.append((time.time() - t0) / 2)
+            nets.unet_forward(sd, xin, ts, tctx, cfg.unet)
+            rounds.append(time.time() - t0)
         t_unet = min(rounds)
         pre = "conditioner.embedders.2.model." if any(k.startswith("conditioner.embedders.2.model.") for k in sd) else "first_stage_model."
         t0 = time.time(); nets.vae_encode_moments(sd, batch["masked"], cfg.vae, pre); t_enc = time.time() - t0
@@ -81,8 +83,8 @@ def main() -> None:
            "unet_call_s": [round(r, 4) for r in rounds], "vae_encode_s": round(t_enc, 4), "vae_decode_s": round(t_dec, 4),
            "label_encoder_s": round(t_label, 4), "weights_generated_s": round(t_weights, 1),
            "sample": f"oracle (fp32 torch CPU, own process, {torch.get_num_threads()} threads bound close to cores): at {size}x{size}: "
-                     f"2 rounds of 2 warm UNet calls on one CFG pair ({rounds[0]:.2f} / {rounds[1]:.2f} s per call, the faster round "
-                     f"counts), 1 VAE encode ({t_enc:.2f} s), 1 VAE decode ({t_dec:.2f} s), LabelEncoder ({t_label:.2f} s); "
+                     f"2 warm UNet calls on one CFG pair, timed one by one ({rounds[0]:.2f} / {rounds[1]:.2f} s, the faster "
+                     f"counts), 1 VAE encode ({t_enc:.2f} s, cold), 1 VAE decode ({t_dec:.2f} s, cold), LabelEncoder ({t_label:.2f} s, warm); "
                      f"extrapolated to {args.sampler_steps} UNet calls per image"}
     if t_c1 is not None:
         out["config1_full_run_s"] = t_c1

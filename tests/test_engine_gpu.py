@@ -35,10 +35,23 @@ def _check(name, got, ref, rel_rms, rel_max=None):
     r, m = _metrics(got, ref)
     os.makedirs(os.path.dirname(REPORT), exist_ok=True)
     with open(REPORT, "a") as f:
-        f.write(f"{name:55s} rel_rms {r:.3e} (tol {rel_rms:.0e})  rel_max {m:.3e}\n")
+        f.write(f"{name:55s} rel_rms {r:.3e} (tol {rel_rms:.1e})  rel_max {m:.3e}\n")
     assert r <= rel_rms, f"{name}: rel_rms {r:.3e} > {rel_rms}"
     if rel_max is not None:
         assert m <= rel_max, f"{name}: rel_max {m:.3e} > {rel_max}"
+
+
+# Config #5 (MX8 linears + e4m3 self-attention) — the stated tolerance is DERIVED, not chosen (round 6):
+#   * one e4m3 operand with a power-of-two block scale carries 2.7 % relative rms error (3 mantissa bits; tests/test_mx8_gpu.py measures
+#     it), an activation x weight product 2.7 % x sqrt(2) = 3.8 %; in a K-term dot product of zero-mean terms the independent errors add
+#     like the terms do, so an MX8 GEMM's output carries ~3.8 % whatever K is (test_mx8_linear_vs_torch...: 3.5-3.9e-2 vs unquantised);
+#   * what that does to one UNet call is computed on the CPU: tests/error_budget.py injects exactly these roundings into the fp32 oracle
+#     (flag L8: the five linears of every 640- / 1280-channel transformer block in their LayerNorm-folded form; A8: the e4m3 attention)
+#     on the G7 call -> 3.96e-2 (linears alone), 4.19e-2 with every bf16 rounding of the HIP path and the e4m3 attention on top
+#     (profiles/r06_error_budget.txt).
+#   Stated: 1.45 x that prediction = 6e-2, for one call AND for the 50-step trajectory (the error must not grow along it).
+#   Measured on MI355X: 4.0-4.4e-2 per call, 3.7-3.8e-2 on the trajectory (profiles/r06_parity_report.txt).
+TOL_CFG5 = 6e-2
 
 
 @pytest.fixture(scope="module")
@@ -166,9 +179,9 @@ def test_unet_call_fp8_linears_vs_reference_golden(engine, cond256, eg, cuda):
     """BASELINE config #5's arithmetic (UDT_FP8=1, second generation): every linear of the 640- / 1280-channel transformer blocks
     on MX8 operands (e4m3 weights with per-channel scales, e4m3 activations with E8M0 block scales written by the producers'
     epilogues, fp32 accumulation), through the call path of the sampling loop (fused text cross-attention, zero-context shortcut
-    for the unconditional sample).  Stated tolerance against the fp32 reference golden: rel_rms <= 8e-2 (e4m3 keeps 3 mantissa
+    for the unconditional sample).  Stated tolerance against the fp32 reference golden: rel_rms <= TOL_CFG5 = 6e-2 (derived above; e4m3 keeps 3 mantissa
     bits: each quantised product carries ~3.6 % error, tests/test_mx8_gpu.py; bf16 path: 2e-2 stated / 1.4e-2 measured); the
-    eps must also stay within 8e-2 of the bf16 path."""
+    eps must also stay within that of the bf16 path.  The e4m3 attention is switched OFF here (hipnn.FP8_ATTENTION = False, asserted through the launch counter): this is the linears-only leg."""
     import sgm.modules.hipnn as H
     from udifftext_amd import ops
     batch, _, _ = cond256
@@ -181,25 +194,33 @@ def test_unet_call_fp8_linears_vs_reference_golden(engine, cond256, eg, cuda):
     unet = engine.model.diffusion_model
     ref_bf16 = _sampler_call(unet, xin, ts, tctx, 1)
     _check("UNet eps on the sampling loop's call path (bf16) vs reference", ref_bf16.cpu(), eg["g7_eps"], 2e-2, 8e-2)
-    prev = H.FP8_LINEARS
-    H.FP8_LINEARS = True
+    prev, prev_a8 = H.FP8_LINEARS, H.FP8_ATTENTION
+    H.FP8_LINEARS, H.FP8_ATTENTION = True, False
     try:
         ops.WORK_COUNTER = {}
         eps = _sampler_call(unet, xin, ts, tctx, 1)
         n8 = ops.WORK_COUNTER.get("gemm_fp8_launches", 0)
+        assert ops.WORK_COUNTER.get("attn_fp8_launches", 0) == 0 and ops.WORK_COUNTER.get("attn_launches", 0) == 16
         ops.WORK_COUNTER = {}
         eps_ref_sig = unet(xin, timesteps=ts, t_context=tctx)        # the reference signature: map-emitting xattn chain, bf16 feed-forward
         n8_ref_sig = ops.WORK_COUNTER.get("gemm_fp8_launches", 0)
+        assert ops.WORK_COUNTER.get("attn_fp8_launches", 0) == 0
+        H.FP8_ATTENTION = True                                       # the complete config #5: + attn1 on e4m3 operands
+        ops.WORK_COUNTER = {}
+        eps_a8 = _sampler_call(unet, xin, ts, tctx, 1)
+        assert ops.WORK_COUNTER.get("attn_fp8_launches", 0) == 16 and ops.WORK_COUNTER.get("attn_launches", 0) == 0
         ops.WORK_COUNTER = None
     finally:
-        H.FP8_LINEARS = prev
+        H.FP8_LINEARS, H.FP8_ATTENTION = prev, prev_a8
     # 10 transformer blocks of width 640 / 1280 x (q|k|v, to_out, GEGLU, ff.net[2], proj_out) + the middle block, whose 4 x 4 map
     # (16 tokens per sample) is below the fused text cross-attention's token tile: unfused t_attn, bf16 feed-forward and proj_out
     assert n8 == 10 * 5 + 2, f"{n8} MX8 GEMM launches on the sampling loop's call path"
     assert n8_ref_sig == 11 * 2, f"{n8_ref_sig} MX8 GEMM launches through the reference signature (q|k|v, to_out)"
-    _check("UNet eps with MX8 linears (config #5 arithmetic) vs reference", eps.cpu(), eg["g7_eps"], 8e-2)
-    _check("UNet eps with MX8 linears vs the bf16 path", eps.cpu(), ref_bf16.cpu(), 8e-2)
-    _check("UNet eps with MX8 linears through unet(x, t, ctx) vs reference", eps_ref_sig.cpu(), eg["g7_eps"], 8e-2)
+    _check("UNet eps with MX8 linears ONLY (bf16 attention) vs reference", eps.cpu(), eg["g7_eps"], TOL_CFG5)
+    _check("UNet eps with MX8 linears ONLY vs the bf16 path", eps.cpu(), ref_bf16.cpu(), TOL_CFG5)
+    _check("UNet eps with MX8 linears ONLY through unet(x, t, ctx) vs reference", eps_ref_sig.cpu(), eg["g7_eps"], TOL_CFG5)
+    _check("UNet eps with MX8 linears + e4m3 attention (config #5) vs reference", eps_a8.cpu(), eg["g7_eps"], TOL_CFG5)
+    assert not torch.equal(eps_a8, eps), "the e4m3 attention leg ran the bf16 attention"
 
 
 def test_zero_context_shortcut_is_bit_exact(engine, cond256, cuda):
@@ -621,7 +642,7 @@ def test_sample_alone_vs_inside_a_batch(engine, cuda, monkeypatch, fp8):
 def test_benchmarked_call_path_vs_oracle_bf16_and_fp8(engine, cuda):
     """EXACTLY the call the benchmark replays — sampling._Stepper.step's forward_nhwc: 64x64 latents, 8 samples (batch 4 with CFG),
     fused text cross-attention on folded tables, the unconditional half on the zero-context shortcut, no attention maps — against
-    the fp32 CPU oracle on 2 + 2 of the samples: the bf16 path (stated 2e-2) and config #5's MX8 linears (stated 8e-2 against the
+    the fp32 CPU oracle on 2 + 2 of the samples: the bf16 path (stated 2e-2) and config #5's MX8 linears, without and with the e4m3 attention (stated TOL_CFG5 = 6e-2 against the
     reference arithmetic and against the bf16 path).  ``unet(x, t, ctx)`` — what the other single-call tests go through — takes the
     map-emitting xattn chain instead of this path."""
     import sgm.modules.hipnn as H
@@ -638,14 +659,15 @@ def test_benchmarked_call_path_vs_oracle_bf16_and_fp8(engine, cuda):
     ops.WORK_COUNTER = {}
     ref_bf16 = _sampler_call(unet, x, ts, tctx, B)
     assert ops.WORK_COUNTER.get("gemm_fp8_launches", 0) == 0
-    prev = H.FP8_LINEARS
-    H.FP8_LINEARS = True
+    prev, prev_a8 = H.FP8_LINEARS, H.FP8_ATTENTION
+    H.FP8_LINEARS, H.FP8_ATTENTION = True, False             # the linears-only leg: attn1 stays on the bf16 flash kernel
     try:
         ops.WORK_COUNTER = {}
         eps = _sampler_call(unet, x, ts, tctx, B)
         n8 = ops.WORK_COUNTER.get("gemm_fp8_launches", 0)
+        assert ops.WORK_COUNTER.get("attn_fp8_launches", 0) == 0 and ops.WORK_COUNTER.get("attn_launches", 0) == 16
     finally:
-        H.FP8_LINEARS = prev
+        H.FP8_LINEARS, H.FP8_ATTENTION = prev, prev_a8
         ops.WORK_COUNTER = None
     assert n8 == 11 * 5, f"{n8} MX8 GEMM launches"
     # ... and with attn1's Q K^T / P V on e4m3 operands too (hipnn.FP8_ATTENTION): all 16 blocks, the 320-channel level included
@@ -665,10 +687,11 @@ def test_benchmarked_call_path_vs_oracle_bf16_and_fp8(engine, cuda):
     with torch.no_grad():
         ref = nets.unet_forward(sd, x[pick].cpu(), ts[pick].cpu(), tctx[pick].float().cpu(), spec.EngineConfig().unet)
     _check("benchmarked call path (fused t_attn, zero-context rows) bf16 vs oracle", ref_bf16[pick].cpu(), ref, 2e-2, 8e-2)
-    _check("benchmarked call path with MX8 linears vs oracle", eps[pick].cpu(), ref, 8e-2)
-    _check("benchmarked call path with MX8 linears vs the bf16 path", eps.cpu(), ref_bf16.cpu(), 8e-2)
-    _check("benchmarked call path with MX8 linears + e4m3 attention vs oracle", eps_a8[pick].cpu(), ref, 8e-2)
-    _check("benchmarked call path with MX8 linears + e4m3 attention vs the bf16 path", eps_a8.cpu(), ref_bf16.cpu(), 8e-2)
+    _check("benchmarked call path with MX8 linears ONLY (bf16 attention) vs oracle", eps[pick].cpu(), ref, TOL_CFG5)
+    _check("benchmarked call path with MX8 linears ONLY vs the bf16 path", eps.cpu(), ref_bf16.cpu(), TOL_CFG5)
+    _check("benchmarked call path with MX8 linears + e4m3 attention vs oracle", eps_a8[pick].cpu(), ref, TOL_CFG5)
+    _check("benchmarked call path with MX8 linears + e4m3 attention vs the bf16 path", eps_a8.cpu(), ref_bf16.cpu(), TOL_CFG5)
+    assert not torch.equal(eps_a8, eps), "the two config-#5 legs ran the same attention"
 
 
 def test_fixed_scale_of_v_in_the_e4m3_attention_neither_saturates_nor_wastes_its_range(engine, cuda, monkeypatch):
@@ -711,8 +734,8 @@ def test_fixed_scale_of_v_in_the_e4m3_attention_neither_saturates_nor_wastes_its
 def test_config2_512_fifty_steps_with_fp8_linears_vs_reference_golden(engine, cuda, monkeypatch, attn8):
     """config #5's arithmetic over a whole trajectory: BASELINE config #2's image (512x512, 9 characters, CFG 5) through 50 Euler
     steps with the MX8 linears, against the REAL reference's latents after 10 / 25 / 50 steps (engine_golden_512.npz).  Stated
-    tolerance: rel_rms <= 8e-2 at every horizon (bf16: 3e-2 stated / 1.2e-2 measured) — the e4m3 error of one call must not grow
-    along the trajectory; decoded image <= 8e-2."""
+    tolerance: rel_rms <= TOL_CFG5 = 6e-2 at every horizon (bf16: 3e-2 stated / 1.2e-2 measured) — the e4m3 error of one call must not grow
+    along the trajectory; decoded image <= 6e-2."""
     import sgm.modules.hipnn as H
     from udifftext_amd import config as C, pipeline, synth
     g12 = np.load(os.path.join(GOLD, "engine_golden_512.npz"))
@@ -735,13 +758,13 @@ def test_config2_512_fifty_steps_with_fp8_linears_vs_reference_golden(engine, cu
     for i in range(50):
         st.step(z, sig[i], sig[i + 1])
         if i + 1 in (10, 25, 50):
-            _check(f"512x512 with MX8 linears{tag}: latent after {i + 1} steps vs reference", z.cpu(), g12[f"g12_latent_{i + 1}"], 8e-2)
+            _check(f"512x512 with MX8 linears{tag}: latent after {i + 1} steps vs reference", z.cpu(), g12[f"g12_latent_{i + 1}"], TOL_CFG5)
     st.check()
     # (the sampler's own entry point, hipGraph replay included, must give the same trajectory)
     z2 = sampler(engine, x0.clone(), cond=c, batch=batch, uc=uc)
     _check(f"512x512 with MX8 linears{tag}: graph-replayed sampler vs eager steps", z2.cpu(), z.cpu(), 1e-6)
     dec = engine.decode_first_stage(z)
-    _check(f"512x512 with MX8 linears{tag}: decoded image of the 50-step latent vs reference", dec[:, :, ::8, ::8].cpu(), g12["g12_decoded_sub"], 8e-2)
+    _check(f"512x512 with MX8 linears{tag}: decoded image of the 50-step latent vs reference", dec[:, :, ::8, ::8].cpu(), g12["g12_decoded_sub"], TOL_CFG5)
 
 
 def test_noise_search_at_benchmarked_latent_size_vs_oracle(engine, cuda):
@@ -881,7 +904,7 @@ def test_checkpoint_load_prepare_free_masters_matches_goldens(engine, cond256, e
         H.FP8_LINEARS = prev_fp8
         ops.WORK_COUNTER = None
     assert n8 == 52
-    _check("ckpt -> prepare(free_masters): UNet eps with MX8 linears vs reference", eps8.cpu(), eg["g7_eps"], 8e-2)
+    _check("ckpt -> prepare(free_masters): UNet eps with MX8 linears vs reference", eps8.cpu(), eg["g7_eps"], TOL_CFG5)
     sampler = pipeline.init_sampling(10, 5.0, cuda)
     cfgs = C.default_runtime_config(steps=10, batch_size=1, noise_iters=0)
     torch.manual_seed(99)

@@ -274,6 +274,33 @@ def test_qkv_projection_of_the_row_resident_kernel_emits_mx8_with_a_fixed_scale_
     assert torch.equal(q8b.data, q8.data) and torch.equal(q8b.scale[: 2 * C // 128], q8.scale[: 2 * C // 128])
 
 
+@pytest.mark.parametrize("M", [520, 264, 300, 8192 + 40])
+def test_row_resident_emitting_kernel_with_ragged_last_tile_is_repeatable(env, cuda, M):
+    """round 6 (ADVICE): the emitting epilogue's stores sit under the row predicate, so a wave whose 64 rows are partly / wholly past
+    M issues fewer of them; its `vmcnt` count at the chunk barrier must not assume the full 16 (it would let the other waves read a
+    weight chunk whose LDS-DMA has not landed).  The rows of the ragged tile against the same rows computed inside a FULL tile (the
+    kernel is row-independent), many times over, while a second stream keeps the memory system busy."""
+    C = 320
+    g = torch.Generator(device="cpu").manual_seed(21)
+    Mfull = ((M + 255) // 256) * 256
+    x = (torch.randn((Mfull, C), generator=g).to(cuda) + 0.3).bfloat16()
+    w = (torch.randn((3 * C, C), generator=g) / math.sqrt(C)).to(cuda)
+    gamma = (1.0 + 0.2 * torch.randn((C,), generator=g)).to(cuda)
+    beta = (0.1 * torch.randn((C,), generator=g)).to(cuda)
+    wp, c, s = env.packing.pack_ln_linear(w, None, gamma, beta)
+    ref = env.ops.ln_linear(x, wp, c, s, emit_q8=True, want_bf16=False, q8_fixed=(2 * C, V_MUL))
+    xr = x[:M].contiguous()
+    noise = torch.empty((64 << 20,), device=cuda, dtype=torch.uint8)
+    side = torch.cuda.Stream()
+    for it in range(12):
+        with torch.cuda.stream(side):
+            noise.add_(1)                                  # (competing traffic: delays the LDS-DMA of the kernel under test)
+        q8 = env.ops.ln_linear(xr, wp, c, s, emit_q8=True, want_bf16=False, q8_fixed=(2 * C, V_MUL))
+        assert torch.equal(q8.data, ref.data[:M]), it
+        assert torch.equal(q8.scale[: 2 * C // 128, :M], ref.scale[: 2 * C // 128, :M]), it     # (whole dwords of q and k)
+    torch.cuda.synchronize()
+
+
 @pytest.mark.parametrize("M,C", [(2048, 640), (520, 1280), (2048, 1280)])
 def test_mx8_layernorm_folded_qkv_projection_emits_mx8_with_a_fixed_scale_v(env, cuda, M, C):
     """the same at the 640 / 1280-channel levels: MX8 in (the block's producer), MX8 out (for the e4m3 attention)"""

@@ -4,9 +4,9 @@ R=$GRAFT_REPO_ROOT; [ -z "$R" ] && R=/root/repo
 O=$R/gpurun_out/${1:-ab_fp8}; shift
 mkdir -p $O
 cd $R
-python bench.py --no-cpu-baseline --no-reference-default "$@" 2>/dev/null | tail -1 > $O/bench_bf16.json
-python bench.py --fp8 --no-cpu-baseline --no-reference-default "$@" 2>/dev/null | tail -1 > $O/bench_fp8.json
-UDT_FP8_ATTN=0 python bench.py --fp8 --no-cpu-baseline --no-reference-default "$@" 2>/dev/null | tail -1 > $O/bench_fp8_linears_only.json
+python bench.py --no-cpu-baseline --no-extra-configs --no-reference-default "$@" 2>/dev/null | tail -1 > $O/bench_bf16.json
+python bench.py --fp8 --no-cpu-baseline --no-extra-configs --no-reference-default "$@" 2>/dev/null | tail -1 > $O/bench_fp8.json
+UDT_FP8_ATTN=0 python bench.py --fp8 --no-cpu-baseline --no-extra-configs --no-reference-default "$@" 2>/dev/null | tail -1 > $O/bench_fp8_linears_only.json
 python - "$O" <<'PY'
 import json, sys
 o = sys.argv[1]

@@ -21,10 +21,10 @@ cd /tmp && export TMPDIR=/tmp
 # 1. the bench line (default flags = what the driver runs)
 (cd $R && python bench.py 2>$O/bench.err | tail -1 > $O/bench.json); jstamp $O/bench.json
 # 2. kernel trace + stats of the bench command (hipGraph replay, three batches in flight)
-rm -rf /tmp/rpA; rocprofv3 --kernel-trace --stats -d /tmp/rpA -o t -- python $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-mode-table --no-reference-default 2>/dev/null | tail -1 > $O/bench_under_rocprof_inflight.json
+rm -rf /tmp/rpA; rocprofv3 --kernel-trace --stats -d /tmp/rpA -o t -- python $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-extra-configs --no-mode-table --no-reference-default 2>/dev/null | tail -1 > $O/bench_under_rocprof_inflight.json
 python $R/tools/rocpd_summary.py $(find /tmp/rpA -name "*.db" | head -1) > $O/kernel_stats_inflight.csv
 # 3. the regime the roofline events are taken in: eager launches, one stream, one batch at a time
-rm -rf /tmp/rpB; UDT_GRAPHS=0 UDT_DUAL_STREAM=0 rocprofv3 --kernel-trace --stats -d /tmp/rpB -o t -- python $R/bench.py --steps 1 --warmup 1 --in-flight 1 --fuse 1 --no-cpu-baseline --no-mode-table --no-reference-default 2>/dev/null | tail -1 > $O/bench_under_rocprof_single.json
+rm -rf /tmp/rpB; UDT_GRAPHS=0 UDT_DUAL_STREAM=0 rocprofv3 --kernel-trace --stats -d /tmp/rpB -o t -- python $R/bench.py --steps 1 --warmup 1 --in-flight 1 --fuse 1 --no-cpu-baseline --no-extra-configs --no-mode-table --no-reference-default 2>/dev/null | tail -1 > $O/bench_under_rocprof_single.json
 python $R/tools/rocpd_summary.py $(find /tmp/rpB -name "*.db" | head -1) > $O/kernel_stats_single_stream.csv
 jstamp $O/bench_under_rocprof_inflight.json $O/bench_under_rocprof_single.json; stamp $O/kernel_stats_inflight.csv $O/kernel_stats_single_stream.csv
 # 4. HBM traffic of the 3x3-conv kernels: PMC passes (no tracing domains) over one batch of the bench workload.
@@ -40,11 +40,11 @@ rm -rf /tmp/pmc_mfma
 UDT_GRAPHS=0 UDT_DUAL_STREAM=0 timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d /tmp/pmc_mfma -o p -- python $R/tools/predict_once.py 4 > /dev/null 2>&1
 python $R/tools/pmc_mfma.py /tmp/pmc_mfma/p_counter_collection.csv > $O/mfma_util.json
 # 6. config #4 (768x768, batch 8, 12 characters) and the fp8-linears mode (config #5's arithmetic on one GPU)
-(cd $R && python bench.py --size 768 --batch 8 --chars 12 --steps 3 --warmup 1 --no-cpu-baseline --no-reference-default 2>/dev/null | tail -1 > $O/bench_config4_768.json)
-(cd $R && python bench.py --fp8 --no-cpu-baseline --no-reference-default 2>/dev/null | tail -1 > $O/bench_fp8.json)
+(cd $R && python bench.py --size 768 --batch 8 --chars 12 --steps 3 --warmup 1 --no-cpu-baseline --no-extra-configs --no-reference-default 2>/dev/null | tail -1 > $O/bench_config4_768.json)
+(cd $R && python bench.py --fp8 --no-cpu-baseline --no-extra-configs --no-reference-default 2>/dev/null | tail -1 > $O/bench_fp8.json)
 jstamp $O/bench_config4_768.json $O/bench_fp8.json
 # 7. launch-mode sweep on this box: batches in flight
-(cd $R && for n in 1 2 3 4 5 6; do python bench.py --in-flight $n --steps 12 --warmup 3 --no-cpu-baseline --no-mode-table --no-reference-default 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('in_flight $n: %.3f images/s, %.1f ms per batch of 4' % (d['value'], d['ms_per_step']))"; done > $O/in_flight_sweep.txt)
+(cd $R && for n in 1 2 3 4 5 6; do python bench.py --in-flight $n --steps 12 --warmup 3 --no-cpu-baseline --no-extra-configs --no-mode-table --no-reference-default 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('in_flight $n: %.3f images/s, %.1f ms per batch of 4' % (d['value'], d['ms_per_step']))"; done > $O/in_flight_sweep.txt)
 (cd $R && python tools/phase_times.py 2>/dev/null | grep -E "alone|predict_many|sampling only" > $O/phase_times.txt)
 # 8. per-shape tables: GEMM shapes (lean family vs the 8-wave kernels), wide vs lean convolution, trace of one step, op micro-benchmarks
 (cd $R && python tools/bench_gemm_shapes.py lean=0 lean=-1 2>/dev/null > $O/gemm_shapes.txt)
@@ -63,7 +63,7 @@ jstamp $O/bench_config4_768.json $O/bench_fp8.json
 #    and the bench line of config #5 with the bf16 attention kept (UDT_FP8_ATTN=0: the MX8 linears alone)
 (cd $R && python tools/bench_attn8.py 2>/dev/null | grep -v amdgpu.ids > $O/attn_mx8_layers.txt)
 (cd $R && python tools/attn_tail.py 2>/dev/null | grep "workgroups" > $O/attn_vs_workgroups.txt)
-(cd $R && UDT_FP8_ATTN=0 python bench.py --fp8 --no-cpu-baseline --no-reference-default 2>/dev/null | tail -1 > $O/bench_fp8_linears_only.json)
+(cd $R && UDT_FP8_ATTN=0 python bench.py --fp8 --no-cpu-baseline --no-extra-configs --no-reference-default 2>/dev/null | tail -1 > $O/bench_fp8_linears_only.json)
 jstamp $O/bench_fp8_linears_only.json
 stamp $O/mx8_layers.txt $O/trace_step_fp8.txt $O/attn_mx8_layers.txt $O/attn_vs_workgroups.txt
 stamp $O/in_flight_sweep.txt $O/phase_times.txt $O/gemm_shapes.txt $O/wide_conv.txt $O/trace_step.txt $O/bench_ops.txt $O/attn512.txt $O/rowres_bench.txt $O/tattn_bench.txt $O/reference_default.txt

@@ -8,7 +8,7 @@ for rep in $(seq $REPS); do
 for spec in "$@"; do
   d=${spec%%:*}; envs=""
   [ "$spec" != "$d" ] && envs=$(echo "${spec#*:}" | tr ',' ' ')
-  (cd "$d" && env $envs python bench.py --steps 6 --warmup 3 --no-cpu-baseline --no-mode-table $BENCH_ARGS 2>/dev/null | tail -1 | python -c "
+  (cd "$d" && env $envs python bench.py --steps 6 --warmup 3 --no-cpu-baseline --no-extra-configs --no-mode-table $BENCH_ARGS 2>/dev/null | tail -1 | python -c "
 import json,sys
 d=json.loads(sys.stdin.read())
 g=d.get('roofline_classes',{}).get('gemm',{}).get('achieved',0)

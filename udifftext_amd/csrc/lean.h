@@ -618,6 +618,13 @@ __global__ void __launch_bounds__(NW * 64, 2) lgemm_kernel(const LParams p) {
         if constexpr (EMIT) {
           // the result again as an MX8 activation: the 4 lanes of an aligned quad hold one 32-column block of the row (every lane
           // executes the cross-lane steps; N % 32 == 0 keeps a quad's lanes valid together)
+          // ... of the values AS ROUNDED FOR `out` (udt_kernels.h q8_out; the GEGLU and row-resident emitting epilogues do the same):
+          // the bf16 residual stream and its e4m3 twin / LayerNorm statistics come from ONE rounding, whichever plan served the layer
+          {
+            const u32x4 rb = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7])};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[2 * j] = bf16_lo(rb[j]), o[2 * j + 1] = bf16_hi(rb[j]);
+          }
           uint32_t sb;
           u32x2 q8 = mx8_quant_row8(o, sb);
           if (n >= p.q8_fixed_col) {                      // (the v third of a q|k|v projection: one scale for the whole tensor)

@@ -362,7 +362,12 @@ __global__ void __launch_bounds__(256, 1) rgemm_kernel(const lg::LParams p) {
     // for all but the PPW youngest operations covers it (vmcnt retires in order and counts stores too)
     // (EMIT: an epilogue issues 16 stores — 8 of e4m3 bytes, 8 of scale bytes — or 24 with the bf16 result: with the plain count the
     // wait would reach into the stores issued a moment ago and expose their latency at every chunk)
-    if (cj + 1 < c1) wait_vm<PPW + (EMIT ? 16 : 0)>(); else wait_vm<0>();
+    // (... but only a wave whose 64 rows all lie inside M issues those 16: the stores sit under the row predicate, hipcc branches around
+    // fully masked VMEM, and a wave with < 8 stores per epilogue would let the wider count reach into chunk cj's own DMA pieces — the
+    // other waves would then read a weight chunk that has not landed.  Ragged waves take the count that is safe for any store count)
+    if (cj + 1 >= c1) wait_vm<0>();
+    else if (EMIT && m0 + 64 <= p.M) wait_vm<PPW + 16>();
+    else wait_vm<PPW>();
     lg::raw_barrier();                                   // every wave is past chunk cj - 1: its ring slot takes chunk cj + 2
     if (cj + 2 < c1 && !RR_DBG(0)) stage(cj + 2);
   };

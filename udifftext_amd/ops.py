@@ -309,9 +309,12 @@ def linear_mx8(x: Mx8Act, wq: torch.Tensor, colscale: torch.Tensor, bias: Option
 
 def ln_linear(x: torch.Tensor, w_folded: torch.Tensor, c: torch.Tensor, s: torch.Tensor, *, eps: float = 1e-5,
               out: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None, flags: int = 0,
-              n_out: Optional[int] = None, emit_q8: bool = False, want_bf16: bool = True, q8_fixed: Optional[tuple] = None):
+              n_out: Optional[int] = None, emit_q8: bool = False, want_bf16: bool = True, q8_fixed: Optional[tuple] = None,
+              q8_or_none: bool = False):
     """out = epilogue(LayerNorm(x) @ W^T + b) in ONE launch (udt_ln_gemm_fwd): x holds the raw rows, (w_folded, c, s) come
-    from packing.pack_ln_linear; the row statistics are taken inside the GEMM (reference attention.py:310-339)."""
+    from packing.pack_ln_linear; the row statistics are taken inside the GEMM (reference attention.py:310-339).
+    q8_or_none: with emit_q8, return None (nothing launched) instead of raising when the library has no emitting plan for the shape
+    (row-resident kernel switched off through udt_debug_set / UDT_LEAN, unaligned rows) — the caller then takes its bf16 path."""
     _bf16(x); _bf16(w_folded)
     K = x.shape[-1]
     x2 = x.reshape(-1, K) if x.is_contiguous() else x
@@ -330,6 +333,8 @@ def ln_linear(x: torch.Tensor, w_folded: torch.Tensor, c: torch.Tensor, s: torch
         # (the row-resident K = 320 kernel's emitting epilogue: q|k|v for the e4m3 self-attention of config #5 at the 64x64 level)
         q8 = _attach_q8(d, M, n_cols, x.device, False, fixed=q8_fixed)
         if q8 is None:
+            if q8_or_none:
+                return None
             raise L.UdtError(f"udt_ln_gemm_fwd has no MX8-emitting plan for M={M} N={N} K={K}")
     lib = L.load()
     need = lib.udt_gemm_workspace_bytes(C.byref(d))

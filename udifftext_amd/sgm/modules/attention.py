@@ -207,8 +207,13 @@ class MemoryEfficientCrossAttention(H._Packed):
                 qkv = ops.linear_mx8(x8, wq, cs, ln_c=c, ln_s=sv, eps=ln.eps).reshape(B, N, 3 * inner)
         elif ln is not None:
             wf, c, sv = self.packed_ln(ln)
+            qkv8 = None
             if a8 and C == 320:                  # (the row-resident K = 320 kernel has the emitting epilogue)
-                qkv8 = ops.ln_linear(x2, wf, c, sv, eps=ln.eps, emit_q8=True, want_bf16=False, q8_fixed=(2 * inner, self.v_mul))
+                # (None: that kernel is switched off — udt_debug_set("rowres", 0), UDT_LEAN=1 / 6 — or x is not 16-byte aligned: the
+                #  level then keeps the bf16 projection + bf16 flash attention, like sampling with UDT_FP8_ATTN=0 does)
+                qkv8 = ops.ln_linear(x2, wf, c, sv, eps=ln.eps, emit_q8=True, want_bf16=False, q8_fixed=(2 * inner, self.v_mul),
+                                     q8_or_none=True)
+            if qkv8 is not None:
                 o = ops.attention_mx8(qkv8, B, self.heads, scale, self.v_mul)
             else:
                 qkv = ops.ln_linear(x2, wf, c, sv, eps=ln.eps).reshape(B, N, 3 * inner)

@@ -491,7 +491,11 @@ class EulerEDMSampler(EDMSampler):
         # a runner that leaves the cache may still have graph replays queued on a lane stream (nothing here synchronises the host):
         # it is parked in ``_retired`` — its graphs and private memory pool stay alive — until the caller has synchronised
         # (pipeline.predict_many -> release_retired); runners of the current call's lanes are never evicted
+        # Bounded without the caller's help too (round 6): every runner records an event behind its last replay; parked runners whose
+        # event has completed are dropped on the next call — a caller that uses sample_lane directly, or an exception between eviction
+        # and release, no longer keeps retired hipGraphs and their memory pools alive indefinitely.
         retired = self.__dict__.setdefault("_retired", [])
+        retired[:] = [r for r in retired if getattr(r, "last_replay", None) is not None and not r.last_replay.query()]
         gs = cache.get(key)
         if gs is not None and gs.fingerprint != fp:            # weights changed: the captured pointers are stale
             retired.append(cache.pop(key))
@@ -517,6 +521,8 @@ class EulerEDMSampler(EDMSampler):
         for i in steps:
             gs.graphs[i].replay()
         out = gs.x.clone()
+        gs.last_replay = torch.cuda.Event()
+        gs.last_replay.record(lane)
         if deferred_checks is not None:
             if gs.st.check not in deferred_checks:
                 deferred_checks.append(gs.st.check)
