@@ -7,6 +7,7 @@ from seeds / the name-keyed synthetic weight recipe, expected outputs are stored
     python tests/golden/make_golden.py            # ~3-4 minutes, needs /root/reference
     python tests/golden/make_golden.py --g11      # only the 50-step trajectory (engine_golden_50.npz), ~3 minutes
     python tests/golden/make_golden.py --g12      # only BASELINE config #2 end to end (engine_golden_512.npz), ~10 minutes
+    python tests/golden/make_golden.py --g13      # only the attend-and-excite update (aae_golden.npz), ~2 minutes
 
 Import recipe: import transformers first; stub the absent third-party modules
 (pytorch_lightning, omegaconf, kornia, open_clip, imageio, seaborn, torchvision, timm); replace xformers'
@@ -154,7 +155,58 @@ def g12(model, S, t0):
     print(f"[golden] G12 512x512 50-step trajectory done ({time.time() - t0:.1f}s)")
 
 
-def main(only_g11: bool = False, only_g12: bool = False):
+def g13(model, S, t0):
+    """G13 — attend-and-excite: ONE update of the real EulerEDMSampler.attend_and_excite (reference sampling.py:233-252:
+    x <- x - alpha * d local_loss / d x, autograd through the whole UNet from the t_attn probability maps of the 16x16 level) on a
+    128x128 image (16x16 latents, 4 characters, B = 1 — the reference's implicit-gradient call only works for one sample), at the
+    sampler's step 2 of 10.  Stored: x, sigma, alpha, the updated x, the local loss and the gradient torch.autograd.grad returned inside that call."""
+    batch = synth.synthetic_batch(1, 128, 128, 4, seed=13)
+    torch.manual_seed(1234)
+    buc = {k: (v.clone() if isinstance(v, torch.Tensor) else list(v)) for k, v in batch.items()}
+    buc["label"] = ["" for _ in batch["label"]]
+    buc["txt"] = ["" for _ in batch["txt"]]
+    c, uc = model.conditioner.get_unconditional_conditioning(batch, batch_uc=buc, force_uc_zero_embeddings=["label"])
+    sampler = S.EulerEDMSampler(
+        num_steps=10,
+        discretization_config={"target": "sgm.modules.diffusionmodules.discretizer.LegacyDDPMDiscretization"},
+        guider_config={"target": "sgm.modules.diffusionmodules.guiders.VanillaCFG", "params": {"scale": 5.0}},
+        s_churn=0.0, s_tmin=0.0, s_tmax=999.0, s_noise=1.0, verbose=False, device="cpu")
+    sigmas = sampler.discretization(10, device="cpu")
+    i = 2
+    g = torch.Generator().manual_seed(13)
+    x = torch.randn((1, 4, 16, 16), generator=g) * float(sigmas[i])
+    sigma = torch.ones([1]) * sigmas[i]
+    alpha = float(20 * np.sqrt(np.linspace(1.0, 0, 11)[i]))
+    grads = []
+    real_grad = torch.autograd.grad
+
+    def recording_grad(*a, **k):          # (x - x') / alpha in fp32 would carry ~2 % of cancellation noise: record the gradient itself
+        r = real_grad(*a, **k)
+        grads.append(r[0].detach().clone())
+        return r
+
+    with torch.enable_grad():
+        torch.autograd.grad = recording_grad
+        try:
+            x2 = sampler.attend_and_excite(x, model, sigma, c, batch, alpha, False, 0.0)
+        finally:
+            torch.autograd.grad = real_grad
+        # the loss value of that call (attend_and_excite does not return it): the same forward once more
+        c_noise = sampler.get_c_noise(x, model, sigma)
+        model.model(x, c_noise, c)
+        ll = model.loss_fn.get_min_local_loss(model.model.diffusion_model.attn_map_cache, batch["mask"], batch["seg_mask"])
+    assert len(grads) == 1
+    grad = grads[0]
+    assert torch.allclose(x - alpha * grad, x2.detach(), rtol=0, atol=1e-6)
+    out = {"g13_x": x.numpy(), "g13_sigma": sigma.numpy(), "g13_alpha": np.array([alpha]), "g13_c_noise": c_noise.numpy(),
+           "g13_x_updated": x2.detach().numpy(), "g13_local_loss": ll.detach().numpy(), "g13_grad": grad.numpy(),
+           "g13_c_concat": c["concat"].numpy(), "g13_c_txt_sub": c["t_crossattn"][:, :, ::16].numpy()}
+    np.savez_compressed(os.path.join(HERE, "aae_golden.npz"), **out)
+    print(f"[golden] G13 attend-and-excite update done ({time.time() - t0:.1f}s): loss {ll.item():.6f}, |grad| rms "
+          f"{grad.pow(2).mean().sqrt().item():.3e}, alpha {alpha:.3f}")
+
+
+def main(only_g11: bool = False, only_g12: bool = False, only_g13: bool = False):
     t0 = time.time()
     torch.set_grad_enabled(False)
     import_reference()
@@ -278,6 +330,9 @@ def main(only_g11: bool = False, only_g12: bool = False):
     if only_g12:
         g12(model, S, t0)
         return
+    if only_g13:
+        g13(model, S, t0)
+        return
     sampler = S.EulerEDMSampler(
         num_steps=10,
         discretization_config={"target": "sgm.modules.diffusionmodules.discretizer.LegacyDDPMDiscretization"},
@@ -389,6 +444,9 @@ def main(only_g11: bool = False, only_g12: bool = False):
 
 
 if __name__ == "__main__":
+    if "--g13" in sys.argv:
+        main(only_g13=True)
+        sys.exit(0)
     main(only_g11="--g11" in sys.argv, only_g12="--g12" in sys.argv)
     if "--all" in sys.argv:
         main(only_g12=True)

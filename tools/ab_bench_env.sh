@@ -5,7 +5,7 @@ VAR=$1; A=$2; B=$3
 R=$GRAFT_REPO_ROOT; [ -z "$R" ] && R=/root/repo
 mkdir -p $R/gpurun_out
 for v in $A $B $A $B; do
-  env $VAR=$v timeout 600 python $R/bench.py --steps 6 --warmup 2 --no-reference-default --no-extra-configs > /tmp/ab_$VAR.json 2> /tmp/ab_$VAR.err
+  env $VAR=$v timeout 600 python $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-reference-default --no-extra-configs > /tmp/ab_$VAR.json 2> /tmp/ab_$VAR.err
   python - <<PY
 import json
 d=json.loads(open("/tmp/ab_$VAR.json").read().strip().splitlines()[-1])

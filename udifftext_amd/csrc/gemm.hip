@@ -758,6 +758,22 @@ int lean_splitk_knob() {
   }
   return v;
 }
+// udt_debug_set("share_splitk", v) / UDT_SHARE_SPLITK: 1 (default) the lean GEMM / lean convolution cut K (channel chunks) to fill
+// THEIR SHARE of the workgroup slots when the launch shares the device with other streams (udt_gemm_desc.cu_share: the batches in
+// flight) — the other lanes fill the CUs a few-tile launch leaves idle, so slices would only add slab round trips (a slice costs
+// ~10 us of CU time, 64 KB of fp32 slab written through and read back: round 5's traffic 3.0x the algorithmic bytes); 0: the
+// round-5 rule (every launch plans for the whole chip).  A lone launch (cu_share 1) is planned as before.
+std::atomic<int> g_share_splitk{-2};
+int share_splitk() {
+  int v = g_share_splitk.load(std::memory_order_relaxed);
+  if (v == -2) {
+    const char* e = getenv("UDT_SHARE_SPLITK");
+    v = e ? (atoi(e) != 0) : 1;
+    g_share_splitk.store(v, std::memory_order_relaxed);
+  }
+  return v;
+}
+int share_of(const udt_gemm_desc* d) { return (share_splitk() && d->cu_share > 1) ? d->cu_share : 1; }
 bool lean_stats_enabled() { return true; }     // statistics-emitting launches run on the lean kernels wherever a lean plan exists
 
 struct LeanPlan {
@@ -897,7 +913,8 @@ bool lean_plan(const udt_gemm_desc* d, LeanPlan& t, bool want_stats) {
   t.tiles = t.tiles_m * t.tiles_n;
   t.nkt = d->K / KT;
   // split K when the tiles alone leave most of the chip idle: slices of >= 4 K-tiles, ~1.5 units per workgroup slot
-  const int slots = device_cus() * ((t.cfg == 1 || t.cfg == 5) ? 2 : 1);
+  int slots = device_cus() * ((t.cfg == 1 || t.cfg == 5) ? 2 : 1) / share_of(d);
+  if (slots < 1) slots = 1;
   int sk = 1;
   const int knob = lean_splitk_knob();
   if (!ln && t.tiles <= 1023) {
@@ -1018,7 +1035,7 @@ bool lean_conv_plan(const udt_gemm_desc* d, lg::C3Params& c, bool want_stats) {
   c.tiles_n = (d->N + c.bn - 1) / c.bn;
   c.tiles = c.tiles_m * c.tiles_n;
   c.chunks = c.C / 64;
-  const int slots = c.geo == 3 ? wide_slots : 2 * device_cus();
+  const int slots = c.geo == 3 ? wide_slots : (2 * device_cus() / share_of(d) > 0 ? 2 * device_cus() / share_of(d) : 1);
   int sk = conv_chunk_slices(c.tiles, slots, c.chunks, lean_splitk_knob());
   while (sk > 1 && (long long)c.tiles * sk * c.tw * c.th * c.bn * 4 > (64LL << 20)) --sk;       // slabs stay inside the workspace
   c.ch_per = (c.chunks + sk - 1) / sk;
@@ -1073,6 +1090,7 @@ extern "C" int udt_debug_set(const char* key, int32_t value) {
   if (!strcmp(key, "lean")) { g_lean.store(value < 0 ? -2 : value); return UDT_OK; }
   if (!strcmp(key, "rowres")) { g_rowres.store(value < 0 ? 1 : (value ? 1 : 0)); return UDT_OK; }
   if (!strcmp(key, "lean_splitk")) { g_lean_splitk.store(value); return UDT_OK; }
+  if (!strcmp(key, "share_splitk")) { g_share_splitk.store(value < 0 ? -2 : (value ? 1 : 0)); return UDT_OK; }
   if (!strcmp(key, "lean_conv")) { g_lean_conv.store(value < 0 ? -1 : (value ? 1 : 0)); return UDT_OK; }
   if (!strcmp(key, "wide_conv")) { g_wide_conv.store(value < 0 ? -1 : (value ? 1 : 0)); return UDT_OK; }
 #ifdef UDT_MEASURE
