@@ -402,6 +402,49 @@ int udt_local_loss(const float* probs, const float* mask, const float* seg_mask,
 int udt_local_loss_tiled(const float* probs, const float* mask, const float* seg_mask, const float* gkernel9,
                          float* loss_accum, int32_t n_samples, int32_t mask_batch, int32_t heads, int32_t size, int32_t L,
                          int32_t seg_l, int32_t Hm, int32_t Wm, void* stream);
+/* ---- backward (dX only) for attend-and-excite, SURVEY 8f-4 — reference sampling.py:233-252: torch.autograd.grad(local_loss, x)
+ * through the UNet; csrc/backward.hip.  Linears / convolutions have no entry of their own: their backward-data is udt_gemm on
+ * re-packed weights (W^T; 180-degree rotated taps with the channel roles swapped). ------------------------------------------------- */
+/* flash-attention backward, head_dim 64 (reference attention.py:236-248 xformers memory_efficient_attention under autograd):
+ * q, k, v: column ranges of one [batch * n, ldq] bf16 matrix (head h at columns h * 64 of each pointer), o / d_o [batch * n, ldo];
+ * dq, dk, dv: column ranges of one [batch * n, ldd] bf16 matrix.  lse_ws / dsum_ws: fp32 [batch * heads * n] scratch each (the
+ * log-sum-exp of every score row and rowsum(dO o O), written by the first launch, read by the second).  Two launches, no atomics. */
+int udt_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* d_o, void* dq, void* dk, void* dv,
+                 float* lse_ws, float* dsum_ws, int32_t batch, int32_t heads, int32_t n, int32_t ldq, int32_t ldo, int32_t ldd,
+                 float scale, void* stream);
+/* text cross-attention backward (reference attention.py:140-175 CrossAttention under autograd; context constant): probs fp32
+ * [batch * heads, nq, L] as udt_xattn_fwd wrote them, d_probs (optional) the loss gradient with respect to them, d_o (optional) bf16
+ * [batch * nq, ldo] the gradient of the attention output -> dq bf16 [batch * nq, lddq] (head h at columns h * 64); L <= 16, and
+ * the sigmoid branch for L == 1. */
+int udt_xattn_bwd(const void* k, const void* v, const float* probs, const float* d_probs, const void* d_o, void* dq, int32_t batch,
+                  int32_t heads, int32_t head_dim, int32_t nq, int32_t L, int32_t ldkv, int32_t ldo, int32_t lddq, float scale,
+                  void* stream);
+/* gradient of udt_local_loss_tiled's per-layer term with respect to probs, times `weight` (1 / number of contributing layers),
+ * ADDED into d_probs fp32 [n_samples * heads, n, L] (zero-initialised by the caller); loss_accum (optional) += the term itself
+ * (reference loss.py:192-235 under autograd: arg-min token, arg-max pixel, the 3x3 blur stencil, the head mean) */
+int udt_local_loss_bwd(const float* probs, const float* mask, const float* seg_mask, const float* gkernel9, float* d_probs,
+                       float* loss_accum, int32_t n_samples, int32_t mask_batch, int32_t heads, int32_t size, int32_t L,
+                       int32_t seg_l, int32_t Hm, int32_t Wm, float weight, void* stream);
+/* LayerNorm backward-data (nn.LayerNorm of attention.py:310-339): x, dy bf16 [rows, C] -> dx bf16 (+ add bf16 [rows, C] if given:
+ * the gradient that arrives over the residual connection); statistics recomputed from x; C % 8 == 0, C <= 2048 */
+int udt_layernorm_bwd(const void* x, const void* dy, const float* gamma, const void* add, void* dx, int64_t rows, int32_t C, float eps,
+                      void* stream);
+/* GroupNorm (+ SiLU when silu != 0) backward-data (GroupNorm32 / nn.SiLU of openaimodel.py:183-187, attention.py:375): x, dy bf16
+ * NHWC [B, HW, C] -> dx (+ add); statistics recomputed from x; (C / groups) even */
+int udt_gn_bwd(const void* x, const void* dy, const float* gamma, const float* beta, const void* add, void* dx, int32_t B, int32_t HW,
+               int32_t C, int32_t groups, float eps, int32_t silu, void* stream);
+/* GEGLU (attention.py:44-52) on STORED pre-activations ag bf16 [rows, 2 * inner] = [x | gate]: out = x * gelu(gate) [rows, inner];
+ * backward: dag [rows, 2 * inner] from dy [rows, inner] (the inference path's fused GEMM epilogue keeps no pre-activations) */
+int udt_geglu_fwd(const void* ag, void* out, int64_t rows, int32_t inner, void* stream);
+int udt_geglu_bwd(const void* ag, const void* dy, void* dag, int64_t rows, int32_t inner, void* stream);
+/* nearest x2 upsampling backward (openaimodel.py:99-101 under autograd): dy bf16 NHWC [B, 2H, 2W, C] -> dx [B, H, W, C] = 2 x 2 sums */
+int udt_sum2x2_bf16(const void* dy, void* dx, int32_t B, int32_t H, int32_t W, int32_t C, void* stream);
+/* context tokens minus their per-sample mean over the L tokens, as bf16: x fp32 [B, L, D] -> out bf16 [B, L, D].  The softmax over the
+ * tokens (attention.py:155-160) and its backward are invariant under that shift of the keys / values; used by the attend-and-excite
+ * tape so that the bf16 k|v projection keeps the DIFFERENCES between the (nearly equal) label-embedding tokens */
+int udt_center_tokens(const float* x, void* out, int32_t B, int32_t L, int32_t D, void* stream);
+/* x fp32 += a * y fp32: the attend-and-excite update x <- x - alpha * grad (sampling.py:247) */
+int udt_axpy_f32(float* x, const float* y, float a, int64_t n, void* stream);
 /* x bf16 += y bf16 (n elements, n % 8 == 0) ; utility for residuals outside GEMM epilogues */
 int udt_add_bf16(void* x, const void* y, int64_t n, void* stream);
 

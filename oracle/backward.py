@@ -53,6 +53,20 @@ def attend_and_excite_grad(sd: SD, cfg: EngineConfig, x: torch.Tensor, sigma: to
     return loss.detach(), g
 
 
+def maps_functional_grad(sd: SD, cfg: EngineConfig, x: torch.Tensor, sigma: torch.Tensor, cond: dict, weights_of, min_attn_size: int = 16):
+    """(value, d value / d x) of the smooth functional sum_k <R_k, attn_map_k> / count over the counted t_attn maps, R_k =
+    weights_of(shape, k): the same reverse pass as attend-and-excite with a DENSE cotangent on every map (golden G13s)"""
+    c_noise = c_noise_of(sd, sigma)
+    with torch.enable_grad():
+        xg = x.detach().clone().requires_grad_(True)
+        maps: list = []
+        nets.unet_forward(sd, torch.cat((xg, cond["concat"]), dim=1), c_noise, cond["t_crossattn"], cfg.unet, attn_maps=maps)
+        used = [m for m in maps if m["name"].endswith("t_attn") and m["size"] >= min_attn_size]
+        val = sum((weights_of(m["attn_map"].shape, k) * m["attn_map"]).sum() for k, m in enumerate(used)) / len(used)
+        (g,) = torch.autograd.grad(val, [xg])
+    return val.detach(), g
+
+
 def attend_and_excite(sd: SD, cfg: EngineConfig, x: torch.Tensor, sigma: torch.Tensor, cond: dict, mask: torch.Tensor,
                       seg_mask: torch.Tensor, alpha: float, iter_enabled: bool, thres: float, max_iter: int = 20) -> torch.Tensor:
     """the update loop of sampling.py:240-252: x <- x - alpha * grad, repeated while iter_enabled and loss > thres and iters <= max_iter"""

@@ -155,12 +155,20 @@ def g12(model, S, t0):
     print(f"[golden] G12 512x512 50-step trajectory done ({time.time() - t0:.1f}s)")
 
 
+sys.path.insert(0, os.path.dirname(HERE))
+from aae_fixture import aae_batch, aae_functional_weights  # noqa: E402
+
+
 def g13(model, S, t0):
     """G13 — attend-and-excite: ONE update of the real EulerEDMSampler.attend_and_excite (reference sampling.py:233-252:
     x <- x - alpha * d local_loss / d x, autograd through the whole UNet from the t_attn probability maps of the 16x16 level) on a
-    128x128 image (16x16 latents, 4 characters, B = 1 — the reference's implicit-gradient call only works for one sample), at the
-    sampler's step 2 of 10.  Stored: x, sigma, alpha, the updated x, the local loss and the gradient torch.autograd.grad returned inside that call."""
-    batch = synth.synthetic_batch(1, 128, 128, 4, seed=13)
+    128x128 image (16x16 latents, B = 1 — the reference's implicit-gradient call only works for one sample), at the sampler's step 2
+    of 10, on ``aae_batch()``.  Stored: x, sigma, alpha, the updated x, the local loss and the gradient torch.autograd.grad returned
+    inside that call.
+    G13s — the same reverse pass with a DENSE cotangent on every counted map: the real reference network under autograd, scalarised by
+    the smooth functional sum_k <R_k, attn_map_k> / count (R_k fixed pseudo-random, ``aae_functional_weights``) instead of the hard
+    min / max loss: d / d x of it."""
+    batch = aae_batch()
     torch.manual_seed(1234)
     buc = {k: (v.clone() if isinstance(v, torch.Tensor) else list(v)) for k, v in batch.items()}
     buc["label"] = ["" for _ in batch["label"]]
@@ -185,25 +193,33 @@ def g13(model, S, t0):
         grads.append(r[0].detach().clone())
         return r
 
+    unet = model.model.diffusion_model
     with torch.enable_grad():
         torch.autograd.grad = recording_grad
         try:
             x2 = sampler.attend_and_excite(x, model, sigma, c, batch, alpha, False, 0.0)
         finally:
             torch.autograd.grad = real_grad
-        # the loss value of that call (attend_and_excite does not return it): the same forward once more
+        # the loss value of that call (attend_and_excite does not return it) and the selection margins: the same forward once more
         c_noise = sampler.get_c_noise(x, model, sigma)
-        model.model(x, c_noise, c)
-        ll = model.loss_fn.get_min_local_loss(model.model.diffusion_model.attn_map_cache, batch["mask"], batch["seg_mask"])
+        xg = x.clone().requires_grad_(True)
+        model.model(xg, c_noise, c)
+        ll = model.loss_fn.get_min_local_loss(unet.attn_map_cache, batch["mask"], batch["seg_mask"])
+        used = [it for it in unet.attn_map_cache if it["name"].endswith("t_attn") and it["size"] >= model.loss_fn.min_attn_size]
+        smooth = sum((aae_functional_weights(it["attn_map"].shape, k) * it["attn_map"]).sum() for k, it in enumerate(used)) / len(used)
+        (gs,) = real_grad(smooth, [xg])
     assert len(grads) == 1
     grad = grads[0]
     assert torch.allclose(x - alpha * grad, x2.detach(), rtol=0, atol=1e-6)
     out = {"g13_x": x.numpy(), "g13_sigma": sigma.numpy(), "g13_alpha": np.array([alpha]), "g13_c_noise": c_noise.numpy(),
            "g13_x_updated": x2.detach().numpy(), "g13_local_loss": ll.detach().numpy(), "g13_grad": grad.numpy(),
-           "g13_c_concat": c["concat"].numpy(), "g13_c_txt_sub": c["t_crossattn"][:, :, ::16].numpy()}
+           "g13_c_concat": c["concat"].numpy(), "g13_c_txt": c["t_crossattn"].numpy(),
+           "g13s_value": np.array([float(smooth)]), "g13s_grad": gs.numpy(),
+           "g13_map_names": np.array([it["name"] for it in used])}
     np.savez_compressed(os.path.join(HERE, "aae_golden.npz"), **out)
     print(f"[golden] G13 attend-and-excite update done ({time.time() - t0:.1f}s): loss {ll.item():.6f}, |grad| rms "
-          f"{grad.pow(2).mean().sqrt().item():.3e}, alpha {alpha:.3f}")
+          f"{grad.pow(2).mean().sqrt().item():.3e}, alpha {alpha:.3f}; smooth functional {float(smooth):.6f}, |grad| rms "
+          f"{gs.pow(2).mean().sqrt().item():.3e}; maps {[it['name'] for it in used]}")
 
 
 def main(only_g11: bool = False, only_g12: bool = False, only_g13: bool = False):

@@ -401,7 +401,9 @@ def test_flash_attention(ops, cuda, B, H, N, Nk):
     _close(out2, out, what=f"attn rowv vs V^T {B,H,N,Nk}")
 
 
-@pytest.mark.parametrize("B,H,N,Nk", [(2, 20, 256, 256), (1, 5, 200, 136), (1, 3, 72, 1096), (3, 2, 130, 40), (2, 10, 1024, 1024)])
+@pytest.mark.parametrize("B,H,N,Nk", [(2, 20, 256, 256), (1, 5, 200, 136), (1, 3, 72, 1096), (3, 2, 130, 40), (2, 10, 1024, 1024),
+                                      (1, 20, 4, 4), (2, 5, 12, 12), (1, 10, 36, 36)])      # (round 6: key counts that are not multiples of 8 —
+#                                       the 2 x 2 middle block of a 128 x 128 image attends over 4 tokens)
 def test_flash_attention_row_major_v_ragged_shapes(ops, cuda, B, H, N, Nk):
     """udt_attn_rowv_fwd (the UNet's self-attention kernel) on ragged query / key counts on both sides of a 128-query block / a
     64-key tile boundary, several samples and heads: signal-relative tolerance against torch SDPA in fp32, bit-reproducible"""

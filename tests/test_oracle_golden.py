@@ -226,3 +226,38 @@ def test_g10_vae_modules(mg):
     sd_ = _msd("vup_64", [("conv.weight", (64, 64, 3, 3)), ("conv.bias", (64,))])
     got = nets._conv(sd_, "g10.vup_64.conv.", F.interpolate(x, scale_factor=2.0, mode="nearest"))
     np.testing.assert_allclose(got.numpy(), mg["vup_64"], **TOL)
+
+
+def test_g13_attend_and_excite_gradient(sd, cfg):
+    """d local_loss / d x of oracle/backward.py (torch.autograd through the functional UNet) against the gradient
+    torch.autograd.grad returned INSIDE the real reference's EulerEDMSampler.attend_and_excite (sampling.py:233-252) — 16x16 latents,
+    B = 1, the sampler's step 2 of 10; then the update x - alpha * grad itself."""
+    from aae_fixture import aae_batch, aae_functional_weights
+    from oracle import backward
+    g13 = np.load(os.path.join(GOLD, "aae_golden.npz"))
+    batch = aae_batch()                                        # (masks that decide the loss's hard selections: see the fixture)
+    torch.manual_seed(1234)
+    c, _ = sampling.conditioning(sd, cfg, batch)
+    np.testing.assert_allclose(c["concat"].numpy(), g13["g13_c_concat"], **TOL)
+    np.testing.assert_allclose(c["t_crossattn"].numpy(), g13["g13_c_txt"], rtol=1e-3, atol=1e-3)
+    # The gradient is taken at the GOLDEN's conditioning: it depends on the DIFFERENCES between the label-embedding tokens, which are
+    # nearly equal vectors — a conditioning that agrees to 1e-2 (the bf16 label encoder of the HIP path) moves it by 28 %
+    # (profiles/r06_aae_debug.txt); the conditioner has its own parity tests (G3 / G6), this one pins the UNet's reverse pass
+    c = {"concat": torch.from_numpy(g13["g13_c_concat"]), "t_crossattn": torch.from_numpy(g13["g13_c_txt"])}
+    x, sigma = torch.from_numpy(g13["g13_x"]), torch.from_numpy(g13["g13_sigma"])
+    assert torch.equal(backward.c_noise_of(sd, sigma), torch.from_numpy(g13["g13_c_noise"]))
+    loss, grad = backward.attend_and_excite_grad(sd, cfg, x, sigma, c, batch["mask"], batch["seg_mask"])
+    np.testing.assert_allclose(loss.numpy(), g13["g13_local_loss"], rtol=1e-4, atol=1e-6)
+    ref = torch.from_numpy(g13["g13_grad"])
+    rel = ((grad - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt()).item()
+    assert rel < 1e-3, rel                                      # fp32 autograd vs fp32 autograd, different association order
+    assert float(ref.abs().max()) > 0.0
+    alpha = float(g13["g13_alpha"][0])
+    x2 = backward.attend_and_excite(sd, cfg, x, sigma, c, batch["mask"], batch["seg_mask"], alpha, False, 0.0)
+    np.testing.assert_allclose(x2.numpy(), g13["g13_x_updated"], rtol=0, atol=2e-6)
+    # G13s: the same reverse pass with a dense cotangent on every counted map (smooth functional of the real reference's maps)
+    val, gs = backward.maps_functional_grad(sd, cfg, x, sigma, c, aae_functional_weights)
+    np.testing.assert_allclose(float(val), float(g13["g13s_value"][0]), rtol=1e-4)
+    ref_s = torch.from_numpy(g13["g13s_grad"])
+    rel_s = ((gs - ref_s).pow(2).mean().sqrt() / ref_s.pow(2).mean().sqrt()).item()
+    assert rel_s < 1e-3, rel_s

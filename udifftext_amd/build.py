@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libudt_kernels.so")
-SOURCES = ["api.hip", "gemm.hip", "lean.hip", "attention.hip", "tattn.hip", "norm.hip", "elementwise.hip", "pack.hip"]
+SOURCES = ["api.hip", "gemm.hip", "lean.hip", "attention.hip", "tattn.hip", "norm.hip", "elementwise.hip", "pack.hip", "backward.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"] + os.environ.get("UDT_EXTRA_FLAGS", "").split()
 

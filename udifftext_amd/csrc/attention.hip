@@ -1178,7 +1178,9 @@ static int attn_fwd_impl(bool vrow, const void* q, const void* k, const void* vt
   if (!q || !k || !vt || !o) return UDT_ERR_BAD_ARG;
   if (q8_out && (!vrow || !q8_scale || ld_q8 < heads * 64 || ld_q8 % 4 != 0 || heads % 2 != 0)) return UDT_ERR_BAD_ARG;
   if (batch <= 0 || heads <= 0 || nq <= 0 || nk <= 0) return UDT_ERR_BAD_SHAPE;
-  if (nk % 8 != 0 || ldq % 8 != 0 || ldk % 8 != 0 || ldvt % 8 != 0 || ldo % 4 != 0) return UDT_ERR_BAD_SHAPE;
+  // (V^T operand: its rows are the keys — 16-byte row pieces need nk % 8 == 0.  Row-major V: any nk — keys past nk read zeros through
+  //  the buffer descriptor and are masked; the 2 x 2 middle block of a 128 x 128 image has 4 keys)
+  if ((!vrow && nk % 8 != 0) || ldq % 8 != 0 || ldk % 8 != 0 || ldvt % 8 != 0 || ldo % 4 != 0) return UDT_ERR_BAD_SHAPE;
   AttnParams p;
   p.q = reinterpret_cast<const uint16_t*>(q);
   p.k = reinterpret_cast<const uint16_t*>(k);

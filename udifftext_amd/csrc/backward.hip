@@ -1,0 +1,833 @@
+// backward.hip — dX-only backward kernels for attend-and-excite (first slice: one ResBlock + one SpatialTransformer).
+//
+// Reference: EulerEDMSampler.attend_and_excite (sgm/modules/diffusionmodules/sampling.py:233-252) takes
+// torch.autograd.grad(local_loss, x) through the UNet; the loss is FullLoss.get_min_local_loss (loss.py:192-235) on the t_attn
+// probability maps.  Only the gradient with respect to ACTIVATIONS is needed (x is updated, the weights are frozen), so:
+//   * linears and convolutions run their backward-data as FORWARD launches of the existing GEMM / convolution kernels on re-packed
+//     weights (W^T; 180-degree rotated taps with the channel roles swapped) — nothing of them lives here;
+//   * this file holds what has no forward twin:
+//       udt_attn_bwd          flash-attention backward (head_dim 64): dQ, dK, dV from Q, K, V, O, dO — two launches of one MFMA kernel
+//                             template (the "owner" tile keeps its fragments in registers, the other side streams through LDS; no
+//                             atomics: dQ is owned by query tiles, dK / dV by key tiles; S is recomputed, never stored)
+//       udt_xattn_bwd         text cross-attention (<= 16 context tokens): dq from the probability gradient (local loss) and dO
+//       udt_local_loss_bwd    d(-min_l max_n(mask * blur(mean_h P))) / dP: a 3x3 stencil around the arg-max of the arg-min token
+//       udt_layernorm_bwd     LayerNorm backward (dX), optional fused add of the gradient that arrives over the residual path
+//       udt_gn_bwd            GroupNorm(32) (+ SiLU) backward (dX), statistics recomputed from x, optional fused add
+//       udt_geglu_fwd / _bwd  GEGLU on stored pre-activations (the fused GEMM epilogue of the inference path keeps none)
+// bf16 storage, fp32 arithmetic; every kernel is deterministic (fixed reduction orders, no atomics).
+#include "common.h"
+#include <math.h>
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------ flash attention backward
+// mfma32(A, B, acc): lane (x, h) of A holds A[i = x][kk = 8 h .. 8 h + 7], of B holds B[j = x][kk = 8 h ..]; the lane (l31, hi) gets
+// acc[r] = sum_kk A[i = 8 (r >> 2) + 4 hi + (r & 3)][kk] * B[j = l31][kk]   (the layout attention.hip's forward kernels rely on).
+// One template serves both launches:
+//   DKV = false ("dq"): owner = 128 queries (Q, dO fragments in registers, LSE and D = rowsum(dO o O) per lane), streamed = keys
+//                       (K, V tiles of 32 rows through LDS).  Pass 1 computes LSE (log2 domain) and D and stores them for the other
+//                       launch; pass 2 accumulates dQ^T[d][q] += sum_k K^T[d][k] dS[k][q].
+//   DKV = true  ("dkv"): owner = 128 keys (K, V fragments in registers), streamed = queries (Q, dO tiles + their LSE, D):
+//                       dV^T[d][k] += sum_q dO^T[d][q] P[q][k],  dK^T[d][k] += sum_q Q^T[d][q] dS[q][k].
+// In both, the lane dimension of the 32 x 32 score tile is the OWNER index and the register dimension the STREAMED index, so P / dS
+// leave the first MFMAs in exactly the B-operand order of the second ones (contraction over the streamed index); the matching A
+// operands are the streamed tiles transposed, which the staging code writes next to the row-major copy.
+struct AttnBwdParams {
+  const uint16_t* q;
+  const uint16_t* k;
+  const uint16_t* v;
+  const uint16_t* o;
+  const uint16_t* d_o;
+  uint16_t* dq;
+  uint16_t* dk;
+  uint16_t* dv;
+  float* lse;              // [batch * heads][n], log2 domain: m + log2(sum)
+  float* dsum;             // [batch * heads][n]
+  int heads, n, tiles;
+  int ldq, ldo, ldd;       // row strides (elements) of q|k|v, of o / d_o, of dq|dk|dv
+  long long sq, so, sd;    // batch strides
+  float scale, scale_log2e;
+};
+
+constexpr int AB_XP = 72;  // row-major pitch (elements): 144 B, rows shift by 4 banks
+constexpr int AB_TP = 40;  // transposed pitch (elements): 80 B
+
+UDT_DEVINL bf16x8_t ab_load8(const uint16_t* p, bool ok) {
+  u32x4 z = {0u, 0u, 0u, 0u};
+  if (ok) z = *reinterpret_cast<const u32x4*>(p);
+  return __builtin_bit_cast(bf16x8_t, z);
+}
+
+template <bool DKV>
+__global__ void __launch_bounds__(256) attn_bwd_kernel(const AttnBwdParams p) {
+  __shared__ __attribute__((aligned(16))) uint16_t x1[32 * AB_XP];
+  __shared__ __attribute__((aligned(16))) uint16_t x2[32 * AB_XP];
+  __shared__ __attribute__((aligned(16))) uint16_t x1t[64 * AB_TP];
+  __shared__ __attribute__((aligned(16))) uint16_t x2t[64 * AB_TP];
+  __shared__ __attribute__((aligned(16))) float sc_lse[32];
+  __shared__ __attribute__((aligned(16))) float sc_d[32];
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
+  const int bh = blockIdx.x / p.tiles;
+  const int tile = blockIdx.x - bh * p.tiles;
+  const int b = bh / p.heads, h = bh - b * p.heads;
+  const uint16_t* Q = p.q + (long long)b * p.sq + h * 64;
+  const uint16_t* K = p.k + (long long)b * p.sq + h * 64;
+  const uint16_t* V = p.v + (long long)b * p.sq + h * 64;
+  const uint16_t* O = p.o + (long long)b * p.so + h * 64;
+  const uint16_t* DO = p.d_o + (long long)b * p.so + h * 64;
+  float* LSE = p.lse + (long long)bh * p.n;
+  float* DS = p.dsum + (long long)bh * p.n;
+  const int orow = tile * 128 + wave * 32 + l31;
+  const bool ook = orow < p.n;
+  const float c = p.scale_log2e;
+
+  // owner fragments (B operands): 8 consecutive head dims at ks * 16 + hi * 8 of this lane's row
+  const uint16_t* Y1 = DKV ? K : Q;
+  const uint16_t* Y2 = DKV ? V : DO;
+  const int ldy2 = DKV ? p.ldq : p.ldo;
+  bf16x8_t y1f[4], y2f[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    y1f[ks] = ab_load8(Y1 + (long long)orow * p.ldq + ks * 16 + hi * 8, ook);
+    y2f[ks] = ab_load8(Y2 + (long long)orow * ldy2 + ks * 16 + hi * 8, ook);
+  }
+  const uint16_t* X1 = DKV ? Q : K;
+  const uint16_t* X2 = DKV ? DO : V;
+  const int ldx2 = DKV ? p.ldo : p.ldq;
+  const int srow = tid >> 3, sch = tid & 7;
+  const int nst = (p.n + 31) / 32;
+
+  // one streamed tile -> LDS: row-major (A fragments of S / dP) and transposed (A fragments of the output products)
+  auto stage = [&](int st, bool second, bool transposed) {
+    const int s = st * 32 + srow;
+    const bool ok = s < p.n;
+    u32x4 a = {0u, 0u, 0u, 0u}, bq = {0u, 0u, 0u, 0u};
+    if (ok) a = *reinterpret_cast<const u32x4*>(X1 + (long long)s * p.ldq + sch * 8);
+    if (ok && second) bq = *reinterpret_cast<const u32x4*>(X2 + (long long)s * ldx2 + sch * 8);
+    *reinterpret_cast<u32x4*>(x1 + srow * AB_XP + sch * 8) = a;
+    if (second) *reinterpret_cast<u32x4*>(x2 + srow * AB_XP + sch * 8) = bq;
+    if (transposed) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        x1t[(sch * 8 + 2 * j) * AB_TP + srow] = (uint16_t)(a[j] & 0xffffu);
+        x1t[(sch * 8 + 2 * j + 1) * AB_TP + srow] = (uint16_t)(a[j] >> 16);
+        if (DKV) {
+          x2t[(sch * 8 + 2 * j) * AB_TP + srow] = (uint16_t)(bq[j] & 0xffffu);
+          x2t[(sch * 8 + 2 * j + 1) * AB_TP + srow] = (uint16_t)(bq[j] >> 16);
+        }
+      }
+    }
+    if (DKV && tid < 32) {
+      const int s2 = st * 32 + tid;
+      sc_lse[tid] = s2 < p.n ? LSE[s2] : 0.f;
+      sc_d[tid] = s2 < p.n ? DS[s2] : 0.f;
+    }
+  };
+  auto scores = [&](const uint16_t* xs, const bf16x8_t (&yf)[4]) {
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(xs + l31 * AB_XP + ks * 16 + hi * 8);
+      acc = mfma32(a, yf[ks], acc);
+    }
+    return acc;
+  };
+  // A fragment of a transposed tile: rows d = it * 32 + l31, the 8 streamed indices of k-step `half` in the order P / dS sit in
+  auto tfrag = [&](const uint16_t* xt, int it, int half) {
+    const uint16_t* base = xt + (it * 32 + l31) * AB_TP + 16 * half + 4 * hi;
+    const u32x2 lo = *reinterpret_cast<const u32x2*>(base);
+    const u32x2 hh = *reinterpret_cast<const u32x2*>(base + 8);
+    const u32x4 v4 = {lo[0], lo[1], hh[0], hh[1]};
+    return __builtin_bit_cast(bf16x8_t, v4);
+  };
+  auto pack8 = [](const float* f) {
+    const u32x4 v4 = {pack_bf16x2(f[0], f[1]), pack_bf16x2(f[2], f[3]), pack_bf16x2(f[4], f[5]), pack_bf16x2(f[6], f[7])};
+    return __builtin_bit_cast(bf16x8_t, v4);
+  };
+
+  float lse_o = 0.f, d_o_sum = 0.f;
+  if constexpr (!DKV) {
+    // ---- pass 1: LSE of this lane's query over all keys (the two half-waves see different keys: merged at the end), and D
+    float m_run = -INFINITY, l_run = 0.f;
+    for (int st = 0; st < nst; ++st) {
+      __syncthreads();
+      stage(st, false, false);
+      __syncthreads();
+      const f32x16 s = scores(x1, y1f);
+      float sv[16];
+      float mx = -INFINITY;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = st * 32 + 8 * (r >> 2) + 4 * hi + (r & 3);
+        sv[r] = key < p.n ? s[r] * c : -INFINITY;
+        mx = fmaxf(mx, sv[r]);
+      }
+      if (mx > -INFINITY) {
+        const float m_new = fmaxf(m_run, mx);
+        float sum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sum += fast_exp2(sv[r] - m_new);
+        l_run = l_run * fast_exp2(m_run - m_new) + sum;
+        m_run = m_new;
+      }
+    }
+    const float m_oth = __shfl_xor(m_run, 32), l_oth = __shfl_xor(l_run, 32);
+    const float m_all = fmaxf(m_run, m_oth);
+    float l_all = 0.f;
+    if (m_run > -INFINITY) l_all += l_run * fast_exp2(m_run - m_all);
+    if (m_oth > -INFINITY) l_all += l_oth * fast_exp2(m_oth - m_all);
+    lse_o = m_all + __log2f(l_all);
+    float part = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const u32x4 ov = __builtin_bit_cast(u32x4, ab_load8(O + (long long)orow * p.ldo + ks * 16 + hi * 8, ook));
+      const u32x4 gv = __builtin_bit_cast(u32x4, y2f[ks]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) part += bf16_lo(ov[j]) * bf16_lo(gv[j]) + bf16_hi(ov[j]) * bf16_hi(gv[j]);
+    }
+    d_o_sum = part + __shfl_xor(part, 32);
+    if (ook && hi == 0) {
+      LSE[orow] = lse_o;
+      DS[orow] = d_o_sum;
+    }
+  }
+
+  f32x16 acc1[2], acc2[2];             // dq: acc1 = dQ^T; dkv: acc1 = dK^T, acc2 = dV^T   ([d tile][...])
+#pragma unroll
+  for (int it = 0; it < 2; ++it)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc1[it][r] = acc2[it][r] = 0.f;
+
+  for (int st = 0; st < nst; ++st) {
+    __syncthreads();
+    stage(st, true, true);
+    __syncthreads();
+    const f32x16 s = scores(x1, y1f);
+    const f32x16 dp = scores(x2, y2f);
+    float pv[16], dsv[16];
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4) {
+      f32x4 ls = {lse_o, lse_o, lse_o, lse_o}, dd = {d_o_sum, d_o_sum, d_o_sum, d_o_sum};
+      if constexpr (DKV) {
+        ls = *reinterpret_cast<const f32x4*>(sc_lse + 8 * q4 + 4 * hi);
+        dd = *reinterpret_cast<const f32x4*>(sc_d + 8 * q4 + 4 * hi);
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int r = q4 * 4 + e;
+        const int sidx = st * 32 + 8 * q4 + 4 * hi + e;
+        const float pr = (sidx < p.n && ook) ? fast_exp2(s[r] * c - ls[e]) : 0.f;
+        pv[r] = pr;
+        dsv[r] = pr * (dp[r] - dd[e]) * p.scale;
+      }
+    }
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      const bf16x8_t dsf = pack8(dsv + half * 8);
+#pragma unroll
+      for (int it = 0; it < 2; ++it) acc1[it] = mfma32(tfrag(x1t, it, half), dsf, acc1[it]);
+      if constexpr (DKV) {
+        const bf16x8_t pf = pack8(pv + half * 8);
+#pragma unroll
+        for (int it = 0; it < 2; ++it) acc2[it] = mfma32(tfrag(x2t, it, half), pf, acc2[it]);
+      }
+    }
+  }
+  if (ook) {
+    uint16_t* o1 = (DKV ? p.dk : p.dq) + (long long)b * p.sd + (long long)orow * p.ldd + h * 64;
+    uint16_t* o2 = p.dv + (long long)b * p.sd + (long long)orow * p.ldd + h * 64;
+#pragma unroll
+    for (int it = 0; it < 2; ++it)
+#pragma unroll
+      for (int q4 = 0; q4 < 4; ++q4) {
+        const int d = it * 32 + 8 * q4 + 4 * hi;
+        const u32x2 a = {pack_bf16x2(acc1[it][q4 * 4], acc1[it][q4 * 4 + 1]), pack_bf16x2(acc1[it][q4 * 4 + 2], acc1[it][q4 * 4 + 3])};
+        *reinterpret_cast<u32x2*>(o1 + d) = a;
+        if constexpr (DKV) {
+          const u32x2 bb = {pack_bf16x2(acc2[it][q4 * 4], acc2[it][q4 * 4 + 1]), pack_bf16x2(acc2[it][q4 * 4 + 2], acc2[it][q4 * 4 + 3])};
+          *reinterpret_cast<u32x2*>(o2 + d) = bb;
+        }
+      }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ text cross-attention backward
+// P = softmax_l(scale q K^T) (or the sigmoid for a single context token, reference attention.py:159-162), out = P V.  Given the
+// gradient of the loss with respect to P (the local loss reads the probabilities directly) and / or with respect to out:
+//   g_l = dP_l + sum_d dO_d V[l][d];   dS_l = P_l (g_l - sum_j P_j g_j)   (sigmoid: P (1 - P) g);   dq_d = scale sum_l dS_l K[l][d].
+// The context is a constant of the problem (the label embedding): no dK / dV.  One lane per (batch, head, query), K and V of the
+// head as fp32 in LDS — the forward kernel's arrangement.
+struct XattnBwdParams {
+  const uint16_t* k;
+  const uint16_t* v;
+  const float* probs;
+  const float* d_probs;
+  const uint16_t* d_o;
+  uint16_t* dq;
+  int heads, nq, L, ldkv, ldo, lddq;
+  float scale;
+};
+constexpr int XB_L = 16;
+
+__global__ void __launch_bounds__(256) xattn_bwd_kernel(const XattnBwdParams p) {
+  __shared__ float ks[XB_L * 64];
+  __shared__ float vs[XB_L * 64];
+  const int h = blockIdx.y, b = blockIdx.z;
+  for (int i = threadIdx.x; i < p.L * 64; i += 256) {
+    const int l = i >> 6, d = i & 63;
+    const long long off = ((long long)b * p.L + l) * p.ldkv + h * 64 + d;
+    ks[i] = bf16_bits_to_f32(p.k[off]);
+    vs[i] = bf16_bits_to_f32(p.v[off]);
+  }
+  __syncthreads();
+  const int qi = blockIdx.x * 256 + threadIdx.x;
+  if (qi >= p.nq) return;
+  const long long prow = (((long long)b * p.heads + h) * p.nq + qi) * p.L;
+  float pr[XB_L], g[XB_L];
+#pragma unroll
+  for (int l = 0; l < XB_L; ++l) {
+    pr[l] = l < p.L ? p.probs[prow + l] : 0.f;
+    g[l] = (l < p.L && p.d_probs) ? p.d_probs[prow + l] : 0.f;
+  }
+  if (p.d_o) {
+    const uint16_t* gr = p.d_o + ((long long)b * p.nq + qi) * p.ldo + h * 64;
+    for (int d0 = 0; d0 < 64; d0 += 8) {
+      const u32x4 gv = *reinterpret_cast<const u32x4*>(gr + d0);
+      const float gf[8] = {bf16_lo(gv[0]), bf16_hi(gv[0]), bf16_lo(gv[1]), bf16_hi(gv[1]), bf16_lo(gv[2]), bf16_hi(gv[2]), bf16_lo(gv[3]), bf16_hi(gv[3])};
+#pragma unroll
+      for (int l = 0; l < XB_L; ++l)
+        if (l < p.L) {
+          const float* vr = vs + l * 64 + d0;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) g[l] += gf[j] * vr[j];
+        }
+    }
+  }
+  float ds[XB_L];
+  if (p.L == 1) {
+    ds[0] = pr[0] * (1.0f - pr[0]) * g[0] * p.scale;
+  } else {
+    float dot = 0.f;
+#pragma unroll
+    for (int l = 0; l < XB_L; ++l) dot += pr[l] * g[l];
+#pragma unroll
+    for (int l = 0; l < XB_L; ++l) ds[l] = pr[l] * (g[l] - dot) * p.scale;
+  }
+  uint16_t* orow = p.dq + ((long long)b * p.nq + qi) * p.lddq + h * 64;
+  for (int d0 = 0; d0 < 64; d0 += 8) {
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int l = 0; l < XB_L; ++l)
+      if (l < p.L) {
+        const float* kr = ks + l * 64 + d0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] += ds[l] * kr[j];
+      }
+    const u32x4 o4 = {pack_bf16x2(acc[0], acc[1]), pack_bf16x2(acc[2], acc[3]), pack_bf16x2(acc[4], acc[5]), pack_bf16x2(acc[6], acc[7])};
+    *reinterpret_cast<u32x4*>(orow + d0) = o4;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ local loss backward
+// forward (elementwise.hip local_loss_kernel, reference loss.py:192-235): per sample and layer
+//   term = -min_l [ max_n( mask[n] * blur3x3(mean_h P[h, n, l])[n] ) + (1 - seg[l]) ].
+// The gradient is the 3x3 stencil of the blur around the arg-max pixel n* of the arg-min token l*, spread evenly over the heads:
+//   dP[h, n* + off(tap), l*] += weight * (-1) * mask[n*] * gk[tap] / heads.
+// One workgroup per sample (the forward's arrangement); arg-max / arg-min take the FIRST extremum, as torch.max / torch.min do on the
+// CPU.  d_probs must be zero-initialised by the caller (other contributions may be accumulated into it afterwards).
+__global__ void __launch_bounds__(256) local_loss_bwd_kernel(const float* __restrict__ probs, const float* __restrict__ mask,
+                                                             const float* __restrict__ seg, const float* __restrict__ gk,
+                                                             float* __restrict__ d_probs, float* __restrict__ loss, int heads, int size,
+                                                             int L, int seg_l, int Hm, int Wm, int mask_batch, float weight) {
+  extern __shared__ __attribute__((aligned(16))) float lbsm[];
+  float* amap = lbsm;                         // [size * size]
+  float* redv = lbsm + size * size;           // [4] wave maxima
+  int* redi = reinterpret_cast<int*>(redv + 4);   // [4] their pixel indices
+  float* best = redv + 8;                     // [0] best value, [1] (int) its token, [2] (int) its pixel
+  const int b = blockIdx.x, bm = b % mask_batch, t = threadIdx.x, n = size * size;
+  if (t == 0) {
+    best[0] = INFINITY;
+    reinterpret_cast<int*>(best)[1] = 0;
+    reinterpret_cast<int*>(best)[2] = 0;
+  }
+  __syncthreads();
+  for (int l = 0; l < seg_l; ++l) {
+    for (int i = t; i < n; i += 256) {
+      float a = 0.f;
+      for (int hh = 0; hh < heads; ++hh) a += probs[(((long long)b * heads + hh) * n + i) * L + l];
+      amap[i] = a / (float)heads;
+    }
+    __syncthreads();
+    float mx = -INFINITY;
+    int mi = 0x7fffffff;
+    for (int i = t; i < n; i += 256) {
+      const int y = i / size, x = i - y * size;
+      float acc = 0.f;
+#pragma unroll
+      for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+        for (int dx = -1; dx <= 1; ++dx) {
+          const int yy = y + dy, xx = x + dx;
+          if (yy >= 0 && yy < size && xx >= 0 && xx < size) acc += gk[(dy + 1) * 3 + dx + 1] * amap[yy * size + xx];
+        }
+      const int my = (int)(((long long)y * Hm) / size), mxx = (int)(((long long)x * Wm) / size);
+      const float val = mask[((long long)bm * Hm + my) * Wm + mxx] * acc;
+      if (val > mx) { mx = val; mi = i; }      // (i ascends per thread: the first maximum of the thread's pixels)
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      const float ov = __shfl_xor(mx, off);
+      const int oi = __shfl_xor(mi, off);
+      if (ov > mx || (ov == mx && oi < mi)) { mx = ov; mi = oi; }
+    }
+    if ((t & 63) == 0) { redv[t >> 6] = mx; redi[t >> 6] = mi; }
+    __syncthreads();
+    if (t == 0) {
+      float m4 = redv[0];
+      int i4 = redi[0];
+      for (int w = 1; w < 4; ++w)
+        if (redv[w] > m4 || (redv[w] == m4 && redi[w] < i4)) { m4 = redv[w]; i4 = redi[w]; }
+      const float pl = m4 + (1.0f - seg[(long long)bm * seg_l + l]);
+      if (pl < best[0]) {
+        best[0] = pl;
+        reinterpret_cast<int*>(best)[1] = l;
+        reinterpret_cast<int*>(best)[2] = i4 == 0x7fffffff ? 0 : i4;
+      }
+    }
+    __syncthreads();
+  }
+  if (t == 0 && loss) loss[b] += -best[0];
+  const int ls = reinterpret_cast<int*>(best)[1], ns = reinterpret_cast<int*>(best)[2];
+  const int ys = ns / size, xs = ns - ys * size;
+  const int my = (int)(((long long)ys * Hm) / size), mxx = (int)(((long long)xs * Wm) / size);
+  const float coef = -weight * mask[((long long)bm * Hm + my) * Wm + mxx] / (float)heads;
+  for (int i = t; i < 9 * heads; i += 256) {
+    const int hh = i / 9, tap = i - hh * 9;
+    const int yy = ys + tap / 3 - 1, xx = xs + tap % 3 - 1;
+    if (yy >= 0 && yy < size && xx >= 0 && xx < size)
+      d_probs[(((long long)b * heads + hh) * n + yy * size + xx) * L + ls] += coef * gk[tap];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ LayerNorm backward
+// y = xhat * gamma + beta, xhat = (x - mean) * rstd over the C channels of a row:
+//   g = dy * gamma;  dx = rstd * (g - mean(g) - xhat * mean(g * xhat))  (+ add: the gradient arriving over the residual path).
+// One wave per row; NCH 16-byte chunks per lane (C <= NCH * 512), the row stays in registers.
+template <int NCH>
+__global__ void __launch_bounds__(256) layernorm_bwd_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ dy,
+                                                            const float* __restrict__ gamma, const uint16_t* __restrict__ add,
+                                                            uint16_t* __restrict__ dx, long long rows, int C, float eps) {
+  const int lane = threadIdx.x & 63;
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int c8 = C >> 3;
+  float xv[NCH][8], gv[NCH][8];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int ch = lane + i * 64;
+    if (ch < c8) {
+      const u32x4 u = *reinterpret_cast<const u32x4*>(x + row * C + ch * 8);
+      const u32x4 w = *reinterpret_cast<const u32x4*>(dy + row * C + ch * 8);
+      const f32x4 g0 = *reinterpret_cast<const f32x4*>(gamma + ch * 8), g1 = *reinterpret_cast<const f32x4*>(gamma + ch * 8 + 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        xv[i][2 * j] = bf16_lo(u[j]);
+        xv[i][2 * j + 1] = bf16_hi(u[j]);
+        gv[i][2 * j] = bf16_lo(w[j]);
+        gv[i][2 * j + 1] = bf16_hi(w[j]);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { gv[i][j] *= g0[j]; gv[i][4 + j] *= g1[j]; }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) xv[i][j] = gv[i][j] = 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s += xv[i][j];
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+  const float mean = s / (float)C;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i)
+    if (lane + i * 64 < c8) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { const float d = xv[i][j] - mean; q += d * d; }
+    }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) q += __shfl_xor(q, off);
+  const float rstd = rsqrtf(q / (float)C + eps);
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i)
+    if (lane + i * 64 < c8) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        xv[i][j] = (xv[i][j] - mean) * rstd;         // xhat
+        s1 += gv[i][j];
+        s2 += gv[i][j] * xv[i][j];
+      }
+    }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { s1 += __shfl_xor(s1, off); s2 += __shfl_xor(s2, off); }
+  s1 /= (float)C;
+  s2 /= (float)C;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int ch = lane + i * 64;
+    if (ch < c8) {
+      float o[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = rstd * (gv[i][j] - s1 - xv[i][j] * s2);
+      if (add) {
+        const u32x4 a = *reinterpret_cast<const u32x4*>(add + row * C + ch * 8);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { o[2 * j] += bf16_lo(a[j]); o[2 * j + 1] += bf16_hi(a[j]); }
+      }
+      const u32x4 pk = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7])};
+      *reinterpret_cast<u32x4*>(dx + row * C + ch * 8) = pk;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ GroupNorm (+ SiLU) backward
+// y = act(xhat * gamma_c + beta_c), xhat = (x - mean) * rstd over the (pixels x channels-of-the-group) of one sample; act = SiLU or
+// identity.  dz = dy * act'(xhat gamma + beta);  g = dz * gamma;  dx = rstd * (g - mean(g) - xhat * mean(g xhat)) (+ add).
+// One workgroup per (sample, group): four passes over the group's elements (sum; squared deviations; the two gradient sums; the
+// result), the later ones out of L2.  Channel-last layout: a pixel's cpg channels are contiguous, cpg is even: dword accesses.
+UDT_DEVINL float block_sum_256(float v, float* red) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ void __launch_bounds__(256) gn_bwd_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ dy,
+                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                     const uint16_t* __restrict__ add, uint16_t* __restrict__ dx, int HW, int C,
+                                                     int groups, float eps, int silu) {
+  __shared__ float red[4];
+  const int b = blockIdx.x / groups, g = blockIdx.x - b * groups;
+  const int cpg = C / groups, hp = cpg >> 1;
+  const long long base = (long long)b * HW * C + g * cpg;
+  const int n2 = HW * hp;                              // dwords of the group
+  const float inv_n = 1.0f / (float)(HW * cpg);
+  auto addr = [&](int e) { const int px = e / hp, j = e - px * hp; return base + (long long)px * C + 2 * j; };
+  float s = 0.f;
+  for (int e = threadIdx.x; e < n2; e += 256) {
+    const uint32_t u = *reinterpret_cast<const uint32_t*>(x + addr(e));
+    s += bf16_lo(u) + bf16_hi(u);
+  }
+  const float mean = block_sum_256(s, red) * inv_n;
+  float q = 0.f;
+  for (int e = threadIdx.x; e < n2; e += 256) {
+    const uint32_t u = *reinterpret_cast<const uint32_t*>(x + addr(e));
+    const float a = bf16_lo(u) - mean, c2 = bf16_hi(u) - mean;
+    q += a * a + c2 * c2;
+  }
+  const float rstd = rsqrtf(block_sum_256(q, red) * inv_n + eps);
+  auto dz = [&](float xh, float dyv, float ga, float be) {
+    if (!silu) return dyv;
+    const float y0 = xh * ga + be;
+    const float sg = 1.0f / (1.0f + __expf(-y0));
+    return dyv * sg * (1.0f + y0 * (1.0f - sg));
+  };
+  float s1 = 0.f, s2 = 0.f;
+  for (int e = threadIdx.x; e < n2; e += 256) {
+    const int j = e % hp;
+    const long long a = addr(e);
+    const uint32_t u = *reinterpret_cast<const uint32_t*>(x + a);
+    const uint32_t w = *reinterpret_cast<const uint32_t*>(dy + a);
+    const float g0 = gamma[g * cpg + 2 * j], g1 = gamma[g * cpg + 2 * j + 1];
+    const float b0 = beta[g * cpg + 2 * j], b1 = beta[g * cpg + 2 * j + 1];
+    const float x0 = (bf16_lo(u) - mean) * rstd, x1 = (bf16_hi(u) - mean) * rstd;
+    const float t0 = dz(x0, bf16_lo(w), g0, b0) * g0, t1 = dz(x1, bf16_hi(w), g1, b1) * g1;
+    s1 += t0 + t1;
+    s2 += t0 * x0 + t1 * x1;
+  }
+  s1 = block_sum_256(s1, red) * inv_n;
+  s2 = block_sum_256(s2, red) * inv_n;
+  for (int e = threadIdx.x; e < n2; e += 256) {
+    const int j = e % hp;
+    const long long a = addr(e);
+    const uint32_t u = *reinterpret_cast<const uint32_t*>(x + a);
+    const uint32_t w = *reinterpret_cast<const uint32_t*>(dy + a);
+    const float g0 = gamma[g * cpg + 2 * j], g1 = gamma[g * cpg + 2 * j + 1];
+    const float b0 = beta[g * cpg + 2 * j], b1 = beta[g * cpg + 2 * j + 1];
+    const float x0 = (bf16_lo(u) - mean) * rstd, x1 = (bf16_hi(u) - mean) * rstd;
+    float o0 = rstd * (dz(x0, bf16_lo(w), g0, b0) * g0 - s1 - x0 * s2);
+    float o1 = rstd * (dz(x1, bf16_hi(w), g1, b1) * g1 - s1 - x1 * s2);
+    if (add) {
+      const uint32_t r = *reinterpret_cast<const uint32_t*>(add + a);
+      o0 += bf16_lo(r);
+      o1 += bf16_hi(r);
+    }
+    *reinterpret_cast<uint32_t*>(dx + a) = pack_bf16x2(o0, o1);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ GEGLU on stored pre-activations
+// ag [rows][2 * inner]: columns [0, inner) = x, [inner, 2 inner) = gate (reference attention.py:44-52: x, gate = proj(x).chunk(2);
+// out = x * gelu(gate), exact-erf GELU).  d x = dy * gelu(gate);  d gate = dy * x * (Phi(gate) + gate * phi(gate)).
+UDT_DEVINL float erf_as(float x) {                     // Abramowitz-Stegun 7.1.26, as gelu_erf_f
+  const float z = fabsf(x);
+  const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);
+  float poly = 1.061405429f;
+  poly = poly * t - 1.453152027f;
+  poly = poly * t + 1.421413741f;
+  poly = poly * t - 0.284496736f;
+  poly = poly * t + 0.254829592f;
+  poly = poly * t;
+  return __builtin_copysignf(1.0f - poly * __builtin_amdgcn_exp2f(-z * z * 1.4426950408889634f), x);
+}
+
+template <bool BWD>
+__global__ void __launch_bounds__(256) geglu_kernel(const uint16_t* __restrict__ ag, const uint16_t* __restrict__ dy,
+                                                    uint16_t* __restrict__ out, long long n8, int inner8) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n8) return;
+  const long long row = i / inner8;
+  const int c = (int)(i - row * inner8) * 8;
+  const long long inner = (long long)inner8 * 8;
+  const uint16_t* pa = ag + row * 2 * inner + c;
+  const u32x4 xv = *reinterpret_cast<const u32x4*>(pa);
+  const u32x4 gvv = *reinterpret_cast<const u32x4*>(pa + inner);
+  float xf[8], gf[8];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    xf[2 * j] = bf16_lo(xv[j]); xf[2 * j + 1] = bf16_hi(xv[j]);
+    gf[2 * j] = bf16_lo(gvv[j]); gf[2 * j + 1] = bf16_hi(gvv[j]);
+  }
+  if constexpr (!BWD) {
+    float o[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = xf[j] * gelu_erf_f(gf[j]);
+    const u32x4 pk = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7])};
+    *reinterpret_cast<u32x4*>(out + row * inner + c) = pk;
+  } else {
+    const u32x4 dv = *reinterpret_cast<const u32x4*>(dy + row * inner + c);
+    float df[8], ox[8], og[8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { df[2 * j] = bf16_lo(dv[j]); df[2 * j + 1] = bf16_hi(dv[j]); }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float phi_c = 0.5f * (1.0f + erf_as(gf[j] * 0.70710678118654752f));
+      const float pdf = 0.3989422804014327f * __expf(-0.5f * gf[j] * gf[j]);
+      ox[j] = df[j] * gf[j] * phi_c;
+      og[j] = df[j] * xf[j] * (phi_c + gf[j] * pdf);
+    }
+    uint16_t* po = out + row * 2 * inner + c;
+    const u32x4 px = {pack_bf16x2(ox[0], ox[1]), pack_bf16x2(ox[2], ox[3]), pack_bf16x2(ox[4], ox[5]), pack_bf16x2(ox[6], ox[7])};
+    const u32x4 pg = {pack_bf16x2(og[0], og[1]), pack_bf16x2(og[2], og[3]), pack_bf16x2(og[4], og[5]), pack_bf16x2(og[6], og[7])};
+    *reinterpret_cast<u32x4*>(po) = px;
+    *reinterpret_cast<u32x4*>(po + inner) = pg;
+  }
+}
+
+// nearest x2 upsampling backward (Upsample.forward, openaimodel.py:99-101: F.interpolate(scale_factor=2, mode="nearest")): every input
+// pixel fed a 2 x 2 block of the upsampled map, its gradient is the sum of the block.  dy [B, 2H, 2W, C] -> dx [B, H, W, C], 8 channels
+// per thread, fp32 sum, one bf16 rounding.
+__global__ void __launch_bounds__(256) sum2x2_kernel(const uint16_t* __restrict__ dy, uint16_t* __restrict__ dx, int H, int W, int c8,
+                                                     long long n8) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n8) return;
+  const int c = (int)(i % c8);
+  long long px = i / c8;
+  const int x = (int)(px % W);
+  px /= W;
+  const int y = (int)(px % H);
+  const long long b = px / H;
+  const long long row = (long long)c8 * 8;
+  const uint16_t* src = dy + (((b * 2 * H + 2 * y) * 2 * W) + 2 * x) * row + c * 8;
+  float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+  for (int dyy = 0; dyy < 2; ++dyy)
+#pragma unroll
+    for (int dxx = 0; dxx < 2; ++dxx) {
+      const u32x4 v = *reinterpret_cast<const u32x4*>(src + ((long long)dyy * 2 * W + dxx) * row);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { acc[2 * j] += bf16_lo(v[j]); acc[2 * j + 1] += bf16_hi(v[j]); }
+    }
+  const u32x4 pk = {pack_bf16x2(acc[0], acc[1]), pack_bf16x2(acc[2], acc[3]), pack_bf16x2(acc[4], acc[5]), pack_bf16x2(acc[6], acc[7])};
+  *reinterpret_cast<u32x4*>(dx + i * 8) = pk;
+}
+
+// Context tokens minus their mean over the L tokens of a sample: out[b, l, :] = bf16(x[b, l, :] - mean_l x[b, l, :]).  The text
+// cross-attention's softmax over the tokens is invariant under a common shift of the keys (every logit moves by q . kbar), and so is its
+// backward under a common shift of the values (dS_l = P_l (g_l - sum_j P_j g_j)): projecting the CENTRED context keeps in bf16 what the
+// softmax and its gradient actually see — the differences between the tokens.  The label embeddings of one string are nearly equal
+// vectors (12 positions of one transformer encoder), and dq = scale sum_l dS_l K_l with sum_l dS_l = 0 cancels their common part:
+// with K rounded to bf16 un-centred, the attend-and-excite gradient carried 7 % of rounding noise (profiles/r06_aae_debug.txt).
+__global__ void __launch_bounds__(256) center_tokens_kernel(const float* __restrict__ x, uint16_t* __restrict__ out, int L, int D) {
+  const int b = blockIdx.y;
+  const int d = blockIdx.x * 256 + threadIdx.x;
+  if (d >= D) return;
+  const float* xb = x + (long long)b * L * D + d;
+  float m = 0.f;
+  for (int l = 0; l < L; ++l) m += xb[(long long)l * D];
+  m /= (float)L;
+  uint16_t* ob = out + (long long)b * L * D + d;
+  for (int l = 0; l < L; ++l) ob[(long long)l * D] = (uint16_t)(pack_bf16x2(xb[(long long)l * D] - m, 0.f) & 0xffffu);
+}
+
+// x += a * y (fp32): the attend-and-excite update x <- x - alpha * grad (reference sampling.py:247) on the sampler's fp32 state
+__global__ void __launch_bounds__(256) axpy_f32_kernel(float* __restrict__ x, const float* __restrict__ y, float a, long long n) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) x[i] = __builtin_fmaf(a, y[i], x[i]);
+}
+
+}  // namespace
+
+#define UDT_BWD_STREAM hipStream_t s = reinterpret_cast<hipStream_t>(stream); UdtProfScope prof(5, s)
+
+extern "C" int udt_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* d_o, void* dq, void* dk, void* dv,
+                            float* lse_ws, float* dsum_ws, int32_t batch, int32_t heads, int32_t n, int32_t ldq, int32_t ldo,
+                            int32_t ldd, float scale, void* stream) {
+  if (!q || !k || !v || !o || !d_o || !dq || !dk || !dv || !lse_ws || !dsum_ws) return UDT_ERR_BAD_ARG;
+  if (batch <= 0 || heads <= 0 || n <= 0 || ldq % 8 != 0 || ldo % 8 != 0 || ldd % 4 != 0 || ldq < 64 || ldo < 64 || ldd < 64)
+    return UDT_ERR_BAD_SHAPE;
+  if ((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(k) | reinterpret_cast<uintptr_t>(v) | reinterpret_cast<uintptr_t>(o) |
+       reinterpret_cast<uintptr_t>(d_o)) & 15) return UDT_ERR_BAD_ARG;
+  if ((reinterpret_cast<uintptr_t>(dq) | reinterpret_cast<uintptr_t>(dk) | reinterpret_cast<uintptr_t>(dv)) & 7) return UDT_ERR_BAD_ARG;
+  UDT_BWD_STREAM;
+  AttnBwdParams p;
+  p.q = static_cast<const uint16_t*>(q); p.k = static_cast<const uint16_t*>(k); p.v = static_cast<const uint16_t*>(v);
+  p.o = static_cast<const uint16_t*>(o); p.d_o = static_cast<const uint16_t*>(d_o);
+  p.dq = static_cast<uint16_t*>(dq); p.dk = static_cast<uint16_t*>(dk); p.dv = static_cast<uint16_t*>(dv);
+  p.lse = lse_ws; p.dsum = dsum_ws;
+  p.heads = heads; p.n = n; p.tiles = (n + 127) / 128;
+  p.ldq = ldq; p.ldo = ldo; p.ldd = ldd;
+  p.sq = (long long)n * ldq; p.so = (long long)n * ldo; p.sd = (long long)n * ldd;
+  p.scale = scale; p.scale_log2e = scale * 1.4426950408889634f;
+  const long long units = (long long)batch * heads * p.tiles;
+  if (units > 0x7fffffffLL) return UDT_ERR_BAD_SHAPE;
+  hipLaunchKernelGGL(attn_bwd_kernel<false>, dim3((unsigned)units), dim3(256), 0, s, p);    // LSE, D, dQ
+  UDT_CHECK_LAUNCH();
+  hipLaunchKernelGGL(attn_bwd_kernel<true>, dim3((unsigned)units), dim3(256), 0, s, p);     // dK, dV (reads LSE, D)
+  UDT_CHECK_LAUNCH();
+  return UDT_OK;
+}
+
+extern "C" int udt_xattn_bwd(const void* k, const void* v, const float* probs, const float* d_probs, const void* d_o, void* dq,
+                             int32_t batch, int32_t heads, int32_t head_dim, int32_t nq, int32_t L, int32_t ldkv, int32_t ldo,
+                             int32_t lddq, float scale, void* stream) {
+  if (!k || !v || !probs || !dq || (!d_probs && !d_o)) return UDT_ERR_BAD_ARG;
+  if (batch <= 0 || heads <= 0 || head_dim != 64 || nq <= 0 || L <= 0 || L > XB_L || lddq % 8 != 0 || (d_o && ldo % 8 != 0))
+    return UDT_ERR_BAD_SHAPE;
+  if ((reinterpret_cast<uintptr_t>(dq) | reinterpret_cast<uintptr_t>(d_o)) & 15) return UDT_ERR_BAD_ARG;
+  UDT_BWD_STREAM;
+  XattnBwdParams p;
+  p.k = static_cast<const uint16_t*>(k); p.v = static_cast<const uint16_t*>(v); p.probs = probs; p.d_probs = d_probs;
+  p.d_o = static_cast<const uint16_t*>(d_o); p.dq = static_cast<uint16_t*>(dq);
+  p.heads = heads; p.nq = nq; p.L = L; p.ldkv = ldkv; p.ldo = ldo; p.lddq = lddq; p.scale = scale;
+  hipLaunchKernelGGL(xattn_bwd_kernel, dim3((nq + 255) / 256, heads, batch), dim3(256), 0, s, p);
+  UDT_CHECK_LAUNCH();
+  return UDT_OK;
+}
+
+extern "C" int udt_local_loss_bwd(const float* probs, const float* mask, const float* seg_mask, const float* gkernel9, float* d_probs,
+                                  float* loss_accum, int32_t n_samples, int32_t mask_batch, int32_t heads, int32_t size, int32_t L,
+                                  int32_t seg_l, int32_t Hm, int32_t Wm, float weight, void* stream) {
+  if (!probs || !mask || !seg_mask || !gkernel9 || !d_probs) return UDT_ERR_BAD_ARG;
+  if (n_samples <= 0 || mask_batch <= 0 || n_samples % mask_batch != 0 || heads <= 0 || size <= 0 || size > 120 || L <= 0 ||
+      seg_l <= 0 || seg_l > L) return UDT_ERR_BAD_SHAPE;
+  UDT_BWD_STREAM;
+  const size_t smem = ((size_t)size * size + 16) * sizeof(float);
+  hipLaunchKernelGGL(local_loss_bwd_kernel, dim3(n_samples), dim3(256), smem, s, probs, mask, seg_mask, gkernel9, d_probs, loss_accum,
+                     heads, size, L, seg_l, Hm, Wm, mask_batch, weight);
+  UDT_CHECK_LAUNCH();
+  return UDT_OK;
+}
+
+extern "C" int udt_layernorm_bwd(const void* x, const void* dy, const float* gamma, const void* add, void* dx, int64_t rows, int32_t C,
+                                 float eps, void* stream) {
+  if (!x || !dy || !gamma || !dx) return UDT_ERR_BAD_ARG;
+  if (rows <= 0 || C <= 0 || C % 8 != 0 || C > 2048) return UDT_ERR_BAD_SHAPE;
+  UDT_BWD_STREAM;
+  const unsigned blocks = (unsigned)((rows + 3) / 4);
+  const int nch = (C / 8 + 63) / 64;
+  const uint16_t* xp = static_cast<const uint16_t*>(x);
+  const uint16_t* dp = static_cast<const uint16_t*>(dy);
+  const uint16_t* ap = static_cast<const uint16_t*>(add);
+  uint16_t* op = static_cast<uint16_t*>(dx);
+  switch (nch) {
+    case 1: hipLaunchKernelGGL(layernorm_bwd_kernel<1>, dim3(blocks), dim3(256), 0, s, xp, dp, gamma, ap, op, (long long)rows, C, eps); break;
+    case 2: hipLaunchKernelGGL(layernorm_bwd_kernel<2>, dim3(blocks), dim3(256), 0, s, xp, dp, gamma, ap, op, (long long)rows, C, eps); break;
+    case 3: hipLaunchKernelGGL(layernorm_bwd_kernel<3>, dim3(blocks), dim3(256), 0, s, xp, dp, gamma, ap, op, (long long)rows, C, eps); break;
+    case 4: hipLaunchKernelGGL(layernorm_bwd_kernel<4>, dim3(blocks), dim3(256), 0, s, xp, dp, gamma, ap, op, (long long)rows, C, eps); break;
+    default: return UDT_ERR_BAD_SHAPE;
+  }
+  UDT_CHECK_LAUNCH();
+  return UDT_OK;
+}
+
+extern "C" int udt_gn_bwd(const void* x, const void* dy, const float* gamma, const float* beta, const void* add, void* dx, int32_t B,
+                          int32_t HW, int32_t C, int32_t groups, float eps, int32_t silu, void* stream) {
+  if (!x || !dy || !gamma || !beta || !dx) return UDT_ERR_BAD_ARG;
+  if (B <= 0 || HW <= 0 || C <= 0 || groups <= 0 || C % groups != 0 || (C / groups) % 2 != 0 || (long long)HW * (C / groups) >= (1LL << 31))
+    return UDT_ERR_BAD_SHAPE;
+  UDT_BWD_STREAM;
+  hipLaunchKernelGGL(gn_bwd_kernel, dim3((unsigned)(B * groups)), dim3(256), 0, s, static_cast<const uint16_t*>(x),
+                     static_cast<const uint16_t*>(dy), gamma, beta, static_cast<const uint16_t*>(add), static_cast<uint16_t*>(dx), HW, C,
+                     groups, eps, silu);
+  UDT_CHECK_LAUNCH();
+  return UDT_OK;
+}
+
+extern "C" int udt_geglu_fwd(const void* ag, void* out, int64_t rows, int32_t inner, void* stream) {
+  if (!ag || !out) return UDT_ERR_BAD_ARG;
+  if (rows <= 0 || inner <= 0 || inner % 8 != 0) return UDT_ERR_BAD_SHAPE;
+  UDT_BWD_STREAM;
+  const long long n8 = rows * (inner / 8);
+  hipLaunchKernelGGL(geglu_kernel<false>, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, s, static_cast<const uint16_t*>(ag), nullptr,
+                     static_cast<uint16_t*>(out), n8, inner / 8);
+  UDT_CHECK_LAUNCH();
+  return UDT_OK;
+}
+
+extern "C" int udt_geglu_bwd(const void* ag, const void* dy, void* dag, int64_t rows, int32_t inner, void* stream) {
+  if (!ag || !dy || !dag) return UDT_ERR_BAD_ARG;
+  if (rows <= 0 || inner <= 0 || inner % 8 != 0) return UDT_ERR_BAD_SHAPE;
+  UDT_BWD_STREAM;
+  const long long n8 = rows * (inner / 8);
+  hipLaunchKernelGGL(geglu_kernel<true>, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, s, static_cast<const uint16_t*>(ag),
+                     static_cast<const uint16_t*>(dy), static_cast<uint16_t*>(dag), n8, inner / 8);
+  UDT_CHECK_LAUNCH();
+  return UDT_OK;
+}
+
+extern "C" int udt_sum2x2_bf16(const void* dy, void* dx, int32_t B, int32_t H, int32_t W, int32_t C, void* stream) {
+  if (!dy || !dx) return UDT_ERR_BAD_ARG;
+  if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 8 != 0) return UDT_ERR_BAD_SHAPE;
+  UDT_BWD_STREAM;
+  const long long n8 = (long long)B * H * W * (C / 8);
+  hipLaunchKernelGGL(sum2x2_kernel, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, s, static_cast<const uint16_t*>(dy),
+                     static_cast<uint16_t*>(dx), H, W, C / 8, n8);
+  UDT_CHECK_LAUNCH();
+  return UDT_OK;
+}
+
+extern "C" int udt_axpy_f32(float* x, const float* y, float a, int64_t n, void* stream) {
+  if (!x || !y) return UDT_ERR_BAD_ARG;
+  if (n <= 0) return UDT_ERR_BAD_SHAPE;
+  UDT_BWD_STREAM;
+  hipLaunchKernelGGL(axpy_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, y, a, (long long)n);
+  UDT_CHECK_LAUNCH();
+  return UDT_OK;
+}
+
+extern "C" int udt_center_tokens(const float* x, void* out, int32_t B, int32_t L, int32_t D, void* stream) {
+  if (!x || !out) return UDT_ERR_BAD_ARG;
+  if (B <= 0 || L <= 0 || D <= 0) return UDT_ERR_BAD_SHAPE;
+  UDT_BWD_STREAM;
+  hipLaunchKernelGGL(center_tokens_kernel, dim3((D + 255) / 256, B), dim3(256), 0, s, x, static_cast<uint16_t*>(out), L, D);
+  UDT_CHECK_LAUNCH();
+  return UDT_OK;
+}

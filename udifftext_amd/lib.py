@@ -108,6 +108,16 @@ SYMBOLS = {
     "udt_mask_downsample": (C.c_int, [_fp, _fp, _i32, _i32, _i32, _vp]),
     "udt_local_loss": (C.c_int, [_fp, _fp, _fp, _fp, _fp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "udt_local_loss_tiled": (C.c_int, [_fp, _fp, _fp, _fp, _fp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "udt_attn_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _fp, _fp, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp]),
+    "udt_xattn_bwd": (C.c_int, [_vp, _vp, _fp, _fp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp]),
+    "udt_local_loss_bwd": (C.c_int, [_fp, _fp, _fp, _fp, _fp, _fp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp]),
+    "udt_layernorm_bwd": (C.c_int, [_vp, _vp, _fp, _vp, _vp, _i64, _i32, _f32, _vp]),
+    "udt_gn_bwd": (C.c_int, [_vp, _vp, _fp, _fp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _i32, _vp]),
+    "udt_geglu_fwd": (C.c_int, [_vp, _vp, _i64, _i32, _vp]),
+    "udt_geglu_bwd": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _vp]),
+    "udt_sum2x2_bf16": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp]),
+    "udt_axpy_f32": (C.c_int, [_fp, _fp, _f32, _i64, _vp]),
+    "udt_center_tokens": (C.c_int, [_fp, _vp, _i32, _i32, _i32, _vp]),
     "udt_add_bf16": (C.c_int, [_vp, _vp, _i64, _vp]),
     "udt_debug_set": (C.c_int, [C.c_char_p, _i32]),
     "udt_bias_add_bf16": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _vp]),

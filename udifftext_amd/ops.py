@@ -849,6 +849,124 @@ def bias_add(x: torch.Tensor, bias: torch.Tensor, out: Optional[torch.Tensor] = 
     return out
 
 
+# ------------------------------------------------------------------------------------------ backward (dX only, csrc/backward.hip)
+def attention_bwd(qkv: torch.Tensor, o: torch.Tensor, d_o: torch.Tensor, heads: int, scale: float) -> torch.Tensor:
+    """flash-attention backward of ``attention_rowv(qkv[..., :C], qkv[..., C:2C], qkv[..., 2C:], heads, scale)``:
+    qkv bf16 [B, N, 3 C], o / d_o bf16 [B, N, C] -> d(qkv) bf16 [B, N, 3 C] (udt_attn_bwd: two launches, deterministic)"""
+    _bf16(qkv); _bf16(o); _bf16(d_o)
+    B, N, C3 = qkv.shape
+    Cc = heads * 64
+    assert C3 == 3 * Cc and qkv.is_contiguous() and o.is_contiguous() and d_o.is_contiguous() and o.shape == (B, N, Cc) == d_o.shape
+    dqkv = torch.empty_like(qkv)
+    ws = torch.empty((2, B * heads * N), dtype=torch.float32, device=qkv.device)
+    es = qkv.element_size()
+    L.check(L.load().udt_attn_bwd(qkv.data_ptr(), qkv.data_ptr() + Cc * es, qkv.data_ptr() + 2 * Cc * es, _ptr(o), _ptr(d_o),
+                                  dqkv.data_ptr(), dqkv.data_ptr() + Cc * es, dqkv.data_ptr() + 2 * Cc * es, ws[0].data_ptr(),
+                                  ws[1].data_ptr(), B, heads, N, C3, Cc, C3, scale, _stream()), "udt_attn_bwd")
+    return dqkv
+
+
+def xattention_bwd(k: torch.Tensor, v: torch.Tensor, probs: torch.Tensor, d_probs: Optional[torch.Tensor],
+                   d_o: Optional[torch.Tensor], heads: int, scale: float) -> torch.Tensor:
+    """dq of the text cross-attention: k, v row views [B, L, *] (as ``xattention``), probs / d_probs fp32 [B * heads, Nq, L],
+    d_o bf16 [B, Nq, heads * 64] -> dq bf16 [B, Nq, heads * 64]"""
+    B, Lc = k.shape[0], k.shape[1]
+    Nq = probs.shape[1]
+    assert probs.dtype == torch.float32 and probs.is_contiguous() and probs.shape == (B * heads, Nq, Lc)
+    assert k.stride(2) == 1 and v.stride(2) == 1 and k.stride(1) == v.stride(1) and k.stride(0) == Lc * k.stride(1) == v.stride(0)
+    if d_probs is not None:
+        assert d_probs.dtype == torch.float32 and d_probs.is_contiguous() and d_probs.shape == probs.shape
+    if d_o is not None:
+        _bf16(d_o)
+        assert d_o.is_contiguous() and d_o.shape == (B, Nq, heads * 64)
+    dq = torch.empty((B, Nq, heads * 64), dtype=torch.bfloat16, device=probs.device)
+    L.check(L.load().udt_xattn_bwd(_ptr(k), _ptr(v), _ptr(probs), _ptr(d_probs), _ptr(d_o), _ptr(dq), B, heads, 64, Nq, Lc,
+                                   k.stride(1), heads * 64, heads * 64, scale, _stream()), "udt_xattn_bwd")
+    return dq
+
+
+def local_loss_bwd(probs: torch.Tensor, mask: torch.Tensor, seg_mask: torch.Tensor, gk9: torch.Tensor, d_probs: torch.Tensor,
+                   loss: Optional[torch.Tensor], heads: int, size: int, weight: float) -> None:
+    """d_probs += weight * d(local-loss term of this layer) / d probs (and loss += the term): udt_local_loss_bwd"""
+    B = mask.shape[0]
+    n = probs.shape[0] // heads
+    Lc = probs.shape[-1]
+    assert probs.is_contiguous() and d_probs.is_contiguous() and d_probs.shape == probs.shape and n % B == 0
+    assert d_probs.dtype == torch.float32 and (loss is None or (loss.is_contiguous() and loss.numel() == n))
+    L.check(L.load().udt_local_loss_bwd(_ptr(probs), _ptr(mask), _ptr(seg_mask), _ptr(gk9), _ptr(d_probs), _ptr(loss), n, B, heads,
+                                        size, Lc, seg_mask.shape[1], mask.shape[2], mask.shape[3], weight, _stream()),
+            "udt_local_loss_bwd")
+
+
+def layer_norm_bwd(x: torch.Tensor, dy: torch.Tensor, gamma: torch.Tensor, eps: float = 1e-5,
+                   add: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """dX of LayerNorm (statistics recomputed from x) + ``add`` (the gradient arriving over the residual connection)"""
+    _bf16(x); _bf16(dy)
+    assert x.is_contiguous() and dy.is_contiguous() and dy.shape == x.shape and (add is None or (add.is_contiguous() and add.shape == x.shape))
+    Cc = x.shape[-1]
+    dx = torch.empty_like(x)
+    L.check(L.load().udt_layernorm_bwd(_ptr(x), _ptr(dy), _ptr(gamma), _ptr(add), _ptr(dx), x.numel() // Cc, Cc, eps, _stream()),
+            "udt_layernorm_bwd")
+    return dx
+
+
+def group_norm_bwd(x: torch.Tensor, dy: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, groups: int, eps: float, silu: bool,
+                   add: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """dX of GroupNorm (+ SiLU) on bf16 NHWC [B, ..., C] (statistics recomputed from x) + ``add``"""
+    _bf16(x); _bf16(dy)
+    assert x.is_contiguous() and dy.is_contiguous() and dy.shape == x.shape and (add is None or (add.is_contiguous() and add.shape == x.shape))
+    B, Cc = x.shape[0], x.shape[-1]
+    dx = torch.empty_like(x)
+    L.check(L.load().udt_gn_bwd(_ptr(x), _ptr(dy), _ptr(gamma), _ptr(beta), _ptr(add), _ptr(dx), B, x.numel() // (B * Cc), Cc, groups,
+                                eps, 1 if silu else 0, _stream()), "udt_gn_bwd")
+    return dx
+
+
+def geglu(ag: torch.Tensor) -> torch.Tensor:
+    """x * gelu(gate) of stored pre-activations ag bf16 [rows, 2 * inner] = [x | gate]"""
+    _bf16(ag)
+    assert ag.is_contiguous() and ag.dim() == 2
+    inner = ag.shape[1] // 2
+    out = torch.empty((ag.shape[0], inner), dtype=torch.bfloat16, device=ag.device)
+    L.check(L.load().udt_geglu_fwd(_ptr(ag), _ptr(out), ag.shape[0], inner, _stream()), "udt_geglu_fwd")
+    return out
+
+
+def geglu_bwd(ag: torch.Tensor, dy: torch.Tensor) -> torch.Tensor:
+    _bf16(ag); _bf16(dy)
+    inner = ag.shape[1] // 2
+    assert ag.is_contiguous() and dy.is_contiguous() and dy.shape == (ag.shape[0], inner)
+    dag = torch.empty_like(ag)
+    L.check(L.load().udt_geglu_bwd(_ptr(ag), _ptr(dy), _ptr(dag), ag.shape[0], inner, _stream()), "udt_geglu_bwd")
+    return dag
+
+
+def sum2x2(dy: torch.Tensor) -> torch.Tensor:
+    """nearest x2 upsampling backward: bf16 NHWC [B, 2H, 2W, C] -> [B, H, W, C]"""
+    _bf16(dy)
+    assert dy.is_contiguous() and dy.shape[1] % 2 == 0 and dy.shape[2] % 2 == 0
+    B, H2, W2, Cc = dy.shape
+    dx = torch.empty((B, H2 // 2, W2 // 2, Cc), dtype=torch.bfloat16, device=dy.device)
+    L.check(L.load().udt_sum2x2_bf16(_ptr(dy), _ptr(dx), B, H2 // 2, W2 // 2, Cc, _stream()), "udt_sum2x2_bf16")
+    return dx
+
+
+def center_tokens(ctx: torch.Tensor) -> torch.Tensor:
+    """fp32 [B, L, D] -> bf16 [B, L, D]: every token minus the mean over the sample's L tokens (udt_center_tokens)"""
+    assert ctx.dtype == torch.float32 and ctx.is_contiguous() and ctx.dim() == 3
+    B, Lc, D = ctx.shape
+    out = torch.empty((B, Lc, D), dtype=torch.bfloat16, device=ctx.device)
+    L.check(L.load().udt_center_tokens(_ptr(ctx), _ptr(out), B, Lc, D, _stream()), "udt_center_tokens")
+    return out
+
+
+def axpy_(x: torch.Tensor, y: torch.Tensor, a: float) -> torch.Tensor:
+    """x += a * y (fp32, in place)"""
+    assert x.dtype == torch.float32 == y.dtype and x.is_contiguous() and y.is_contiguous() and x.numel() == y.numel()
+    L.check(L.load().udt_axpy_f32(_ptr(x), _ptr(y), a, x.numel(), _stream()), "udt_axpy_f32")
+    return x
+
+
 # ------------------------------------------------------------------------------------------ profiling
 def prof_enable(mask: int) -> None:
     L.check(L.load().udt_prof_enable(mask), "udt_prof_enable")

@@ -165,8 +165,9 @@ class _Stepper:
             self._emb_cache[idx] = rows
         return rows
 
-    def step(self, x: torch.Tensor, sigma: float, sigma_next: float, emit_maps: bool = False) -> None:
-        """in-place Euler update of x (fp32 NCHW [B,4,h,w])"""
+    def step(self, x: torch.Tensor, sigma: float, sigma_next: float, emit_maps: bool = False,
+             denoised: Optional[torch.Tensor] = None) -> None:
+        """in-place Euler update of x (fp32 NCHW [B,4,h,w]); denoised (optional): receives the guided denoised latent"""
         idx, sq = self.quantise(sigma)
         c_in = 1.0 / (sq * sq + 1.0) ** 0.5
         ops.unet_input(x, self.xin, c_in)
@@ -179,7 +180,7 @@ class _Stepper:
             with ops.launch_context(cu_share=self.cu_share, workspace=self.ws):
                 eps = self.unet.forward_nhwc(self.xin, emb, self.t_kv, emit_maps=emit_maps,
                                              zero_ctx_rows=self.zero_ctx_rows, t_fused=self.t_fused)
-        ops.cfg_euler_step(x, eps, sigma, sigma_next, self.scale, c_out=-sq)
+        ops.cfg_euler_step(x, eps, sigma, sigma_next, self.scale, denoised=denoised, c_out=-sq)
 
     def check(self) -> None:
         """synchronise and raise if a stream-K launch of this stepper timed out (library err word)"""
@@ -340,13 +341,41 @@ class EulerEDMSampler(EDMSampler):
         stack = torch.stack(cands, 0)                                     # [iters, B, 4, h, w]
         return stack[best, torch.arange(shape[0], device=dev)].contiguous()
 
+    # --------------------------------------------------------------------------------- attend-and-excite
+    def get_c_noise(self, x, model, sigma):
+        """reference sampling.py:224-231: the quantised timestep index of sigma (EpsScaling: c_noise = sigma)"""
+        sigma = model.denoiser.possibly_quantize_sigma(sigma)
+        return model.denoiser.possibly_quantize_c_noise(sigma.reshape(-1))
+
+    def attend_and_excite(self, x, model, sigma, cond, batch, alpha, iter_enabled, thres, max_iter=20):
+        """reference sampling.py:233-252: x <- x - alpha * d local_loss / d x, once, or (iter_enabled) until the loss falls to
+        ``thres`` or max_iter is passed.  The network sees the RAW x (no c_in scaling — the reference calls model.model directly)
+        and only the conditional batch; the gradient runs through the HIP path's written-out reverse pass
+        (udifftext_amd.backward.unet_local_loss_grad) — per sample, where the reference only accepts B = 1."""
+        from udifftext_amd import backward
+        require_gpu(x, "EulerEDMSampler.attend_and_excite")
+        c_noise = self.get_c_noise(x, model, sigma)
+        unet = model.model.diffusion_model
+        x = x.detach().clone().float().contiguous()
+        iters = 0
+        while True:
+            loss, grad = backward.unet_local_loss_grad(unet, model.loss_fn, x, c_noise.float(), cond["concat"], cond["t_crossattn"],
+                                                       batch["mask"], batch["seg_mask"])
+            ops.axpy_(x, grad, -float(alpha))
+            iters += 1
+            if not iter_enabled or bool((loss <= thres).all()) or iters > max_iter:
+                break
+        return x
+
     # ------------------------------------------------------------------------------------------- API step
     def sampler_step(self, sigma, next_sigma, model, x, cond, batch=None, uc=None, gamma=0.0, alpha=0, iter_enabled=False,
                      thres=None, update=False, name=None, save_loss=False, save_attn=False, save_inter=False):
         """reference-shaped single step on tensors (sigma / next_sigma are [B] tensors); returns
         (x_next, denoised_decode, local_loss).  Generic formulation via denoiser + guider."""
-        if gamma > 0 or update:
-            raise NotImplementedError("churn / attend-and-excite are out of scope (DESIGN.md)")
+        if gamma > 0:
+            raise NotImplementedError("s_churn > 0 (stochastic sampling) is not used by UDiffText (util.py:39)")
+        if update:
+            x = self.attend_and_excite(x, model, sigma, cond, batch, alpha, iter_enabled, thres)
         denoised = self.denoise(x, model, sigma, cond, uc)
         inter = model.decode_first_stage(denoised) if save_inter else None
         if save_loss:
@@ -372,12 +401,11 @@ class EulerEDMSampler(EDMSampler):
     # --------------------------------------------------------------------------------------------- loop
     def __call__(self, model, x, cond, batch=None, uc=None, num_steps=None, init_step=0, name=None, aae_enabled=False,
                  detailed=False):
-        if aae_enabled:
-            raise NotImplementedError("attend-and-excite needs a backward pass through the UNet — out of scope "
-                                      "(SURVEY.md §8f rank 4)")
         self._check_fast_path()
         require_gpu(x, "EulerEDMSampler")
         uc = default(uc, cond)
+        if aae_enabled:
+            return self._sample_with_attend_and_excite(model, x, cond, batch, uc, num_steps, init_step, name, detailed)
         sig = self._host_sigmas(num_steps)
         x = x.float().contiguous()
         x *= (1.0 + sig[0] ** 2.0) ** 0.5                                  # in place, like the reference :54
@@ -406,6 +434,50 @@ class EulerEDMSampler(EDMSampler):
             stepper.step(x, sig[i], sig[i + 1], emit_maps=False)
         stepper.unet.cache_attn_maps = prev
         stepper.check()
+        return x
+
+    def _sample_with_attend_and_excite(self, model, x, cond, batch, uc, num_steps, init_step, name, detailed):
+        """reference sampling.py:355-420 with aae_enabled: before every denoising step the latent takes attend-and-excite updates
+        (alpha = 20 sqrt(scale_i); iterated at steps 5, 9, ..., 25 down to thresholds -0.5 ... -0.8), the local loss of every step
+        is collected and every intermediate denoised latent decoded (the reference writes them as a GIF; imageio is optional
+        here).  Eager launches: the update's step count is data-dependent."""
+        import numpy as np
+        sig = self._host_sigmas(num_steps)
+        num_sigmas = len(sig)
+        x = x.float().contiguous()
+        x *= (1.0 + sig[0] ** 2.0) ** 0.5
+        name = name if name is not None else (batch["name"][0] if batch is not None and "name" in batch else "sample")
+        scales = np.linspace(start=1.0, stop=0, num=num_sigmas)
+        iter_lst = np.linspace(start=5, stop=25, num=6, dtype=np.int32)
+        thres_lst = np.linspace(start=-0.5, stop=-0.8, num=6)
+        B = x.shape[0]
+        stepper = _Stepper(model, cond, uc, B, x.shape[2:], self.guider.scale)
+        s_in = x.new_ones([B])
+        inters, local_losses = [], []
+        mid = (num_sigmas - 1) // 2
+        for i in self.get_sigma_gen(num_sigmas, init_step=init_step):
+            alpha = 20 * np.sqrt(scales[i])
+            iter_enabled = i in iter_lst
+            thres = float(thres_lst[list(iter_lst).index(i)]) if iter_enabled else 0.0
+            x = self.attend_and_excite(x, model, s_in * sig[i], cond, batch, alpha, iter_enabled, thres)
+            den = torch.empty_like(x)
+            stepper.step(x, sig[i], sig[i + 1], emit_maps=True, denoised=den)
+            ll = model.loss_fn.get_min_local_loss(stepper.unet.attn_map_cache, batch["mask"], batch["seg_mask"], cond_only=True)
+            local_losses.append(float(ll.mean()))
+            if detailed and i == mid:
+                attn_map = stepper.unet.save_attn_map(save_name=name, tokens=batch["label"][0])
+                self.save_segment_map(attn_map, tokens=batch["label"][0], save_name=name)
+            inter = torch.clamp((model.decode_first_stage(den) + 1.0) / 2.0, min=0.0, max=1.0)[0]
+            inters.append((inter.float().cpu().numpy().transpose(1, 2, 0) * 255).astype(np.uint8))
+        stepper.check()
+        print(f"Local losses: {local_losses}")
+        self.last_local_losses, self.last_inters = local_losses, inters
+        try:
+            import imageio
+            os.makedirs("./temp/inters", exist_ok=True)
+            imageio.mimsave(f"./temp/inters/{name}.gif", inters, "GIF", duration=0.02)
+        except ImportError:                                            # (no imageio in this image: the frames stay on the sampler)
+            pass
         return x
 
     # ------------------------------------------------------------------------------- batches in flight
