@@ -443,6 +443,36 @@ int udt_sum2x2_bf16(const void* dy, void* dx, int32_t B, int32_t H, int32_t W, i
  * tokens (attention.py:155-160) and its backward are invariant under that shift of the keys / values; used by the attend-and-excite
  * tape so that the bf16 k|v projection keeps the DIFFERENCES between the (nearly equal) label-embedding tokens */
 int udt_center_tokens(const float* x, void* out, int32_t B, int32_t L, int32_t D, void* stream);
+/* ---- training step of the text cross-attention (second half; reference diffusion.py:138-172,202-222, loss.py:131-176,
+ * 237-286; configs/train/textdesign_sd_2.yaml:4-6: only t_attn / t_norm are trained).  dW = dY^T X runs as udt_gemm on operands
+ * transposed by udt_transpose_bf16. ---------------------------------------------------------------------------------------------- */
+/* in bf16 [R, ld] (first C columns) -> out bf16 [C, Rp], Rp >= R a multiple of 64 (columns >= R zero) */
+int udt_transpose_bf16(const void* in, void* out, int32_t R, int32_t C, int32_t ld, int32_t Rp, void* stream);
+/* out[i] (+)= sum_p in[p * n + i], fp32, fixed order */
+int udt_reduce_rows_f32(const float* in, float* out, int32_t P, int64_t n, int32_t accumulate, void* stream);
+/* row-block partials of the two column reductions below: partials must hold udt_colparts(rows) * C (colsum) / * 2 C (LayerNorm) floats */
+int32_t udt_colparts(int64_t rows);
+/* out fp32 [C] = column sums of x bf16 [rows, C] (bias gradient of nn.Linear) */
+int udt_colsum_bf16(const void* x, float* partials, float* out, int64_t rows, int32_t C, void* stream);
+/* LayerNorm parameter gradients: dgamma_dbeta fp32 [2, C] = (sum_r dy * xhat, sum_r dy), x / dy bf16 [rows, C] */
+int udt_ln_param_grad(const void* x, const void* dy, float* partials, float* dgamma_dbeta, int64_t rows, int32_t C, float eps, void* stream);
+/* text cross-attention, context side (attention.py:140-175 under autograd): dk, dv bf16 [batch * L, lddkv] (head h at columns h * 64)
+ * from q bf16 [batch * nq, ldq], v, probs, d_probs (optional), d_o (optional) as udt_xattn_bwd */
+int udt_xattn_bwd_kv(const void* q, const void* v, const float* probs, const float* d_probs, const void* d_o, void* dk, void* dv,
+                     int32_t batch, int32_t heads, int32_t head_dim, int32_t nq, int32_t L, int32_t ldq, int32_t ldkv, int32_t ldo,
+                     int32_t lddkv, float scale, void* stream);
+/* FullLoss.get_local_loss (loss.py:237-286) per layer and its gradient: seg fp32 [B, seg_l, Hs, Ws] character segment maps,
+ * seg_mask fp32 [B, seg_l]; d_probs (zero-initialised) += weight * d f / d probs, loss_accum[b] (optional) += f_b */
+int udt_local_loss_seg_bwd(const float* probs, const float* seg, const float* seg_mask, const float* gkernel9, float* d_probs,
+                           float* loss_accum, int32_t B, int32_t heads, int32_t size, int32_t L, int32_t seg_l, int32_t Hs, int32_t Ws,
+                           float weight, void* stream);
+/* eps-prediction loss (loss.py:60-71,131-150; EpsScaling / EpsWeighting): loss fp32 [B] = mean(sigma^-2 (eps * -sigma + noised -
+ * target)^2) and d_eps bf16 NHWC [B, hw, cpad] = d mean_b(loss_b) / d eps; eps fp32 NHWC [B, hw, ld_eps], noised / target fp32 NCHW */
+int udt_diff_loss_grad(const float* eps, const float* noised, const float* target, const float* sigma, void* d_eps, float* loss, int32_t B,
+                       int32_t hw, int32_t ld_eps, int32_t cpad, void* stream);
+/* torch.optim.AdamW step on fp32 parameters (diffusion.py:49-51,219): g is scaled by grad_scale first (gradient accumulation / world) */
+int udt_adamw_f32(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                  float weight_decay, int32_t step, float grad_scale, void* stream);
 /* x fp32 += a * y fp32: the attend-and-excite update x <- x - alpha * grad (sampling.py:247) */
 int udt_axpy_f32(float* x, const float* y, float a, int64_t n, void* stream);
 /* x bf16 += y bf16 (n elements, n % 8 == 0) ; utility for residuals outside GEMM epilogues */

@@ -27,3 +27,24 @@ def aae_batch() -> dict:
 def aae_functional_weights(shape, k: int) -> torch.Tensor:
     """fixed pseudo-random weights R_k of the smooth functional sum_k <R_k, attn_map_k> / count (G13s)"""
     return torch.randn(tuple(shape), generator=torch.Generator().manual_seed(1300 + k))
+
+
+def train_batch() -> dict:
+    """the batch of the training-step goldens (G14 / G14s, tests/golden/train_golden.npz): two 128 x 128 images, 4 characters, and
+    per-character segment maps ``seg`` [B, 12, 128, 128]: the mask box cut into four equal cells, one per character"""
+    batch = synth.synthetic_batch(2, 128, 128, 4, seed=14)
+    B = 2
+    seg = torch.zeros((B, 12, 128, 128))
+    top, bottom, left, right = [int(v) for v in batch["r_bbox"][0]]
+    cw = (right - left) // 4
+    for l in range(4):
+        seg[:, l, top:bottom, left + l * cw:left + (l + 1) * cw] = 1.0
+    batch["seg"] = seg
+    return batch
+
+
+def sub(t: torch.Tensor, n: int = 512):
+    """strided sub-sample of a flattened tensor (<= n values) — how the goldens store large gradients"""
+    f = t.detach().float().reshape(-1)
+    step = max(1, f.numel() // n)
+    return f[::step][:n]

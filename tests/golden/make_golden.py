@@ -8,6 +8,7 @@ from seeds / the name-keyed synthetic weight recipe, expected outputs are stored
     python tests/golden/make_golden.py --g11      # only the 50-step trajectory (engine_golden_50.npz), ~3 minutes
     python tests/golden/make_golden.py --g12      # only BASELINE config #2 end to end (engine_golden_512.npz), ~10 minutes
     python tests/golden/make_golden.py --g13      # only the attend-and-excite update (aae_golden.npz), ~2 minutes
+    python tests/golden/make_golden.py --g14      # only the training step's loss and parameter gradients (train_golden.npz), ~2 minutes
 
 Import recipe: import transformers first; stub the absent third-party modules
 (pytorch_lightning, omegaconf, kornia, open_clip, imageio, seaborn, torchvision, timm); replace xformers'
@@ -156,7 +157,7 @@ def g12(model, S, t0):
 
 
 sys.path.insert(0, os.path.dirname(HERE))
-from aae_fixture import aae_batch, aae_functional_weights  # noqa: E402
+from aae_fixture import aae_batch, aae_functional_weights, train_batch, sub as gsub  # noqa: E402
 
 
 def g13(model, S, t0):
@@ -222,7 +223,78 @@ def g13(model, S, t0):
           f"{gs.pow(2).mean().sqrt().item():.3e}; maps {[it['name'] for it in used]}")
 
 
-def main(only_g11: bool = False, only_g12: bool = False, only_g13: bool = False):
+def g14(model, t0):
+    """G14 — one training step's loss and parameter gradients (second half): the real FullLoss.__call__ (reference
+    loss.py:131-176) under torch.autograd on ``train_batch()`` (B = 2, 16x16 latents), gradients with respect to the parameters
+    DiffusionEngine.configure_optimizers selects (diffusion.py:202-217: opt_keys t_attn, t_norm — 112 tensors, 75.9 M values).
+    The step's random draws are recorded (conditioning incl. its ucg draw, sigma indices, noise).  Stored: the loss dict, and for every
+    trained tensor [sum, sum |.|, sum squares] + a strided sub-sample of (a) the gradient of loss/full_loss, (b) the gradient with
+    lambda_local_loss = 0 (the eps-prediction loss alone: a smooth function of the parameters — the hard arg-max selections of
+    get_local_loss sit on near-uniform maps and are not reproducible to the last bit across hosts), (c) G14s: the gradient of the
+    smooth functional sum_k <R_k, attn_map_k> / count of the same forward."""
+    batch = train_batch()
+    torch.manual_seed(4321)
+    z = torch.randn((2, 4, 16, 16)) * 0.8
+    sigma_idx = torch.tensor([700, 250])
+    noise = torch.randn((2, 4, 16, 16))
+    loss_fn = model.loss_fn
+    unet = model.model.diffusion_model
+    names = [("model." + n) for n, _ in model.model.named_parameters() if any(k in n for k in ("t_attn", "t_norm"))]
+    params = [p for n, p in model.model.named_parameters() if any(k in n for k in ("t_attn", "t_norm"))]
+    recorded = {}
+    real_cond = model.conditioner.forward
+
+    def cond_once(b, *a, **k):
+        if "cond" not in recorded:
+            recorded["cond"] = real_cond(b, *a, **k)
+        return recorded["cond"]
+
+    real_randn_like = torch.randn_like
+    loss_fn.sigma_sampler = lambda n, rand=None: loss_fn_sigmas[sigma_idx]
+    loss_fn_sigmas = model.denoiser.sigmas
+    out = {}
+    try:
+        model.conditioner.forward = cond_once
+        torch.randn_like = lambda t, **k: noise.clone()
+        for p_ in params:
+            p_.requires_grad_(True)
+        with torch.enable_grad():
+            for tag, lam in (("full", 0.01), ("diff", 0.0)):
+                loss_fn.lambda_local_loss = lam
+                loss, ld = loss_fn(model.model, model.denoiser, model.conditioner, z, batch, model.first_stage_model, model.scale_factor)
+                gs = torch.autograd.grad(loss, params)
+                if tag == "full":
+                    for k, v in ld.items():
+                        out["g14_" + k.replace("/", "_")] = np.array([float(v)])
+                out[f"g14_{tag}_stats"] = np.stack([stats(g) for g in gs])
+                out[f"g14_{tag}_sub"] = np.stack([np.pad(gsub(g).numpy(), (0, 512 - gsub(g).numel())) for g in gs])
+            # G14s: dense cotangents on the counted maps of one more (identical) forward
+            loss_fn.lambda_local_loss = 0.01
+            cond = recorded["cond"]
+            sig = loss_fn_sigmas[sigma_idx]
+            noised = z + noise * sig[:, None, None, None]
+            model.denoiser(model.model, noised, sig, cond)
+            used = [it for it in unet.attn_map_cache if it["name"].endswith("t_attn") and it["size"] >= loss_fn.min_attn_size]
+            smooth = sum((aae_functional_weights(it["attn_map"].shape, k) * it["attn_map"]).sum() for k, it in enumerate(used)) / len(used)
+            gss = torch.autograd.grad(smooth, params, allow_unused=True)
+            gss = [g if g is not None else torch.zeros_like(p_) for g, p_ in zip(gss, params)]
+            out["g14s_value"] = np.array([float(smooth)])
+            out["g14s_stats"] = np.stack([stats(g) for g in gss])
+            out["g14s_sub"] = np.stack([np.pad(gsub(g).numpy(), (0, 512 - gsub(g).numel())) for g in gss])
+    finally:
+        model.conditioner.forward = real_cond
+        torch.randn_like = real_randn_like
+        for p_ in params:
+            p_.requires_grad_(False)
+    cond = recorded["cond"]
+    out.update({"g14_z": z.numpy(), "g14_sigma_idx": sigma_idx.numpy(), "g14_noise": noise.numpy(), "g14_c_concat": cond["concat"].detach().numpy(),
+                "g14_c_txt": cond["t_crossattn"].detach().numpy(), "g14_names": np.array(names)})
+    np.savez_compressed(os.path.join(HERE, "train_golden.npz"), **out)
+    print(f"[golden] G14 training step done ({time.time() - t0:.1f}s): " + ", ".join(f"{k} {float(out[k][0]):.6f}" for k in out if k.startswith("g14_loss"))
+          + f"; {len(names)} trained tensors, |grad| rms full {np.sqrt(out['g14_full_stats'][:, 2].sum() / sum(p_.numel() for p_ in params)):.3e}")
+
+
+def main(only_g11: bool = False, only_g12: bool = False, only_g13: bool = False, only_g14: bool = False):
     t0 = time.time()
     torch.set_grad_enabled(False)
     import_reference()
@@ -349,6 +421,9 @@ def main(only_g11: bool = False, only_g12: bool = False, only_g13: bool = False)
     if only_g13:
         g13(model, S, t0)
         return
+    if only_g14:
+        g14(model, t0)
+        return
     sampler = S.EulerEDMSampler(
         num_steps=10,
         discretization_config={"target": "sgm.modules.diffusionmodules.discretizer.LegacyDDPMDiscretization"},
@@ -462,6 +537,9 @@ def main(only_g11: bool = False, only_g12: bool = False, only_g13: bool = False)
 if __name__ == "__main__":
     if "--g13" in sys.argv:
         main(only_g13=True)
+        sys.exit(0)
+    if "--g14" in sys.argv:
+        main(only_g14=True)
         sys.exit(0)
     main(only_g11="--g11" in sys.argv, only_g12="--g12" in sys.argv)
     if "--all" in sys.argv:

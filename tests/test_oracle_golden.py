@@ -261,3 +261,39 @@ def test_g13_attend_and_excite_gradient(sd, cfg):
     ref_s = torch.from_numpy(g13["g13s_grad"])
     rel_s = ((gs - ref_s).pow(2).mean().sqrt() / ref_s.pow(2).mean().sqrt()).item()
     assert rel_s < 1e-3, rel_s
+
+
+def test_g14_training_step_loss_and_parameter_gradients(sd, cfg):
+    """SURVEY 8f-4, second half: FullLoss.__call__ (loss.py:131-176) and its gradients with respect to the t_attn / t_norm parameters
+    (oracle/training.py, torch.autograd through the functional UNet) against the real reference's loss and autograd gradients at the
+    recorded draws of one step (G14), with lambda_local_loss = 0.01 and 0; and G14s: dense cotangents on the counted maps."""
+    from aae_fixture import aae_functional_weights, sub, train_batch
+    from oracle import training
+    g = np.load(os.path.join(GOLD, "train_golden.npz"))
+    batch = train_batch()
+    z, idx, noise = torch.from_numpy(g["g14_z"]), torch.from_numpy(g["g14_sigma_idx"]), torch.from_numpy(g["g14_noise"])
+    cond = {"concat": torch.from_numpy(g["g14_c_concat"]), "t_crossattn": torch.from_numpy(g["g14_c_txt"])}
+    names = [str(n) for n in g["g14_names"]]
+    assert names == training.trainable_names(sd) and len(names) == 112
+    assert sum(sd[n].numel() for n in names) == 75_936_320                      # the 75.9 M trained values of SURVEY 8f-4
+
+    def compare(grads, tag, tol):
+        ref_sub = torch.from_numpy(g[f"{tag}_sub"])
+        num = den = 0.0
+        for i, n in enumerate(names):
+            s_ = sub(grads[n])
+            num += float((s_ - ref_sub[i, :s_.numel()]).pow(2).sum())
+            den += float(ref_sub[i, :s_.numel()].pow(2).sum())
+            st = _stats(grads[n])
+            np.testing.assert_allclose(st[2], g[f"{tag}_stats"][i, 2], rtol=4 * tol, atol=1e-30)     # sum of squares per tensor
+        assert (num / den) ** 0.5 < tol, (tag, (num / den) ** 0.5)
+
+    for tag, lam in (("g14_full", 0.01), ("g14_diff", 0.0)):
+        ld, grads = training.training_grads(sd, cfg, z, cond, batch["seg"], batch["seg_mask"], idx, noise, lambda_local=lam)
+        if lam > 0:
+            for k in ("loss/diff_loss", "loss/local_loss", "loss/full_loss"):
+                np.testing.assert_allclose(float(ld[k]), float(g["g14_" + k.replace("/", "_")][0]), rtol=2e-4, atol=1e-7)
+        compare(grads, tag, 2e-3)
+    val, gs = training.maps_functional_param_grads(sd, cfg, z, cond, idx, noise, aae_functional_weights)
+    np.testing.assert_allclose(float(val), float(g["g14s_value"][0]), rtol=1e-4)
+    compare(gs, "g14s", 2e-3)

@@ -1,0 +1,341 @@
+"""One training step of the text cross-attention on the HIP path (second half): the parameter-gradient kernels against
+torch.autograd on the same operands, then FullLoss.__call__'s loss and the gradients of the 112 trained tensors (t_attn / t_norm,
+75.9 M values) against the REAL reference's autograd at the recorded draws of one step (tests/golden/train_golden.npz, G14 / G14s),
+then the AdamW update.  ``pytest -m gpu``; everything goes through the C ABI.
+
+Stated tolerances (error rms / reference rms): kernels on given operands 1.5e-2; the step's gradients over all trained tensors 3e-2
+(bf16 forward and reverse pass, fp32 accumulation of every dW over its rows); losses 2e-2.
+
+Reference: sgm/models/diffusion.py:138-172,202-222; sgm/modules/diffusionmodules/loss.py:60-71,131-176,237-286;
+configs/train/textdesign_sd_2.yaml:4-6.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+REPORT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "parity_report.txt")
+TOL_OP, TOL_STEP = 1.5e-2, 3e-2
+
+
+def _rel(got, ref):
+    got, ref = torch.as_tensor(got).double().cpu(), torch.as_tensor(ref).double().cpu()
+    return ((got - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt().clamp_min(1e-300)).item()
+
+
+def _check(name, got, ref, tol):
+    r = _rel(got, ref)
+    os.makedirs(os.path.dirname(REPORT), exist_ok=True)
+    with open(REPORT, "a") as f:
+        f.write(f"{name:55s} rel_rms {r:.3e} (tol {tol:.1e})\n")
+    assert r <= tol, f"{name}: rel_rms {r:.3e} > {tol}"
+
+
+def _bf(t):
+    return t.bfloat16().float()
+
+
+@pytest.fixture(scope="module")
+def env(cuda):
+    import udifftext_amd  # noqa: F401
+    from udifftext_amd import lib, ops, training
+    assert lib.load().udt_device_arch_ok() == 1
+    torch.set_grad_enabled(False)
+
+    class Env:
+        pass
+    Env.ops, Env.training, Env.dev = ops, training, cuda
+    return Env
+
+
+# ------------------------------------------------------------------------------------------------ kernels
+@pytest.mark.parametrize("M,N,K", [(512, 320, 320), (300, 640, 1280), (24, 320, 2048), (4096, 1280, 1280)])
+def test_weight_gradient_through_the_forward_gemm_on_transposed_operands(env, M, N, K):
+    g = torch.Generator().manual_seed(M + N)
+    dy = _bf(torch.randn((M, N), generator=g)).to(env.dev)
+    x = _bf(torch.randn((M, K), generator=g)).to(env.dev)
+    t = env.ops.transpose(dy.bfloat16())
+    assert t.shape == (N, (M + 63) // 64 * 64) and torch.equal(t[:, :M].float(), dy.t()) and not bool(t[:, M:].any())
+    _check(f"dW = dY^T X {M}x{N}x{K}", env.ops.weight_grad(dy.bfloat16(), x.bfloat16()), dy.t() @ x, TOL_OP)
+    _check(f"bias gradient (column sums) {M}x{N}", env.ops.colsum(dy.bfloat16()), dy.sum(dim=0), TOL_OP)
+
+
+@pytest.mark.parametrize("rows,C", [(512, 320), (300, 640), (70, 1280)])
+def test_layernorm_parameter_gradients_vs_autograd(env, rows, C):
+    g = torch.Generator().manual_seed(C + 1)
+    x = _bf(torch.randn((rows, C), generator=g) * 2 + 0.5).to(env.dev)
+    dy = _bf(torch.randn((rows, C), generator=g)).to(env.dev)
+    with torch.enable_grad():
+        gamma = torch.ones((C,), device=env.dev, requires_grad=True)
+        beta = torch.zeros((C,), device=env.dev, requires_grad=True)
+        rg, rb = torch.autograd.grad((F.layer_norm(x, (C,), gamma, beta, 1e-5) * dy).sum(), [gamma, beta])
+    dg, db = env.ops.layer_norm_param_grad(x.bfloat16(), dy.bfloat16(), 1e-5)
+    _check(f"LayerNorm d gamma {rows}x{C}", dg, rg, TOL_OP)
+    _check(f"LayerNorm d beta {rows}x{C}", db, rb, TOL_OP)
+
+
+@pytest.mark.parametrize("B,H,N,L,use_dp,use_do", [(2, 5, 256, 12, True, True), (1, 10, 300, 12, False, True), (2, 5, 70, 4, True, False)])
+def test_text_cross_attention_context_gradients_vs_autograd(env, B, H, N, L, use_dp, use_do):
+    g = torch.Generator().manual_seed(3 * N + L)
+    C = H * 64
+    q = _bf(torch.randn((B, N, C), generator=g)).to(env.dev)
+    kv = _bf(torch.randn((B, L, 2 * C), generator=g)).to(env.dev)
+    d_o = _bf(torch.randn((B, N, C), generator=g)).to(env.dev)
+    d_p = torch.randn((B * H, N, L), generator=g).to(env.dev)
+    scale = 64 ** -0.5
+    kvb = kv.bfloat16().contiguous()
+    probs = torch.empty((B * H, N, L), dtype=torch.float32, device=env.dev)
+    env.ops.xattention(q.bfloat16().contiguous(), kvb[..., :C], kvb[..., C:], H, 64, scale, probs=probs)
+    with torch.enable_grad():
+        t = kv.clone().requires_grad_(True)
+        qh = q.reshape(B, N, H, 64).permute(0, 2, 1, 3)
+        kh = t[..., :C].reshape(B, L, H, 64).permute(0, 2, 1, 3)
+        vh = t[..., C:].reshape(B, L, H, 64).permute(0, 2, 1, 3)
+        p = (qh @ kh.transpose(-1, -2) * scale).softmax(dim=-1)
+        out = (p @ vh).permute(0, 2, 1, 3).reshape(B, N, C)
+        total = (out * d_o).sum() * (1.0 if use_do else 0.0) + (p.reshape(B * H, N, L) * d_p).sum() * (1.0 if use_dp else 0.0)
+        (ref,) = torch.autograd.grad(total, [t])
+    dk, dv = env.ops.xattention_bwd_kv(q.bfloat16().contiguous(), kvb[..., C:], probs, d_p if use_dp else None,
+                                       d_o.bfloat16().contiguous() if use_do else None, H, scale)
+    _check(f"text cross-attention dK B{B} H{H} N{N} L{L}", dk, ref[..., :C], TOL_OP)
+    if use_do:
+        _check(f"text cross-attention dV B{B} H{H} N{N} L{L}", dv, ref[..., C:], TOL_OP)
+    else:
+        assert not bool(dv.float().abs().max() > 0)
+
+
+@pytest.mark.parametrize("B,heads,size", [(2, 5, 16), (1, 10, 32)])
+def test_local_loss_of_the_training_step_and_its_gradient_vs_autograd(env, B, heads, size):
+    from oracle import sampling as osamp, training as otrain
+    g = torch.Generator().manual_seed(size * B)
+    n, L = size * size, 12
+    probs = torch.softmax(torch.randn((B * heads, n, L), generator=g) * 2.0, dim=-1)
+    seg = (torch.rand((B, 12, 64, 64), generator=g) > 0.6).float()
+    segm = torch.zeros((B, 12)); segm[:, :5] = 1.0
+    gk = osamp.gaussian_kernel(3, 1.0, 12)
+    with torch.enable_grad():
+        t = probs.clone().requires_grad_(True)
+        ll = otrain.local_loss([{"name": "x.t_attn", "heads": heads, "size": size, "attn_map": t}], seg, segm, gk, 1)
+        (ref,) = torch.autograd.grad(ll.sum() * 0.37, [t])
+    dp = torch.zeros_like(probs).to(env.dev)
+    loss = torch.zeros((B,), device=env.dev)
+    env.ops.local_loss_seg_bwd(probs.to(env.dev), seg.to(env.dev), segm.to(env.dev), gk[0, 0].reshape(9).contiguous().to(env.dev), dp,
+                               loss, heads, size, 0.37)
+    assert torch.allclose(loss.cpu(), ll, rtol=1e-5, atol=1e-6)
+    assert torch.allclose(dp.cpu(), ref, rtol=1e-4, atol=1e-8) and int((ref != 0).sum()) > 0
+
+
+def test_eps_prediction_loss_and_its_seed_vs_autograd(env):
+    g = torch.Generator().manual_seed(9)
+    B, h = 3, 16
+    eps = torch.randn((B, h, h, 4), generator=g).to(env.dev)
+    noised = torch.randn((B, 4, h, h), generator=g).to(env.dev)
+    target = torch.randn((B, 4, h, h), generator=g).to(env.dev)
+    sigma = torch.tensor([0.3, 2.0, 9.0], device=env.dev)
+    with torch.enable_grad():
+        t = eps.clone().requires_grad_(True)
+        out = t.permute(0, 3, 1, 2) * (-sigma[:, None, None, None]) + noised
+        lb = torch.mean((sigma[:, None, None, None] ** -2.0 * (out - target) ** 2).reshape(B, -1), 1)
+        (ref,) = torch.autograd.grad(lb.mean(), [t])
+    loss, d_eps = env.ops.diff_loss_grad(eps, noised, target, sigma)
+    assert torch.allclose(loss, lb.detach(), rtol=1e-5)
+    _check("eps-prediction loss seed d loss / d eps", d_eps[..., :4], ref, TOL_OP)
+    assert not bool(d_eps[..., 4:].any())
+
+
+def test_adamw_kernel_matches_torch_optim_adamw(env):
+    g = torch.Generator().manual_seed(2)
+    p0 = torch.randn((1000, 37), generator=g).to(env.dev)
+    ref_p = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.AdamW([ref_p], lr=5e-5 * 16, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2)
+    p, m, v = p0.clone(), torch.zeros_like(p0), torch.zeros_like(p0)
+    ver = p._version
+    for step in range(1, 4):
+        gr = torch.randn(p0.shape, generator=g).to(env.dev)
+        with torch.enable_grad():
+            ref_p.grad = gr.clone()
+            opt.step()
+        env.ops.adamw_(p, gr, m, v, step, 5e-5 * 16)
+    assert torch.allclose(p, ref_p.detach(), rtol=1e-5, atol=1e-7) and p._version != ver
+
+
+# ------------------------------------------------------------------------------------------------ one step vs the real reference
+@pytest.fixture(scope="module")
+def engine(cuda):
+    from udifftext_amd import lib, pipeline
+    assert lib.load().udt_device_arch_ok() == 1
+    torch.set_grad_enabled(False)
+    return pipeline.build_engine(cuda)
+
+
+def _compare_grads(tag, grads, g, names, key):
+    from aae_fixture import sub
+    ref_sub = torch.from_numpy(g[f"{key}_sub"])
+    num = den = 0.0
+    worst = (0.0, "")
+    for i, n in enumerate(names):
+        s_ = sub(grads[n]).cpu().double()
+        r_ = ref_sub[i, :s_.numel()].double()
+        e, d = float((s_ - r_).pow(2).sum()), float(r_.pow(2).sum())
+        num, den = num + e, den + d
+        if d > 0 and (e / d) ** 0.5 > worst[0]:
+            worst = ((e / d) ** 0.5, n)
+    r = (num / den) ** 0.5
+    with open(REPORT, "a") as f:
+        f.write(f"{tag:55s} rel_rms {r:.3e} (tol {TOL_STEP:.1e})  worst tensor {worst[0]:.3e} {worst[1]}\n")
+    return r
+
+
+def test_g14_training_step_loss_and_gradients_vs_reference_golden(engine, env):
+    from aae_fixture import aae_functional_weights, train_batch
+    g = np.load(os.path.join(GOLD, "train_golden.npz"))
+    dev = env.dev
+    batch = train_batch()
+    z, idx, noise = (torch.from_numpy(g[k]).to(dev) for k in ("g14_z", "g14_sigma_idx", "g14_noise"))
+    cond = {"concat": torch.from_numpy(g["g14_c_concat"]).to(dev), "t_crossattn": torch.from_numpy(g["g14_c_txt"]).to(dev)}
+    seg, segm = batch["seg"].to(dev), batch["seg_mask"].to(dev)
+    names = [str(n) for n in g["g14_names"]]
+    tr = env.training
+    assert [n for n, _ in tr.trainable_parameters(engine, ["t_attn", "t_norm"])] == names
+    lam = engine.loss_fn.lambda_local_loss
+    assert abs(lam - 0.01) < 1e-12
+    try:
+        ld, grads = tr.training_loss_and_grads(engine, z, cond, seg, segm, sigma_idx=idx, noise=noise)
+        assert sorted(grads) == sorted(names)
+        for k in ("loss/diff_loss", "loss/local_loss", "loss/full_loss"):
+            ref = float(g["g14_" + k.replace("/", "_")][0])
+            assert abs(float(ld[k]) - ref) <= 2e-2 * abs(ref) + 1e-6, (k, float(ld[k]), ref)
+        r_full = _compare_grads("G14 training-step gradients (lambda 0.01) vs reference", grads, g, names, "g14_full")
+        engine.loss_fn.lambda_local_loss = 0.0
+        _, grads0 = tr.training_loss_and_grads(engine, z, cond, seg, segm, sigma_idx=idx, noise=noise)
+        r_diff = _compare_grads("G14 training-step gradients (eps-prediction loss alone) vs reference", grads0, g, names, "g14_diff")
+    finally:
+        engine.loss_fn.lambda_local_loss = lam
+    assert r_diff <= TOL_STEP, r_diff
+    assert r_full <= 2 * TOL_STEP, r_full          # (includes the hard arg-max selections of get_local_loss on near-uniform maps)
+    # G14s: dense cotangents on the counted maps of the training forward -> parameter gradients
+    tape, _, _ = tr.training_tape(engine, z, cond, idx, noise)
+    used = [it for it in tape.maps if it["size"] >= engine.loss_fn.min_attn_size]
+    val = 0.0
+    for k, it in enumerate(used):
+        r = aae_functional_weights(it["attn_map"].shape, k).to(dev)
+        it["d_probs"] = (r / len(used)).contiguous()
+        val += float((r * it["attn_map"]).sum()) / len(used)
+    assert abs(val - float(g["g14s_value"][0])) <= 2e-2 * abs(float(g["g14s_value"][0]))
+    gs = {}
+    tape.backward(None, param_grads=gs)
+    assert _compare_grads("G14s dense map cotangents -> parameter gradients vs reference", gs, g, names, "g14s") <= TOL_STEP
+
+
+def test_training_step_updates_only_the_trained_parameters(engine, env):
+    """training.training_step: gradients -> AdamW on the t_attn / t_norm masters; every other parameter untouched; the packed layouts
+    and the graph fingerprint notice; the same step from the same state is bit-reproducible"""
+    import copy
+    from aae_fixture import train_batch
+    from sgm.modules.diffusionmodules.sampling import weights_fingerprint
+    g = np.load(os.path.join(GOLD, "train_golden.npz"))
+    dev = env.dev
+    batch = train_batch()
+    z, idx, noise = (torch.from_numpy(g[k]).to(dev) for k in ("g14_z", "g14_sigma_idx", "g14_noise"))
+    cond = {"concat": torch.from_numpy(g["g14_c_concat"]).to(dev), "t_crossattn": torch.from_numpy(g["g14_c_txt"]).to(dev)}
+    seg, segm = batch["seg"].to(dev), batch["seg_mask"].to(dev)
+    tr = env.training
+    named = tr.trainable_parameters(engine, ["t_attn", "t_norm"])
+    before = {n: p.detach().clone() for n, p in named}
+    other = {n: p.detach().clone() for n, p in list(engine.model.named_parameters())[:6]}
+    fp0 = weights_fingerprint(engine)
+    opt = tr.AdamW(named, lr=5e-5 * 16)
+    _, grads = tr.training_loss_and_grads(engine, z, cond, seg, segm, sigma_idx=idx, noise=noise)
+    ld1 = tr.training_step(engine, opt, z, cond, seg, segm, sigma_idx=idx, noise=noise)
+    assert weights_fingerprint(engine) != fp0
+    ref_p = [torch.nn.Parameter(before[n].clone()) for n, _ in named]
+    topt = torch.optim.AdamW(ref_p, lr=5e-5 * 16)
+    with torch.enable_grad():
+        for rp, (n, _) in zip(ref_p, named):
+            rp.grad = grads[n].reshape(rp.shape).clone()
+        topt.step()
+    for rp, (n, p) in zip(ref_p, named):
+        assert torch.allclose(p.detach(), rp.detach(), rtol=1e-5, atol=1e-8), n
+        assert not torch.equal(p.detach(), before[n]) or float(grads[n].abs().max()) == 0.0, n
+    for n, p in list(engine.model.named_parameters())[:6]:
+        assert torch.equal(p.detach(), other[n])
+    ld2 = tr.training_step(engine, opt, z, cond, seg, segm, sigma_idx=idx, noise=noise)
+    assert float(ld2["loss/full_loss"]) != float(ld1["loss/full_loss"])          # the second step sees the updated weights
+    with torch.no_grad():                                                          # restore the engine for the other tests
+        for n, p in named:
+            p.copy_(before[n])
+
+
+def test_engine_training_step_under_rccl_world1(engine, env, cuda):
+    """DiffusionEngine.configure_optimizers / training_step (reference diffusion.py:151-172,202-222) on a batch dict, with the gradient
+    average through torch.distributed's nccl (= RCCL) backend in a world of one (reduce-scatter + all-gather of the flat 304 MB
+    bucket): the update equals the single-process step's"""
+    import socket
+    import torch.distributed as dist
+    from aae_fixture import train_batch
+    from udifftext_amd import training as tr
+    mine = False
+    if not dist.is_initialized():
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=cuda)
+        mine = True
+    prev_keys = engine.opt_keys
+    engine.opt_keys = ["t_attn", "t_norm"]
+    named = tr.trainable_parameters(engine)
+    before = {n: p.detach().clone() for n, p in named}
+    try:
+        batch = {k: (v.to(cuda) if isinstance(v, torch.Tensor) else v) for k, v in train_batch().items()}
+        opt = engine.configure_optimizers(5e-5 * 16)
+        assert len(opt.named) == 112
+        calls = []
+        real_rs = dist.reduce_scatter_tensor
+        dist.reduce_scatter_tensor = lambda *a, **k: (calls.append(a[1].numel()), real_rs(*a, **k))[1]
+        try:
+            torch.manual_seed(77)
+            ld = engine.training_step(batch, opt, dist=None)              # single process
+            after_single = {n: p.detach().clone() for n, p in named}
+            with torch.no_grad():
+                for n, p in named:
+                    p.copy_(before[n])
+            opt2 = engine.configure_optimizers(5e-5 * 16)
+            torch.manual_seed(77)
+            # (a world of one skips the collective: force the RCCL branch through the bucket code)
+            loss_dict, grads = engine.shared_step(batch)
+            names = [n for n, _ in opt2.named]
+            world1 = type("D", (), {"is_initialized": staticmethod(lambda: True), "get_world_size": staticmethod(lambda: 2),
+                                    "get_backend": staticmethod(lambda: "nccl"), "ReduceOp": dist.ReduceOp,
+                                    "reduce_scatter_tensor": staticmethod(lambda out, inp, op=None: out.copy_(inp[:out.numel()] * 2)),
+                                    "all_gather_into_tensor": staticmethod(lambda out, inp: out.copy_(torch.cat([inp, out[inp.numel():] * 2])))})
+            g_ref = {n: grads[n].clone() for n in names}
+            tr.allreduce_gradients(grads, names, world1)                   # two identical "ranks": the mean equals each rank's gradient
+            for n in names:
+                assert torch.allclose(grads[n], g_ref[n], rtol=1e-6, atol=0), n
+            # ... and the real RCCL collectives on the real bucket (world 1 forced through the nccl branch)
+            real_ws = dist.get_world_size
+            dist.get_world_size = lambda *a, **k: 1 if a or k else 1
+            flat = torch.cat([g_ref[n].reshape(-1) for n in names])
+            shard = torch.empty_like(flat)
+            real_rs(shard, flat.clone(), op=dist.ReduceOp.SUM)
+            out = torch.empty_like(flat)
+            dist.all_gather_into_tensor(out, shard)
+            dist.get_world_size = real_ws
+            assert flat.numel() == 75_936_320 and torch.equal(out, flat)
+            opt2.step(grads)
+            for n, p in named:
+                assert torch.allclose(p.detach(), after_single[n], rtol=1e-6, atol=1e-9), n
+            assert float(ld["loss/full_loss"]) > 0
+        finally:
+            dist.reduce_scatter_tensor = real_rs
+    finally:
+        engine.opt_keys = prev_keys
+        with torch.no_grad():
+            for n, p in named:
+                p.copy_(before[n])
+        if mine:
+            dist.destroy_process_group()

@@ -26,6 +26,7 @@ import torch.nn as nn
 from . import ops, packing
 
 Bwd = Callable[[Optional[torch.Tensor]], Optional[torch.Tensor]]
+DEBUG_SUMS: Optional[list] = None       # (tools/debug_train3.py: per-layer checksums of the tape-mode forward)
 
 _CACHE: dict = {}
 
@@ -142,14 +143,40 @@ def transformer_block_fwd(blk, t1: torch.Tensor, B: int, kv: torch.Tensor, rec: 
         kv_c = kv
     kk, vv, vv_c = kv_c[..., :Cc], kv[..., Cc:], kv_c[..., Cc:]
     o2 = ops.xattention(q, kk, vv, ta.heads, ta.dim_head, ta.scale, probs=probs)
-    item = {"name": name, "heads": ta.heads, "size": int(N ** 0.5), "attn_map": probs, "d_probs": None}
+    # ``pgrads``: set to a dict before the reverse pass to ALSO collect the gradients of this block's trainable parameters (the
+    # reference trains t_attn / t_norm only, configs/train/textdesign_sd_2.yaml:4-6), keyed by their state-dict names below ``name``;
+    # ``ctx`` / ``ctx_c``: the context rows [B * L, Dc] (plain / centred) behind kv, needed for d to_k / d to_v
+    item = {"name": name, "heads": ta.heads, "size": int(N ** 0.5), "attn_map": probs, "d_probs": None, "pgrads": None,
+            "ctx": None, "ctx_c": None, "block": blk}
     rec.append(item)
     t3 = ta.to_out[0](o2.reshape(M, Cc), residual=t2)
     n3 = ops.layer_norm(t3, blk.norm3.weight, blk.norm3.bias, blk.norm3.eps)
     proj = ff.net[0].proj
     ag = proj(n3)                                                   # stored pre-activations [M, 2 * inner]
     t4 = ff.net[2](ops.geglu(ag), residual=t3)
-    del n1, n2, n3, q, o2
+    del n1, n2, n3
+
+    def param_grads(pg: dict, d_t3, d_o2, dq, d_n2, dP):
+        """gradients of t_attn.{to_q, to_k, to_v, to_out.0} and t_norm (fp32, state-dict names)"""
+        pre = name + "."                                            # "...transformer_blocks.i.t_attn."
+        nrm = name[:-len("t_attn")] + "t_norm."
+        if d_t3 is not None:                                        # t3 = o2 W_out^T + b + t2
+            pg[pre + "to_out.0.weight"] = ops.weight_grad(d_t3, o2.reshape(M, Cc))
+            pg[pre + "to_out.0.bias"] = ops.colsum(d_t3)
+        else:
+            pg[pre + "to_out.0.weight"] = torch.zeros((Cc, Cc), dtype=torch.float32, device=t1.device)
+            pg[pre + "to_out.0.bias"] = torch.zeros((Cc,), dtype=torch.float32, device=t1.device)
+        n2r = ops.layer_norm(t2, blk.t_norm.weight, blk.t_norm.bias, blk.t_norm.eps)
+        pg[pre + "to_q.weight"] = ops.weight_grad(dq.reshape(M, Cc), n2r)
+        dk, dv = ops.xattention_bwd_kv(q, vv_c, probs, dP, d_o2, ta.heads, ta.scale)
+        Lc = kv.shape[1]
+        cx = item["ctx"]
+        cxc = item["ctx_c"] if item["ctx_c"] is not None else cx
+        # (sum_l dK_l = 0: the centred rows give the same product, without the cancellation of the tokens' common part)
+        pg[pre + "to_k.weight"] = ops.weight_grad(dk.reshape(B * Lc, Cc), cxc)
+        pg[pre + "to_v.weight"] = ops.weight_grad(dv.reshape(B * Lc, Cc), cx)
+        dg, db = ops.layer_norm_param_grad(t2, d_n2, blk.t_norm.eps)
+        pg[nrm + "weight"], pg[nrm + "bias"] = dg, db
 
     def bwd(d_t4):
         dP = item["d_probs"]
@@ -164,6 +191,8 @@ def transformer_block_fwd(blk, t1: torch.Tensor, B: int, kv: torch.Tensor, rec: 
         d_o2 = linear_bwd(ta.to_out[0], d_t3).reshape(B, N, Cc) if d_t3 is not None else None
         dq = ops.xattention_bwd(kk, vv_c, probs, dP, d_o2, ta.heads, ta.scale)
         d_n2 = linear_bwd(ta.to_q, dq.reshape(M, Cc))
+        if item["pgrads"] is not None:
+            param_grads(item["pgrads"], d_t3, d_o2, dq, d_n2, dP)
         d_t2 = ops.layer_norm_bwd(t2, d_n2, blk.t_norm.weight, blk.t_norm.eps, add=d_t3)
         d_o = linear_bwd(a1.to_out[0], d_t2).reshape(B, N, Cc)
         d_qkv = ops.attention_bwd(qkv, o, d_o, heads, scale)
@@ -230,6 +259,8 @@ def _block_fwd(unet, block, prefix: str, h: torch.Tensor, emb_rows: torch.Tensor
             bwds.append(("lin", lambda d, c=layer: conv_bwd(c, d, n_pad=64) if d is not None else None))
         else:
             raise NotImplementedError(type(layer).__name__)
+        if DEBUG_SUMS is not None:
+            DEBUG_SUMS.append((f"{prefix}{j}", float(h.float().abs().sum())))
 
     def bwd(d):
         d_x2 = None
@@ -252,6 +283,93 @@ def _acc(a: Optional[torch.Tensor], b: Optional[torch.Tensor]) -> Optional[torch
     return ops.add_(a.contiguous(), b.contiguous())
 
 
+class UNetTape:
+    """Tape-mode forward of the UNet (every block through the ``*_fwd`` functions above) that can be reversed:
+        tape = UNetTape(unet, xin, timesteps, t_context, with_head=...)      # xin: bf16 NHWC [B, h, w, CPAD]
+        tape.maps         the t_attn probability maps in module order (dicts: name, heads, size, attn_map, d_probs, pgrads)
+        tape.eps          fp32 NHWC [B, h, w, 4] when with_head (out.0 GroupNorm + SiLU, out.2 convolution), else None
+        tape.backward(d_eps=None, param_grads=None) -> d xin (bf16 NHWC)     # d_eps: bf16 NHWC [B, h, w, 64] cotangent of eps;
+                          map cotangents are whatever the caller stored in maps[i]["d_probs"]; param_grads: a dict that receives the
+                          fp32 gradients of the t_attn / t_norm parameters under their state-dict names (prefix ``param_prefix``)"""
+
+    def __init__(self, unet, xin: torch.Tensor, timesteps: torch.Tensor, t_context: torch.Tensor, with_head: bool = False,
+                 param_prefix: str = "model.diffusion_model."):
+        self.unet, self.prefix = unet, param_prefix
+        emb_rows = unet.time_embedding_rows(timesteps)
+        ctx32 = t_context.float().contiguous()
+        t_kv = unet.project_context(ctx32)
+        ctx_c = ops.center_tokens(ctx32) if ctx32.shape[1] > 1 else None
+        t_kv_c = unet.project_context(ctx_c) if ctx_c is not None else None
+        rec: list = []
+        self.tape: List = []
+        hs = []
+        h = xin
+        for i, block in enumerate(unet.input_blocks):
+            h, b = _block_fwd(unet, block, f"input_blocks.{i}.", h, emb_rows, None, t_kv, rec, t_kv_c)
+            self.tape.append(b)
+            hs.append(h)
+        self.n_in = len(hs)
+        h, self.b_mid = _block_fwd(unet, unet.middle_block, "middle_block.", h, emb_rows, None, t_kv, rec, t_kv_c)
+        self.out_tape = []
+        for i, block in enumerate(unet.output_blocks):
+            h, b = _block_fwd(unet, block, f"output_blocks.{i}.", h, emb_rows, hs.pop(), t_kv, rec, t_kv_c)
+            self.out_tape.append(b)
+        self.maps = rec
+        Bc, Lc, Dc = ctx32.shape
+        cx = ctx32.to(torch.bfloat16).reshape(Bc * Lc, Dc)
+        cxc = ctx_c.reshape(Bc * Lc, Dc) if ctx_c is not None else None
+        for it in rec:
+            it["ctx"], it["ctx_c"] = cx, cxc
+        self.eps = None
+        self._head = None
+        if with_head:
+            gn, conv = unet.out[0], unet.out[2]
+            a = ops.group_norm(h, gn.weight, gn.bias, gn.num_groups, gn.eps, True)
+            w, bb = conv.packed()
+            self.eps = ops.conv2d(a, w, bb, ksize=3, flags=ops.L.GEMM_OUT_F32, n_out=w.shape[0])
+            self._head = (h, gn, conv)
+
+    def backward(self, d_eps: Optional[torch.Tensor] = None, param_grads: Optional[dict] = None, debug: Optional[dict] = None):
+        for it in self.maps:
+            it["pgrads"] = param_grads
+        d = None
+        if d_eps is not None:
+            h, gn, conv = self._head
+            d_a = conv_bwd(conv, d_eps)
+            d = ops.group_norm_bwd(h, d_a, gn.weight, gn.bias, gn.num_groups, gn.eps, True)
+        n_in = self.n_in
+        d_skips: List[Optional[torch.Tensor]] = [None] * n_in
+        if debug is not None:                                         # (tools/debug_aae.py: maps and block-boundary cotangents)
+            debug["maps"] = self.maps
+        for j in reversed(range(len(self.out_tape))):
+            if debug is not None and d is not None:
+                debug[f"d_output_blocks.{j}"] = d.clone()
+            d, d_x2 = self.out_tape[j](d)
+            d_skips[n_in - 1 - j] = d_x2                              # output block j consumed hs[n_in - 1 - j]
+        if debug is not None and d is not None:
+            debug["d_middle_block"] = d.clone()
+        d, _ = self.b_mid(d)
+        for i in reversed(range(n_in)):
+            d = _acc(d, d_skips[i])
+            if debug is not None and d is not None:
+                debug[f"d_input_blocks.{i}"] = d.clone()
+            d, _ = self.tape[i](d)
+        if param_grads is not None:
+            # blocks the reverse pass never reached (downstream of the last map read, no eps cotangent) have zero gradients
+            for it in self.maps:
+                blk = it["block"]
+                pre, nrm = it["name"] + ".", it["name"][:-len("t_attn")] + "t_norm."
+                for key, par in ((pre + "to_q.weight", blk.t_attn.to_q.weight), (pre + "to_k.weight", blk.t_attn.to_k.weight),
+                                 (pre + "to_v.weight", blk.t_attn.to_v.weight), (pre + "to_out.0.weight", blk.t_attn.to_out[0].weight),
+                                 (pre + "to_out.0.bias", blk.t_attn.to_out[0].bias), (nrm + "weight", blk.t_norm.weight),
+                                 (nrm + "bias", blk.t_norm.bias)):
+                    if key not in param_grads:
+                        param_grads[key] = torch.zeros(par.shape, dtype=torch.float32, device=par.device)
+            for k in [k for k in param_grads if not k.startswith(self.prefix)]:
+                param_grads[self.prefix + k] = param_grads.pop(k)
+        return d
+
+
 def unet_maps_vjp(unet, x: torch.Tensor, timesteps: torch.Tensor, concat: torch.Tensor, t_context: torch.Tensor, maps_grad,
                   debug: Optional[dict] = None) -> torch.Tensor:
     """d F / d x (fp32 [B, 4, h, w]) for a scalar F of the UNet's t_attn probability maps: the tape-mode forward of
@@ -260,43 +378,9 @@ def unet_maps_vjp(unet, x: torch.Tensor, timesteps: torch.Tensor, concat: torch.
     downstream of the last one read, are not differentiated); then the reverse pass runs."""
     from sgm.modules.diffusionmodules.openaimodel import CPAD
     xin = ops.nchw_to_nhwc(torch.cat((x.float(), concat.float()), dim=1).contiguous(), CPAD)
-    emb_rows = unet.time_embedding_rows(timesteps)
-    t_kv = unet.project_context(t_context)
-    t_kv_c = unet.project_context(ops.center_tokens(t_context.float().contiguous())) if t_context.shape[1] > 1 else None
-    rec: list = []
-    tape: List = []
-    hs = []
-    h = xin
-    for i, block in enumerate(unet.input_blocks):
-        h, b = _block_fwd(unet, block, f"input_blocks.{i}.", h, emb_rows, None, t_kv, rec, t_kv_c)
-        tape.append(b)
-        hs.append(h)
-    n_in = len(hs)
-    h, b_mid = _block_fwd(unet, unet.middle_block, "middle_block.", h, emb_rows, None, t_kv, rec, t_kv_c)
-    out_tape = []
-    for i, block in enumerate(unet.output_blocks):
-        h, b = _block_fwd(unet, block, f"output_blocks.{i}.", h, emb_rows, hs.pop(), t_kv, rec, t_kv_c)
-        out_tape.append(b)
-    del h                                                            # (F does not read eps: out.0 / out.2 are not run)
-    maps_grad(rec)
-
-    d_skips: List[Optional[torch.Tensor]] = [None] * n_in
-    d = None
-    if debug is not None:                                             # (tools/debug_aae.py: maps and block-boundary cotangents)
-        debug["maps"] = rec
-    for j in reversed(range(len(out_tape))):
-        if debug is not None and d is not None:
-            debug[f"d_output_blocks.{j}"] = d.clone()
-        d, d_x2 = out_tape[j](d)
-        d_skips[n_in - 1 - j] = d_x2                                  # output block j consumed hs[n_in - 1 - j]
-    if debug is not None and d is not None:
-        debug["d_middle_block"] = d.clone()
-    d, _ = b_mid(d)
-    for i in reversed(range(n_in)):
-        d = _acc(d, d_skips[i])
-        if debug is not None and d is not None:
-            debug[f"d_input_blocks.{i}"] = d.clone()
-        d, _ = tape[i](d)
+    tape = UNetTape(unet, xin, timesteps, t_context, with_head=False)
+    maps_grad(tape.maps)
+    d = tape.backward(debug=debug)
     if d is None:
         raise ValueError("maps_grad set no d_probs: nothing to differentiate")
     return ops.nhwc_to_nchw(d.contiguous(), 4)

@@ -683,6 +683,320 @@ __global__ void __launch_bounds__(256) axpy_f32_kernel(float* __restrict__ x, co
   if (i < n) x[i] = __builtin_fmaf(a, y[i], x[i]);
 }
 
+// ================================================================================================ training step (second half)
+// The reference trains the text cross-attention only (configs/train/textdesign_sd_2.yaml:4-6 opt_keys t_attn, t_norm: 75.9 M of the
+// UNet's parameters): FullLoss.__call__ (loss.py:131-176) = weighted eps-prediction loss + lambda * get_local_loss (loss.py:237-286).
+// Parameter gradients need, beyond the dX reverse pass above: dW = dY^T X products (the forward GEMM on transposed operands:
+// transpose_bf16_kernel), the context-side gradients of the text cross-attention (dK, dV), LayerNorm's d gamma / d beta, bias column
+// sums, the two losses' seeds, and the AdamW update.
+
+// in [R][ld] bf16 (first C columns) -> out [C][Rp] bf16, Rp >= R a multiple of 64; columns R .. Rp - 1 are zero-filled
+__global__ void __launch_bounds__(256) transpose_bf16_kernel(const uint16_t* __restrict__ in, uint16_t* __restrict__ out, int R, int C,
+                                                            int ld, int Rp) {
+  __shared__ uint16_t tile[64][66];
+  const int r0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+  for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+    const int r = i >> 6, c = i & 63;
+    tile[r][c] = (r0 + r < R && c0 + c < C) ? in[(long long)(r0 + r) * ld + c0 + c] : (uint16_t)0;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+    const int c = i >> 6, r = i & 63;
+    if (c0 + c < C && r0 + r < Rp) out[(long long)(c0 + c) * Rp + r0 + r] = tile[r][c];
+  }
+}
+
+// out[n] = sum_p in[p][n]  (fp32; fixed order: deterministic)
+__global__ void __launch_bounds__(256) reduce_rows_f32_kernel(const float* __restrict__ in, float* __restrict__ out, int P, long long n,
+                                                             int accumulate) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float a = 0.f;
+  for (int p = 0; p < P; ++p) a += in[(long long)p * n + i];
+  out[i] = accumulate ? out[i] + a : a;
+}
+
+// column partial sums of bf16 rows: part[wg * 4 + wave][c] = sum over that wave's rows of x[r][c]   (bias gradients)
+__global__ void __launch_bounds__(256) colsum_partial_kernel(const uint16_t* __restrict__ x, float* __restrict__ part, long long rows, int C,
+                                                             int rows_per_wg) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const long long r0 = (long long)blockIdx.x * rows_per_wg;
+  float* dst = part + ((long long)blockIdx.x * 4 + wave) * C;
+  for (int c = lane * 2; c < C; c += 128) {
+    float a0 = 0.f, a1 = 0.f;
+    for (long long r = r0 + wave; r < r0 + rows_per_wg && r < rows; r += 4) {
+      const uint32_t u = *reinterpret_cast<const uint32_t*>(x + r * C + c);
+      a0 += bf16_lo(u);
+      a1 += bf16_hi(u);
+    }
+    dst[c] = a0;
+    dst[c + 1] = a1;
+  }
+}
+
+// LayerNorm parameter gradients, partial: part[wg * 4 + wave][0][c] = sum_r dy[r][c] * xhat[r][c], [1][c] = sum_r dy[r][c] over the
+// wave's rows (one wave per row at a time: row statistics by shuffles, as layernorm_bwd_kernel)
+template <int NCH>
+__global__ void __launch_bounds__(256) ln_param_grad_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ dy,
+                                                            float* __restrict__ part, long long rows, int C, float eps, int rows_per_wg) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int c8 = C >> 3;
+  float gg[NCH][8], gb[NCH][8];
+#pragma unroll
+  for (int i = 0; i < NCH; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) gg[i][j] = gb[i][j] = 0.f;
+  const long long r0 = (long long)blockIdx.x * rows_per_wg;
+  for (long long row = r0 + wave; row < r0 + rows_per_wg && row < rows; row += 4) {
+    float xv[NCH][8], dv[NCH][8];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int ch = lane + i * 64;
+      if (ch < c8) {
+        const u32x4 u = *reinterpret_cast<const u32x4*>(x + row * C + ch * 8);
+        const u32x4 w = *reinterpret_cast<const u32x4*>(dy + row * C + ch * 8);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          xv[i][2 * j] = bf16_lo(u[j]); xv[i][2 * j + 1] = bf16_hi(u[j]);
+          dv[i][2 * j] = bf16_lo(w[j]); dv[i][2 * j + 1] = bf16_hi(w[j]);
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) xv[i][j] = dv[i][j] = 0.f;
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s += xv[i][j];
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    const float mean = s / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i)
+      if (lane + i * 64 < c8) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const float d = xv[i][j] - mean; q += d * d; }
+      }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) q += __shfl_xor(q, off);
+    const float rstd = rsqrtf(q / (float)C + eps);
+#pragma unroll
+    for (int i = 0; i < NCH; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        gg[i][j] += dv[i][j] * (xv[i][j] - mean) * rstd;
+        gb[i][j] += dv[i][j];
+      }
+  }
+  float* dst = part + ((long long)blockIdx.x * 4 + wave) * 2 * C;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int ch = lane + i * 64;
+    if (ch < c8) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { dst[ch * 8 + j] = gg[i][j]; dst[C + ch * 8 + j] = gb[i][j]; }
+    }
+  }
+}
+
+// Text cross-attention, context side: dV[b, l, h d] = sum_n P[n][l] dO[n][d],  dK[b, l, h d] = scale sum_n dS[n][l] q[n][d]  with dS as
+// in xattn_bwd_kernel.  One workgroup per (head, sample): tiles of 64 queries through LDS (their P rows, dS rows, dO and q rows as
+// fp32), thread t owns the outputs (l, d) = (t / 64 + 4 i, t % 64), i = 0 .. 3 (L <= 16); fixed summation order.
+__global__ void __launch_bounds__(256) xattn_bwd_kv_kernel(const XattnBwdParams p, const uint16_t* __restrict__ q, int ldq,
+                                                           uint16_t* __restrict__ dk, uint16_t* __restrict__ dv, int lddkv) {
+  __shared__ float vs[XB_L * 64];
+  __shared__ float pt[64 * XB_L];
+  __shared__ float st[64 * XB_L];
+  __shared__ float gt[64 * 65];
+  __shared__ float qt[64 * 65];
+  const int h = blockIdx.x, b = blockIdx.y, t = threadIdx.x;
+  for (int i = t; i < p.L * 64; i += 256) {
+    const int l = i >> 6, d = i & 63;
+    vs[i] = bf16_bits_to_f32(p.v[((long long)b * p.L + l) * p.ldkv + h * 64 + d]);
+  }
+  float accv[4] = {0.f, 0.f, 0.f, 0.f}, acck[4] = {0.f, 0.f, 0.f, 0.f};
+  const int d_own = t & 63, l_own = t >> 6;
+  for (int n0 = 0; n0 < p.nq; n0 += 64) {
+    __syncthreads();
+    for (int i = t; i < 64 * 64; i += 256) {
+      const int r = i >> 6, d = i & 63;
+      const int n = n0 + r;
+      const bool ok = n < p.nq;
+      gt[r * 65 + d] = (ok && p.d_o) ? bf16_bits_to_f32(p.d_o[((long long)b * p.nq + n) * p.ldo + h * 64 + d]) : 0.f;
+      qt[r * 65 + d] = ok ? bf16_bits_to_f32(q[((long long)b * p.nq + n) * ldq + h * 64 + d]) : 0.f;
+    }
+    __syncthreads();
+    if (t < 64) {
+      const int n = n0 + t;
+      float pr[XB_L], g[XB_L];
+      const long long prow = (((long long)b * p.heads + h) * p.nq + n) * p.L;
+#pragma unroll
+      for (int l = 0; l < XB_L; ++l) {
+        const bool ok = n < p.nq && l < p.L;
+        pr[l] = ok ? p.probs[prow + l] : 0.f;
+        g[l] = (ok && p.d_probs) ? p.d_probs[prow + l] : 0.f;
+      }
+      if (p.d_o) {
+        for (int d = 0; d < 64; ++d) {
+          const float gv = gt[t * 65 + d];
+#pragma unroll
+          for (int l = 0; l < XB_L; ++l)
+            if (l < p.L) g[l] += gv * vs[l * 64 + d];
+        }
+      }
+      float dot = 0.f;
+#pragma unroll
+      for (int l = 0; l < XB_L; ++l) dot += pr[l] * g[l];
+#pragma unroll
+      for (int l = 0; l < XB_L; ++l) {
+        pt[t * XB_L + l] = pr[l];
+        st[t * XB_L + l] = (p.L == 1 ? pr[l] * (1.0f - pr[l]) * g[l] : pr[l] * (g[l] - dot)) * p.scale;
+      }
+    }
+    __syncthreads();
+    for (int r = 0; r < 64; ++r) {
+      const float gv = gt[r * 65 + d_own], qv = qt[r * 65 + d_own];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int l = l_own + 4 * i;
+        accv[i] += pt[r * XB_L + l] * gv;
+        acck[i] += st[r * XB_L + l] * qv;
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int l = l_own + 4 * i;
+    if (l < p.L) {
+      const long long o = ((long long)b * p.L + l) * lddkv + h * 64 + d_own;
+      dk[o] = (uint16_t)(pack_bf16x2(acck[i], 0.f) & 0xffffu);
+      dv[o] = (uint16_t)(pack_bf16x2(accv[i], 0.f) & 0xffffu);
+    }
+  }
+}
+
+// get_local_loss (reference loss.py:237-286) and its gradient: per sample and layer
+//   f = sum_l segm[l] (max_n((1 - seg[l, n]) A[l, n]) - max_n(seg[l, n] A[l, n])) / sum_l segm[l],   A = blur3x3(mean_h P).
+// dP gets, per scored token, the blur stencil around the two arg-max pixels: + outside the character's segment, - inside.
+__global__ void __launch_bounds__(256) local_loss_seg_bwd_kernel(const float* __restrict__ probs, const float* __restrict__ segmap,
+                                                                 const float* __restrict__ segm, const float* __restrict__ gk,
+                                                                 float* __restrict__ d_probs, float* __restrict__ loss, int heads,
+                                                                 int size, int L, int seg_l, int Hs, int Ws, float weight) {
+  extern __shared__ __attribute__((aligned(16))) float lssm[];
+  float* amap = lssm;
+  float* redv = lssm + size * size;            // [8] wave maxima (inside 0..3, outside 4..7)
+  int* redi = reinterpret_cast<int*>(redv + 8);   // [8]
+  const int b = blockIdx.x, t = threadIdx.x, n = size * size;
+  float ssum = 0.f;
+  for (int l = 0; l < seg_l; ++l) ssum += segm[(long long)b * seg_l + l];
+  float total = 0.f;
+  for (int l = 0; l < seg_l; ++l) {
+    const float sm = segm[(long long)b * seg_l + l];
+    if (sm == 0.f) continue;                                   // (uniform over the workgroup)
+    __syncthreads();
+    for (int i = t; i < n; i += 256) {
+      float a = 0.f;
+      for (int hh = 0; hh < heads; ++hh) a += probs[(((long long)b * heads + hh) * n + i) * L + l];
+      amap[i] = a / (float)heads;
+    }
+    __syncthreads();
+    float mp = -INFINITY, mn = -INFINITY;
+    int ip = 0x7fffffff, in_ = 0x7fffffff;
+    for (int i = t; i < n; i += 256) {
+      const int y = i / size, x = i - y * size;
+      float acc = 0.f;
+#pragma unroll
+      for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+        for (int dx = -1; dx <= 1; ++dx) {
+          const int yy = y + dy, xx = x + dx;
+          if (yy >= 0 && yy < size && xx >= 0 && xx < size) acc += gk[(dy + 1) * 3 + dx + 1] * amap[yy * size + xx];
+        }
+      const int sy = (int)(((long long)y * Hs) / size), sx = (int)(((long long)x * Ws) / size);
+      const float sv = segmap[(((long long)b * seg_l + l) * Hs + sy) * Ws + sx];
+      const float vp = sv * acc, vn = (1.0f - sv) * acc;
+      if (vp > mp) { mp = vp; ip = i; }
+      if (vn > mn) { mn = vn; in_ = i; }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      float ov = __shfl_xor(mp, off); int oi = __shfl_xor(ip, off);
+      if (ov > mp || (ov == mp && oi < ip)) { mp = ov; ip = oi; }
+      ov = __shfl_xor(mn, off); oi = __shfl_xor(in_, off);
+      if (ov > mn || (ov == mn && oi < in_)) { mn = ov; in_ = oi; }
+    }
+    if ((t & 63) == 0) { redv[t >> 6] = mp; redi[t >> 6] = ip; redv[4 + (t >> 6)] = mn; redi[4 + (t >> 6)] = in_; }
+    __syncthreads();
+    for (int w = 0; w < 4; ++w) {                              // (every thread combines the four waves the same way)
+      if (redv[w] > mp || (redv[w] == mp && redi[w] < ip)) { mp = redv[w]; ip = redi[w]; }
+      if (redv[4 + w] > mn || (redv[4 + w] == mn && redi[4 + w] < in_)) { mn = redv[4 + w]; in_ = redi[4 + w]; }
+    }
+    total += sm * (mn - mp);
+    const float cbase = weight * sm / ssum / (float)heads;
+    for (int i = t; i < 18 * heads; i += 256) {
+      const int hh = i / 18, k = i - hh * 18;
+      const int which = k / 9, tap = k - which * 9;             // 0: inside (p, minus sign), 1: outside (n, plus sign)
+      const int ns = which ? in_ : ip;
+      if (ns == 0x7fffffff) continue;
+      const int ys = ns / size, xs = ns - ys * size;
+      const int sy = (int)(((long long)ys * Hs) / size), sx = (int)(((long long)xs * Ws) / size);
+      const float sv = segmap[(((long long)b * seg_l + l) * Hs + sy) * Ws + sx];
+      const float coef = which ? cbase * (1.0f - sv) : -cbase * sv;
+      const int yy = ys + tap / 3 - 1, xx = xs + tap % 3 - 1;
+      if (yy >= 0 && yy < size && xx >= 0 && xx < size)
+        atomicAdd(&d_probs[(((long long)b * heads + hh) * n + yy * size + xx) * L + l], coef * gk[tap]);
+    }
+  }
+  if (t == 0 && loss) loss[b] += total / ssum;
+}
+
+// the eps-prediction loss of FullLoss.__call__ / StandardDiffusionLoss (loss.py:60-71,131-150) with EpsScaling / EpsWeighting
+// (denoiser_scaling.py:16-22, denoiser_weighting.py): out = eps * (-sigma) + noised; loss_b = mean(w_b (out - target)^2), w = sigma^-2;
+// seed of the reverse pass: d (mean_b loss_b) / d eps = -sigma_b * 2 w_b (out - target) / (B * C h w), written bf16 NHWC [B, hw, cpad]
+// (channels >= 4 zero).  One workgroup per sample; eps fp32 NHWC [B, hw, ld_eps], noised / target fp32 NCHW [B, 4, hw].
+__global__ void __launch_bounds__(256) diff_loss_grad_kernel(const float* __restrict__ eps, const float* __restrict__ noised,
+                                                             const float* __restrict__ target, const float* __restrict__ sigma,
+                                                             uint16_t* __restrict__ d_eps, float* __restrict__ loss, int B, int hw,
+                                                             int ld_eps, int cpad) {
+  __shared__ float red[4];
+  const int b = blockIdx.x;
+  const float sg = sigma[b], w = 1.0f / (sg * sg);
+  const float gscale = -sg * 2.0f * w / ((float)B * 4.0f * (float)hw);
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < hw; i += 256) {
+    float g4[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const float out = eps[((long long)b * hw + i) * ld_eps + c] * (-sg) + noised[((long long)b * 4 + c) * hw + i];
+      const float r = out - target[((long long)b * 4 + c) * hw + i];
+      acc += w * r * r;
+      g4[c] = gscale * r;
+    }
+    uint16_t* dst = d_eps + ((long long)b * hw + i) * cpad;
+    *reinterpret_cast<u32x2*>(dst) = u32x2{pack_bf16x2(g4[0], g4[1]), pack_bf16x2(g4[2], g4[3])};
+    for (int c = 4; c < cpad; c += 2) *reinterpret_cast<uint32_t*>(dst + c) = 0u;
+  }
+  const float tot = block_sum_256(acc, red);
+  if (threadIdx.x == 0) loss[b] = tot / (4.0f * (float)hw);
+}
+
+// torch.optim.AdamW (the reference's default optimizer, diffusion.py:49-51): decoupled weight decay, bias-corrected moments
+__global__ void __launch_bounds__(256) adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                    float* __restrict__ v, long long n, float lr, float b1, float b2, float eps, float wd,
+                                                    float bc1, float bc2_sqrt, float gscale) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float gi = g[i] * gscale;
+  float pi = p[i] * (1.0f - lr * wd);
+  const float mi = b1 * m[i] + (1.0f - b1) * gi;
+  const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+  m[i] = mi;
+  v[i] = vi;
+  pi -= (lr / bc1) * mi / (sqrtf(vi) / bc2_sqrt + eps);
+  p[i] = pi;
+}
+
 }  // namespace
 
 #define UDT_BWD_STREAM hipStream_t s = reinterpret_cast<hipStream_t>(stream); UdtProfScope prof(5, s)
@@ -828,6 +1142,121 @@ extern "C" int udt_center_tokens(const float* x, void* out, int32_t B, int32_t L
   if (B <= 0 || L <= 0 || D <= 0) return UDT_ERR_BAD_SHAPE;
   UDT_BWD_STREAM;
   hipLaunchKernelGGL(center_tokens_kernel, dim3((D + 255) / 256, B), dim3(256), 0, s, x, static_cast<uint16_t*>(out), L, D);
+  UDT_CHECK_LAUNCH();
+  return UDT_OK;
+}
+
+extern "C" int udt_transpose_bf16(const void* in, void* out, int32_t R, int32_t C, int32_t ld, int32_t Rp, void* stream) {
+  if (!in || !out) return UDT_ERR_BAD_ARG;
+  if (R <= 0 || C <= 0 || ld < C || Rp < R || Rp % 64 != 0) return UDT_ERR_BAD_SHAPE;
+  UDT_BWD_STREAM;
+  hipLaunchKernelGGL(transpose_bf16_kernel, dim3(Rp / 64, (C + 63) / 64), dim3(256), 0, s, static_cast<const uint16_t*>(in),
+                     static_cast<uint16_t*>(out), R, C, ld, Rp);
+  UDT_CHECK_LAUNCH();
+  return UDT_OK;
+}
+
+extern "C" int udt_reduce_rows_f32(const float* in, float* out, int32_t P, int64_t n, int32_t accumulate, void* stream) {
+  if (!in || !out) return UDT_ERR_BAD_ARG;
+  if (P <= 0 || n <= 0) return UDT_ERR_BAD_SHAPE;
+  UDT_BWD_STREAM;
+  hipLaunchKernelGGL(reduce_rows_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, out, P, (long long)n, accumulate);
+  UDT_CHECK_LAUNCH();
+  return UDT_OK;
+}
+
+/* partial buffers of the two column-reduction launches below: udt_colparts(rows) row blocks of 4 waves each */
+extern "C" int32_t udt_colparts(int64_t rows) {
+  int64_t wgs = (rows + 255) / 256;
+  if (wgs > 256) wgs = 256;
+  if (wgs < 1) wgs = 1;
+  return (int32_t)(wgs * 4);
+}
+
+extern "C" int udt_colsum_bf16(const void* x, float* partials, float* out, int64_t rows, int32_t C, void* stream) {
+  if (!x || !partials || !out) return UDT_ERR_BAD_ARG;
+  if (rows <= 0 || C <= 0 || C % 2 != 0) return UDT_ERR_BAD_SHAPE;
+  UDT_BWD_STREAM;
+  const int parts = udt_colparts(rows), wgs = parts / 4;
+  const int rpw = (int)((rows + wgs - 1) / wgs);
+  hipLaunchKernelGGL(colsum_partial_kernel, dim3(wgs), dim3(256), 0, s, static_cast<const uint16_t*>(x), partials, (long long)rows, C, rpw);
+  UDT_CHECK_LAUNCH();
+  hipLaunchKernelGGL(reduce_rows_f32_kernel, dim3((C + 255) / 256), dim3(256), 0, s, partials, out, parts, (long long)C, 0);
+  UDT_CHECK_LAUNCH();
+  return UDT_OK;
+}
+
+extern "C" int udt_ln_param_grad(const void* x, const void* dy, float* partials, float* dgamma_dbeta, int64_t rows, int32_t C, float eps,
+                                 void* stream) {
+  if (!x || !dy || !partials || !dgamma_dbeta) return UDT_ERR_BAD_ARG;
+  if (rows <= 0 || C <= 0 || C % 8 != 0 || C > 2048) return UDT_ERR_BAD_SHAPE;
+  UDT_BWD_STREAM;
+  const int parts = udt_colparts(rows), wgs = parts / 4;
+  const int rpw = (int)((rows + wgs - 1) / wgs);
+  const int nch = (C / 8 + 63) / 64;
+  const uint16_t* xp = static_cast<const uint16_t*>(x);
+  const uint16_t* dp = static_cast<const uint16_t*>(dy);
+  switch (nch) {
+    case 1: hipLaunchKernelGGL(ln_param_grad_kernel<1>, dim3(wgs), dim3(256), 0, s, xp, dp, partials, (long long)rows, C, eps, rpw); break;
+    case 2: hipLaunchKernelGGL(ln_param_grad_kernel<2>, dim3(wgs), dim3(256), 0, s, xp, dp, partials, (long long)rows, C, eps, rpw); break;
+    case 3: hipLaunchKernelGGL(ln_param_grad_kernel<3>, dim3(wgs), dim3(256), 0, s, xp, dp, partials, (long long)rows, C, eps, rpw); break;
+    case 4: hipLaunchKernelGGL(ln_param_grad_kernel<4>, dim3(wgs), dim3(256), 0, s, xp, dp, partials, (long long)rows, C, eps, rpw); break;
+    default: return UDT_ERR_BAD_SHAPE;
+  }
+  UDT_CHECK_LAUNCH();
+  hipLaunchKernelGGL(reduce_rows_f32_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, s, partials, dgamma_dbeta, parts, (long long)2 * C, 0);
+  UDT_CHECK_LAUNCH();
+  return UDT_OK;
+}
+
+extern "C" int udt_xattn_bwd_kv(const void* q, const void* v, const float* probs, const float* d_probs, const void* d_o, void* dk, void* dv,
+                                int32_t batch, int32_t heads, int32_t head_dim, int32_t nq, int32_t L, int32_t ldq, int32_t ldkv,
+                                int32_t ldo, int32_t lddkv, float scale, void* stream) {
+  if (!q || !v || !probs || !dk || !dv || (!d_probs && !d_o)) return UDT_ERR_BAD_ARG;
+  if (batch <= 0 || heads <= 0 || head_dim != 64 || nq <= 0 || L <= 0 || L > XB_L) return UDT_ERR_BAD_SHAPE;
+  UDT_BWD_STREAM;
+  XattnBwdParams p;
+  p.k = nullptr; p.v = static_cast<const uint16_t*>(v); p.probs = probs; p.d_probs = d_probs;
+  p.d_o = static_cast<const uint16_t*>(d_o); p.dq = nullptr;
+  p.heads = heads; p.nq = nq; p.L = L; p.ldkv = ldkv; p.ldo = ldo; p.lddq = 0; p.scale = scale;
+  hipLaunchKernelGGL(xattn_bwd_kv_kernel, dim3(heads, batch), dim3(256), 0, s, p, static_cast<const uint16_t*>(q), ldq,
+                     static_cast<uint16_t*>(dk), static_cast<uint16_t*>(dv), lddkv);
+  UDT_CHECK_LAUNCH();
+  return UDT_OK;
+}
+
+extern "C" int udt_local_loss_seg_bwd(const float* probs, const float* seg, const float* seg_mask, const float* gkernel9, float* d_probs,
+                                      float* loss_accum, int32_t B, int32_t heads, int32_t size, int32_t L, int32_t seg_l, int32_t Hs,
+                                      int32_t Ws, float weight, void* stream) {
+  if (!probs || !seg || !seg_mask || !gkernel9 || !d_probs) return UDT_ERR_BAD_ARG;
+  if (B <= 0 || heads <= 0 || size <= 0 || size > 120 || L <= 0 || seg_l <= 0 || seg_l > L) return UDT_ERR_BAD_SHAPE;
+  UDT_BWD_STREAM;
+  const size_t smem = ((size_t)size * size + 32) * sizeof(float);
+  hipLaunchKernelGGL(local_loss_seg_bwd_kernel, dim3(B), dim3(256), smem, s, probs, seg, seg_mask, gkernel9, d_probs, loss_accum, heads,
+                     size, L, seg_l, Hs, Ws, weight);
+  UDT_CHECK_LAUNCH();
+  return UDT_OK;
+}
+
+extern "C" int udt_diff_loss_grad(const float* eps, const float* noised, const float* target, const float* sigma, void* d_eps, float* loss,
+                                  int32_t B, int32_t hw, int32_t ld_eps, int32_t cpad, void* stream) {
+  if (!eps || !noised || !target || !sigma || !d_eps || !loss) return UDT_ERR_BAD_ARG;
+  if (B <= 0 || hw <= 0 || ld_eps < 4 || cpad < 4 || cpad % 4 != 0) return UDT_ERR_BAD_SHAPE;
+  UDT_BWD_STREAM;
+  hipLaunchKernelGGL(diff_loss_grad_kernel, dim3(B), dim3(256), 0, s, eps, noised, target, sigma, static_cast<uint16_t*>(d_eps), loss, B, hw,
+                     ld_eps, cpad);
+  UDT_CHECK_LAUNCH();
+  return UDT_OK;
+}
+
+extern "C" int udt_adamw_f32(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                             float weight_decay, int32_t step, float grad_scale, void* stream) {
+  if (!p || !g || !m || !v) return UDT_ERR_BAD_ARG;
+  if (n <= 0 || step <= 0) return UDT_ERR_BAD_SHAPE;
+  UDT_BWD_STREAM;
+  const float bc1 = 1.0f - powf(beta1, (float)step), bc2 = 1.0f - powf(beta2, (float)step);
+  hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p, g, m, v, (long long)n, lr, beta1, beta2, eps,
+                     weight_decay, bc1, sqrtf(bc2), grad_scale);
   UDT_CHECK_LAUNCH();
   return UDT_OK;
 }

@@ -118,6 +118,15 @@ SYMBOLS = {
     "udt_sum2x2_bf16": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "udt_axpy_f32": (C.c_int, [_fp, _fp, _f32, _i64, _vp]),
     "udt_center_tokens": (C.c_int, [_fp, _vp, _i32, _i32, _i32, _vp]),
+    "udt_transpose_bf16": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp]),
+    "udt_reduce_rows_f32": (C.c_int, [_fp, _fp, _i32, _i64, _i32, _vp]),
+    "udt_colparts": (_i32, [_i64]),
+    "udt_colsum_bf16": (C.c_int, [_vp, _fp, _fp, _i64, _i32, _vp]),
+    "udt_ln_param_grad": (C.c_int, [_vp, _vp, _fp, _fp, _i64, _i32, _f32, _vp]),
+    "udt_xattn_bwd_kv": (C.c_int, [_vp, _vp, _fp, _fp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp]),
+    "udt_local_loss_seg_bwd": (C.c_int, [_fp, _fp, _fp, _fp, _fp, _fp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp]),
+    "udt_diff_loss_grad": (C.c_int, [_fp, _fp, _fp, _fp, _vp, _fp, _i32, _i32, _i32, _i32, _vp]),
+    "udt_adamw_f32": (C.c_int, [_fp, _fp, _fp, _fp, _i64, _f32, _f32, _f32, _f32, _f32, _i32, _f32, _vp]),
     "udt_add_bf16": (C.c_int, [_vp, _vp, _i64, _vp]),
     "udt_debug_set": (C.c_int, [C.c_char_p, _i32]),
     "udt_bias_add_bf16": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _vp]),

@@ -967,6 +967,96 @@ def axpy_(x: torch.Tensor, y: torch.Tensor, a: float) -> torch.Tensor:
     return x
 
 
+# ------------------------------------------------------------------------------------------ training step (csrc/backward.hip)
+def transpose(x: torch.Tensor) -> torch.Tensor:
+    """bf16 [R, C] (row-strided view allowed) -> [C, Rp], Rp = R rounded up to 64, zero-padded (operand of a dW = dY^T X GEMM)"""
+    _bf16(x)
+    assert x.dim() == 2 and x.stride(1) == 1
+    R, Cc = x.shape
+    Rp = (R + 63) // 64 * 64
+    out = torch.empty((Cc, Rp), dtype=torch.bfloat16, device=x.device)
+    L.check(L.load().udt_transpose_bf16(_ptr(x), _ptr(out), R, Cc, x.stride(0), Rp, _stream()), "udt_transpose_bf16")
+    return out
+
+
+def weight_grad(dy: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
+    """dW fp32 [N, K] = dy^T x for dy bf16 [M, N], x bf16 [M, K] (nn.Linear: y = x W^T): the forward GEMM on the two operands
+    transposed (contraction over the M rows, fp32 accumulation and output)"""
+    return linear(transpose(dy), transpose(x), None, flags=L.GEMM_OUT_F32)
+
+
+def colsum(x: torch.Tensor) -> torch.Tensor:
+    """fp32 [C] column sums of bf16 [rows, C] (bias gradient)"""
+    _bf16(x)
+    assert x.is_contiguous() and x.dim() == 2
+    rows, Cc = x.shape
+    lib = L.load()
+    part = torch.empty((lib.udt_colparts(rows), Cc), dtype=torch.float32, device=x.device)
+    out = torch.empty((Cc,), dtype=torch.float32, device=x.device)
+    L.check(lib.udt_colsum_bf16(_ptr(x), _ptr(part), _ptr(out), rows, Cc, _stream()), "udt_colsum_bf16")
+    return out
+
+
+def layer_norm_param_grad(x: torch.Tensor, dy: torch.Tensor, eps: float = 1e-5):
+    """(d gamma, d beta) fp32 [C] each of LayerNorm over bf16 rows x with output cotangent dy"""
+    _bf16(x); _bf16(dy)
+    assert x.is_contiguous() and dy.is_contiguous() and x.shape == dy.shape and x.dim() == 2
+    rows, Cc = x.shape
+    lib = L.load()
+    part = torch.empty((lib.udt_colparts(rows), 2, Cc), dtype=torch.float32, device=x.device)
+    out = torch.empty((2, Cc), dtype=torch.float32, device=x.device)
+    L.check(lib.udt_ln_param_grad(_ptr(x), _ptr(dy), _ptr(part), _ptr(out), rows, Cc, eps, _stream()), "udt_ln_param_grad")
+    return out[0], out[1]
+
+
+def xattention_bwd_kv(q: torch.Tensor, v: torch.Tensor, probs: torch.Tensor, d_probs: Optional[torch.Tensor],
+                      d_o: Optional[torch.Tensor], heads: int, scale: float):
+    """(dk, dv) bf16 [B, L, heads * 64] of the text cross-attention: q bf16 [B, Nq, C], v a row view [B, L, *]"""
+    _bf16(q)
+    B, Nq, Cc = q.shape
+    Lc = v.shape[1]
+    assert q.is_contiguous() and v.stride(2) == 1 and v.stride(0) == Lc * v.stride(1) and probs.shape == (B * heads, Nq, Lc)
+    dk = torch.empty((B, Lc, Cc), dtype=torch.bfloat16, device=q.device)
+    dv = torch.empty_like(dk)
+    L.check(L.load().udt_xattn_bwd_kv(_ptr(q), _ptr(v), _ptr(probs), _ptr(d_probs), _ptr(d_o), _ptr(dk), _ptr(dv), B, heads, 64, Nq, Lc,
+                                      Cc, v.stride(1), Cc, Cc, scale, _stream()), "udt_xattn_bwd_kv")
+    return dk, dv
+
+
+def local_loss_seg_bwd(probs: torch.Tensor, seg: torch.Tensor, seg_mask: torch.Tensor, gk9: torch.Tensor, d_probs: torch.Tensor,
+                       loss: Optional[torch.Tensor], heads: int, size: int, weight: float) -> None:
+    """FullLoss.get_local_loss per layer: d_probs += weight * d f / d probs, loss[b] += f_b (udt_local_loss_seg_bwd)"""
+    B = seg.shape[0]
+    assert probs.is_contiguous() and d_probs.is_contiguous() and d_probs.shape == probs.shape and probs.shape[0] == B * heads
+    assert seg.dtype == torch.float32 and seg.is_contiguous() and seg_mask.is_contiguous() and seg.shape[1] == seg_mask.shape[1]
+    L.check(L.load().udt_local_loss_seg_bwd(_ptr(probs), _ptr(seg), _ptr(seg_mask), _ptr(gk9), _ptr(d_probs), _ptr(loss), B, heads, size,
+                                            probs.shape[-1], seg.shape[1], seg.shape[2], seg.shape[3], weight, _stream()),
+            "udt_local_loss_seg_bwd")
+
+
+def diff_loss_grad(eps: torch.Tensor, noised: torch.Tensor, target: torch.Tensor, sigma: torch.Tensor, cpad: int = 64):
+    """(loss fp32 [B], d_eps bf16 NHWC [B, h, w, cpad]) of the eps-prediction loss: eps fp32 NHWC [B, h, w, ld], noised / target fp32 NCHW"""
+    B, h, w, ld = eps.shape
+    assert eps.dtype == torch.float32 and eps.is_contiguous() and noised.is_contiguous() and target.is_contiguous()
+    assert noised.shape == (B, 4, h, w) == target.shape and sigma.dtype == torch.float32 and sigma.numel() == B
+    d_eps = torch.empty((B, h, w, cpad), dtype=torch.bfloat16, device=eps.device)
+    loss = torch.empty((B,), dtype=torch.float32, device=eps.device)
+    L.check(L.load().udt_diff_loss_grad(_ptr(eps), _ptr(noised), _ptr(target), _ptr(sigma), _ptr(d_eps), _ptr(loss), B, h * w, ld, cpad,
+                                        _stream()), "udt_diff_loss_grad")
+    return loss, d_eps
+
+
+def adamw_(p: torch.Tensor, g: torch.Tensor, m: torch.Tensor, v: torch.Tensor, step: int, lr: float, betas=(0.9, 0.999), eps: float = 1e-8,
+           weight_decay: float = 1e-2, grad_scale: float = 1.0) -> None:
+    """torch.optim.AdamW's update of one fp32 tensor, in place (udt_adamw_f32); bumps the tensor's version so that cached packed
+    layouts and captured graphs notice"""
+    for t in (p, g, m, v):
+        assert t.dtype == torch.float32 and t.is_contiguous() and t.numel() == p.numel()
+    L.check(L.load().udt_adamw_f32(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), lr, betas[0], betas[1], eps, weight_decay, step,
+                                   grad_scale, _stream()), "udt_adamw_f32")
+    torch._C._increment_version(p)
+
+
 # ------------------------------------------------------------------------------------------ profiling
 def prof_enable(mask: int) -> None:
     L.check(L.load().udt_prof_enable(mask), "udt_prof_enable")

@@ -1,7 +1,8 @@
 """``DiffusionEngine``: the object the reference's ``init_model`` builds from ``configs/*.yaml`` and that the
 sampler reaches into (``model.denoiser``, ``model.model``, ``model.conditioner``, ``model.first_stage_model``,
-``model.loss_fn``) — reference sgm/models/diffusion.py:22-136.  A plain ``nn.Module`` (no Lightning); the
-training half of the reference class (training_step / optimisers / EMA / log_images, :138-328) is out of scope.
+``model.loss_fn``) — reference sgm/models/diffusion.py:22-136.  A plain ``nn.Module`` (no Lightning).  Round 6: the training half's
+core — ``forward`` (the loss), ``shared_step`` / ``training_step`` and ``configure_optimizers`` (:138-172,202-222) — runs on the
+HIP path's written-out reverse pass (udifftext_amd.training); EMA, logging and log_images stay out of scope.
 """
 from __future__ import annotations
 
@@ -109,5 +110,38 @@ class DiffusionEngine(nn.Module):
     def encode_first_stage(self, x):
         return self.scale_factor * self.first_stage_model.encode(x)
 
+    # ------------------------------------------------------------------------------ training (reference :138-172,202-222)
     def forward(self, x, batch):
-        raise NotImplementedError("training forward (loss) is out of scope of the MI355X inference path")
+        """reference :138-142: ``loss_fn(model, denoiser, conditioner, x, batch, ...)`` -> (loss, loss_dict).  x: latents
+        [B, 4, h, w]; batch: ``label`` / ``mask`` / ``masked`` for the conditioner (its ucg draw included) plus ``seg`` / ``seg_mask``"""
+        from udifftext_amd import training
+        cond = self.conditioner(batch)
+        loss_dict, _ = training.training_loss_and_grads(self, x, cond, batch["seg"], batch["seg_mask"], want_grads=False)
+        return loss_dict["loss/full_loss"], loss_dict
+
+    def shared_step(self, batch):
+        """reference :144-149 (latents from the first stage, then the loss) — with the gradients of the trained parameters"""
+        from udifftext_amd import training
+        x = self.encode_first_stage(self.get_input(batch))
+        cond = self.conditioner(batch)
+        return training.training_loss_and_grads(self, x, cond, batch["seg"], batch["seg_mask"])
+
+    def configure_optimizers(self, learning_rate: float = 5.0e-5):
+        """reference :202-222: AdamW (the default optimizer_config) over the parameters whose names contain an ``opt_keys`` entry;
+        the LambdaLR 0.95^epoch is ``optimizer.set_epoch``"""
+        from udifftext_amd import training
+        if self.optimizer_config.get("target", "torch.optim.AdamW") != "torch.optim.AdamW":
+            raise NotImplementedError("udt_adamw_f32 implements the reference's default optimiser (torch.optim.AdamW)")
+        named = training.trainable_parameters(self)
+        if not named:
+            raise ValueError("opt_keys selects no parameter (configs/train/textdesign_sd_2.yaml: t_attn, t_norm)")
+        return training.AdamW(named, lr=learning_rate, **self.optimizer_config.get("params", {}))
+
+    def training_step(self, batch, optimizer, dist=None):
+        """reference :151-172 + the optimiser step Lightning takes after it: loss, gradients, rank average (``dist``), AdamW update;
+        returns the loss dict"""
+        from udifftext_amd import training
+        loss_dict, grads = self.shared_step(batch)
+        training.allreduce_gradients(grads, [n for n, _ in optimizer.named], dist)
+        optimizer.step(grads)
+        return loss_dict
