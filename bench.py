@@ -100,6 +100,18 @@ def measured_traffic():
     return None, None
 
 
+def measured_traffic_inflight_plans():
+    """the same counters with every launch PLANNED for three batches in flight (tools/predict_once.py UDT_PLAN_SHARE=3: the split-K /
+    tile plans of the headline mode; profiles/rNN_traffic_inflight_plans.json) — None if absent"""
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic_inflight_plans.json")), reverse=True):
+        try:
+            d = json.load(open(path))
+            return float((d.get("conv3") or d["conv3p"])["hbm_bytes_per_launch"]), os.path.basename(path) + (" @ " + str(d["head"]) if d.get("head") else "")
+        except Exception:
+            continue
+    return None, None
+
+
 def physical_cores() -> int:
     try:
         import psutil
@@ -465,7 +477,9 @@ def main():
                    "LDS-staged patches" + (" / c3p::conv3p_kernel (GroupNorm+SiLU on the staged patch)" if Hn.FUSE_GN else "") +
                    " + g8::gemm8_kernel<CONV> (stride-2 gathers), UNet + VAE",
                    conv_flops, conv_bytes, conv_ms, conv_launches)
+        traffic_if, traffic_if_file = measured_traffic_inflight_plans()
         conv.update({"traffic": traffic, "traffic_source": traffic_file,
+                     "traffic_inflight_plans": traffic_if, "traffic_inflight_plans_source": traffic_if_file,
                      "traffic_hbm_gbps": (traffic / (conv["avg_launch_us"] * 1e-6) / 1e9) if traffic else None,
                      "traffic_frac_of_hbm_peak": (traffic / (conv["avg_launch_us"] * 1e-6) / PEAK_HBM) if traffic else None,
                      "traffic_scope": "patch-staged 3x3 launches (wd::wconv3_kernel + lg::lconv3_kernel: %d of the %d launches of the class): algorithmic "

@@ -1,0 +1,48 @@
+"""Round 6: time of one attend-and-excite gradient (tape-mode forward + reverse pass through the whole UNet, B = 1) and
+of one training step's loss + parameter gradients (B = 4) at 64 x 64 latents (512 x 512 images), with the per-class split from the
+library's launch profiler.  Correctness-first kernels: the numbers say where this path stands, not where it could be."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import torch
+import udifftext_amd
+from udifftext_amd import backward, pipeline, synth, training as tr, ops, lib as L
+dev = torch.device("cuda", 0); torch.set_grad_enabled(False)
+engine = pipeline.build_engine(dev)
+unet = engine.model.diffusion_model
+
+def timed(fn, n=3):
+    fn(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n * 1e3
+
+for size, B in ((512, 1), (256, 1)):
+    batch = synth.synthetic_batch(B, size, size, 9, seed=3)
+    torch.manual_seed(1)
+    batch, buc = pipeline.prepare_batch(batch, dev)
+    c, uc = engine.conditioner.get_unconditional_conditioning(batch, batch_uc=buc, force_uc_zero_embeddings=["label"])
+    h = size // 8
+    x = torch.randn((B, 4, h, h), device=dev) * 5.0
+    ts = torch.full((B,), 500.0, device=dev)
+    f = lambda: backward.unet_local_loss_grad(unet, engine.loss_fn, x, ts, c["concat"], c["t_crossattn"], batch["mask"], batch["seg_mask"])
+    ms = timed(f)
+    sampler = pipeline.init_sampling(50, 5.0, dev)
+    print(f"attend-and-excite gradient, {size}x{size}, B={B}: {ms:.1f} ms per evaluation (tape-mode forward + reverse pass, eager launches)")
+for size, B in ((512, 4), (256, 4)):
+    h = size // 8
+    z = torch.randn((B, 4, h, h), device=dev)
+    batch = synth.synthetic_batch(B, size, size, 9, seed=4)
+    torch.manual_seed(2)
+    batch, buc = pipeline.prepare_batch(batch, dev)
+    cond = engine.conditioner(batch)
+    seg = torch.zeros((B, 12, size, size), device=dev); seg[:, :9, size // 2 - 16:size // 2 + 16, :] = 1.0
+    idx = torch.tensor([100, 400, 700, 900][:B])
+    noise = torch.randn((B, 4, h, h), device=dev)
+    f = lambda: tr.training_loss_and_grads(engine, z, cond, seg, batch["seg_mask"], sigma_idx=idx, noise=noise)
+    ms = timed(f)
+    f2 = lambda: tr.training_loss_and_grads(engine, z, cond, seg, batch["seg_mask"], sigma_idx=idx, noise=noise, want_grads=False)
+    ms2 = timed(f2)
+    print(f"training step loss + gradients of the 112 t_attn / t_norm tensors, {size}x{size}, B={B}: {ms:.1f} ms (tape-mode forward alone {ms2:.1f} ms; "
+          f"inference forward of the same 4 samples: see unet_ms_per_sampler_step / 2)")

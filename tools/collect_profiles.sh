@@ -35,6 +35,13 @@ for n in 2 10; do for c in FETCH_SIZE WRITE_SIZE; do
   UDT_GRAPHS=0 UDT_DUAL_STREAM=0 timeout 600 rocprofv3 --pmc $c --output-format csv -d /tmp/pmc_${c}_$n -o p -- python $R/tools/predict_once.py $n > /dev/null 2>&1
 done; done
 python $R/tools/pmc_extrapolate.py /tmp/pmc_FETCH_SIZE_2/p_counter_collection.csv /tmp/pmc_WRITE_SIZE_2/p_counter_collection.csv /tmp/pmc_FETCH_SIZE_10/p_counter_collection.csv /tmp/pmc_WRITE_SIZE_10/p_counter_collection.csv > $O/traffic.json
+#    ... and the same with every launch PLANNED for three batches in flight (the headline mode's split-K / tile plans: round 6's
+#    share-aware split-K removes slices there)
+for n in 2 10; do for c in FETCH_SIZE WRITE_SIZE; do
+  rm -rf /tmp/pmci_${c}_$n
+  UDT_PLAN_SHARE=3 UDT_GRAPHS=0 UDT_DUAL_STREAM=0 timeout 600 rocprofv3 --pmc $c --output-format csv -d /tmp/pmci_${c}_$n -o p -- python $R/tools/predict_once.py $n > /dev/null 2>&1
+done; done
+python $R/tools/pmc_extrapolate.py /tmp/pmci_FETCH_SIZE_2/p_counter_collection.csv /tmp/pmci_WRITE_SIZE_2/p_counter_collection.csv /tmp/pmci_FETCH_SIZE_10/p_counter_collection.csv /tmp/pmci_WRITE_SIZE_10/p_counter_collection.csv > $O/traffic_inflight_plans.json
 # 5. MFMA utilisation per kernel (one PMC pass over a 4-step batch)
 rm -rf /tmp/pmc_mfma
 UDT_GRAPHS=0 UDT_DUAL_STREAM=0 timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d /tmp/pmc_mfma -o p -- python $R/tools/predict_once.py 4 > /dev/null 2>&1
@@ -65,6 +72,9 @@ jstamp $O/bench_config4_768.json $O/bench_fp8.json
 (cd $R && python tools/attn_tail.py 2>/dev/null | grep "workgroups" > $O/attn_vs_workgroups.txt)
 (cd $R && UDT_FP8_ATTN=0 python bench.py --fp8 --no-cpu-baseline --no-extra-configs --no-reference-default 2>/dev/null | tail -1 > $O/bench_fp8_linears_only.json)
 jstamp $O/bench_fp8_linears_only.json
+#    round 6: attend-and-excite gradient and one training step at the benchmark's latent size
+(cd $R && python tools/bench_aae.py 2>/dev/null | grep -v amdgpu.ids > $O/aae_training_bench.txt)
+stamp $O/aae_training_bench.txt
 stamp $O/mx8_layers.txt $O/trace_step_fp8.txt $O/attn_mx8_layers.txt $O/attn_vs_workgroups.txt
 stamp $O/in_flight_sweep.txt $O/phase_times.txt $O/gemm_shapes.txt $O/wide_conv.txt $O/trace_step.txt $O/bench_ops.txt $O/attn512.txt $O/rowres_bench.txt $O/tattn_bench.txt $O/reference_default.txt
 ls -la $O; cut -c1-400 $O/bench.json; cat $O/traffic.json | head -40; head -30 $O/mfma_util.json

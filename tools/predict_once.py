@@ -13,6 +13,10 @@ cfgs = C.default_runtime_config(steps=steps, batch_size=4, noise_iters=0, gpu=0)
 b = synth.synthetic_batch(4, 512, 512, 9, seed=0)
 b = {k: (v.to(dev) if isinstance(v, torch.Tensor) else v) for k, v in b.items()}
 print("stage: predict", flush=True)
-out, z = pipeline.predict(cfgs, model, sampler, b, dev)
+# UDT_PLAN_SHARE=n: every launch is PLANNED as one of n batches in flight (udt_gemm_desc.cu_share: the share-aware split-K / tile
+# rules of the headline mode) while this process still runs one batch alone — counter collection serialises kernels anyway
+from udifftext_amd import ops
+with ops.launch_context(cu_share=int(os.environ.get("UDT_PLAN_SHARE", "1"))):
+    out, z = pipeline.predict(cfgs, model, sampler, b, dev)
 torch.cuda.synchronize()
 print("done", out.shape, flush=True)

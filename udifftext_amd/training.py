@@ -95,12 +95,12 @@ def trainable_parameters(engine, opt_keys: Optional[List[str]] = None) -> List[T
 
 
 # ------------------------------------------------------------------------------------------------ data-parallel gradient average
-def allreduce_gradients(grads: Dict[str, torch.Tensor], names: List[str], dist=None) -> None:
+def allreduce_gradients(grads: Dict[str, torch.Tensor], names: List[str], dist=None, force: bool = False) -> None:
     """average the gradients over the ranks, in place: ONE flat fp32 bucket in the order ``names`` (the same on every rank).  On RCCL:
     reduce-scatter + all-gather of the padded bucket — on the xGMI full mesh both are direct peer exchanges, 2 (N - 1) / N of the
     bucket per GPU; with gloo (CPU tests): all_reduce."""
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
-        return
+    if dist is None or not dist.is_initialized() or (dist.get_world_size() == 1 and not force):
+        return                                                           # (force: run the collectives in a world of one — tests)
     world = dist.get_world_size()
     flat = torch.cat([grads[n].reshape(-1) for n in names])
     n = flat.numel()
