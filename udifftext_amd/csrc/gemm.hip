@@ -796,8 +796,28 @@ int lean_mode() {
 
 // udt_debug_set("rowres", v): 1 (default) the row-resident kernel where it applies, 0 never (same-process A/B, tools/ab_step.py;
 // a tuning knob of the debug interface like "lean_splitk", not an environment switch)
-std::atomic<int> g_rowres{1};
-bool rowres_on() { return g_rowres.load(std::memory_order_relaxed) != 0; }
+std::atomic<int> g_rowres{-2};
+bool rowres_on() {
+  int v = g_rowres.load(std::memory_order_relaxed);
+  if (v == -2) {
+    const char* e = getenv("UDT_ROWRES");                  // (A/B of whole bench runs; udt_debug_set("rowres") for same-process A/Bs)
+    v = e ? (atoi(e) != 0) : 1;
+    g_rowres.store(v, std::memory_order_relaxed);
+  }
+  return v != 0;
+}
+// UDT_LEAN256_LANES (default 1): the 256 x 256 / one-workgroup-per-CU tile also for launches that share the device with other
+// streams (0: under lanes the co-resident 128 x 128 tile; round 6 A/B, profiles/r06_ab_one_per_cu_under_lanes.txt)
+std::atomic<int> g_lean256_lanes{-2};
+bool lean256_under_lanes() {
+  int v = g_lean256_lanes.load(std::memory_order_relaxed);
+  if (v == -2) {
+    const char* e = getenv("UDT_LEAN256_LANES");
+    v = e ? (atoi(e) != 0) : 1;
+    g_lean256_lanes.store(v, std::memory_order_relaxed);
+  }
+  return v != 0;
+}
 
 bool lean_plan(const udt_gemm_desc* d, LeanPlan& t, bool want_stats) {
   const int mode = lean_mode();
@@ -883,7 +903,8 @@ bool lean_plan(const udt_gemm_desc* d, LeanPlan& t, bool want_stats) {
   // many tiles and a wide output: the 256 x 256 tile (8 waves, one workgroup per CU) halves the LDS-DMA instructions per MFMA.
   // Measured (profiles/r03_gemm_shapes_256.txt): faster from ~2 tiles per CU up (32768x2560x320 GEGLU 93 -> 81 us,
   // 32768x960x320 33 -> 32 us), slower below (every M <= 2048 shape)
-  if (mode <= 0 && d->N >= 768 && (long long)((d->M + 255) / 256) * ((d->N + 255) / 256) >= 2LL * device_cus()) t.cfg = 6;
+  if (mode <= 0 && d->N >= 768 && (long long)((d->M + 255) / 256) * ((d->N + 255) / 256) >= 2LL * device_cus() &&
+      (d->cu_share <= 1 || lean256_under_lanes())) t.cfg = 6;
   }
   t.stats_rows = 0;
   if (want_stats) {
@@ -1089,6 +1110,7 @@ extern "C" int udt_debug_set(const char* key, int32_t value) {
   if (!strcmp(key, "rows_epi")) { g_rows_epi.store(value ? 1 : 0); return UDT_OK; }
   if (!strcmp(key, "lean")) { g_lean.store(value < 0 ? -2 : value); return UDT_OK; }
   if (!strcmp(key, "rowres")) { g_rowres.store(value < 0 ? 1 : (value ? 1 : 0)); return UDT_OK; }
+  if (!strcmp(key, "lean256_lanes")) { g_lean256_lanes.store(value < 0 ? -2 : (value ? 1 : 0)); return UDT_OK; }
   if (!strcmp(key, "lean_splitk")) { g_lean_splitk.store(value); return UDT_OK; }
   if (!strcmp(key, "share_splitk")) { g_share_splitk.store(value < 0 ? -2 : (value ? 1 : 0)); return UDT_OK; }
   if (!strcmp(key, "lean_conv")) { g_lean_conv.store(value < 0 ? -1 : (value ? 1 : 0)); return UDT_OK; }
