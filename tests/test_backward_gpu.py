@@ -330,3 +330,23 @@ def test_sampling_with_attend_and_excite_runs_and_lowers_the_local_loss(engine, 
     assert sampler.last_inters[0].shape == (128, 128, 3)
     z_plain = sampler(engine, x0.clone(), cond=c, batch=batch, uc=uc, aae_enabled=False)
     assert not torch.equal(z, z_plain)
+
+
+def test_predict_with_aae_enabled_end_to_end(engine, env):
+    """configs/test.yaml ``aae_enabled: True`` through pipeline.predict (= test.py:19-40): conditioner -> noise -> the sampler's
+    attend-and-excite loop -> decode; frames finite and in range, and different from the plain run's"""
+    from udifftext_amd import config as C, pipeline
+    dev = env.dev
+    sampler = pipeline.init_sampling(6, 5.0, dev)
+    outs = []
+    for aae in (True, False):
+        cfgs = C.default_runtime_config(steps=6, batch_size=1, noise_iters=0)
+        cfgs.aae_enabled = aae
+        batch = {k: (v.to(dev) if isinstance(v, torch.Tensor) else v) for k, v in env.synth.synthetic_batch(1, 128, 128, 4, seed=21).items()}
+        torch.manual_seed(3)
+        frames, z = pipeline.predict(cfgs, engine, sampler, batch, dev)
+        assert frames.shape == (1, 3, 128, 128) and bool(torch.isfinite(frames).all())
+        assert float(frames.min()) >= 0.0 and float(frames.max()) <= 1.0
+        outs.append(z)
+    assert not torch.equal(outs[0], outs[1])
+    assert len(sampler.last_local_losses) == 6

@@ -41,7 +41,7 @@ def env(cuda):
 
         @staticmethod
         def reset():
-            for k in ("lean", "lean_splitk", "lean_conv", "wide_conv", "rowres"):
+            for k in ("lean", "lean_splitk", "lean_conv", "wide_conv", "rowres", "share_splitk", "lean256_lanes"):
                 L.check(lib.udt_debug_set(k.encode(), -1), "udt_debug_set " + k)
     yield Env
     Env.reset()
@@ -288,6 +288,36 @@ def test_lean_conv3x3_vs_torch(env, cuda, case):
             assert math.isfinite(e) and e < REL_RMS, f"conv3x3 lean_conv={lean_conv} {case}: rel rms {e:.3e}"
             outs[lean_conv] = out
         assert _rel(outs[1], outs[0]) < REL_RMS
+    finally:
+        env.reset()
+
+
+def test_share_aware_split_k_plans_and_results(env, cuda):
+    """round 6 (UDT_SHARE_SPLITK): a launch that shares the device with two other streams (cu_share 3) cuts K to fill ITS share of
+    the workgroup slots — the deep-K few-tile GEMM and the 16x16-level convolution of the benchmarked call run whole tiles where the
+    round-5 rule cut 3 slices.  Both rules agree with the fp32 reference; the results differ in the last bits (another summation
+    order), which is how the test knows the plan changed; a lone launch (cu_share 1) is bit-identical under both."""
+    x, wp, bp, kw, y = _linear_case(env, cuda, 2048, 1280, 5120, 0, True, 0, seed=12)
+    g = torch.Generator(device="cpu").manual_seed(13)
+    xc = torch.randn((8, 16, 16, 1280), generator=g).to(cuda).bfloat16()
+    w4 = (torch.randn((1280, 1280, 3, 3), generator=g) / math.sqrt(9 * 1280)).to(cuda)
+    bc = torch.randn((1280,), generator=g).to(cuda)
+    yc = F.conv2d(xc.float().permute(0, 3, 1, 2), w4.bfloat16().float(), bc, padding=1).permute(0, 2, 3, 1)
+    wc = env.packing.pack_conv(w4)
+    try:
+        res = {}
+        for share in (3, 1):
+            for rule in (1, 0):
+                env.dbg("share_splitk", rule)
+                with env.ops.launch_context(cu_share=share):
+                    a = env.ops.linear(x, wp, bp, **kw)
+                    b = env.ops.conv2d(xc, wc, bc, ksize=3)
+                torch.cuda.synchronize()
+                assert _rel(a, y) < REL_RMS and _rel(b, yc) < REL_RMS
+                res[(share, rule)] = (a, b)
+        assert not torch.equal(res[(3, 1)][0], res[(3, 0)][0]) and not torch.equal(res[(3, 1)][1], res[(3, 0)][1])
+        assert torch.equal(res[(1, 1)][0], res[(1, 0)][0]) and torch.equal(res[(1, 1)][1], res[(1, 0)][1])
+        assert torch.equal(res[(3, 0)][0], res[(1, 0)][0])            # (the round-5 rule ignored cu_share for these kernels)
     finally:
         env.reset()
 
