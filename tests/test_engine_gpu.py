@@ -999,7 +999,7 @@ def test_predict_sharded_under_nccl_world1(engine, cuda, monkeypatch, n_images, 
 
 
 @pytest.mark.parametrize("switch", ["UDT_LEAN=0", "UDT_LEAN_CONV=0", "UDT_WIDE_CONV=0", "UDT_LEAN_SPLITK=1", "UDT_GN_EPI=0", "UDT_LN_GEMM=0",
-                                    "UDT_DUAL_STREAM=1", "fused text cross-attention off"])
+                                    "UDT_DUAL_STREAM=1", "fused text cross-attention off", "UDT_FF_PROJ=0"])
 def test_unet_call_with_each_switch_in_its_non_default_position(engine, cuda, monkeypatch, switch):
     """every surviving launch-path switch (the environment variables are read once at import / first use,
     so the test sets what they set) gives the same UNet call as the default path up to the other kernel family's rounding:
@@ -1039,6 +1039,8 @@ def test_unet_call_with_each_switch_in_its_non_default_position(engine, cuda, mo
             monkeypatch.setattr(H, "LN_GEMM", False)
         elif switch == "UDT_DUAL_STREAM=1":
             monkeypatch.setattr(S, "DUAL_STREAM", True)
+        elif switch == "UDT_FF_PROJ=0":
+            monkeypatch.setattr(A, "FF_PROJ", False)          # (round 6: ff.net[2] and proj_out as two launches again)
         else:
             monkeypatch.setattr(A, "TATTN_FUSED", False)
         if switch == "UDT_DUAL_STREAM=1":

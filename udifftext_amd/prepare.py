@@ -82,6 +82,7 @@ def prepare(engine, free_masters: bool = False, dedup_vae: bool = True) -> Dict[
                     report["packed_bytes"] += m.prepare_ln(freeze=free_masters)
                 elif isinstance(m, SpatialTransformer):
                     report["packed_bytes"] += m.prepare_mx8(freeze=free_masters)
+                    report["packed_bytes"] += m.prepare_ffproj(freeze=free_masters)      # (round 6: [W_po W_2 | W_po], attention.FF_PROJ)
         # ---- release the masters
         if free_masters:
             victims = []

@@ -28,6 +28,14 @@ from .diffusionmodules.util import zero_module
 # return attention probabilities (noise search) and for contexts the tables do not cover (1 token, > 12 tokens).
 TATTN_FUSED = True          # (tests switch it off to compare the two forms)
 
+# UDT_FF_PROJ (default 1, round 6): the last block's ff.net[2] and the SpatialTransformer's proj_out run as ONE GEMM.  Both are linear
+# and nothing sits between them but a residual add (reference attention.py:69-70,336-339,409-411):
+#     proj_out(ff.net[2](h) + t3) + x  =  [h | t3] [W_po W_2 | W_po]^T + (W_po b_2 + b_po) + x
+# — the product W_po W_2 is formed once, in fp32, when the weights are packed; the launch is the two-source 1x1 form of the lean GEMM
+# (the ResBlocks' skip_connection kernel) with K = 4 C + C, the same FLOPs as the two launches, one launch / one [M, C] round trip
+# less per transformer (16 per UNet call), and no bf16 rounding of the intermediate.  Config #5's MX8 chain keeps its two launches.
+FF_PROJ = os.environ.get("UDT_FF_PROJ", "1") != "0"
+
 
 class GEGLU(H._Packed):
     def __init__(self, dim_in: int, dim_out: int):
@@ -244,7 +252,7 @@ class BasicTransformerBlock(nn.Module):
                 and n_tokens % (32 if C >= 640 else 64) == 0)       # (the kernel's token tile: csrc/tattn.hip tattn_tt)
 
     def forward(self, x, t_context=None, v_context=None, t_kv=None, emit_map: bool = False, zero_ctx_rows: int = 0,
-                t_fused=None, x8=None, emit_rowstats: bool = False):
+                t_fused=None, x8=None, emit_rowstats: bool = False, defer_ff_out: bool = False):
         """zero_ctx_rows: the first n samples of the batch attend to an all-zero text context (the unconditional
         half of a CFG pair under force_uc_zero_embeddings) — their t_attn branch is x + to_out.bias, no GEMMs.
         t_fused: the block's folded context tables (ops.TattnTables for the samples of x) -> one fused launch.
@@ -272,6 +280,10 @@ class BasicTransformerBlock(nn.Module):
         x2 = x.reshape(B * N, C)
         if fold:
             x8b = ops.mx8_of(x) if mx else None               # (None: the unfused text cross-attention ran — bf16 feed-forward)
+            if defer_ff_out and x8b is None:
+                # FF_PROJ: hand (GEGLU hidden activation, the rows the feed-forward's residual adds) to the SpatialTransformer, whose
+                # ONE launch applies ff.net[2], the residual and proj_out
+                return self.ff.net[0](x2, ln=self.norm3), x2
             out = self.ff(x2, residual=x2, ln=self.norm3, x8=x8b, emit_q8=x8b is not None, emit_rowstats=emit_rowstats)
             return H.carry_mx8(out.reshape(B, N, C), out)
         return self.ff(self.norm3(x2), residual=x2).reshape(B, N, C)
@@ -335,14 +347,52 @@ class SpatialTransformer(nn.Module):
         t2 = self.proj_in(self.norm(x).reshape(B * N, C), emit_q8=mx, emit_rowstats=mx)
         t = H.carry_mx8(t2.reshape(B, N, -1), t2)
         nb = len(self.transformer_blocks)
+        defer = FF_PROJ and H.LN_GEMM and not mx
         for i, blk in enumerate(self.transformer_blocks):
             t = blk(t, t_context=t_context, t_kv=(t_kv[i] if t_kv is not None else None), emit_map=emit_map,
                     zero_ctx_rows=zero_ctx_rows, t_fused=(t_fused[i] if t_fused is not None else None),
-                    x8=ops.mx8_of(t) if mx else None, emit_rowstats=(i + 1 < nb))
+                    x8=ops.mx8_of(t) if mx else None, emit_rowstats=(i + 1 < nb), defer_ff_out=(defer and i + 1 == nb))
+        if isinstance(t, tuple):
+            hid, t3 = t
+            w, b = self.packed_ffproj()
+            st = H.want_stats(B, N, w.shape[0])
+            out = ops.conv2d(hid.reshape(B, Hh, Ww, -1), w, b, x2=t3.reshape(B, Hh, Ww, -1), ksize=1, pad=(0, 0), residual=x,
+                             n_out=w.shape[0], colstats=st)
+            if ops.WORK_COUNTER is not None:          # (algorithmic work of the two linears it replaces)
+                inner = hid.shape[-1]
+                H.count_flops("gemm", 2.0 * B * N * C * (inner + C))
+                H.count_flops("gemm_bytes", 2.0 * B * N * (inner + 3 * C) + 2.0 * C * (inner + C))
+                H.count_flops("gemm_launches", 1.0)
+            return out
         # the output feeds a ResBlock's GroupNorm (and maybe a skip concat): statistics from the GEMM epilogue
         out = self.proj_out(t.reshape(B * N, -1), residual=x.reshape(B * N, C), rows_per_batch=N, colstats=True,
                             x8=ops.mx8_of(t) if mx else None)
         return H.carry_stats(out.reshape(B, Hh, Ww, C), out)
+
+    def packed_ffproj(self):
+        """[W_po W_2 | W_po] as a two-source 1x1-convolution weight (bf16 [C, 4 C + C]) and the bias W_po b_2 + b_po; cached by
+        the two modules' parameter versions, frozen by prepare(free_masters=True)"""
+        if getattr(self, "_pkfp_frozen", False):
+            return self._pkfp
+        lin2, po = self.transformer_blocks[-1].ff.net[2], self.proj_out
+        key = (lin2._key(), po._key())
+        if getattr(self, "_pkfp_key", None) != key:
+            with torch.no_grad():
+                w2, wpo = lin2.weight.float(), po.weight.float()
+                wf = torch.cat([wpo @ w2, wpo], dim=1)
+                bias = wpo @ lin2.bias.float() + po.bias.float()
+                self._pkfp = (packing.pack_conv(wf[:, :, None, None], [w2.shape[1], wpo.shape[1]]), packing.pad_bias(bias))
+            self._pkfp_key = key
+        return self._pkfp
+
+    def prepare_ffproj(self, freeze: bool = False) -> int:
+        n = 0
+        if FF_PROJ and H.LN_GEMM:
+            for t in self.packed_ffproj():
+                n += t.numel() * t.element_size()
+            if freeze:
+                self._pkfp_frozen = True
+        return n
 
     def prepare_mx8(self, freeze: bool = False) -> int:
         """config #5: the e4m3 layout of proj_out (proj_in stays a bf16 GEMM: its input is a GroupNorm output); bytes"""
