@@ -423,16 +423,20 @@ int udt_xattn_bwd(const void* k, const void* v, const float* probs, const float*
  * ADDED into d_probs fp32 [n_samples * heads, n, L] (zero-initialised by the caller); loss_accum (optional) += the term itself
  * (reference loss.py:192-235 under autograd: arg-min token, arg-max pixel, the 3x3 blur stencil, the head mean) */
 int udt_local_loss_bwd(const float* probs, const float* mask, const float* seg_mask, const float* gkernel9, float* d_probs,
-                       float* loss_accum, int32_t n_samples, int32_t mask_batch, int32_t heads, int32_t size, int32_t L,
-                       int32_t seg_l, int32_t Hm, int32_t Wm, float weight, void* stream);
+                       float* loss_accum, float* scratch /* n_samples * seg_l * 2 floats: the tokens' scores */, int32_t n_samples,
+                       int32_t mask_batch, int32_t heads, int32_t size, int32_t L, int32_t seg_l, int32_t Hm, int32_t Wm, float weight,
+                       void* stream);
 /* LayerNorm backward-data (nn.LayerNorm of attention.py:310-339): x, dy bf16 [rows, C] -> dx bf16 (+ add bf16 [rows, C] if given:
  * the gradient that arrives over the residual connection); statistics recomputed from x; C % 8 == 0, C <= 2048 */
 int udt_layernorm_bwd(const void* x, const void* dy, const float* gamma, const void* add, void* dx, int64_t rows, int32_t C, float eps,
                       void* stream);
 /* GroupNorm (+ SiLU when silu != 0) backward-data (GroupNorm32 / nn.SiLU of openaimodel.py:183-187, attention.py:375): x, dy bf16
- * NHWC [B, HW, C] -> dx (+ add); statistics recomputed from x; (C / groups) even */
-int udt_gn_bwd(const void* x, const void* dy, const float* gamma, const float* beta, const void* add, void* dx, int32_t B, int32_t HW,
-               int32_t C, int32_t groups, float eps, int32_t silu, void* stream);
+ * NHWC [B, HW, C] -> dx (+ add); statistics recomputed from x; (C / groups) even.  partials: fp32 scratch of
+ * 2 * B * udt_gn_nchunks(HW, C) * groups * 2 values — with it (and C % 8 == 0, 256 % groups == 0) the gradient runs as three launches
+ * at the forward GroupNorm's parallelism (chunk partials of sum x / sum x^2, of sum t / sum t xhat, then the result); NULL: one
+ * workgroup per (sample, group) */
+int udt_gn_bwd(const void* x, const void* dy, const float* gamma, const float* beta, const void* add, void* dx, float* partials, int32_t B,
+               int32_t HW, int32_t C, int32_t groups, float eps, int32_t silu, void* stream);
 /* GEGLU (attention.py:44-52) on STORED pre-activations ag bf16 [rows, 2 * inner] = [x | gate]: out = x * gelu(gate) [rows, inner];
  * backward: dag [rows, 2 * inner] from dy [rows, inner] (the inference path's fused GEMM epilogue keeps no pre-activations) */
 int udt_geglu_fwd(const void* ag, void* out, int64_t rows, int32_t inner, void* stream);
@@ -456,16 +460,26 @@ int32_t udt_colparts(int64_t rows);
 int udt_colsum_bf16(const void* x, float* partials, float* out, int64_t rows, int32_t C, void* stream);
 /* LayerNorm parameter gradients: dgamma_dbeta fp32 [2, C] = (sum_r dy * xhat, sum_r dy), x / dy bf16 [rows, C] */
 int udt_ln_param_grad(const void* x, const void* dy, float* partials, float* dgamma_dbeta, int64_t rows, int32_t C, float eps, void* stream);
+/* weight gradient of nn.Linear (y = x W^T under autograd; attention.py:108-112,193-199 for the trained t_attn projections):
+ * dw fp32 [N, K] = dy^T x for dy bf16 [R, N] (row stride ldy), x bf16 [R, K] (row stride ldx); N, K, ldy, ldx multiples of 8, 16-byte
+ * aligned operands.  The rows are cut into udt_wgrad_splits(R, N, K) ranges; partials: fp32 scratch of splits * N * K values (may be
+ * NULL when splits == 1), summed in range order */
+int32_t udt_wgrad_splits(int64_t R, int32_t N, int32_t K);
+int udt_wgrad_bf16(const void* dy, const void* x, float* dw, float* partials, int64_t R, int32_t N, int32_t K, int32_t ldy, int32_t ldx,
+                   void* stream);
 /* text cross-attention, context side (attention.py:140-175 under autograd): dk, dv bf16 [batch * L, lddkv] (head h at columns h * 64)
- * from q bf16 [batch * nq, ldq], v, probs, d_probs (optional), d_o (optional) as udt_xattn_bwd */
+ * from q bf16 [batch * nq, ldq], v, probs, d_probs (optional), d_o (optional) as udt_xattn_bwd.  The queries are cut into
+ * udt_xattn_kv_splits(nq) ranges, one workgroup per (head, sample, range); partials: fp32 scratch of
+ * splits * batch * L * heads * 64 * 2 values, summed in ascending range order */
+int32_t udt_xattn_kv_splits(int32_t nq);
 int udt_xattn_bwd_kv(const void* q, const void* v, const float* probs, const float* d_probs, const void* d_o, void* dk, void* dv,
-                     int32_t batch, int32_t heads, int32_t head_dim, int32_t nq, int32_t L, int32_t ldq, int32_t ldkv, int32_t ldo,
-                     int32_t lddkv, float scale, void* stream);
+                     float* partials, int32_t batch, int32_t heads, int32_t head_dim, int32_t nq, int32_t L, int32_t ldq, int32_t ldkv,
+                     int32_t ldo, int32_t lddkv, float scale, void* stream);
 /* FullLoss.get_local_loss (loss.py:237-286) per layer and its gradient: seg fp32 [B, seg_l, Hs, Ws] character segment maps,
  * seg_mask fp32 [B, seg_l]; d_probs (zero-initialised) += weight * d f / d probs, loss_accum[b] (optional) += f_b */
 int udt_local_loss_seg_bwd(const float* probs, const float* seg, const float* seg_mask, const float* gkernel9, float* d_probs,
-                           float* loss_accum, int32_t B, int32_t heads, int32_t size, int32_t L, int32_t seg_l, int32_t Hs, int32_t Ws,
-                           float weight, void* stream);
+                           float* loss_accum, float* scratch /* B * seg_l floats: the tokens' terms */, int32_t B, int32_t heads,
+                           int32_t size, int32_t L, int32_t seg_l, int32_t Hs, int32_t Ws, float weight, void* stream);
 /* eps-prediction loss (loss.py:60-71,131-150; EpsScaling / EpsWeighting): loss fp32 [B] = mean(sigma^-2 (eps * -sigma + noised -
  * target)^2) and d_eps bf16 NHWC [B, hw, cpad] = d mean_b(loss_b) / d eps; eps fp32 NHWC [B, hw, ld_eps], noised / target fp32 NCHW */
 int udt_diff_loss_grad(const float* eps, const float* noised, const float* target, const float* sigma, void* d_eps, float* loss, int32_t B,

@@ -292,6 +292,16 @@ def test_g13_attend_and_excite_gradient_and_update_vs_reference_golden(engine, e
     x2 = sampler.attend_and_excite(x, engine, sigma, c, batch, alpha, False, 0.0)
     step_ref = torch.from_numpy(g13["g13_x_updated"] - g13["g13_x"])
     _check("G13 attend-and-excite update x' - x vs reference", (x2 - x).cpu(), step_ref, TOL_UNET)
+    # the sampler replays the evaluation as ONE hipGraph (backward.GraphedLocalLossGrad): same launches, same results, at any input
+    runner = sampler._aae_runner
+    assert runner is not None and runner.graph is not None
+    args = (c_noise.float(), c["concat"], c["t_crossattn"], batch["mask"], batch["seg_mask"])
+    for xx, ts in ((x, args[0]), (x2, args[0]), (x2 * 0.5, args[0] - 300.0)):
+        l_g, g_g = runner(xx, ts, *args[1:])
+        l_e, g_e = env.bw.unet_local_loss_grad(unet, engine.loss_fn, xx, ts, *args[1:])
+        assert torch.equal(g_g, g_e) and torch.allclose(l_g, l_e, rtol=1e-5, atol=1e-6)
+    runner.check()
+    assert sampler.attend_and_excite(x, engine, sigma, c, batch, alpha, False, 0.0).equal(x2) and sampler._aae_runner is runner
     # G13s: a DENSE cotangent on every counted map (the smooth functional sum_k <R_k, map_k> / count of the real reference's maps)
     names = [str(n) for n in g13["g13_map_names"]]
 

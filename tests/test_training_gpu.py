@@ -53,14 +53,29 @@ def env(cuda):
 
 
 # ------------------------------------------------------------------------------------------------ kernels
-@pytest.mark.parametrize("M,N,K", [(512, 320, 320), (300, 640, 1280), (24, 320, 2048), (4096, 1280, 1280)])
-def test_weight_gradient_through_the_forward_gemm_on_transposed_operands(env, M, N, K):
+@pytest.mark.parametrize("M,N,K", [(512, 320, 320), (300, 640, 1280), (24, 320, 2048), (4096, 1280, 1280), (16384, 320, 320), (1000, 648, 72),
+                                   (33, 8, 8)])
+def test_weight_gradient_kernel_and_the_forward_gemm_on_transposed_operands(env, M, N, K):
+    """dW = dY^T X: udt_wgrad_bf16 (row-major operands, transposed through LDS, the rows cut into ranges summed in order) and the
+    round-6 first form (two transposes + the forward GEMM with fp32 output) against fp32; also with row-strided operand views"""
     g = torch.Generator().manual_seed(M + N)
     dy = _bf(torch.randn((M, N), generator=g)).to(env.dev)
     x = _bf(torch.randn((M, K), generator=g)).to(env.dev)
     t = env.ops.transpose(dy.bfloat16())
     assert t.shape == (N, (M + 63) // 64 * 64) and torch.equal(t[:, :M].float(), dy.t()) and not bool(t[:, M:].any())
-    _check(f"dW = dY^T X {M}x{N}x{K}", env.ops.weight_grad(dy.bfloat16(), x.bfloat16()), dy.t() @ x, TOL_OP)
+    ref = dy.t() @ x
+    got = env.ops.weight_grad(dy.bfloat16(), x.bfloat16())
+    _check(f"dW = dY^T X {M}x{N}x{K} (udt_wgrad_bf16)", got, ref, TOL_OP)
+    assert torch.equal(got, env.ops.weight_grad(dy.bfloat16(), x.bfloat16())), "fixed summation order: repeatable bit for bit"
+    wide_y = torch.zeros((M, N + 64), dtype=torch.bfloat16, device=env.dev); wide_y[:, 8:N + 8] = dy.bfloat16()
+    wide_x = torch.zeros((M, 2 * K), dtype=torch.bfloat16, device=env.dev); wide_x[:, K:] = x.bfloat16()
+    assert torch.equal(got, env.ops.weight_grad(wide_y[:, 8:N + 8], wide_x[:, K:]))
+    if N % 64 == 0 and K % 64 == 0:
+        try:
+            env.ops.WGRAD_KERNEL = False
+            _check(f"dW = dY^T X {M}x{N}x{K} (transposes + forward GEMM)", env.ops.weight_grad(dy.bfloat16(), x.bfloat16()), ref, TOL_OP)
+        finally:
+            env.ops.WGRAD_KERNEL = True
     _check(f"bias gradient (column sums) {M}x{N}", env.ops.colsum(dy.bfloat16()), dy.sum(dim=0), TOL_OP)
 
 

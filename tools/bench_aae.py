@@ -30,6 +30,11 @@ for size, B in ((512, 1), (256, 1)):
     ms = timed(f)
     sampler = pipeline.init_sampling(50, 5.0, dev)
     print(f"attend-and-excite gradient, {size}x{size}, B={B}: {ms:.1f} ms per evaluation (tape-mode forward + reverse pass, eager launches)")
+    args = (ts, c["concat"], c["t_crossattn"], batch["mask"], batch["seg_mask"])
+    runner = backward.GraphedLocalLossGrad(unet, engine.loss_fn, x, *args)
+    msg = timed(lambda: runner(x, *args), n=10)
+    print(f"attend-and-excite gradient, {size}x{size}, B={B}: {msg:.1f} ms per evaluation replayed as one hipGraph")
+    del runner
 for size, B in ((512, 4), (256, 4)):
     h = size // 8
     z = torch.randn((B, 4, h, h), device=dev)

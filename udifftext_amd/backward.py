@@ -406,3 +406,60 @@ def unet_local_loss_grad(unet, loss_fn, x: torch.Tensor, timesteps: torch.Tensor
         count[0] = len(used)
     grad = unet_maps_vjp(unet, x, timesteps, concat, t_context, maps_grad, debug=debug)
     return loss / count[0], grad
+
+
+# ------------------------------------------------------------------------------------------------ hipGraph replay
+class GraphedLocalLossGrad:
+    """hipGraph replay of ``unet_local_loss_grad`` for ONE set of shapes.  An attend-and-excite gradient is ≈ 2 100 launches whose
+    arguments depend on the shapes only (the timestep index, the latent and the conditioning are device data), and the sampler asks for
+    one to twenty-one of them before EVERY denoising step (reference sampling.py:240-252, 379-386): the whole evaluation — tape-mode
+    forward, loss seeds, reverse pass — is captured once into a hipGraph on a private memory pool (the tape's activations live there)
+    and replayed; the host issues one graph launch instead of the kernel launches (B = 1: the eager evaluation is host-bound).
+    The inputs are copied into static buffers; ``loss`` / ``grad`` are static outputs, valid until the next call."""
+
+    def __init__(self, unet, loss_fn, x, timesteps, concat, t_context, mask, seg_mask):
+        from sgm.modules.diffusionmodules.sampling import weights_fingerprint
+        self.unet, self.loss_fn = unet, loss_fn
+        self.key = self.key_of(x, timesteps, concat, t_context, mask, seg_mask)
+        self.fingerprint = weights_fingerprint(unet)
+        mk = lambda t: t.detach().float().contiguous().clone()
+        self.inputs = [mk(t) for t in (x, timesteps, concat, t_context, mask, seg_mask)]
+        dev = x.device
+        self.ws = ops.Workspace(dev)
+        self.pool = torch.cuda.graph_pool_handle()
+        self.stream = torch.cuda.Stream(device=dev)
+        self.graph: Optional[torch.cuda.CUDAGraph] = None
+        self.loss = self.grad = None
+
+    @staticmethod
+    def key_of(*tensors) -> tuple:
+        return tuple((tuple(t.shape), str(t.device)) for t in tensors)
+
+    def valid_for(self, unet, *tensors) -> bool:
+        from sgm.modules.diffusionmodules.sampling import weights_fingerprint
+        return unet is self.unet and self.key == self.key_of(*tensors) and self.fingerprint == weights_fingerprint(unet)
+
+    def _evaluate(self):
+        with ops.launch_context(cu_share=1, workspace=self.ws):
+            return unet_local_loss_grad(self.unet, self.loss_fn, *self.inputs)
+
+    def _capture(self) -> None:
+        torch.cuda.synchronize()
+        with torch.cuda.stream(self.stream):                              # eager pass: weight re-packs, kernel attributes, library pages
+            self._evaluate()
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, pool=self.pool, stream=self.stream, capture_error_mode="thread_local"):
+            self.loss, self.grad = self._evaluate()
+        self.graph = g
+
+    def __call__(self, x, timesteps, concat, t_context, mask, seg_mask):
+        for dst, src in zip(self.inputs, (x, timesteps, concat, t_context, mask, seg_mask)):
+            dst.copy_(src)
+        if self.graph is None:
+            self._capture()
+        self.graph.replay()
+        return self.loss, self.grad
+
+    def check(self) -> None:
+        self.ws.check()

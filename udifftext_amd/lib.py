@@ -110,9 +110,9 @@ SYMBOLS = {
     "udt_local_loss_tiled": (C.c_int, [_fp, _fp, _fp, _fp, _fp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "udt_attn_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _fp, _fp, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp]),
     "udt_xattn_bwd": (C.c_int, [_vp, _vp, _fp, _fp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp]),
-    "udt_local_loss_bwd": (C.c_int, [_fp, _fp, _fp, _fp, _fp, _fp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp]),
+    "udt_local_loss_bwd": (C.c_int, [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp]),
     "udt_layernorm_bwd": (C.c_int, [_vp, _vp, _fp, _vp, _vp, _i64, _i32, _f32, _vp]),
-    "udt_gn_bwd": (C.c_int, [_vp, _vp, _fp, _fp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _i32, _vp]),
+    "udt_gn_bwd": (C.c_int, [_vp, _vp, _fp, _fp, _vp, _vp, _fp, _i32, _i32, _i32, _i32, _f32, _i32, _vp]),
     "udt_geglu_fwd": (C.c_int, [_vp, _vp, _i64, _i32, _vp]),
     "udt_geglu_bwd": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _vp]),
     "udt_sum2x2_bf16": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp]),
@@ -123,8 +123,11 @@ SYMBOLS = {
     "udt_colparts": (_i32, [_i64]),
     "udt_colsum_bf16": (C.c_int, [_vp, _fp, _fp, _i64, _i32, _vp]),
     "udt_ln_param_grad": (C.c_int, [_vp, _vp, _fp, _fp, _i64, _i32, _f32, _vp]),
-    "udt_xattn_bwd_kv": (C.c_int, [_vp, _vp, _fp, _fp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp]),
-    "udt_local_loss_seg_bwd": (C.c_int, [_fp, _fp, _fp, _fp, _fp, _fp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp]),
+    "udt_xattn_bwd_kv": (C.c_int, [_vp, _vp, _fp, _fp, _vp, _vp, _vp, _fp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp]),
+    "udt_xattn_kv_splits": (_i32, [_i32]),
+    "udt_wgrad_splits": (_i32, [_i64, _i32, _i32]),
+    "udt_wgrad_bf16": (C.c_int, [_vp, _vp, _fp, _fp, _i64, _i32, _i32, _i32, _i32, _vp]),
+    "udt_local_loss_seg_bwd": (C.c_int, [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp]),
     "udt_diff_loss_grad": (C.c_int, [_fp, _fp, _fp, _fp, _vp, _fp, _i32, _i32, _i32, _i32, _vp]),
     "udt_adamw_f32": (C.c_int, [_fp, _fp, _fp, _fp, _i64, _f32, _f32, _f32, _f32, _f32, _i32, _f32, _vp]),
     "udt_add_bf16": (C.c_int, [_vp, _vp, _i64, _vp]),

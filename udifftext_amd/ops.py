@@ -893,8 +893,9 @@ def local_loss_bwd(probs: torch.Tensor, mask: torch.Tensor, seg_mask: torch.Tens
     Lc = probs.shape[-1]
     assert probs.is_contiguous() and d_probs.is_contiguous() and d_probs.shape == probs.shape and n % B == 0
     assert d_probs.dtype == torch.float32 and (loss is None or (loss.is_contiguous() and loss.numel() == n))
-    L.check(L.load().udt_local_loss_bwd(_ptr(probs), _ptr(mask), _ptr(seg_mask), _ptr(gk9), _ptr(d_probs), _ptr(loss), n, B, heads,
-                                        size, Lc, seg_mask.shape[1], mask.shape[2], mask.shape[3], weight, _stream()),
+    scratch = torch.empty((n, seg_mask.shape[1], 2), dtype=torch.float32, device=probs.device)
+    L.check(L.load().udt_local_loss_bwd(_ptr(probs), _ptr(mask), _ptr(seg_mask), _ptr(gk9), _ptr(d_probs), _ptr(loss), _ptr(scratch), n, B,
+                                        heads, size, Lc, seg_mask.shape[1], mask.shape[2], mask.shape[3], weight, _stream()),
             "udt_local_loss_bwd")
 
 
@@ -910,15 +911,21 @@ def layer_norm_bwd(x: torch.Tensor, dy: torch.Tensor, gamma: torch.Tensor, eps: 
     return dx
 
 
+GN_BWD_CHUNKED = os.environ.get("UDT_GN_BWD_CHUNKED", "1") != "0"     # 0: one workgroup per (sample, group) (A/B, tests)
+
+
 def group_norm_bwd(x: torch.Tensor, dy: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, groups: int, eps: float, silu: bool,
                    add: Optional[torch.Tensor] = None) -> torch.Tensor:
     """dX of GroupNorm (+ SiLU) on bf16 NHWC [B, ..., C] (statistics recomputed from x) + ``add``"""
     _bf16(x); _bf16(dy)
     assert x.is_contiguous() and dy.is_contiguous() and dy.shape == x.shape and (add is None or (add.is_contiguous() and add.shape == x.shape))
     B, Cc = x.shape[0], x.shape[-1]
+    HW = x.numel() // (B * Cc)
     dx = torch.empty_like(x)
-    L.check(L.load().udt_gn_bwd(_ptr(x), _ptr(dy), _ptr(gamma), _ptr(beta), _ptr(add), _ptr(dx), B, x.numel() // (B * Cc), Cc, groups,
-                                eps, 1 if silu else 0, _stream()), "udt_gn_bwd")
+    lib = L.load()
+    part = torch.empty((2, B, lib.udt_gn_nchunks(HW, Cc), groups, 2), dtype=torch.float32, device=x.device) if GN_BWD_CHUNKED else None
+    L.check(lib.udt_gn_bwd(_ptr(x), _ptr(dy), _ptr(gamma), _ptr(beta), _ptr(add), _ptr(dx), _ptr(part), B, HW, Cc, groups,
+                           eps, 1 if silu else 0, _stream()), "udt_gn_bwd")
     return dx
 
 
@@ -979,10 +986,25 @@ def transpose(x: torch.Tensor) -> torch.Tensor:
     return out
 
 
+WGRAD_KERNEL = os.environ.get("UDT_WGRAD_KERNEL", "1") != "0"     # 0: transposes + the forward GEMM (A/B, tests)
+
+
 def weight_grad(dy: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
-    """dW fp32 [N, K] = dy^T x for dy bf16 [M, N], x bf16 [M, K] (nn.Linear: y = x W^T): the forward GEMM on the two operands
-    transposed (contraction over the M rows, fp32 accumulation and output)"""
-    return linear(transpose(dy), transpose(x), None, flags=L.GEMM_OUT_F32)
+    """dW fp32 [N, K] = dy^T x for dy bf16 [M, N], x bf16 [M, K] (nn.Linear: y = x W^T), contraction over the M rows with fp32
+    accumulation and output: udt_wgrad_bf16 straight from the row-major operands (or, switched off / for shapes it does not take, the
+    forward GEMM on the two operands transposed)"""
+    _bf16(dy); _bf16(x)
+    assert dy.dim() == 2 and x.dim() == 2 and dy.shape[0] == x.shape[0] and dy.stride(1) == 1 and x.stride(1) == 1
+    R, N = dy.shape
+    K = x.shape[1]
+    lib = L.load()
+    if not WGRAD_KERNEL or N % 8 or K % 8 or dy.stride(0) % 8 or x.stride(0) % 8 or (dy.data_ptr() | x.data_ptr()) & 15:
+        return linear(transpose(dy), transpose(x), None, flags=L.GEMM_OUT_F32)
+    dw = torch.empty((N, K), dtype=torch.float32, device=dy.device)
+    S = lib.udt_wgrad_splits(R, N, K)
+    part = torch.empty((S, N, K), dtype=torch.float32, device=dy.device) if S > 1 else None
+    L.check(lib.udt_wgrad_bf16(_ptr(dy), _ptr(x), _ptr(dw), _ptr(part), R, N, K, dy.stride(0), x.stride(0), _stream()), "udt_wgrad_bf16")
+    return dw
 
 
 def colsum(x: torch.Tensor) -> torch.Tensor:
@@ -1018,8 +1040,10 @@ def xattention_bwd_kv(q: torch.Tensor, v: torch.Tensor, probs: torch.Tensor, d_p
     assert q.is_contiguous() and v.stride(2) == 1 and v.stride(0) == Lc * v.stride(1) and probs.shape == (B * heads, Nq, Lc)
     dk = torch.empty((B, Lc, Cc), dtype=torch.bfloat16, device=q.device)
     dv = torch.empty_like(dk)
-    L.check(L.load().udt_xattn_bwd_kv(_ptr(q), _ptr(v), _ptr(probs), _ptr(d_probs), _ptr(d_o), _ptr(dk), _ptr(dv), B, heads, 64, Nq, Lc,
-                                      Cc, v.stride(1), Cc, Cc, scale, _stream()), "udt_xattn_bwd_kv")
+    lib = L.load()
+    part = torch.empty((lib.udt_xattn_kv_splits(Nq), B * Lc, Cc, 2), dtype=torch.float32, device=q.device)
+    L.check(lib.udt_xattn_bwd_kv(_ptr(q), _ptr(v), _ptr(probs), _ptr(d_probs), _ptr(d_o), _ptr(dk), _ptr(dv), _ptr(part), B, heads, 64, Nq,
+                                 Lc, Cc, v.stride(1), Cc, Cc, scale, _stream()), "udt_xattn_bwd_kv")
     return dk, dv
 
 
@@ -1029,8 +1053,9 @@ def local_loss_seg_bwd(probs: torch.Tensor, seg: torch.Tensor, seg_mask: torch.T
     B = seg.shape[0]
     assert probs.is_contiguous() and d_probs.is_contiguous() and d_probs.shape == probs.shape and probs.shape[0] == B * heads
     assert seg.dtype == torch.float32 and seg.is_contiguous() and seg_mask.is_contiguous() and seg.shape[1] == seg_mask.shape[1]
-    L.check(L.load().udt_local_loss_seg_bwd(_ptr(probs), _ptr(seg), _ptr(seg_mask), _ptr(gk9), _ptr(d_probs), _ptr(loss), B, heads, size,
-                                            probs.shape[-1], seg.shape[1], seg.shape[2], seg.shape[3], weight, _stream()),
+    scratch = torch.empty((B, seg.shape[1]), dtype=torch.float32, device=probs.device)
+    L.check(L.load().udt_local_loss_seg_bwd(_ptr(probs), _ptr(seg), _ptr(seg_mask), _ptr(gk9), _ptr(d_probs), _ptr(loss), _ptr(scratch), B,
+                                            heads, size, probs.shape[-1], seg.shape[1], seg.shape[2], seg.shape[3], weight, _stream()),
             "udt_local_loss_seg_bwd")
 
 

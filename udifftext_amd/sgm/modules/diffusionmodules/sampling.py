@@ -276,6 +276,9 @@ class _GraphedSteps:
         return out
 
 
+AAE_GRAPH = os.environ.get("UDT_AAE_GRAPH", "1") != "0"      # hipGraph replay of the attend-and-excite gradient (A/B switch)
+
+
 class EulerEDMSampler(EDMSampler):
     use_graphs = os.environ.get("UDT_GRAPHS", "1") != "0"      # hipGraph replay of the main loop (eager launches if off)
 
@@ -357,10 +360,28 @@ class EulerEDMSampler(EDMSampler):
         c_noise = self.get_c_noise(x, model, sigma)
         unet = model.model.diffusion_model
         x = x.detach().clone().float().contiguous()
+        args = (c_noise.float(), cond["concat"], cond["t_crossattn"], batch["mask"], batch["seg_mask"])
+        evaluate = lambda xx: backward.unet_local_loss_grad(unet, model.loss_fn, xx, *args)
+        if self.use_graphs and AAE_GRAPH:
+            # the evaluation's launch sequence depends on the shapes only: captured once per sampler, replayed for every update of
+            # every step (the timestep index, latent and conditioning are device data in static buffers)
+            runner = getattr(self, "_aae_runner", None)
+            if runner is None or not runner.valid_for(unet, x, *args):
+                runner = self._aae_runner = None                           # (drop the old pool before the new capture)
+                try:
+                    runner = backward.GraphedLocalLossGrad(unet, model.loss_fn, x, *args)
+                    runner(x, *args)
+                    self._aae_runner = runner
+                except Exception as e:
+                    if not _is_capture_failure(e):
+                        raise
+                    print(f"[udifftext_amd] attend-and-excite: hipGraph capture unavailable ({type(e).__name__}: {e}); eager launches")
+                    runner = None
+            if runner is not None:
+                evaluate = lambda xx: runner(xx, *args)
         iters = 0
         while True:
-            loss, grad = backward.unet_local_loss_grad(unet, model.loss_fn, x, c_noise.float(), cond["concat"], cond["t_crossattn"],
-                                                       batch["mask"], batch["seg_mask"])
+            loss, grad = evaluate(x)
             ops.axpy_(x, grad, -float(alpha))
             iters += 1
             if not iter_enabled or bool((loss <= thres).all()) or iters > max_iter:
