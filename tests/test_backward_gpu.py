@@ -143,8 +143,11 @@ def test_layernorm_backward_vs_autograd(env, rows, C):
            ref + add, TOL_OP)
 
 
-@pytest.mark.parametrize("B,hw,C,silu", [(2, 16, 320, True), (1, 8, 640, False), (2, 8, 1280, True), (1, 32, 320, False)])
+@pytest.mark.parametrize("B,hw,C,silu", [(2, 16, 320, True), (1, 8, 640, False), (2, 8, 1280, True), (1, 32, 320, False), (1, 64, 320, True),
+                                         (2, 16, 2560, True), (1, 3, 960, False)])
 def test_groupnorm_backward_vs_autograd(env, B, hw, C, silu):
+    """both forms: three launches at the forward GroupNorm's parallelism (chunk partials; the default) and one workgroup per
+    (sample, group) (UDT_GN_BWD_CHUNKED=0)"""
     g = torch.Generator().manual_seed(C + hw)
     x = _bf(torch.randn((B, hw, hw, C), generator=g) * 1.5 + 0.3).to(env.dev)
     dy = _bf(torch.randn((B, hw, hw, C), generator=g)).to(env.dev)
@@ -158,6 +161,14 @@ def test_groupnorm_backward_vs_autograd(env, B, hw, C, silu):
         (ref,) = torch.autograd.grad((y.permute(0, 2, 3, 1) * dy).sum(), [t])
     got = env.ops.group_norm_bwd(x.bfloat16(), dy.bfloat16(), gamma, beta, 32, 1e-5, silu, add=add.bfloat16())
     _check(f"GroupNorm{'+SiLU' if silu else ''} backward B{B} {hw}x{hw}x{C} + add", got, ref + add, TOL_OP)
+    _check(f"GroupNorm{'+SiLU' if silu else ''} backward B{B} {hw}x{hw}x{C}, no add",
+           env.ops.group_norm_bwd(x.bfloat16(), dy.bfloat16(), gamma, beta, 32, 1e-5, silu), ref, TOL_OP)
+    try:
+        env.ops.GN_BWD_CHUNKED = False
+        got1 = env.ops.group_norm_bwd(x.bfloat16(), dy.bfloat16(), gamma, beta, 32, 1e-5, silu, add=add.bfloat16())
+    finally:
+        env.ops.GN_BWD_CHUNKED = True
+    _check(f"GroupNorm{'+SiLU' if silu else ''} backward B{B} {hw}x{hw}x{C} + add (one workgroup per group)", got1, ref + add, TOL_OP)
 
 
 def test_geglu_forward_backward_vs_autograd(env):
@@ -302,6 +313,14 @@ def test_g13_attend_and_excite_gradient_and_update_vs_reference_golden(engine, e
         assert torch.equal(g_g, g_e) and torch.allclose(l_g, l_e, rtol=1e-5, atol=1e-6)
     runner.check()
     assert sampler.attend_and_excite(x, engine, sigma, c, batch, alpha, False, 0.0).equal(x2) and sampler._aae_runner is runner
+    import sgm.modules.diffusionmodules.sampling as S
+    try:                                                                   # UDT_AAE_GRAPH=0: eager launches, same update
+        S.AAE_GRAPH = False
+        s2 = pipeline.init_sampling(10, 5.0, dev)
+        x3 = s2.attend_and_excite(x, engine, sigma, c, batch, alpha, False, 0.0)
+        assert getattr(s2, "_aae_runner", None) is None and torch.equal(x3, x2)
+    finally:
+        S.AAE_GRAPH = True
     # G13s: a DENSE cotangent on every counted map (the smooth functional sum_k <R_k, map_k> / count of the real reference's maps)
     names = [str(n) for n in g13["g13_map_names"]]
 

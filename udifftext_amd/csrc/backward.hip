@@ -60,7 +60,8 @@ UDT_DEVINL bf16x8_t ab_load8(const uint16_t* p, bool ok) {
 }
 
 // AB_PF: streamed tiles whose global loads are in flight (a register ring)
-template <bool DKV, int AB_PF>
+// FULL: n is a multiple of 128 (every UNet level): no bounds tests on the scores
+template <bool DKV, int AB_PF, bool FULL>
 __global__ void __launch_bounds__(256) attn_bwd_kernel(const AttnBwdParams p) {
   __shared__ __attribute__((aligned(16))) uint16_t x1[32 * AB_XP];
   __shared__ __attribute__((aligned(16))) uint16_t x2[32 * AB_XP];
@@ -185,7 +186,7 @@ __global__ void __launch_bounds__(256) attn_bwd_kernel(const AttnBwdParams p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int key = st * 32 + 8 * (r >> 2) + 4 * hi + (r & 3);
-        sv[r] = key < p.n ? s[r] * c : -INFINITY;
+        sv[r] = (FULL || key < p.n) ? s[r] * c : -INFINITY;
         mx = fmaxf(mx, sv[r]);
       }
       if (mx > -INFINITY) {
@@ -249,9 +250,9 @@ __global__ void __launch_bounds__(256) attn_bwd_kernel(const AttnBwdParams p) {
       for (int e = 0; e < 4; ++e) {
         const int r = q4 * 4 + e;
         const int sidx = st * 32 + 8 * q4 + 4 * hi + e;
-        const float pr = (sidx < p.n && ook) ? fast_exp2(s[r] * c - ls[e]) : 0.f;
+        const float pr = (FULL || (sidx < p.n && ook)) ? fast_exp2(s[r] * c - ls[e]) : 0.f;
         pv[r] = pr;
-        dsv[r] = pr * (dp[r] - dd[e]) * p.scale;
+        dsv[r] = pr * (dp[r] - dd[e]);                          // (the softmax scale multiplies the finished dQ / dK sums)
       }
     }
 #pragma unroll
@@ -274,7 +275,8 @@ __global__ void __launch_bounds__(256) attn_bwd_kernel(const AttnBwdParams p) {
 #pragma unroll
       for (int q4 = 0; q4 < 4; ++q4) {
         const int d = it * 32 + 8 * q4 + 4 * hi;
-        const u32x2 a = {pack_bf16x2(acc1[it][q4 * 4], acc1[it][q4 * 4 + 1]), pack_bf16x2(acc1[it][q4 * 4 + 2], acc1[it][q4 * 4 + 3])};
+        const u32x2 a = {pack_bf16x2(acc1[it][q4 * 4] * p.scale, acc1[it][q4 * 4 + 1] * p.scale),
+                         pack_bf16x2(acc1[it][q4 * 4 + 2] * p.scale, acc1[it][q4 * 4 + 3] * p.scale)};
         *reinterpret_cast<u32x2*>(o1 + d) = a;
         if constexpr (DKV) {
           const u32x2 bb = {pack_bf16x2(acc2[it][q4 * 4], acc2[it][q4 * 4 + 1]), pack_bf16x2(acc2[it][q4 * 4 + 2], acc2[it][q4 * 4 + 3])};
@@ -1396,15 +1398,20 @@ extern "C" int udt_attn_bwd(const void* q, const void* k, const void* v, const v
   // co-resident workgroups do (and the ring's registers would cost them their residency)
   static const int pf_env = getenv("UDT_ATTN_BWD_PF") ? atoi(getenv("UDT_ATTN_BWD_PF")) : 0;
   const bool deep = pf_env ? pf_env >= 4 : units <= 2 * 256;        // (MI355X: 256 CUs)
+  const bool full = n % 128 == 0;
+  const dim3 grid((unsigned)units), blk(256);
+#define UDT_AB_LAUNCH(PF, FULLV)                                                                      \
+  do {                                                                                                \
+    hipLaunchKernelGGL((attn_bwd_kernel<false, PF, FULLV>), grid, blk, 0, s, p); /* LSE, D, dQ */     \
+    UDT_CHECK_LAUNCH();                                                                               \
+    hipLaunchKernelGGL((attn_bwd_kernel<true, PF, FULLV>), grid, blk, 0, s, p);  /* dK, dV */         \
+  } while (0)
   if (deep) {
-    hipLaunchKernelGGL((attn_bwd_kernel<false, 4>), dim3((unsigned)units), dim3(256), 0, s, p);    // LSE, D, dQ
-    UDT_CHECK_LAUNCH();
-    hipLaunchKernelGGL((attn_bwd_kernel<true, 4>), dim3((unsigned)units), dim3(256), 0, s, p);     // dK, dV (reads LSE, D)
+    if (full) UDT_AB_LAUNCH(4, true); else UDT_AB_LAUNCH(4, false);
   } else {
-    hipLaunchKernelGGL((attn_bwd_kernel<false, 1>), dim3((unsigned)units), dim3(256), 0, s, p);
-    UDT_CHECK_LAUNCH();
-    hipLaunchKernelGGL((attn_bwd_kernel<true, 1>), dim3((unsigned)units), dim3(256), 0, s, p);
+    if (full) UDT_AB_LAUNCH(1, true); else UDT_AB_LAUNCH(1, false);
   }
+#undef UDT_AB_LAUNCH
   UDT_CHECK_LAUNCH();
   return UDT_OK;
 }
