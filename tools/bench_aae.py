@@ -51,3 +51,24 @@ for size, B in ((512, 4), (256, 4)):
     ms2 = timed(f2)
     print(f"training step loss + gradients of the 112 t_attn / t_norm tensors, {size}x{size}, B={B}: {ms:.1f} ms (tape-mode forward alone {ms2:.1f} ms; "
           f"inference forward of the same 4 samples: see unet_ms_per_sampler_step / 2)")
+
+# end to end: predict (test.py:19-40) of ONE 512 x 512 image, 50 steps, with and without attend-and-excite
+from udifftext_amd import config as C
+for aae in (False, True):
+    sampler = pipeline.init_sampling(50, 5.0, dev)
+    cfgs = C.default_runtime_config(steps=50, batch_size=1, noise_iters=0)
+    cfgs.aae_enabled = aae
+    ts = []
+    for rep in range(2):
+        batch = {k: (v.to(dev) if isinstance(v, torch.Tensor) else v) for k, v in synth.synthetic_batch(1, 512, 512, 9, seed=30 + rep).items()}
+        torch.manual_seed(7 + rep)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        import io, contextlib
+        with contextlib.redirect_stdout(io.StringIO()):
+            frames, z = pipeline.predict(cfgs, engine, sampler, batch, dev)
+        torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
+    extra = ""
+    if aae:
+        st = getattr(sampler, "last_aae_stats", None)
+        extra = f" ({st})" if st else ""
+    print(f"predict, one 512x512 image, 50 steps, aae_enabled={aae}: {ts[-1]:.2f} s (first call {ts[0]:.2f} s){extra}")

@@ -75,6 +75,10 @@ jstamp $O/bench_fp8_linears_only.json
 #    round 6: attend-and-excite gradient and one training step at the benchmark's latent size
 (cd $R && python tools/bench_aae.py 2>/dev/null | grep -v amdgpu.ids > $O/aae_training_bench.txt)
 stamp $O/aae_training_bench.txt
+#    ... and the steady-state kernel split of the two (rocprofv3 --kernel-trace --stats, 4 evaluations minus 1)
+bash $R/tools/prof_reverse_pass.sh > /dev/null 2>&1
+(echo "## attend-and-excite gradient, 512x512, B = 1 (eager launches under the profiler)"; head -40 $R/gpurun_out/prof_aae_ss.txt; echo; echo "## training step loss + gradients, 512x512, B = 4"; head -48 $R/gpurun_out/prof_train_ss.txt) > $O/reverse_pass_kernel_split.txt
+stamp $O/reverse_pass_kernel_split.txt
 stamp $O/mx8_layers.txt $O/trace_step_fp8.txt $O/attn_mx8_layers.txt $O/attn_vs_workgroups.txt
 stamp $O/in_flight_sweep.txt $O/phase_times.txt $O/gemm_shapes.txt $O/wide_conv.txt $O/trace_step.txt $O/bench_ops.txt $O/attn512.txt $O/rowres_bench.txt $O/tattn_bench.txt $O/reference_default.txt
 ls -la $O; cut -c1-400 $O/bench.json; cat $O/traffic.json | head -40; head -30 $O/mfma_util.json

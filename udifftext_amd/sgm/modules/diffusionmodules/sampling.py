@@ -386,6 +386,7 @@ class EulerEDMSampler(EDMSampler):
             iters += 1
             if not iter_enabled or bool((loss <= thres).all()) or iters > max_iter:
                 break
+        self.aae_evaluations = getattr(self, "aae_evaluations", 0) + iters     # (how many gradients a sampling run took)
         return x
 
     # ------------------------------------------------------------------------------------------- API step
@@ -474,6 +475,7 @@ class EulerEDMSampler(EDMSampler):
         B = x.shape[0]
         stepper = _Stepper(model, cond, uc, B, x.shape[2:], self.guider.scale)
         s_in = x.new_ones([B])
+        evals0 = getattr(self, "aae_evaluations", 0)
         inters, local_losses = [], []
         mid = (num_sigmas - 1) // 2
         for i in self.get_sigma_gen(num_sigmas, init_step=init_step):
@@ -493,6 +495,7 @@ class EulerEDMSampler(EDMSampler):
         stepper.check()
         print(f"Local losses: {local_losses}")
         self.last_local_losses, self.last_inters = local_losses, inters
+        self.last_aae_stats = f"{self.aae_evaluations - evals0} gradient evaluations"
         try:
             import imageio
             os.makedirs("./temp/inters", exist_ok=True)
