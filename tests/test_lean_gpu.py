@@ -41,7 +41,7 @@ def env(cuda):
 
         @staticmethod
         def reset():
-            for k in ("lean", "lean_splitk", "lean_conv", "wide_conv", "rowres", "share_splitk", "lean256_lanes"):
+            for k in ("lean", "lean_splitk", "lean_conv", "wide_conv", "rowres", "share_splitk", "lean256_lanes", "conv_n4"):
                 L.check(lib.udt_debug_set(k.encode(), -1), "udt_debug_set " + k)
     yield Env
     Env.reset()
@@ -288,6 +288,40 @@ def test_lean_conv3x3_vs_torch(env, cuda, case):
             assert math.isfinite(e) and e < REL_RMS, f"conv3x3 lean_conv={lean_conv} {case}: rel rms {e:.3e}"
             outs[lean_conv] = out
         assert _rel(outs[1], outs[0]) < REL_RMS
+    finally:
+        env.reset()
+
+
+@pytest.mark.parametrize("case", [(2, 64, 64, 320, 4), (1, 96, 96, 320, 4), (2, 40, 24, 128, 3), (1, 13, 9, 64, 4), (3, 8, 8, 640, 4)],
+                         ids=lambda c: "x".join(str(int(v)) for v in c))
+def test_conv3x3_with_four_output_channels_fp32(env, cuda, case):
+    """round 6, conv_n4.h: the UNet's `out` convolution (320 -> 4, reference openaimodel.py:486-490) and the VAE decoder's conv_out
+    (128 -> 3, model.py:586-588) as a dot-product kernel (v_dot2_f32_bf16, halo tile in LDS, weights by scalar loads) instead of an
+    MFMA tile padded to 64 columns; fp32 output; against torch and against the MFMA kernel (UDT_CONV_N4=0)"""
+    B, H, W, C, N = case
+    g = torch.Generator(device="cpu").manual_seed(H + C)
+    x = torch.randn((B, H, W, C), generator=g).to(cuda).bfloat16()
+    w4 = (torch.randn((N, C, 3, 3), generator=g) / math.sqrt(9 * C)).to(cuda)
+    b = torch.randn((N,), generator=g).to(cuda)
+    y = F.conv2d(x.float().permute(0, 3, 1, 2), w4.bfloat16().float(), b, padding=1).permute(0, 2, 3, 1)
+    w, bp = env.packing.pack_conv(w4), env.packing.pad_bias(b)
+    assert w.shape[0] == 4
+    from udifftext_amd import lib as L
+    try:
+        outs = {}
+        for mode in (1, 0):
+            env.dbg("conv_n4", mode)
+            out = env.ops.conv2d(x, w, bp, ksize=3, flags=L.GEMM_OUT_F32, n_out=4)
+            torch.cuda.synchronize()
+            assert out.dtype == torch.float32 and out.shape == (B, H, W, 4)
+            e = _rel(out[..., :N], y)
+            assert math.isfinite(e) and e < REL_RMS, f"conv3x3 N=4 conv_n4={mode} {case}: rel rms {e:.3e}"
+            if N < 4:
+                assert not bool(out[..., N:].any())
+            outs[mode] = out
+        assert _rel(outs[1], outs[0]) < 1e-3          # (two fp32 summation orders of the same bf16 products)
+        env.dbg("conv_n4", 1)
+        assert torch.equal(env.ops.conv2d(x, w, bp, ksize=3, flags=L.GEMM_OUT_F32, n_out=4), outs[1])
     finally:
         env.reset()
 

@@ -458,6 +458,7 @@ __global__ void __launch_bounds__(256) gemm_fixup_kernel(const GemmParams p) {
 
 #include "gemm8.h"
 #include "conv3p.h"
+#include "conv_n4.h"
 #include "lean_params.h"
 
 struct TilePlan {
@@ -819,6 +820,26 @@ bool lean256_under_lanes() {
   return v != 0;
 }
 
+// udt_debug_set("conv_n4", v) / UDT_CONV_N4: 1 (default) the dot-product kernel of conv_n4.h for 3x3 convolutions with four output
+// channels and fp32 output, 0: the gathered MFMA kernel on a 64-column tile
+std::atomic<int> g_conv_n4{-2};
+bool conv_n4_applies(const udt_gemm_desc* d) {
+  int v = g_conv_n4.load(std::memory_order_relaxed);
+  if (v == -2) {
+    const char* e = getenv("UDT_CONV_N4");
+    v = e ? (atoi(e) != 0) : 1;
+    g_conv_n4.store(v, std::memory_order_relaxed);
+  }
+  if (!v) return false;
+  if (d->flags != (UDT_GEMM_CONV | UDT_GEMM_OUT_F32) || d->ksize != 3 || d->stride != 1 || d->pad_t != 1 || d->pad_l != 1 || d->upsample)
+    return false;
+  if (d->N != 4 || d->C2 != 0 || d->C1 % 64 != 0 || d->C1 > 512 || d->Hout != d->Hin || d->Wout != d->Win || d->ldo % 4 != 0) return false;
+  if (d->residual || d->rowvec || d->in_scsh || d->colstats || d->colscale || d->batch > 1 || d->alpha != 1.0f) return false;
+  if ((d->ldw > 0 ? d->ldw : d->K) % 8 != 0) return false;
+  if ((reinterpret_cast<uintptr_t>(d->a) | reinterpret_cast<uintptr_t>(d->w) | reinterpret_cast<uintptr_t>(d->out)) & 15) return false;
+  return true;
+}
+
 bool lean_plan(const udt_gemm_desc* d, LeanPlan& t, bool want_stats) {
   const int mode = lean_mode();
   if (mode == 0) return false;
@@ -1110,6 +1131,7 @@ extern "C" int udt_debug_set(const char* key, int32_t value) {
   if (!strcmp(key, "rows_epi")) { g_rows_epi.store(value ? 1 : 0); return UDT_OK; }
   if (!strcmp(key, "lean")) { g_lean.store(value < 0 ? -2 : value); return UDT_OK; }
   if (!strcmp(key, "rowres")) { g_rowres.store(value < 0 ? 1 : (value ? 1 : 0)); return UDT_OK; }
+  if (!strcmp(key, "conv_n4")) { g_conv_n4.store(value < 0 ? -2 : (value ? 1 : 0)); return UDT_OK; }
   if (!strcmp(key, "lean256_lanes")) { g_lean256_lanes.store(value < 0 ? -2 : (value ? 1 : 0)); return UDT_OK; }
   if (!strcmp(key, "lean_splitk")) { g_lean_splitk.store(value); return UDT_OK; }
   if (!strcmp(key, "share_splitk")) { g_share_splitk.store(value < 0 ? -2 : (value ? 1 : 0)); return UDT_OK; }
@@ -1186,6 +1208,7 @@ extern "C" int udt_ln_gemm_fwd(const udt_gemm_desc* d, void* workspace, size_t w
 
 extern "C" size_t udt_gemm_workspace_bytes(const udt_gemm_desc* d) {
   if (!d || d->K <= 0 || d->M <= 0 || d->N <= 0 || d->K % k_tile(d) != 0) return 0;
+  if (conv_n4_applies(d)) return 0;
   {
     LeanPlan lt;
     if (lean_plan(d, lt, d->colstats != nullptr)) return lean_workspace(lt);
@@ -1257,6 +1280,28 @@ extern "C" int udt_gemm(const udt_gemm_desc* d, void* workspace, size_t workspac
   if (d->rowvec && d->rows_per_batch <= 0) return UDT_ERR_BAD_ARG;
 
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (conv_n4_applies(d)) {
+    // four output channels, fp32 output (the UNet's `out` convolution, the VAE decoder's conv_out): the dot-product kernel of conv_n4.h
+    cn4::Params cp;
+    cp.a = reinterpret_cast<const uint16_t*>(d->a); cp.w = reinterpret_cast<const uint16_t*>(d->w); cp.bias = d->bias;
+    cp.out = reinterpret_cast<float*>(d->out);
+    cp.B = d->M / (d->Hout * d->Wout); cp.H = d->Hin; cp.W = d->Win; cp.C = d->C1;
+    cp.ldw = d->ldw > 0 ? d->ldw : d->K; cp.ldo = d->ldo;
+    cp.tiles_x = (d->Win + 7) / 8; cp.tiles_y = (d->Hin + 7) / 8;
+    const size_t smem = (size_t)100 * (d->C1 + 8) * 2 + (size_t)4 * 9 * d->C1 * 2;      // halo + weights (>= the 4 KiB of the reduction)
+    static AttrOnce once;
+    hipError_t ea = once.ensure(reinterpret_cast<const void*>(cn4::conv3x3_n4_kernel), 100 * (512 + 8) * 2 + 4 * 9 * 512 * 2);
+    if (ea != hipSuccess) return udt_set_hip_error(ea);
+    UdtProfScope profn(0, s);
+    if (profn.rec) {
+      char tag[96];
+      snprintf(tag, sizeof(tag), "conv_n4 M=%d N=%d K=%d %dx%d", d->M, d->N, d->K, d->Hin, d->Win);
+      udt_prof_tag(profn.rec, tag);
+    }
+    hipLaunchKernelGGL(cn4::conv3x3_n4_kernel, dim3((unsigned)(cp.B * cp.tiles_x * cp.tiles_y)), dim3(256), smem, s, cp);
+    UDT_CHECK_LAUNCH();
+    return UDT_OK;
+  }
   TilePlan t = plan_tiles(d);
 
   GemmParams p;
