@@ -85,12 +85,20 @@ def parse():
     return ap.parse_args()
 
 
+def _round_files(suffix: str):
+    """profiles/rNN_<suffix> of the newest round first — the round's FINAL collection only (rNN_, not the earlier rNNa_ / rNNe_ ones)"""
+    import re
+    pat = re.compile(r"r(\d+)_" + re.escape(suffix) + "$")
+    hits = [(int(m.group(1)), p) for p in glob.glob(os.path.join(ROOT, "profiles", "r*_" + suffix)) for m in [pat.match(os.path.basename(p))] if m]
+    return [p for _, p in sorted(hits, reverse=True)]
+
+
 def measured_traffic():
     """HBM bytes per launch of the patch-staged 3x3 convolution kernels (wd::wconv3_kernel + lg::lconv3_kernel: the dominant
     kernels) over one batch of this workload, from the committed rocprofv3 PMC passes (profiles/rNN_traffic.json, newest round; tools/collect_profiles.sh +
     tools/pmc_extrapolate.py: FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, separate passes).  Counter collection
     cannot run inside the timed region, hence the file; None if absent."""
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")), reverse=True):
+    for path in _round_files("traffic.json"):
         try:
             d = json.load(open(path))
             src = os.path.basename(path) + (" @ " + str(d["head"]) if d.get("head") else "")      # the commit it was collected at
@@ -103,7 +111,7 @@ def measured_traffic():
 def measured_traffic_inflight_plans():
     """the same counters with every launch PLANNED for three batches in flight (tools/predict_once.py UDT_PLAN_SHARE=3: the split-K /
     tile plans of the headline mode; profiles/rNN_traffic_inflight_plans.json) — None if absent"""
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic_inflight_plans.json")), reverse=True):
+    for path in _round_files("traffic_inflight_plans.json"):
         try:
             d = json.load(open(path))
             return float((d.get("conv3") or d["conv3p"])["hbm_bytes_per_launch"]), os.path.basename(path) + (" @ " + str(d["head"]) if d.get("head") else "")
