@@ -36,3 +36,21 @@ def test_bench_sharded_global_batch_smaller_than_world_times_micro():
 def test_bench_single_rank_stub():
     d = _run([])
     assert d["n_gpus"] == 1 and d["value"] > 0
+
+
+def test_bench_cites_the_final_collection_of_the_newest_round(tmp_path, monkeypatch):
+    """`roofline.traffic` comes from profiles/rNN_traffic.json of the newest round — the round's FINAL collection, not an earlier one
+    of the same round (rNNa_ / rNNe_ sort after rNN_ alphabetically and were picked up once)"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    for name, val in (("r05_traffic.json", 1.0), ("r06_traffic.json", 2.0), ("r06a_traffic.json", 3.0), ("r06e_traffic.json", 4.0)):
+        (prof / name).write_text(json.dumps({"head": name, "conv3": {"hbm_bytes_per_launch": val}}))
+    (prof / "r06_traffic_inflight_plans.json").write_text(json.dumps({"conv3": {"hbm_bytes_per_launch": 5.0}}))
+    (prof / "r06e_traffic_inflight_plans.json").write_text(json.dumps({"conv3": {"hbm_bytes_per_launch": 6.0}}))
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    assert bench.measured_traffic() == (2.0, "r06_traffic.json @ r06_traffic.json")
+    assert bench.measured_traffic_inflight_plans()[0] == 5.0
