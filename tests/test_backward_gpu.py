@@ -56,7 +56,7 @@ def _bf(t):
 
 
 # ------------------------------------------------------------------------------------------------ kernels vs autograd
-@pytest.mark.parametrize("B,H,N", [(2, 5, 256), (1, 5, 200), (2, 10, 1024), (1, 20, 64), (1, 5, 40)])
+@pytest.mark.parametrize("B,H,N", [(2, 5, 256), (1, 5, 200), (2, 10, 1024), (1, 20, 64), (1, 5, 40), (1, 5, 4096), (5, 5, 4096)])
 def test_flash_attention_backward_vs_autograd(env, B, H, N):
     g = torch.Generator().manual_seed(N)
     C = H * 64
@@ -339,6 +339,36 @@ def test_g13_attend_and_excite_gradient_and_update_vs_reference_golden(engine, e
     _, grad2 = env.bw.unet_local_loss_grad(unet, engine.loss_fn, x, c_noise.float(), c["concat"], c["t_crossattn"], batch["mask"],
                                            batch["seg_mask"])
     assert torch.equal(grad, grad2)
+
+
+def test_reverse_pass_at_512_vs_oracle_autograd(engine, env):
+    """the benchmark's latent size (64 x 64: all four UNet levels, the 4096-token flash backward with its deep load ring, the wide
+    convolution as backward-data kernel): d / d x of the smooth map functional sum_k <R_k, t_attn map_k> / count, B = 1, HIP reverse pass
+    against torch.autograd through the fp32 CPU oracle with the same synthetic weights"""
+    from aae_fixture import aae_functional_weights
+    from oracle import backward as obw, spec
+    from udifftext_amd import pipeline
+    dev = env.dev
+    batch = env.synth.synthetic_batch(1, 512, 512, 9, seed=6)
+    torch.manual_seed(17)
+    batch, buc = pipeline.prepare_batch(batch, dev)
+    c, uc = engine.conditioner.get_unconditional_conditioning(batch, batch_uc=buc, force_uc_zero_embeddings=["label"])
+    x = torch.randn((1, 4, 64, 64), device=dev) * 3.0
+    sigma = torch.full((1,), 2.5, device=dev)
+    sampler = pipeline.init_sampling(10, 5.0, dev)
+    c_noise = sampler.get_c_noise(x, engine, sigma)
+    unet = engine.model.diffusion_model
+    min_size = engine.loss_fn.min_attn_size
+
+    def maps_grad(rec):
+        used = [it for it in rec if it["size"] >= min_size]
+        for k, it in enumerate(used):
+            it["d_probs"] = (aae_functional_weights(it["attn_map"].shape, k).to(dev) / len(used)).contiguous()
+    got = env.bw.unet_maps_vjp(unet, x, c_noise.float(), c["concat"], c["t_crossattn"], maps_grad).cpu()
+    sd = {k: v.detach().float().cpu() for k, v in engine.state_dict().items()}
+    cond = {"concat": c["concat"].float().cpu(), "t_crossattn": c["t_crossattn"].float().cpu()}
+    _, ref = obw.maps_functional_grad(sd, spec.EngineConfig(), x.cpu(), sigma.cpu(), cond, aae_functional_weights, min_size)
+    _check("reverse pass at 64x64 latents (dense map cotangents) vs oracle autograd", got, ref, 3e-2)
 
 
 def test_sampling_with_attend_and_excite_runs_and_lowers_the_local_loss(engine, env):
