@@ -246,6 +246,44 @@ def test_g14_training_step_loss_and_gradients_vs_reference_golden(engine, env):
     assert _compare_grads("G14s dense map cotangents -> parameter gradients vs reference", gs, g, names, "g14s") <= TOL_STEP
 
 
+def test_training_gradients_at_512_vs_oracle_autograd(engine, env):
+    """the benchmark's image size (64 x 64 latents, B = 1: every kernel of the reverse pass at its large shapes — 4096-row weight
+    gradients with row ranges, the query-range split of the text attention's context gradients, chunked GroupNorm backward):
+    FullLoss's eps-prediction term, gradients of the 112 trained tensors against torch.autograd through the fp32 CPU oracle"""
+    from oracle import spec, training as otr
+    from udifftext_amd import pipeline, synth
+    dev = env.dev
+    tr = env.training
+    batch = synth.synthetic_batch(1, 512, 512, 9, seed=8)
+    torch.manual_seed(23)
+    batch, _ = pipeline.prepare_batch(batch, dev)
+    cond = engine.conditioner(batch)
+    z = torch.randn((1, 4, 64, 64), device=dev)
+    idx = torch.tensor([600])
+    noise = torch.randn((1, 4, 64, 64), device=dev)
+    seg = torch.zeros((1, 12, 512, 512), device=dev)
+    seg[:, :9, 240:272, :] = 1.0
+    lam = engine.loss_fn.lambda_local_loss
+    try:
+        engine.loss_fn.lambda_local_loss = 0.0               # (the smooth term: the hard arg-max selections have their own goldens)
+        ld, grads = tr.training_loss_and_grads(engine, z, cond, seg, batch["seg_mask"], sigma_idx=idx, noise=noise)
+    finally:
+        engine.loss_fn.lambda_local_loss = lam
+    sd = {k: v.detach().float().cpu() for k, v in engine.state_dict().items()}
+    cpu = lambda t: t.detach().float().cpu()
+    ldr, gref = otr.training_grads(sd, spec.EngineConfig(), cpu(z), {k: cpu(v) for k, v in cond.items() if torch.is_tensor(v)}, cpu(seg),
+                                   cpu(batch["seg_mask"]), idx, cpu(noise), 0.0)
+    assert abs(float(ld["loss/diff_loss"]) - float(ldr["loss/diff_loss"])) <= 2e-2 * abs(float(ldr["loss/diff_loss"]))
+    num = sum(float((grads[n].cpu() - gref[n]).pow(2).sum()) for n in gref)
+    den = sum(float(gref[n].pow(2).sum()) for n in gref)
+    worst = max(((float((grads[n].cpu() - gref[n]).norm() / gref[n].norm().clamp_min(1e-30)), n) for n in gref if float(gref[n].norm()) > 1e-3 * (den ** 0.5 / len(gref))))
+    rel = (num / den) ** 0.5
+    os.makedirs(os.path.dirname(REPORT), exist_ok=True)
+    with open(REPORT, "a") as f:
+        f.write(f"{'training-step gradients at 64x64 latents vs oracle autograd':55s} rel_rms {rel:.3e} (tol {TOL_STEP:.1e})  worst tensor {worst[0]:.3e} {worst[1]}\n")
+    assert rel <= TOL_STEP and worst[0] <= 3 * TOL_STEP, (rel, worst)
+
+
 def test_training_step_updates_only_the_trained_parameters(engine, env):
     """training.training_step: gradients -> AdamW on the t_attn / t_norm masters; every other parameter untouched; the packed layouts
     and the graph fingerprint notice; the same step from the same state is bit-reproducible"""
