@@ -41,7 +41,7 @@ def env(cuda):
 
         @staticmethod
         def reset():
-            for k in ("lean", "lean_splitk", "lean_conv", "wide_conv", "rowres", "share_splitk", "lean256_lanes", "conv_n4"):
+            for k in ("lean", "lean_splitk", "lean_conv", "wide_conv", "rowres", "share_splitk", "lean256_lanes", "conv_n4", "wide_lanes_eff"):
                 L.check(lib.udt_debug_set(k.encode(), -1), "udt_debug_set " + k)
     yield Env
     Env.reset()
@@ -322,6 +322,34 @@ def test_conv3x3_with_four_output_channels_fp32(env, cuda, case):
         assert _rel(outs[1], outs[0]) < 1e-3          # (two fp32 summation orders of the same bf16 products)
         env.dbg("conv_n4", 1)
         assert torch.equal(env.ops.conv2d(x, w, bp, ksize=3, flags=L.GEMM_OUT_F32, n_out=4), outs[1])
+    finally:
+        env.reset()
+
+
+def test_wide_conv_at_the_16x16_level_with_batches_in_flight(env, cuda):
+    """round 6 (UDT_WIDE_LANES_EFF): a launch that shares the device with two other streams (cu_share 3) takes the wide convolution
+    already when its tiles fill 3/4 of its share of the CUs — the 16 x 16 level of a UNet call (64 tiles of 256 pixels x 160 channels,
+    whole tiles, no channel slices) — where the round-5 rule (85 %) took the lean kernel; a lone launch is planned as before.  Both
+    plans agree with fp32; the results differ in the last bits (another tile shape), which is how the test knows the plan changed."""
+    B, H, W, C, N = 8, 16, 16, 1280, 1280
+    g = torch.Generator(device="cpu").manual_seed(31)
+    x = torch.randn((B, H, W, C), generator=g).to(cuda).bfloat16()
+    w4 = (torch.randn((N, C, 3, 3), generator=g) / math.sqrt(9 * C)).to(cuda)
+    b = torch.randn((N,), generator=g).to(cuda)
+    y = F.conv2d(x.float().permute(0, 3, 1, 2), w4.bfloat16().float(), b, padding=1).permute(0, 2, 3, 1)
+    w = env.packing.pack_conv(w4)
+    try:
+        outs = {}
+        for share in (1, 3):
+            for eff in (85, 70):
+                env.dbg("wide_lanes_eff", eff)
+                with env.ops.launch_context(cu_share=share):
+                    out = env.ops.conv2d(x, w, b, ksize=3)
+                torch.cuda.synchronize()
+                assert _rel(out, y) < REL_RMS, (share, eff, _rel(out, y))
+                outs[(share, eff)] = out
+        assert torch.equal(outs[(1, 85)], outs[(1, 70)]), "a lone launch must not be re-planned"
+        assert not torch.equal(outs[(3, 85)], outs[(3, 70)]), "with batches in flight the 16 x 16 level should have gone wide"
     finally:
         env.reset()
 

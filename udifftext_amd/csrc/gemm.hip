@@ -1003,6 +1003,19 @@ int wide_conv_mode() {
 std::atomic<int> g_lconv_dbg{0};   // cost attribution of the lean convolution's loop (C3Params.dbg): wrong results
 #endif
 
+// udt_debug_set("wide_lanes_eff", percent) / UDT_WIDE_LANES_EFF: the share of its CUs a launch must fill to take the wide convolution
+// when three or more launch streams share the device (default 70; 85 = the rule of a lone launch)
+std::atomic<int> g_wide_lanes_eff{-2};
+double wide_lanes_eff() {
+  int v = g_wide_lanes_eff.load(std::memory_order_relaxed);
+  if (v == -2) {
+    const char* e = getenv("UDT_WIDE_LANES_EFF");
+    v = e ? atoi(e) : 70;
+    g_wide_lanes_eff.store(v, std::memory_order_relaxed);
+  }
+  return v / 100.0;
+}
+
 // channel-chunk slices per tile of the lean / wide convolution (ticket split-K): ONE rule for the plan and for the wide kernel's
 // eligibility test (which used to predict chunks / 5 and ignore the forced knob while the plan cut chunks / 4)
 int conv_chunk_slices(long long tiles, int slots, int chunks, int knob) {
@@ -1052,7 +1065,10 @@ bool lean_conv_plan(const udt_gemm_desc* d, lg::C3Params& c, bool want_stats) {
       const long long units = wt * sk;
       const long long rounds = (units + cus - 1) / cus;
       const double eff = units > cus ? (double)units / (double)(rounds * cus) : ((double)units * share >= cus ? 1.0 : (double)units * share / cus);
-      wide = (wm > 0) || (sk <= 2 && eff >= 0.85);
+      // round 6: with three or more batches in flight a launch that fills only 3/4 of its share still goes wide — the 16 x 16 level's
+      // 64 whole tiles (one per CU for all 20 channel chunks, no slab exchange) against 160 lean workgroups: +1.2 % images/s
+      // (profiles/r06_ab_wide_conv_16x16_under_lanes.txt); alone (four slices per tile) the lean kernel stays 3 us ahead
+      wide = (wm > 0) || (sk <= 2 && eff >= (share >= 3 ? wide_lanes_eff() : 0.85));
     }
   }
   if (wide) { c.geo = 3; c.tw = 16; c.th = 16; c.bn = 160; c.wgm = 4; }
@@ -1131,6 +1147,7 @@ extern "C" int udt_debug_set(const char* key, int32_t value) {
   if (!strcmp(key, "rows_epi")) { g_rows_epi.store(value ? 1 : 0); return UDT_OK; }
   if (!strcmp(key, "lean")) { g_lean.store(value < 0 ? -2 : value); return UDT_OK; }
   if (!strcmp(key, "rowres")) { g_rowres.store(value < 0 ? 1 : (value ? 1 : 0)); return UDT_OK; }
+  if (!strcmp(key, "wide_lanes_eff")) { g_wide_lanes_eff.store(value < 0 ? -2 : value); return UDT_OK; }
   if (!strcmp(key, "conv_n4")) { g_conv_n4.store(value < 0 ? -2 : (value ? 1 : 0)); return UDT_OK; }
   if (!strcmp(key, "lean256_lanes")) { g_lean256_lanes.store(value < 0 ? -2 : (value ? 1 : 0)); return UDT_OK; }
   if (!strcmp(key, "lean_splitk")) { g_lean_splitk.store(value); return UDT_OK; }
