@@ -338,19 +338,35 @@ def test_wide_conv_at_the_16x16_level_with_batches_in_flight(env, cuda):
     b = torch.randn((N,), generator=g).to(cuda)
     y = F.conv2d(x.float().permute(0, 3, 1, 2), w4.bfloat16().float(), b, padding=1).permute(0, 2, 3, 1)
     w = env.packing.pack_conv(w4)
+    import os, tempfile
+    from udifftext_amd import lib as L
+    lib = L.load()
+
+    def run(share, eff):
+        """(result, the launch's tag in the library's profiler: 'wconv3 ...' / 'lconv3 ...')"""
+        env.dbg("wide_lanes_eff", eff)
+        env.ops.prof_reset(); lib.udt_prof_trace(1); env.ops.prof_enable(0x3f)
+        with env.ops.launch_context(cu_share=share):
+            out = env.ops.conv2d(x, w, b, ksize=3)
+        torch.cuda.synchronize()
+        env.ops.prof_enable(0)
+        path = os.path.join(tempfile.gettempdir(), "udt_wide_lanes_trace.csv")
+        lib.udt_prof_dump(path.encode())
+        lib.udt_prof_trace(0)
+        tags = [ln.split(",", 2)[2] for ln in open(path).read().splitlines()[1:]]
+        assert len(tags) == 1, tags
+        return out, tags[0]
     try:
-        outs = {}
+        plans = {}
         for share in (1, 3):
             for eff in (85, 70):
-                env.dbg("wide_lanes_eff", eff)
-                with env.ops.launch_context(cu_share=share):
-                    out = env.ops.conv2d(x, w, b, ksize=3)
-                torch.cuda.synchronize()
+                out, tag = run(share, eff)
                 assert _rel(out, y) < REL_RMS, (share, eff, _rel(out, y))
-                outs[(share, eff)] = out
-        assert torch.equal(outs[(1, 85)], outs[(1, 70)]), "a lone launch must not be re-planned"
-        assert not torch.equal(outs[(3, 85)], outs[(3, 70)]), "with batches in flight the 16 x 16 level should have gone wide"
+                plans[(share, eff)] = tag
+        assert plans[(1, 85)] == plans[(1, 70)] and plans[(1, 70)].startswith("lconv3"), plans      # a lone launch: four slices -> lean
+        assert plans[(3, 85)].startswith("lconv3") and plans[(3, 70)].startswith("wconv3") and "splitk=1" in plans[(3, 70)], plans
     finally:
+        env.ops.prof_enable(0)
         env.reset()
 
 
@@ -368,6 +384,7 @@ def test_share_aware_split_k_plans_and_results(env, cuda):
     wc = env.packing.pack_conv(w4)
     try:
         res = {}
+        env.dbg("wide_lanes_eff", 85)                 # (this test is about the lean kernels' slices: keep the convolution on them)
         for share in (3, 1):
             for rule in (1, 0):
                 env.dbg("share_splitk", rule)

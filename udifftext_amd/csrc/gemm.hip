@@ -1068,7 +1068,7 @@ bool lean_conv_plan(const udt_gemm_desc* d, lg::C3Params& c, bool want_stats) {
       // round 6: with three or more batches in flight a launch that fills only 3/4 of its share still goes wide — the 16 x 16 level's
       // 64 whole tiles (one per CU for all 20 channel chunks, no slab exchange) against 160 lean workgroups: +1.2 % images/s
       // (profiles/r06_ab_wide_conv_16x16_under_lanes.txt); alone (four slices per tile) the lean kernel stays 3 us ahead
-      wide = (wm > 0) || (sk <= 2 && eff >= (share >= 3 ? wide_lanes_eff() : 0.85));
+      wide = (wm > 0) || (sk <= 2 && eff >= ((share >= 3 && share_of(d) >= 3) ? wide_lanes_eff() : 0.85));
     }
   }
   if (wide) { c.geo = 3; c.tw = 16; c.th = 16; c.bn = 160; c.wgm = 4; }
