@@ -39,6 +39,14 @@
  *   udt_timestep_embedding  timestep_embedding  sgm/modules/diffusionmodules/util.py:206-230
  *   udt_mask_downsample SpatialRescaler (bilinear x0.125)  sgm/modules/encoders/modules.py:843-857
  *   udt_local_loss_maps head-mean + 3x3 blur + masked max of t_attn maps  sgm/modules/diffusionmodules/loss.py:192-235
+ *   the reverse pass (round 6; torch.autograd under attend_and_excite, sgm/modules/diffusionmodules/sampling.py:233-252, and under
+ *   DiffusionEngine.training_step, sgm/models/diffusion.py:138-172 with loss.py:131-176,237-286):
+ *     udt_attn_bwd, udt_xattn_bwd, udt_xattn_bwd_kv       autograd of the two attention call sites above
+ *     udt_gn_bwd, udt_layernorm_bwd, udt_ln_param_grad, udt_geglu_fwd / _bwd   autograd of the norms / GEGLU
+ *     udt_local_loss_bwd, udt_local_loss_seg_bwd, udt_diff_loss_grad          FullLoss.get_min_local_loss / get_local_loss / __call__
+ *     udt_wgrad_bf16, udt_colsum_bf16                     weight / bias gradients of the trained nn.Linear layers
+ *     udt_adamw_f32                                       torch.optim.AdamW.step (diffusion.py:49-51,202-222)
+ *     (backward-data of linears and convolutions: udt_gemm on re-packed weights)
  *
  * Conventions
  *   - every pointer is a DEVICE pointer owned by the caller; kernels borrow it for the stream-ordered
